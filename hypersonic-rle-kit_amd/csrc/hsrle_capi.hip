@@ -1,0 +1,768 @@
+// hsrle_capi.hip -- the C ABI of libhsrle_hip.so (include/hsrle.h): drop-in rle.h entry points, the device-resident
+// block container API, container assembly kernels (size scan + slot compaction) and the synthetic workload generator.
+//
+// Host code here is plain C-style C++ behind `extern "C"`; no torch types, no CPU codec.  If no HIP device is usable
+// every entry point fails loudly (0 / HSRLE_ERR_DEVICE) -- there is no fallback path.
+#include "../../include/hsrle.h"
+
+#include "hsrle_common.hip.h"
+#include "hsrle_launch.h"
+
+#include <mutex>
+#include <string.h>
+
+namespace hsrle {
+
+// ------------------------------------------------------------------------------------------------------------------
+// codec table (names follow the reference: src/rle.h, src/codec_funcs.h:270-410)
+
+static const char *const kCodecNames[kCodecCount] = {
+  "rle8_multi", "rle8_packed_multi", "rle8_3symlut", "rle8_7symlut", "rle8_single", "rle8_packed_single",
+  "rle16_sym", "rle16_sym_packed", "rle16_3symlut_sym", "rle16_7symlut_sym", "rle16_byte", "rle16_byte_packed", "rle16_3symlut_byte", "rle16_7symlut_byte",
+  "rle24_sym", "rle24_sym_packed", "rle24_3symlut_sym", "rle24_7symlut_sym", "rle24_byte", "rle24_byte_packed", "rle24_3symlut_byte", "rle24_7symlut_byte",
+  "rle32_sym", "rle32_sym_packed", "rle32_3symlut_sym", "rle32_7symlut_sym", "rle32_byte", "rle32_byte_packed", "rle32_3symlut_byte", "rle32_7symlut_byte",
+  "rle48_sym", "rle48_sym_packed", "rle48_3symlut_sym", "rle48_7symlut_sym", "rle48_byte", "rle48_byte_packed", "rle48_3symlut_byte", "rle48_7symlut_byte",
+  "rle64_sym", "rle64_sym_packed", "rle64_3symlut_sym", "rle64_7symlut_sym", "rle64_byte", "rle64_byte_packed", "rle64_3symlut_byte", "rle64_7symlut_byte",
+  "rle128_sym", "rle128_sym_packed", "rle128_byte", "rle128_byte_packed",
+};
+
+static inline bool codec_is_lut(int c) { return c == 2 || c == 3 || (c >= 6 && c < 46 && (((c - 6) & 3) >= 2)); }
+static inline uint32_t codec_header_size(int c) { return (c < 6 && !codec_is_lut(c)) ? 9u : 8u; }
+
+static DecodeLaunch g_dec[kCodecCount];
+static EncodeLaunch g_enc[kCodecCount];
+static std::once_flag g_tableOnce;
+
+static void init_tables()
+{
+  std::call_once(g_tableOnce, [] {
+    register_w8(g_dec, g_enc);
+    register_w16(g_dec, g_enc);
+    register_w24(g_dec, g_enc);
+    register_w32(g_dec, g_enc);
+    register_w48(g_dec, g_enc);
+    register_w64(g_dec, g_enc);
+    register_w128(g_dec, g_enc);
+  });
+}
+
+static inline uint32_t bounds32(uint32_t n) { return (n > (1u << 30)) ? 0u : n + (16 + 4 + 1 + 4 + 1 + 64) * 2 + (3 * 4) + 1; }
+static inline uint32_t slot_stride(uint32_t B) { return (bounds32(B) + 15u) & ~15u; }
+static inline uint64_t block_count(uint64_t U, uint32_t B) { return (U + B - 1) / B; }
+static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+static bool valid_block_size(uint32_t B) { return B >= HSRLE_MIN_BLOCK_SIZE && B <= HSRLE_MAX_BLOCK_SIZE && (B % 128u) == 0; }
+
+// ------------------------------------------------------------------------------------------------------------------
+// container assembly kernels
+
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kScanThreads * kScanItems; // 2048 elements per workgroup
+
+__device__ __forceinline__ uint64_t wg_exclusive_scan_u64(uint64_t v, uint64_t *total)
+{
+  // wave scan by shuffles, then a scan of the (up to 4) wave totals through LDS
+  __shared__ uint64_t waveTotals[kScanThreads / 64];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint64_t x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1)
+  {
+    const uint64_t y = __shfl_up(x, d, 64);
+    if ((int)lane >= d) x += y;
+  }
+  if (lane == 63u) waveTotals[wave] = x;
+  __syncthreads();
+  uint64_t base = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < kScanThreads / 64; w++)
+  {
+    const uint64_t t = waveTotals[w];
+    if ((uint32_t)w < wave) base += t;
+    all += t;
+  }
+  __syncthreads();
+  *total = all;
+  return base + x - v;
+}
+
+// sums[wg] = sum of in[wg * 2048 .. +2048)
+template <typename TIN>
+__global__ __launch_bounds__(kScanThreads) void k_tile_sums(const TIN *__restrict__ in, uint64_t n, uint64_t *__restrict__ sums)
+{
+  const uint64_t base = (uint64_t)blockIdx.x * kScanTile;
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++)
+  {
+    const uint64_t idx = base + (uint64_t)k * kScanThreads + threadIdx.x;
+    if (idx < n) acc += (uint64_t)in[idx];
+  }
+  uint64_t total;
+  wg_exclusive_scan_u64(acc, &total);
+  if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// out[i] = tileBase[wg] + exclusive prefix of in within the tile; out[n] = grand total when writeTotal.
+// `in` and `out` may alias (in-place scan of a sums level): every thread reads its items before it writes them.
+template <typename TIN>
+__global__ __launch_bounds__(kScanThreads) void k_tile_scan(const TIN *in, uint64_t n, const uint64_t *tileBase, uint64_t *out, int writeTotal)
+{
+  const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
+  uint64_t v[kScanItems];
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++)
+  {
+    v[k] = (base + k < n) ? (uint64_t)in[base + k] : 0;
+    acc += v[k];
+  }
+  uint64_t total;
+  uint64_t run = wg_exclusive_scan_u64(acc, &total) + (tileBase ? tileBase[blockIdx.x] : 0);
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++)
+  {
+    if (base + k < n) out[base + k] = run;
+    run += v[k];
+  }
+  if (writeTotal && n > 0 && base <= n - 1 && n - 1 < base + kScanItems) // the thread that owns the last element
+    out[n] = run;
+}
+
+// one wave per block: copy the slot stream to its place in the payload (destination-aligned 16-byte stores)
+__global__ __launch_bounds__(256) void k_compact(const uint8_t *__restrict__ slots, uint32_t slotStride, const uint64_t *__restrict__ offsets,
+                                                 uint8_t *__restrict__ payload, uint32_t nBlocks)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t b = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (b >= nBlocks)
+    return;
+
+  const uint64_t off = offsets[b];
+  const uint32_t size = (uint32_t)(offsets[b + 1] - off);
+  const uint8_t *src = slots + (uint64_t)b * slotStride;
+  uint8_t *dst = payload + off;
+
+  uint32_t head = (uint32_t)((16u - ((uintptr_t)dst & 15u)) & 15u);
+  if (head > size) head = size;
+  if (lane < head) dst[lane] = src[lane];
+
+  const uint32_t body = (size - head) & ~15u;
+  for (uint32_t k = lane * 16u; k < body; k += 64u * 16u)
+    st128(dst + head + k, ld128(src + head + k));
+
+  const uint32_t tail = size - head - body;
+  if (lane < tail) dst[head + body + lane] = src[head + body + lane];
+}
+
+struct ContainerHeader
+{
+  char magic[8];
+  uint32_t version, codec;
+  uint64_t uncompressedSize;
+  uint32_t blockSize, blockCount;
+  uint64_t payloadSize, totalSize;
+  uint8_t reserved[16];
+};
+static_assert(sizeof(ContainerHeader) == HSRLE_CONTAINER_HEADER_SIZE, "container header is 64 bytes");
+
+__global__ void k_finish_container(uint8_t *__restrict__ container, uint32_t codec, uint64_t U, uint32_t B, uint32_t nBlocks)
+{
+  // offsets[nBlocks] was written by the scan; fill the header and the zero tail pad
+  const uint64_t *offsets = (const uint64_t *)(container + HSRLE_CONTAINER_HEADER_SIZE);
+  const uint64_t payloadSize = offsets[nBlocks];
+  const uint64_t payloadStart = HSRLE_CONTAINER_HEADER_SIZE + 8ull * ((uint64_t)nBlocks + 1ull);
+
+  if (threadIdx.x == 0)
+  {
+    ContainerHeader h;
+    const char m[8] = { 'H', 'S', 'R', 'L', 'E', 'K', 'I', 'T' };
+    for (int k = 0; k < 8; k++) h.magic[k] = m[k];
+    h.version = 1;
+    h.codec = codec;
+    h.uncompressedSize = U;
+    h.blockSize = B;
+    h.blockCount = nBlocks;
+    h.payloadSize = payloadSize;
+    h.totalSize = payloadStart + payloadSize + HSRLE_CONTAINER_TAIL_PAD;
+    for (int k = 0; k < 16; k++) h.reserved[k] = 0;
+    *(ContainerHeader *)container = h;
+  }
+
+  if (threadIdx.x < HSRLE_CONTAINER_TAIL_PAD)
+    container[payloadStart + payloadSize + threadIdx.x] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// synthetic workloads.  One lane generates one 64 KiB chunk; chunks are independent so the same
+// bytes can be produced on the CPU (oracle/hsrle_synth.c, tests/hsrle_testlib.py:synth_chunk_py) for any slice.
+
+constexpr uint32_t kSynthChunk = 65536u;
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t &state)
+{
+  state += 0x9E3779B97F4A7C15ull;
+  uint64_t z = state;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(64) void k_synth(int kind, int S, uint64_t seed, uint8_t *__restrict__ out, uint64_t size)
+{
+  const uint64_t chunk = (uint64_t)blockIdx.x * 64u + threadIdx.x;
+  const uint64_t start = chunk * kSynthChunk;
+  if (start >= size)
+    return;
+
+  const uint32_t len = (uint32_t)((size - start) < kSynthChunk ? (size - start) : kSynthChunk);
+  uint8_t *o = out + start;
+  uint64_t st = seed * 0x9E3779B97F4A7C15ull + chunk * 0xD1B54A32D192ED03ull + (uint64_t)kind;
+  uint32_t at = 0;
+
+  if (kind == HSRLE_SYNTH_RUNS)
+  {
+    while (at < len)
+    {
+      uint64_t r = splitmix64(st);
+      uint32_t L = 1u + (uint32_t)(r % 63u);
+      for (uint32_t k = 0; k < L; k += 8)
+      {
+        const uint64_t v = splitmix64(st);
+        for (uint32_t j = 0; j < 8 && k + j < L; j++)
+          if (at + k + j < len) o[at + k + j] = (uint8_t)(v >> (8 * j));
+      }
+      at += L;
+
+      r = splitmix64(st);
+      const uint32_t R = 2u + (uint32_t)(r % 62u);
+      uint8_t sym[16];
+      for (int k = 0; k < S; k += 8)
+      {
+        const uint64_t v = splitmix64(st);
+        for (int j = 0; j < 8 && k + j < S; j++) sym[k + j] = (uint8_t)(v >> (8 * j));
+      }
+      for (uint32_t k = 0; k < R * (uint32_t)S && at + k < len; k++)
+        o[at + k] = sym[k % (uint32_t)S];
+      at += R * (uint32_t)S;
+    }
+  }
+  else
+  {
+    const uint8_t vals[6] = { 0x01, 0x02, 0x03, 0xFF, 0xFE, 0x04 };
+    while (at < len)
+    {
+      uint64_t r = splitmix64(st);
+      const uint32_t Z = 8u + (uint32_t)(r % 120u);
+      for (uint32_t k = 0; k < Z && at + k < len; k++) o[at + k] = 0;
+      at += Z;
+      r = splitmix64(st);
+      const uint32_t Bn = 1u + (uint32_t)(r % 6u);
+      for (uint32_t k = 0; k < Bn && at + k < len; k++) o[at + k] = vals[(r >> (8 + 8 * k)) % 6u];
+      at += Bn;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// device state
+
+struct DeviceState
+{
+  std::mutex mu;
+  int deviceChecked = 0; // 0 = not yet, 1 = ok, -1 = no device
+  void *ws = nullptr;    // cached compression workspace
+  uint64_t wsSize = 0;
+  void *monoIn = nullptr, *monoOut = nullptr, *monoAux = nullptr; // staging of the drop-in (host pointer) path
+  uint64_t monoInSize = 0, monoOutSize = 0;
+};
+
+static DeviceState g_dev;
+
+static bool device_ok()
+{
+  std::lock_guard<std::mutex> lock(g_dev.mu);
+  if (g_dev.deviceChecked == 0)
+  {
+    int n = 0;
+    g_dev.deviceChecked = (hipGetDeviceCount(&n) == hipSuccess && n > 0) ? 1 : -1;
+  }
+  return g_dev.deviceChecked == 1;
+}
+
+static bool grow(void **p, uint64_t *have, uint64_t need)
+{
+  if (*have >= need && *p)
+    return true;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  *have = 0;
+  if (hipMalloc(p, need) != hipSuccess)
+    return false;
+  *have = need;
+  return true;
+}
+
+// workspace layout: [slots][sizes u32][level-1 sums u64][level-2 sums u64][level-3 sums u64]
+struct Workspace
+{
+  uint64_t nBlocks, t1, t2, t3;
+  uint64_t offSlots, offSizes, offL1, offL2, offL3, total;
+};
+
+static Workspace plan_workspace(uint64_t U, uint32_t B)
+{
+  Workspace w;
+  w.nBlocks = block_count(U, B);
+  w.t1 = (w.nBlocks + kScanTile - 1) / kScanTile;
+  w.t2 = (w.t1 + kScanTile - 1) / kScanTile;
+  w.t3 = (w.t2 + kScanTile - 1) / kScanTile;
+  uint64_t at = 0;
+  w.offSlots = at; at += align_up(w.nBlocks * (uint64_t)slot_stride(B), 256);
+  w.offSizes = at; at += align_up(w.nBlocks * 4ull, 256);
+  w.offL1 = at; at += align_up((w.t1 + 1) * 8ull, 256);
+  w.offL2 = at; at += align_up((w.t2 + 1) * 8ull, 256);
+  w.offL3 = at; at += align_up((w.t3 + 1) * 8ull, 256);
+  w.total = at;
+  return w;
+}
+
+// exclusive scan of `n` values (u32 at level 0) into out[0..n] (out[n] = total) using the pre-planned sum levels
+static hipError_t scan_sizes(const uint32_t *sizes, uint64_t n, uint64_t *out, uint8_t *ws, const Workspace &w, hipStream_t st)
+{
+  uint64_t *l1 = (uint64_t *)(ws + w.offL1), *l2 = (uint64_t *)(ws + w.offL2), *l3 = (uint64_t *)(ws + w.offL3);
+
+  if (w.t1 > 1)
+  {
+    hipLaunchKernelGGL(k_tile_sums<uint32_t>, dim3((uint32_t)w.t1), dim3(kScanThreads), 0, st, sizes, n, l1);
+    if (w.t2 > 1)
+    {
+      hipLaunchKernelGGL(k_tile_sums<uint64_t>, dim3((uint32_t)w.t2), dim3(kScanThreads), 0, st, l1, w.t1, l2);
+      if (w.t3 > 1)
+        return hipErrorInvalidValue; // > 2048^3 blocks: not representable anyway
+      hipLaunchKernelGGL(k_tile_scan<uint64_t>, dim3(1), dim3(kScanThreads), 0, st, l2, w.t2, (const uint64_t *)nullptr, l3, 0);
+      hipLaunchKernelGGL(k_tile_scan<uint64_t>, dim3((uint32_t)w.t2), dim3(kScanThreads), 0, st, l1, w.t1, l3, l1, 0);
+    }
+    else
+    {
+      hipLaunchKernelGGL(k_tile_scan<uint64_t>, dim3(1), dim3(kScanThreads), 0, st, l1, w.t1, (const uint64_t *)nullptr, l1, 0);
+    }
+    hipLaunchKernelGGL(k_tile_scan<uint32_t>, dim3((uint32_t)w.t1), dim3(kScanThreads), 0, st, sizes, n, l1, out, 1);
+  }
+  else
+  {
+    hipLaunchKernelGGL(k_tile_scan<uint32_t>, dim3(1), dim3(kScanThreads), 0, st, sizes, n, (const uint64_t *)nullptr, out, 1);
+  }
+
+  return hipGetLastError();
+}
+
+static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, uint64_t cap, uint32_t B, void *dWs, uint64_t wsSize, hipStream_t st)
+{
+  if (codec < 0 || codec >= kCodecCount || dIn == nullptr || dOut == nullptr || U == 0)
+    return HSRLE_ERR_ARGUMENT;
+  if (B == 0) B = HSRLE_DEFAULT_BLOCK_SIZE;
+  if (!valid_block_size(B))
+    return HSRLE_ERR_ARGUMENT;
+  if (cap < hsrle_container_bound(U, B))
+    return HSRLE_ERR_CAPACITY;
+  if (block_count(U, B) > 0xFFFFFFF0ull)
+    return HSRLE_ERR_ARGUMENT;
+  if (!device_ok())
+    return HSRLE_ERR_DEVICE;
+
+  init_tables();
+  if (!g_enc[codec])
+    return HSRLE_ERR_UNSUPPORTED;
+
+  const Workspace w = plan_workspace(U, B);
+
+  if (dWs == nullptr)
+  {
+    std::lock_guard<std::mutex> lock(g_dev.mu);
+    if (!grow(&g_dev.ws, &g_dev.wsSize, w.total))
+      return HSRLE_ERR_DEVICE;
+    dWs = g_dev.ws;
+  }
+  else if (wsSize < w.total)
+    return HSRLE_ERR_CAPACITY;
+
+  uint8_t *ws = (uint8_t *)dWs;
+  uint8_t *container = (uint8_t *)dOut;
+  const uint32_t nBlocks = (uint32_t)w.nBlocks;
+  uint64_t *offsets = (uint64_t *)(container + HSRLE_CONTAINER_HEADER_SIZE);
+  uint8_t *payload = container + HSRLE_CONTAINER_HEADER_SIZE + 8ull * ((uint64_t)nBlocks + 1ull);
+
+  EncodeArgs ea{ (const uint8_t *)dIn, U, B, nBlocks, ws + w.offSlots, slot_stride(B), (uint32_t *)(ws + w.offSizes) };
+  if (g_enc[codec](ea, st) != hipSuccess)
+    return HSRLE_ERR_DEVICE;
+  if (scan_sizes(ea.sizes, nBlocks, offsets, ws, w, st) != hipSuccess)
+    return HSRLE_ERR_DEVICE;
+
+  hipLaunchKernelGGL(k_compact, dim3((nBlocks + 3u) / 4u), dim3(256), 0, st, ea.slots, ea.slotStride, (const uint64_t *)offsets, payload, nBlocks);
+  hipLaunchKernelGGL(k_finish_container, dim3(1), dim3(64), 0, st, container, (uint32_t)codec, U, B, nBlocks);
+  return hipGetLastError() == hipSuccess ? HSRLE_OK : HSRLE_ERR_DEVICE;
+}
+
+static int check_info(const ContainerHeader &h, uint64_t containerSize, hsrle_container_info_t *info)
+{
+  static const char m[8] = { 'H', 'S', 'R', 'L', 'E', 'K', 'I', 'T' };
+  if (memcmp(h.magic, m, 8) != 0 || h.version != 1 || h.codec >= (uint32_t)kCodecCount)
+    return HSRLE_ERR_FORMAT;
+  if (!valid_block_size(h.blockSize) || h.uncompressedSize == 0)
+    return HSRLE_ERR_FORMAT;
+  if (h.blockCount != block_count(h.uncompressedSize, h.blockSize))
+    return HSRLE_ERR_FORMAT;
+  const uint64_t payloadStart = HSRLE_CONTAINER_HEADER_SIZE + 8ull * ((uint64_t)h.blockCount + 1ull);
+  if (h.totalSize != payloadStart + h.payloadSize + HSRLE_CONTAINER_TAIL_PAD || h.totalSize > containerSize)
+    return HSRLE_ERR_FORMAT;
+  info->version = h.version;
+  info->codec = h.codec;
+  info->uncompressedSize = h.uncompressedSize;
+  info->blockSize = h.blockSize;
+  info->blockCount = h.blockCount;
+  info->payloadSize = h.payloadSize;
+  info->totalSize = h.totalSize;
+  return HSRLE_OK;
+}
+
+static int decompress_blocks_async(const void *dContainer, const hsrle_container_info_t *info, uint32_t first, uint32_t count, void *dOut, uint64_t cap,
+                                   uint32_t *dStatus, hipStream_t st)
+{
+  if (dContainer == nullptr || info == nullptr || dOut == nullptr)
+    return HSRLE_ERR_ARGUMENT;
+  if (info->codec >= (uint32_t)kCodecCount || !valid_block_size(info->blockSize) || info->blockCount != block_count(info->uncompressedSize, info->blockSize))
+    return HSRLE_ERR_FORMAT;
+  if ((uint64_t)first + count > info->blockCount)
+    return HSRLE_ERR_ARGUMENT;
+  if (cap < info->uncompressedSize)
+    return HSRLE_ERR_CAPACITY;
+  if (!device_ok())
+    return HSRLE_ERR_DEVICE;
+  if (count == 0)
+    return HSRLE_OK;
+
+  init_tables();
+  if (!g_dec[info->codec])
+    return HSRLE_ERR_UNSUPPORTED;
+
+  const uint8_t *container = (const uint8_t *)dContainer;
+  const uint8_t *payload = container + HSRLE_CONTAINER_HEADER_SIZE + 8ull * ((uint64_t)info->blockCount + 1ull);
+  DecodeArgs da{ payload, (const uint64_t *)(container + HSRLE_CONTAINER_HEADER_SIZE), payload + info->payloadSize + HSRLE_CONTAINER_TAIL_PAD,
+                 (uint8_t *)dOut, info->uncompressedSize, info->blockSize, first, count, dStatus };
+  return g_dec[info->codec](da, st) == hipSuccess ? HSRLE_OK : HSRLE_ERR_DEVICE;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// drop-in (host pointer, monolithic stream) path: one block spanning the whole input.
+
+static uint32_t mono_compress(int codec, const uint8_t *pIn, uint32_t inSize, uint8_t *pOut, uint32_t outSize)
+{
+  // argument checks of the reference (rle8_extreme_cpu.h:88-89, rleX_extreme_cpu.h:49-50, rleX_Xsl.h:271-272)
+  if (pIn == nullptr || inSize == 0 || pOut == nullptr || outSize < bounds32(inSize))
+    return 0;
+  if (inSize > (1u << 30)) // A.5 q8: sizes above 1 GiB cannot be bounded; treated as unsupported
+    return 0;
+  if (codec < 0 || codec >= kCodecCount || !device_ok())
+    return 0;
+
+  init_tables();
+  if (!g_enc[codec])
+    return 0;
+
+  std::lock_guard<std::mutex> lock(g_dev.mu);
+  const uint32_t stride = (bounds32(inSize) + 15u) & ~15u;
+  if (!grow(&g_dev.monoIn, &g_dev.monoInSize, (uint64_t)inSize + 64) || !grow(&g_dev.monoOut, &g_dev.monoOutSize, (uint64_t)stride + 64))
+    return 0;
+  if (!g_dev.monoAux && hipMalloc(&g_dev.monoAux, 256) != hipSuccess)
+    return 0;
+
+  if (hipMemcpy(g_dev.monoIn, pIn, inSize, hipMemcpyHostToDevice) != hipSuccess)
+    return 0;
+
+  EncodeArgs ea{ (const uint8_t *)g_dev.monoIn, inSize, inSize, 1u, (uint8_t *)g_dev.monoOut, stride, (uint32_t *)g_dev.monoAux };
+  if (g_enc[codec](ea, nullptr) != hipSuccess)
+    return 0;
+
+  uint32_t size = 0;
+  if (hipMemcpy(&size, g_dev.monoAux, 4, hipMemcpyDeviceToHost) != hipSuccess || size == 0 || size > outSize)
+    return 0;
+  if (hipMemcpy(pOut, g_dev.monoOut, size, hipMemcpyDeviceToHost) != hipSuccess)
+    return 0;
+  return size;
+}
+
+static uint32_t mono_decompress(int codec, const uint8_t *pIn, uint32_t inSize, uint8_t *pOut, uint32_t outSize)
+{
+  // argument + header checks of the reference (rle8_extreme_cpu.h:704-712, rleX_extreme_cpu.h:84-91, rleX_Xsl.h:1850-1858)
+  if (pIn == nullptr || pOut == nullptr || inSize == 0 || outSize == 0)
+    return 0;
+  if (codec < 0 || codec >= kCodecCount)
+    return 0;
+  const uint32_t hs = codec_header_size(codec);
+  if (inSize < hs)
+    return 0;
+
+  uint32_t U, C;
+  memcpy(&U, pIn, 4);
+  memcpy(&C, pIn + 4, 4);
+
+  if (U > outSize || C > inSize)
+    return 0;
+  if (hs == 9 && pIn[8] > 1) // unknown mode (rle8_extreme_cpu.h:759-760)
+    return 0;
+  if (U == 0 || C < hs || !device_ok())
+    return 0;
+
+  init_tables();
+  if (!g_dec[codec])
+    return 0;
+
+  std::lock_guard<std::mutex> lock(g_dev.mu);
+  if (!grow(&g_dev.monoIn, &g_dev.monoInSize, (uint64_t)C + 64) || !grow(&g_dev.monoOut, &g_dev.monoOutSize, (uint64_t)U + 64))
+    return 0;
+  if (!g_dev.monoAux && hipMalloc(&g_dev.monoAux, 256) != hipSuccess)
+    return 0;
+
+  uint8_t *aux = (uint8_t *)g_dev.monoAux;
+  const uint64_t table[2] = { 0, C };
+  uint32_t zero = 0;
+  if (hipMemcpy(g_dev.monoIn, pIn, C, hipMemcpyHostToDevice) != hipSuccess || hipMemset((uint8_t *)g_dev.monoIn + C, 0, 64) != hipSuccess ||
+      hipMemcpy(aux, table, sizeof(table), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(aux + 64, &zero, 4, hipMemcpyHostToDevice) != hipSuccess)
+    return 0;
+
+  // one block of (rounded-up) size: the kernel clips everything to U
+  const uint32_t B = (U > HSRLE_MAX_BLOCK_SIZE - 128u) ? HSRLE_MAX_BLOCK_SIZE : (uint32_t)align_up(U, 128);
+  if (U > B)
+    return 0; // a single stream above 1 GiB cannot come from the reference encoder (rle_compress_bounds)
+
+  DecodeArgs da{ (const uint8_t *)g_dev.monoIn, (const uint64_t *)aux, (const uint8_t *)g_dev.monoIn + C + HSRLE_CONTAINER_TAIL_PAD, (uint8_t *)g_dev.monoOut, U, B, 0u, 1u,
+                 (uint32_t *)(aux + 64) };
+  if (g_dec[codec](da, nullptr) != hipSuccess)
+    return 0;
+
+  uint32_t status = 1;
+  if (hipMemcpy(&status, aux + 64, 4, hipMemcpyDeviceToHost) != hipSuccess || status != 0)
+    return 0;
+  if (hipMemcpy(pOut, g_dev.monoOut, U, hipMemcpyDeviceToHost) != hipSuccess)
+    return 0;
+  return U;
+}
+
+} // namespace hsrle
+
+// ====================================================================================================================
+using namespace hsrle;
+
+extern "C" {
+
+int hsrle_codec_from_name(const char *name)
+{
+  if (!name) return -1;
+  for (int k = 0; k < kCodecCount; k++)
+    if (strcmp(name, kCodecNames[k]) == 0) return k;
+  return -1;
+}
+
+const char *hsrle_codec_name(int codec) { return (codec >= 0 && codec < kCodecCount) ? kCodecNames[codec] : nullptr; }
+
+const char *hsrle_status_string(int s)
+{
+  switch (s)
+  {
+  case HSRLE_OK: return "ok";
+  case HSRLE_ERR_ARGUMENT: return "invalid argument";
+  case HSRLE_ERR_CAPACITY: return "buffer too small";
+  case HSRLE_ERR_FORMAT: return "malformed container or stream";
+  case HSRLE_ERR_DEVICE: return "no usable HIP device / HIP runtime error";
+  case HSRLE_ERR_UNSUPPORTED: return "codec not available in this build";
+  }
+  return "unknown";
+}
+
+const char *hsrle_version(void) { return "hsrle-hip 0.1 (gfx950)"; }
+
+int hsrle_device_count(void)
+{
+  int n = 0;
+  return (hipGetDeviceCount(&n) == hipSuccess) ? n : 0;
+}
+
+uint32_t rle_compress_bounds(const uint32_t inSize) { return bounds32(inSize); }
+uint32_t rle_decompress_additional_size(void) { return 128; }
+
+uint32_t hsrle_compress_mono(int codec, const uint8_t *pIn, uint32_t inSize, uint8_t *pOut, uint32_t outSize) { return mono_compress(codec, pIn, inSize, pOut, outSize); }
+uint32_t hsrle_decompress_mono(int codec, const uint8_t *pIn, uint32_t inSize, uint8_t *pOut, uint32_t outSize) { return mono_decompress(codec, pIn, inSize, pOut, outSize); }
+
+#define HSRLE_DEF_PAIR(name, id)                                                                                                                             \
+  uint32_t name##_compress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize) { return mono_compress(id, pIn, inSize, pOut, outSize); } \
+  uint32_t name##_decompress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize) { return mono_decompress(id, pIn, inSize, pOut, outSize); }
+#define HSRLE_DEF_WIDTH(W, base)                                                                                               \
+  HSRLE_DEF_PAIR(rle##W##_sym, base + 0) HSRLE_DEF_PAIR(rle##W##_sym_packed, base + 1) HSRLE_DEF_PAIR(rle##W##_3symlut_sym, base + 2) \
+  HSRLE_DEF_PAIR(rle##W##_7symlut_sym, base + 3) HSRLE_DEF_PAIR(rle##W##_byte, base + 4) HSRLE_DEF_PAIR(rle##W##_byte_packed, base + 5) \
+  HSRLE_DEF_PAIR(rle##W##_3symlut_byte, base + 6) HSRLE_DEF_PAIR(rle##W##_7symlut_byte, base + 7)
+
+uint32_t rle8_multi_compress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize) { return mono_compress(HSRLE_RLE8_MULTI, pIn, inSize, pOut, outSize); }
+uint32_t rle8_single_compress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize) { return mono_compress(HSRLE_RLE8_SINGLE, pIn, inSize, pOut, outSize); }
+uint32_t rle8_decompress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize) { return mono_decompress(HSRLE_RLE8_MULTI, pIn, inSize, pOut, outSize); }
+uint32_t rle8_packed_multi_compress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize) { return mono_compress(HSRLE_RLE8_PACKED_MULTI, pIn, inSize, pOut, outSize); }
+uint32_t rle8_packed_single_compress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize) { return mono_compress(HSRLE_RLE8_PACKED_SINGLE, pIn, inSize, pOut, outSize); }
+uint32_t rle8_packed_decompress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize) { return mono_decompress(HSRLE_RLE8_PACKED_MULTI, pIn, inSize, pOut, outSize); }
+HSRLE_DEF_PAIR(rle8_3symlut, HSRLE_RLE8_3SYMLUT)
+HSRLE_DEF_PAIR(rle8_7symlut, HSRLE_RLE8_7SYMLUT)
+HSRLE_DEF_WIDTH(16, 6)
+HSRLE_DEF_WIDTH(24, 14)
+HSRLE_DEF_WIDTH(32, 22)
+HSRLE_DEF_WIDTH(48, 30)
+HSRLE_DEF_WIDTH(64, 38)
+HSRLE_DEF_PAIR(rle128_sym, HSRLE_RLE128_SYM)
+HSRLE_DEF_PAIR(rle128_sym_packed, HSRLE_RLE128_SYM_PACKED)
+HSRLE_DEF_PAIR(rle128_byte, HSRLE_RLE128_BYTE)
+HSRLE_DEF_PAIR(rle128_byte_packed, HSRLE_RLE128_BYTE_PACKED)
+
+// ---- container API ----
+
+uint64_t hsrle_container_bound(uint64_t inSize, uint32_t blockSize)
+{
+  if (blockSize == 0) blockSize = HSRLE_DEFAULT_BLOCK_SIZE;
+  if (!valid_block_size(blockSize) || inSize == 0) return 0;
+  const uint64_t nb = block_count(inSize, blockSize);
+  return HSRLE_CONTAINER_HEADER_SIZE + 8ull * (nb + 1) + nb * (uint64_t)slot_stride(blockSize) + HSRLE_CONTAINER_TAIL_PAD;
+}
+
+uint64_t hsrle_compress_workspace_size(uint64_t inSize, uint32_t blockSize)
+{
+  if (blockSize == 0) blockSize = HSRLE_DEFAULT_BLOCK_SIZE;
+  if (!valid_block_size(blockSize) || inSize == 0) return 0;
+  return plan_workspace(inSize, blockSize).total;
+}
+
+int hsrle_compress_dev_async(int codec, const void *dIn, uint64_t inSize, void *dOut, uint64_t outCapacity, uint32_t blockSize, void *dWorkspace,
+                             uint64_t workspaceSize, void *stream)
+{
+  return compress_async(codec, dIn, inSize, dOut, outCapacity, blockSize, dWorkspace, workspaceSize, (hipStream_t)stream);
+}
+
+int hsrle_compress_dev(int codec, const void *dIn, uint64_t inSize, void *dOut, uint64_t outCapacity, uint32_t blockSize, uint64_t *pContainerSize, void *stream)
+{
+  const int rc = compress_async(codec, dIn, inSize, dOut, outCapacity, blockSize, nullptr, 0, (hipStream_t)stream);
+  if (rc != HSRLE_OK) return rc;
+  ContainerHeader h;
+  if (hipMemcpyAsync(&h, dOut, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess || hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+    return HSRLE_ERR_DEVICE;
+  if (pContainerSize) *pContainerSize = h.totalSize;
+  return HSRLE_OK;
+}
+
+int hsrle_container_info_host(const void *pContainer, uint64_t containerSize, hsrle_container_info_t *pInfo)
+{
+  if (!pContainer || !pInfo || containerSize < HSRLE_CONTAINER_HEADER_SIZE) return HSRLE_ERR_ARGUMENT;
+  ContainerHeader h;
+  memcpy(&h, pContainer, sizeof(h));
+  return check_info(h, containerSize, pInfo);
+}
+
+int hsrle_container_info_dev(const void *dContainer, uint64_t containerSize, hsrle_container_info_t *pInfo, void *stream)
+{
+  if (!dContainer || !pInfo || containerSize < HSRLE_CONTAINER_HEADER_SIZE) return HSRLE_ERR_ARGUMENT;
+  if (!device_ok()) return HSRLE_ERR_DEVICE;
+  ContainerHeader h;
+  if (hipMemcpyAsync(&h, dContainer, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess || hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+    return HSRLE_ERR_DEVICE;
+  return check_info(h, containerSize, pInfo);
+}
+
+int hsrle_decompress_blocks_dev_async(const void *dContainer, const hsrle_container_info_t *info, uint32_t firstBlock, uint32_t blockCount, void *dOut,
+                                      uint64_t outCapacity, uint32_t *dStatus, void *stream)
+{
+  return decompress_blocks_async(dContainer, info, firstBlock, blockCount, dOut, outCapacity, dStatus, (hipStream_t)stream);
+}
+
+int hsrle_decompress_dev_async(const void *dContainer, const hsrle_container_info_t *info, void *dOut, uint64_t outCapacity, uint32_t *dStatus, void *stream)
+{
+  if (!info) return HSRLE_ERR_ARGUMENT;
+  return decompress_blocks_async(dContainer, info, 0, info->blockCount, dOut, outCapacity, dStatus, (hipStream_t)stream);
+}
+
+int hsrle_decompress_dev(const void *dContainer, uint64_t containerSize, void *dOut, uint64_t outCapacity, uint64_t *pUncompressedSize, void *stream)
+{
+  hsrle_container_info_t info;
+  int rc = hsrle_container_info_dev(dContainer, containerSize, &info, stream);
+  if (rc != HSRLE_OK) return rc;
+
+  uint32_t *dStatus = nullptr;
+  if (hipMalloc((void **)&dStatus, 4) != hipSuccess) return HSRLE_ERR_DEVICE;
+  uint32_t status = 0;
+  bool ok = hipMemsetAsync(dStatus, 0, 4, (hipStream_t)stream) == hipSuccess;
+  if (ok)
+  {
+    rc = decompress_blocks_async(dContainer, &info, 0, info.blockCount, dOut, outCapacity, dStatus, (hipStream_t)stream);
+    ok = hipMemcpyAsync(&status, dStatus, 4, hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess && hipStreamSynchronize((hipStream_t)stream) == hipSuccess;
+  }
+  (void)hipFree(dStatus);
+  if (rc != HSRLE_OK) return rc;
+  if (!ok) return HSRLE_ERR_DEVICE;
+  if (status != 0) return HSRLE_ERR_FORMAT;
+  if (pUncompressedSize) *pUncompressedSize = info.uncompressedSize;
+  return HSRLE_OK;
+}
+
+int hsrle_compress_host(int codec, const void *pIn, uint64_t inSize, void *pOut, uint64_t outCapacity, uint32_t blockSize, uint64_t *pContainerSize)
+{
+  if (!pIn || !pOut || inSize == 0) return HSRLE_ERR_ARGUMENT;
+  if (!device_ok()) return HSRLE_ERR_DEVICE;
+  const uint64_t bound = hsrle_container_bound(inSize, blockSize);
+  if (bound == 0) return HSRLE_ERR_ARGUMENT;
+
+  void *dIn = nullptr, *dOut = nullptr;
+  int rc = HSRLE_ERR_DEVICE;
+  uint64_t total = 0;
+  if (hipMalloc(&dIn, inSize) == hipSuccess && hipMalloc(&dOut, bound) == hipSuccess && hipMemcpy(dIn, pIn, inSize, hipMemcpyHostToDevice) == hipSuccess)
+  {
+    rc = hsrle_compress_dev(codec, dIn, inSize, dOut, bound, blockSize, &total, nullptr);
+    if (rc == HSRLE_OK)
+    {
+      if (total > outCapacity) rc = HSRLE_ERR_CAPACITY;
+      else if (hipMemcpy(pOut, dOut, total, hipMemcpyDeviceToHost) != hipSuccess) rc = HSRLE_ERR_DEVICE;
+    }
+  }
+  if (dIn) (void)hipFree(dIn);
+  if (dOut) (void)hipFree(dOut);
+  if (rc == HSRLE_OK && pContainerSize) *pContainerSize = total;
+  return rc;
+}
+
+int hsrle_decompress_host(const void *pContainer, uint64_t containerSize, void *pOut, uint64_t outCapacity, uint64_t *pUncompressedSize)
+{
+  hsrle_container_info_t info;
+  int rc = hsrle_container_info_host(pContainer, containerSize, &info);
+  if (rc != HSRLE_OK) return rc;
+  if (!pOut || outCapacity < info.uncompressedSize) return HSRLE_ERR_CAPACITY;
+  if (!device_ok()) return HSRLE_ERR_DEVICE;
+
+  void *dIn = nullptr, *dOut = nullptr;
+  rc = HSRLE_ERR_DEVICE;
+  if (hipMalloc(&dIn, info.totalSize) == hipSuccess && hipMalloc(&dOut, info.uncompressedSize) == hipSuccess &&
+      hipMemcpy(dIn, pContainer, info.totalSize, hipMemcpyHostToDevice) == hipSuccess)
+  {
+    uint64_t U = 0;
+    rc = hsrle_decompress_dev(dIn, info.totalSize, dOut, info.uncompressedSize, &U, nullptr);
+    if (rc == HSRLE_OK && hipMemcpy(pOut, dOut, U, hipMemcpyDeviceToHost) != hipSuccess) rc = HSRLE_ERR_DEVICE;
+    if (rc == HSRLE_OK && pUncompressedSize) *pUncompressedSize = U;
+  }
+  if (dIn) (void)hipFree(dIn);
+  if (dOut) (void)hipFree(dOut);
+  return rc;
+}
+
+int hsrle_synth_dev_async(int kind, int symbolBytes, uint64_t seed, void *dOut, uint64_t size, void *stream)
+{
+  if (!dOut || size == 0 || (kind != HSRLE_SYNTH_RUNS && kind != HSRLE_SYNTH_VIDEO) || symbolBytes < 1 || symbolBytes > 16) return HSRLE_ERR_ARGUMENT;
+  if (!device_ok()) return HSRLE_ERR_DEVICE;
+  const uint64_t chunks = (size + kSynthChunk - 1) / kSynthChunk;
+  hipLaunchKernelGGL(k_synth, dim3((uint32_t)((chunks + 63) / 64)), dim3(64), 0, (hipStream_t)stream, kind, symbolBytes, seed, (uint8_t *)dOut, size);
+  return hipGetLastError() == hipSuccess ? HSRLE_OK : HSRLE_ERR_DEVICE;
+}
+
+} // extern "C"

@@ -1,0 +1,26 @@
+// 128 bit symbols: rle128_{sym,byte}[_packed]  (reference: src/rle.h:124-125, :146-147, :168-169, :194-195)
+#include "hsrle_decode.hip.h"
+#include "hsrle_encode.hip.h"
+#include "hsrle_launch.h"
+
+namespace hsrle {
+
+static hipError_t dec_sym(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PLAIN, 16, 1, kDecodeTile>, a, st); }
+static hipError_t dec_sym_packed(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PACKED, 16, 1, kDecodeTile>, a, st); }
+static hipError_t dec_byte(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PLAIN, 16, 0, kDecodeTile>, a, st); }
+static hipError_t dec_byte_packed(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PACKED, 16, 0, kDecodeTile>, a, st); }
+
+static hipError_t enc_sym(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<PLAIN, 16, 1>, a, st); }
+static hipError_t enc_sym_packed(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<PACKED, 16, 1>, a, st); }
+static hipError_t enc_byte(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<PLAIN, 16, 0>, a, st); }
+static hipError_t enc_byte_packed(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<PACKED, 16, 0>, a, st); }
+
+void register_w128(DecodeLaunch *dec, EncodeLaunch *enc)
+{
+  dec[46] = dec_sym;         enc[46] = enc_sym;
+  dec[47] = dec_sym_packed;  enc[47] = enc_sym_packed;
+  dec[48] = dec_byte;        enc[48] = enc_byte;
+  dec[49] = dec_byte_packed; enc[49] = enc_byte_packed;
+}
+
+} // namespace hsrle

@@ -1,0 +1,32 @@
+// 8 bit symbols: rle8_multi / rle8_single / rle8_packed_multi / rle8_packed_single / rle8_{3,7}symlut
+// (reference: src/rle.h:101-103, :173-175, :199-208).  rle8_decompress / rle8_packed_decompress decode both the multi
+// and the single mode, so the Single codec ids share the multi decode kernels.
+#include "hsrle_decode.hip.h"
+#include "hsrle_encode.hip.h"
+#include "hsrle_launch.h"
+
+namespace hsrle {
+
+static hipError_t dec_plain(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PLAIN, 1, 0, kDecodeTile>, a, st); }
+static hipError_t dec_packed(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PACKED, 1, 0, kDecodeTile>, a, st); }
+static hipError_t dec_lut3(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<LUT3, 1, 0, kDecodeTile>, a, st); }
+static hipError_t dec_lut7(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<LUT7, 1, 0, kDecodeTile>, a, st); }
+
+static hipError_t enc_plain(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<PLAIN, 1, 0>, a, st); }
+static hipError_t enc_packed(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<PACKED, 1, 0>, a, st); }
+static hipError_t enc_lut3(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<LUT3, 1, 0>, a, st); }
+static hipError_t enc_lut7(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<LUT7, 1, 0>, a, st); }
+static hipError_t enc_single(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<SINGLE, 1, 0>, a, st); }
+static hipError_t enc_packed_single(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<PACKED_SINGLE, 1, 0>, a, st); }
+
+void register_w8(DecodeLaunch *dec, EncodeLaunch *enc)
+{
+  dec[0] = dec_plain;  enc[0] = enc_plain;
+  dec[1] = dec_packed; enc[1] = enc_packed;
+  dec[2] = dec_lut3;   enc[2] = enc_lut3;
+  dec[3] = dec_lut7;   enc[3] = enc_lut7;
+  dec[4] = dec_plain;  enc[4] = enc_single;
+  dec[5] = dec_packed; enc[5] = enc_packed_single;
+}
+
+} // namespace hsrle

@@ -1,0 +1,278 @@
+"""hsrle -- thin ctypes binding of libhsrle_hip.so (include/hsrle.h) for tests, bench.py and the multi-GPU driver.
+
+PyTorch is used only as plumbing: device allocations (uint8 tensors), streams and torch.distributed.  Every codec call goes
+through the C ABI into the hand-written gfx950 kernels; there is no Python or CPU implementation behind this module -- if the
+shared library is missing or no GPU is present the calls raise.
+
+The codec table mirrors the reference's plugin table (reference: src/codec_funcs.h:262-410): `CODECS[i]` is the name of the
+(compress, decompress) pair with id i, e.g. "rle8_packed_multi", "rle64_3symlut_byte".
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_DIR = os.path.dirname(os.path.dirname(_HERE))
+LIB_PATH = os.path.join(PKG_DIR, "libhsrle_hip.so")
+
+OK, ERR_ARGUMENT, ERR_CAPACITY, ERR_FORMAT, ERR_DEVICE, ERR_UNSUPPORTED = range(6)
+SYNTH_RUNS, SYNTH_VIDEO = 0, 1
+DEFAULT_BLOCK_SIZE = 4096
+HEADER_SIZE = 64
+TAIL_PAD = 32
+
+
+class HsrleError(RuntimeError):
+    def __init__(self, status, what):
+        self.status = status
+        super().__init__(f"{what}: {_lib().hsrle_status_string(status).decode()} ({status})")
+
+
+class ContainerInfo(ctypes.Structure):
+    _fields_ = [
+        ("version", ctypes.c_uint32),
+        ("codec", ctypes.c_uint32),
+        ("uncompressedSize", ctypes.c_uint64),
+        ("blockSize", ctypes.c_uint32),
+        ("blockCount", ctypes.c_uint32),
+        ("payloadSize", ctypes.c_uint64),
+        ("totalSize", ctypes.c_uint64),
+    ]
+
+    @property
+    def payload_start(self):
+        return HEADER_SIZE + 8 * (self.blockCount + 1)
+
+
+_LIB = None
+
+
+def _lib():
+    """Load libhsrle_hip.so (built by `make -C hypersonic-rle-kit_amd` / __graft_entry__.build()).  Fails loudly."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C {PKG_DIR}` (hipcc, gfx950); there is no fallback codec")
+    L = ctypes.CDLL(LIB_PATH)
+    u8p, u32, u64, vp, ci = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int
+    L.hsrle_codec_from_name.restype = ci
+    L.hsrle_codec_from_name.argtypes = [ctypes.c_char_p]
+    L.hsrle_codec_name.restype = ctypes.c_char_p
+    L.hsrle_codec_name.argtypes = [ci]
+    L.hsrle_status_string.restype = ctypes.c_char_p
+    L.hsrle_status_string.argtypes = [ci]
+    L.hsrle_version.restype = ctypes.c_char_p
+    L.hsrle_device_count.restype = ci
+    L.rle_compress_bounds.restype = u32
+    L.rle_compress_bounds.argtypes = [u32]
+    L.rle_decompress_additional_size.restype = u32
+    for nm in ("hsrle_compress_mono", "hsrle_decompress_mono"):
+        f = getattr(L, nm)
+        f.restype = u32
+        f.argtypes = [ci, u8p, u32, u8p, u32]
+    L.hsrle_container_bound.restype = u64
+    L.hsrle_container_bound.argtypes = [u64, u32]
+    L.hsrle_compress_workspace_size.restype = u64
+    L.hsrle_compress_workspace_size.argtypes = [u64, u32]
+    L.hsrle_compress_dev_async.restype = ci
+    L.hsrle_compress_dev_async.argtypes = [ci, vp, u64, vp, u64, u32, vp, u64, vp]
+    L.hsrle_compress_dev.restype = ci
+    L.hsrle_compress_dev.argtypes = [ci, vp, u64, vp, u64, u32, ctypes.POINTER(u64), vp]
+    L.hsrle_container_info_dev.restype = ci
+    L.hsrle_container_info_dev.argtypes = [vp, u64, ctypes.POINTER(ContainerInfo), vp]
+    L.hsrle_container_info_host.restype = ci
+    L.hsrle_container_info_host.argtypes = [vp, u64, ctypes.POINTER(ContainerInfo)]
+    L.hsrle_decompress_dev_async.restype = ci
+    L.hsrle_decompress_dev_async.argtypes = [vp, ctypes.POINTER(ContainerInfo), vp, u64, vp, vp]
+    L.hsrle_decompress_blocks_dev_async.restype = ci
+    L.hsrle_decompress_blocks_dev_async.argtypes = [vp, ctypes.POINTER(ContainerInfo), u32, u32, vp, u64, vp, vp]
+    L.hsrle_decompress_dev.restype = ci
+    L.hsrle_decompress_dev.argtypes = [vp, u64, vp, u64, ctypes.POINTER(u64), vp]
+    L.hsrle_compress_host.restype = ci
+    L.hsrle_compress_host.argtypes = [ci, vp, u64, vp, u64, u32, ctypes.POINTER(u64)]
+    L.hsrle_decompress_host.restype = ci
+    L.hsrle_decompress_host.argtypes = [vp, u64, vp, u64, ctypes.POINTER(u64)]
+    L.hsrle_synth_dev_async.restype = ci
+    L.hsrle_synth_dev_async.argtypes = [ci, ci, u64, vp, u64, vp]
+    _LIB = L
+    return L
+
+
+def lib():
+    return _lib()
+
+
+CODEC_COUNT = 50
+
+
+def codec_names():
+    L = _lib()
+    return [L.hsrle_codec_name(i).decode() for i in range(CODEC_COUNT)]
+
+
+def codec_id(name_or_id):
+    if isinstance(name_or_id, int):
+        return name_or_id
+    cid = _lib().hsrle_codec_from_name(name_or_id.encode())
+    if cid < 0:
+        raise KeyError(name_or_id)
+    return cid
+
+
+def compress_bounds(n):
+    return _lib().rle_compress_bounds(n)
+
+
+def container_bound(n, block_size=DEFAULT_BLOCK_SIZE):
+    return _lib().hsrle_container_bound(n, block_size)
+
+
+def workspace_size(n, block_size=DEFAULT_BLOCK_SIZE):
+    return _lib().hsrle_compress_workspace_size(n, block_size)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# drop-in (host pointer, monolithic stream) path
+
+
+def mono_compress(codec, data):
+    """Reference-compatible single stream (what `<codec>_compress` of rle.h returns).  bytes -> bytes | None (failure)."""
+    data = bytes(data)
+    n = len(data)
+    cap = compress_bounds(n) if n else 0
+    out = ctypes.create_string_buffer(max(cap, 1))
+    size = _lib().hsrle_compress_mono(codec_id(codec), data, n, out, cap)
+    return out.raw[:size] if size else None
+
+
+def mono_decompress(codec, stream, out_size=None):
+    stream = bytes(stream)
+    if out_size is None:
+        out_size = int.from_bytes(stream[:4], "little")
+    out = ctypes.create_string_buffer(max(out_size, 1))
+    size = _lib().hsrle_decompress_mono(codec_id(codec), stream, len(stream), out, out_size)
+    return out.raw[:size] if size else None
+
+
+def call_dropin(name, data, out_cap):
+    """Call one of the rle.h-named exports directly, e.g. call_dropin("rle8_packed_multi_compress", data, cap)."""
+    f = getattr(_lib(), name)
+    f.restype = ctypes.c_uint32
+    f.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]
+    data = bytes(data)
+    out = ctypes.create_string_buffer(max(out_cap, 1))
+    size = f(data, len(data), out, out_cap)
+    return size, out.raw[:size]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# device-resident container path (torch tensors as device memory)
+
+
+def _stream_ptr(stream=None):
+    import torch
+
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return ctypes.c_void_p(s.cuda_stream)
+
+
+def _check_u8_cuda(t, what):
+    import torch
+
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()):
+        raise TypeError(f"{what} must be a contiguous CUDA uint8 tensor")
+
+
+def compress_async(codec, src, dst, block_size=DEFAULT_BLOCK_SIZE, workspace=None, stream=None):
+    """Enqueue compression of `src` into the container buffer `dst` (capacity >= container_bound)."""
+    _check_u8_cuda(src, "src")
+    _check_u8_cuda(dst, "dst")
+    wptr, wsize = (None, 0)
+    if workspace is not None:
+        _check_u8_cuda(workspace, "workspace")
+        wptr, wsize = ctypes.c_void_p(workspace.data_ptr()), workspace.numel()
+    rc = _lib().hsrle_compress_dev_async(codec_id(codec), ctypes.c_void_p(src.data_ptr()), src.numel(), ctypes.c_void_p(dst.data_ptr()), dst.numel(),
+                                         block_size, wptr, wsize, _stream_ptr(stream))
+    if rc != OK:
+        raise HsrleError(rc, "hsrle_compress_dev_async")
+
+
+def compress(codec, src, block_size=DEFAULT_BLOCK_SIZE, dst=None):
+    """Compress a CUDA uint8 tensor; returns (container tensor trimmed to its size, ContainerInfo)."""
+    import torch
+
+    _check_u8_cuda(src, "src")
+    if dst is None:
+        dst = torch.empty(container_bound(src.numel(), block_size), dtype=torch.uint8, device=src.device)
+    total = ctypes.c_uint64(0)
+    rc = _lib().hsrle_compress_dev(codec_id(codec), ctypes.c_void_p(src.data_ptr()), src.numel(), ctypes.c_void_p(dst.data_ptr()), dst.numel(), block_size,
+                                   ctypes.byref(total), _stream_ptr())
+    if rc != OK:
+        raise HsrleError(rc, "hsrle_compress_dev")
+    container = dst[: total.value]
+    return container, container_info(container)
+
+
+def container_info(container):
+    info = ContainerInfo()
+    if hasattr(container, "is_cuda"):
+        if container.is_cuda:
+            rc = _lib().hsrle_container_info_dev(ctypes.c_void_p(container.data_ptr()), container.numel(), ctypes.byref(info), _stream_ptr())
+        else:
+            rc = _lib().hsrle_container_info_host(ctypes.c_void_p(container.data_ptr()), container.numel(), ctypes.byref(info))
+    else:
+        b = bytes(container)
+        rc = _lib().hsrle_container_info_host(b, len(b), ctypes.byref(info))
+    if rc != OK:
+        raise HsrleError(rc, "hsrle_container_info")
+    return info
+
+
+def decompress_async(container, info, dst, status=None, first_block=0, block_count=None, stream=None):
+    """Enqueue decompression (of a block range) of a device container into `dst`; `status` is an optional int32/uint32 CUDA tensor."""
+    _check_u8_cuda(container, "container")
+    _check_u8_cuda(dst, "dst")
+    if block_count is None:
+        block_count = info.blockCount - first_block
+    sp = ctypes.c_void_p(status.data_ptr()) if status is not None else None
+    rc = _lib().hsrle_decompress_blocks_dev_async(ctypes.c_void_p(container.data_ptr()), ctypes.byref(info), first_block, block_count,
+                                                  ctypes.c_void_p(dst.data_ptr()), dst.numel(), sp, _stream_ptr(stream))
+    if rc != OK:
+        raise HsrleError(rc, "hsrle_decompress_blocks_dev_async")
+
+
+def decompress(container, dst=None):
+    import torch
+
+    _check_u8_cuda(container, "container")
+    info = container_info(container)
+    if dst is None:
+        dst = torch.empty(info.uncompressedSize, dtype=torch.uint8, device=container.device)
+    n = ctypes.c_uint64(0)
+    rc = _lib().hsrle_decompress_dev(ctypes.c_void_p(container.data_ptr()), container.numel(), ctypes.c_void_p(dst.data_ptr()), dst.numel(), ctypes.byref(n), _stream_ptr())
+    if rc != OK:
+        raise HsrleError(rc, "hsrle_decompress_dev")
+    return dst[: n.value]
+
+
+def synth(kind, symbol_bytes, seed, size, device="cuda", out=None):
+    """Deterministic synthetic workload generated on the device; same bytes as the C/python generators."""
+    import torch
+
+    if out is None:
+        out = torch.empty(size, dtype=torch.uint8, device=device)
+    rc = _lib().hsrle_synth_dev_async(kind, symbol_bytes, seed, ctypes.c_void_p(out.data_ptr()), size, _stream_ptr())
+    if rc != OK:
+        raise HsrleError(rc, "hsrle_synth_dev_async")
+    return out
+
+
+def split_container(container_bytes):
+    """Host-side view of a container: (ContainerInfo, [block stream bytes ...])."""
+    b = bytes(container_bytes)
+    info = container_info(b)
+    import struct
+
+    offs = struct.unpack_from(f"<{info.blockCount + 1}Q", b, HEADER_SIZE)
+    p0 = info.payload_start
+    return info, [b[p0 + offs[i] : p0 + offs[i + 1]] for i in range(info.blockCount)]

@@ -1,0 +1,219 @@
+/*
+ * hsrle.h -- C ABI of libhsrle_hip.so: the MI355X-native implementation of the hypersonic-rle-kit
+ * `rleX_extreme` encode / decode hot path (8/16/24/32/48/64/128 bit symbols; plain, Packed, 3/7 symbol LUT
+ * and Single variants).
+ *
+ * Three layers, all `extern "C"`, plain pointers and sizes:
+ *
+ *  1. DROP-IN entry points with exactly the names, signatures and error behaviour of the reference's public
+ *     header (reference: src/rle.h:100-394; registered in src/codec_funcs.h:270-410).  Host pointers in, host
+ *     pointers out, one monolithic reference stream.  A maintainer links libhsrle_hip.so instead of
+ *     rle8_extreme_cpu.c / rleX_extreme_cpu.c / rle{24,48,128}_extreme_cpu.c / rleX_Xsl.c.
+ *
+ *  2. Device-resident block API (`hsrle_*_dev`): the input is cut into fixed-size blocks, every block is encoded
+ *     as an independent, self-terminating reference stream (bit-exact with what the reference encoder produces
+ *     for that block) and the streams are concatenated behind an offset table.  This is the throughput path; its
+ *     layout follows the reference's own sub-section container for rle8m
+ *     (reference: src/rle8_low_entropy_cpu.c:131-250).
+ *
+ *  3. Host convenience wrappers around 2 (`hsrle_compress_host`, `hsrle_decompress_host`).
+ *
+ * All functions are thread safe; device state is created lazily on first use (like the reference's
+ * rle8m_opencl_decompress does, reference: src/rle8_ocl.c:324).  The library never falls back to a CPU codec:
+ * if no HIP device is usable every entry point fails (drop-in functions return 0, hsrle_* return an error code).
+ */
+#ifndef HSRLE_H
+#define HSRLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------------------------------------------------- */
+/* codec ids.  One per (compress, decompress) pair of the reference's table that belongs to the hot path.      */
+
+typedef enum hsrle_codec
+{
+  HSRLE_RLE8_MULTI = 0,          /* rle8_multi_compress / rle8_decompress                     rle.h:101,103 */
+  HSRLE_RLE8_PACKED_MULTI = 1,   /* rle8_packed_multi_compress / rle8_packed_decompress       rle.h:173,175 */
+  HSRLE_RLE8_3SYMLUT = 2,        /* rle8_3symlut_*                                            rle.h:199-200 */
+  HSRLE_RLE8_7SYMLUT = 3,        /* rle8_7symlut_*                                            rle.h:207-208 */
+  HSRLE_RLE8_SINGLE = 4,         /* rle8_single_compress / rle8_decompress                    rle.h:102,103 */
+  HSRLE_RLE8_PACKED_SINGLE = 5,  /* rle8_packed_single_compress / rle8_packed_decompress      rle.h:174,175 */
+
+  /* for W in 16,24,32,48,64:  base = 6 + 8 * index(W);  base + k with k = */
+  /*   0 sym  1 sym_packed  2 3symlut_sym  3 7symlut_sym  4 byte  5 byte_packed  6 3symlut_byte  7 7symlut_byte */
+  HSRLE_RLE16_SYM = 6, HSRLE_RLE16_SYM_PACKED, HSRLE_RLE16_3SYMLUT_SYM, HSRLE_RLE16_7SYMLUT_SYM,
+  HSRLE_RLE16_BYTE, HSRLE_RLE16_BYTE_PACKED, HSRLE_RLE16_3SYMLUT_BYTE, HSRLE_RLE16_7SYMLUT_BYTE,
+  HSRLE_RLE24_SYM = 14, HSRLE_RLE24_SYM_PACKED, HSRLE_RLE24_3SYMLUT_SYM, HSRLE_RLE24_7SYMLUT_SYM,
+  HSRLE_RLE24_BYTE, HSRLE_RLE24_BYTE_PACKED, HSRLE_RLE24_3SYMLUT_BYTE, HSRLE_RLE24_7SYMLUT_BYTE,
+  HSRLE_RLE32_SYM = 22, HSRLE_RLE32_SYM_PACKED, HSRLE_RLE32_3SYMLUT_SYM, HSRLE_RLE32_7SYMLUT_SYM,
+  HSRLE_RLE32_BYTE, HSRLE_RLE32_BYTE_PACKED, HSRLE_RLE32_3SYMLUT_BYTE, HSRLE_RLE32_7SYMLUT_BYTE,
+  HSRLE_RLE48_SYM = 30, HSRLE_RLE48_SYM_PACKED, HSRLE_RLE48_3SYMLUT_SYM, HSRLE_RLE48_7SYMLUT_SYM,
+  HSRLE_RLE48_BYTE, HSRLE_RLE48_BYTE_PACKED, HSRLE_RLE48_3SYMLUT_BYTE, HSRLE_RLE48_7SYMLUT_BYTE,
+  HSRLE_RLE64_SYM = 38, HSRLE_RLE64_SYM_PACKED, HSRLE_RLE64_3SYMLUT_SYM, HSRLE_RLE64_7SYMLUT_SYM,
+  HSRLE_RLE64_BYTE, HSRLE_RLE64_BYTE_PACKED, HSRLE_RLE64_3SYMLUT_BYTE, HSRLE_RLE64_7SYMLUT_BYTE,
+
+  HSRLE_RLE128_SYM = 46,         /* rle128_sym_*          rle.h:124-125 */
+  HSRLE_RLE128_SYM_PACKED = 47,  /* rle128_sym_packed_*   rle.h:146-147 */
+  HSRLE_RLE128_BYTE = 48,        /* rle128_byte_*         rle.h:168-169 */
+  HSRLE_RLE128_BYTE_PACKED = 49, /* rle128_byte_packed_*  rle.h:194-195 */
+
+  HSRLE_CODEC_COUNT = 50
+} hsrle_codec_t;
+
+typedef enum hsrle_status
+{
+  HSRLE_OK = 0,
+  HSRLE_ERR_ARGUMENT = 1,    /* NULL pointer, zero size, unknown codec, bad block size                       */
+  HSRLE_ERR_CAPACITY = 2,    /* output / workspace buffer too small                                          */
+  HSRLE_ERR_FORMAT = 3,      /* container or block stream header inconsistent / stream malformed             */
+  HSRLE_ERR_DEVICE = 4,      /* no usable HIP device, or a HIP runtime call failed                           */
+  HSRLE_ERR_UNSUPPORTED = 5  /* kernel for this codec is not available in this build                         */
+} hsrle_status_t;
+
+/* name <-> id, using the reference's naming ("rle8_packed_multi", "rle64_3symlut_byte", ...).  -1 if unknown. */
+int hsrle_codec_from_name(const char *name);
+const char *hsrle_codec_name(int codec);
+const char *hsrle_status_string(int status);
+
+/* ---------------------------------------------------------------------------------------------------------- */
+/* 1. drop-in entry points (reference: src/rle.h).  0 = failure.                                               */
+
+uint32_t rle_compress_bounds(const uint32_t inSize);   /* rle.h:100, rle8_extreme_cpu.c:22-28 */
+uint32_t rle_decompress_additional_size(void);         /* rle.h:105, rle8_extreme_cpu.c:17-20 */
+
+#define HSRLE_DECL_PAIR(name) \
+  uint32_t name##_compress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize); \
+  uint32_t name##_decompress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize);
+#define HSRLE_DECL_WIDTH(W) \
+  HSRLE_DECL_PAIR(rle##W##_sym) HSRLE_DECL_PAIR(rle##W##_sym_packed) HSRLE_DECL_PAIR(rle##W##_byte) HSRLE_DECL_PAIR(rle##W##_byte_packed) \
+  HSRLE_DECL_PAIR(rle##W##_3symlut_sym) HSRLE_DECL_PAIR(rle##W##_7symlut_sym) HSRLE_DECL_PAIR(rle##W##_3symlut_byte) HSRLE_DECL_PAIR(rle##W##_7symlut_byte)
+
+/* 8 bit (irregular names; rle.h:101-103, :173-175, :199-200, :207-208) */
+uint32_t rle8_multi_compress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize);
+uint32_t rle8_single_compress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize);
+uint32_t rle8_decompress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize);
+uint32_t rle8_packed_multi_compress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize);
+uint32_t rle8_packed_single_compress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize);
+uint32_t rle8_packed_decompress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize);
+HSRLE_DECL_PAIR(rle8_3symlut)
+HSRLE_DECL_PAIR(rle8_7symlut)
+
+/* 16 / 24 / 32 / 48 / 64 bit (rle.h:107-122, :129-144, :151-166, :177-192, :250-258, :284-292, :318-326, :352-360, :386-394) */
+HSRLE_DECL_WIDTH(16)
+HSRLE_DECL_WIDTH(24)
+HSRLE_DECL_WIDTH(32)
+HSRLE_DECL_WIDTH(48)
+HSRLE_DECL_WIDTH(64)
+
+/* 128 bit (rle.h:124-125, :146-147, :168-169, :194-195) */
+HSRLE_DECL_PAIR(rle128_sym)
+HSRLE_DECL_PAIR(rle128_sym_packed)
+HSRLE_DECL_PAIR(rle128_byte)
+HSRLE_DECL_PAIR(rle128_byte_packed)
+
+#undef HSRLE_DECL_WIDTH
+#undef HSRLE_DECL_PAIR
+
+/* Generic form of the above (what the macro-declared functions forward to): one monolithic reference stream,
+ * host pointers.  Mirrors `codecCallbacks[codec].compress_func / .decompress_func` (codec_funcs.h:262-266). */
+uint32_t hsrle_compress_mono(int codec, const uint8_t *pIn, uint32_t inSize, uint8_t *pOut, uint32_t outSize);
+uint32_t hsrle_decompress_mono(int codec, const uint8_t *pIn, uint32_t inSize, uint8_t *pOut, uint32_t outSize);
+
+/* ---------------------------------------------------------------------------------------------------------- */
+/* 2. device-resident block container API                                                                      */
+
+/*
+ * Container layout (little endian):
+ *   [ 0] char     magic[8]  = "HSRLEKIT"
+ *   [ 8] uint32_t version   = 1
+ *   [12] uint32_t codec     (hsrle_codec_t)
+ *   [16] uint64_t uncompressedSize
+ *   [24] uint32_t blockSize (uncompressed bytes per block; the last block may be shorter)
+ *   [28] uint32_t blockCount
+ *   [32] uint64_t payloadSize (sum of the block streams)
+ *   [40] uint64_t totalSize   (header + table + payload + 32 bytes of zero padding)
+ *   [48] uint8_t  reserved[16]
+ *   [64] uint64_t offset[blockCount + 1]   (relative to the payload start; offset[blockCount] == payloadSize)
+ *   [64 + 8 * (blockCount + 1)] payload: block streams back to back, each a complete reference stream
+ *   32 zero bytes (lets the decoder use 16-byte vector loads up to the last stream byte)
+ */
+#define HSRLE_CONTAINER_HEADER_SIZE 64u
+#define HSRLE_CONTAINER_TAIL_PAD 32u
+#define HSRLE_DEFAULT_BLOCK_SIZE 4096u
+#define HSRLE_MIN_BLOCK_SIZE 128u
+#define HSRLE_MAX_BLOCK_SIZE (1u << 30)
+
+typedef struct hsrle_container_info
+{
+  uint32_t version, codec;
+  uint64_t uncompressedSize;
+  uint32_t blockSize, blockCount;
+  uint64_t payloadSize, totalSize;
+} hsrle_container_info_t;
+
+/* Upper bound of the container size for `inSize` input bytes cut into blocks of `blockSize` (0 = default). */
+uint64_t hsrle_container_bound(uint64_t inSize, uint32_t blockSize);
+/* Scratch the compressor needs in device memory (per-block staging streams, sizes, scan partials). */
+uint64_t hsrle_compress_workspace_size(uint64_t inSize, uint32_t blockSize);
+
+/*
+ * Enqueue compression of dIn[0, inSize) (device memory) into the container at dOut (device memory, capacity
+ * outCapacity >= hsrle_container_bound()).  dWorkspace may be NULL: the library then keeps a cached allocation of
+ * its own (not graph-capturable).  `stream` is a hipStream_t (NULL = default stream).  Asynchronous: the
+ * container (including its header with totalSize) is complete when the stream reaches this point.
+ */
+int hsrle_compress_dev_async(int codec, const void *dIn, uint64_t inSize, void *dOut, uint64_t outCapacity,
+                             uint32_t blockSize, void *dWorkspace, uint64_t workspaceSize, void *stream);
+/* Same, then waits for the stream and returns the container size. */
+int hsrle_compress_dev(int codec, const void *dIn, uint64_t inSize, void *dOut, uint64_t outCapacity,
+                       uint32_t blockSize, uint64_t *pContainerSize, void *stream);
+
+/* Read (device -> host, synchronising `stream`) and validate a container header. */
+int hsrle_container_info_dev(const void *dContainer, uint64_t containerSize, hsrle_container_info_t *pInfo, void *stream);
+/* Validate a container header that is already in host memory. */
+int hsrle_container_info_host(const void *pContainer, uint64_t containerSize, hsrle_container_info_t *pInfo);
+
+/*
+ * Enqueue decompression of a container in device memory into dOut (device memory, capacity >= uncompressedSize;
+ * no slack is needed and nothing outside [0, uncompressedSize) is written).  `info` must describe the container
+ * (from hsrle_container_info_dev, or remembered from compression).  dStatus (device uint32_t, may be NULL) receives 0 or
+ * a non-zero error mask if a block stream is malformed.
+ */
+int hsrle_decompress_dev_async(const void *dContainer, const hsrle_container_info_t *info, void *dOut, uint64_t outCapacity,
+                               uint32_t *dStatus, void *stream);
+/* Same, including the header read, a wait on the stream and the status check. */
+int hsrle_decompress_dev(const void *dContainer, uint64_t containerSize, void *dOut, uint64_t outCapacity,
+                         uint64_t *pUncompressedSize, void *stream);
+
+/* Decode only blocks [firstBlock, firstBlock + blockCount) of a container into dOut + firstBlock * blockSize
+ * (used by the multi-GPU sharding: every rank decodes its contiguous block range). */
+int hsrle_decompress_blocks_dev_async(const void *dContainer, const hsrle_container_info_t *info, uint32_t firstBlock, uint32_t blockCount,
+                                      void *dOut, uint64_t outCapacity, uint32_t *dStatus, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------- */
+/* 3. host convenience wrappers (allocate device buffers, copy, run 2, copy back)                              */
+
+int hsrle_compress_host(int codec, const void *pIn, uint64_t inSize, void *pOut, uint64_t outCapacity, uint32_t blockSize, uint64_t *pContainerSize);
+int hsrle_decompress_host(const void *pContainer, uint64_t containerSize, void *pOut, uint64_t outCapacity, uint64_t *pUncompressedSize);
+
+/* ---------------------------------------------------------------------------------------------------------- */
+/* synthetic workloads of BASELINE.json generated directly in device memory (bench / tests)     */
+
+#define HSRLE_SYNTH_RUNS 0  /* run-distributed(W): ~50 % of the bytes in runs, mean segment ~32 symbols          */
+#define HSRLE_SYNTH_VIDEO 1 /* video-frame-shaped: zero dominated, short bursts of small values                  */
+int hsrle_synth_dev_async(int kind, int symbolBytes, uint64_t seed, void *dOut, uint64_t size, void *stream);
+
+/* library / device introspection */
+int hsrle_device_count(void);
+const char *hsrle_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* HSRLE_H */

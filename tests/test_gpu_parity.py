@@ -1,0 +1,135 @@
+"""GPU parity tests: the HIP path, called through the C ABI (libhsrle_hip.so), against the oracle on the same inputs.
+
+Bit-exact bar (integer / byte work): every block stream must equal the oracle's (= the reference's, see
+test_oracle_vs_ref.py / test_oracle_golden.py) stream for that block, and every decode must reproduce the input exactly.
+"""
+import random
+import struct
+
+import pytest
+
+from hsrle_testlib import CODECS, CODEC_BY_KEY, FUZZ_LENGTHS, Oracle, fuzz_sections, mixed_runs, single_symbol_mix
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hs():
+    import torch
+
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    import hsrle
+
+    hsrle.lib()  # fails loudly if the HIP library is missing
+    return hsrle
+
+
+def _inputs(seed, count):
+    rng = random.Random(seed)
+    out = []
+    for it in range(count):
+        k = it % 4
+        if k == 0:
+            d = fuzz_sections(rng)
+        elif k == 1:
+            d = mixed_runs(rng, rng.choice([1, 2, 3, 5, 8, 15, 16, 17, 31, 32, 33, 34, 40, 47, 48, 49, 63, 64, 65, 66, 70, 90, 100, 128, 200, 333, 1000, 3000]))
+        elif k == 2:
+            d = single_symbol_mix(rng, rng.choice([1, 2, 5, 15, 16, 17, 18, 20, 31, 32, 33, 34, 40, 47, 48, 49, 63, 64, 65, 66, 70, 90, 100, 128, 200, 333, 1000, 3000, 9000]))
+        else:
+            d = fuzz_sections(rng, lengths=FUZZ_LENGTHS, max_sections=4)
+        if d:
+            out.append(d)
+    return out
+
+
+def _to_dev(b):
+    import torch
+
+    return torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda()
+
+
+@pytest.mark.parametrize("codec", CODECS, ids=lambda c: c.key)
+def test_blocks_bit_exact_and_roundtrip(hs, oracle, codec):
+    """Concatenate fuzz inputs, cut into small blocks: every block stream == oracle stream; decode == input."""
+    inputs = _inputs(1234 + CODECS.index(codec), 40)
+    data = b"".join(inputs)
+    for block_size in (128, 384, 4096):
+        src = _to_dev(data)
+        container, info = hs.compress(codec.key, src, block_size=block_size)
+        cinfo, streams = hs.split_container(container.cpu().numpy().tobytes())
+        assert cinfo.blockCount == (len(data) + block_size - 1) // block_size == len(streams)
+        for i, s in enumerate(streams):
+            expect = oracle.compress(codec, data[i * block_size : (i + 1) * block_size])
+            assert s == expect, f"{codec.key} block {i} (size {block_size}) differs from the oracle"
+        out = hs.decompress(container)
+        assert out.cpu().numpy().tobytes() == data
+
+
+@pytest.mark.parametrize("codec", CODECS, ids=lambda c: c.key)
+def test_dropin_monolithic(hs, oracle, codec):
+    """rle.h-named entry points (host pointers, one stream): stream == oracle; decode of oracle stream == input; error returns."""
+    for d in _inputs(77 + CODECS.index(codec), 24):
+        cap = hs.compress_bounds(len(d))
+        size, stream = hs.call_dropin(codec.cname, d, cap)
+        expect = oracle.compress(codec, d)
+        assert size == len(expect) and stream == expect
+        size, dec = hs.call_dropin(codec.dname, expect, len(d))  # outSize == inputSize exactly, like the reference fuzzer
+        assert size == len(d) and dec == d
+    # error behaviour (reference: rle8_extreme_cpu.h:88-89, :704-712)
+    d = b"abcabcabc" * 10
+    assert hs.call_dropin(codec.cname, d, hs.compress_bounds(len(d)) - 1)[0] == 0  # outSize < bounds
+    assert hs.call_dropin(codec.cname, b"", 1000)[0] == 0  # inSize == 0
+    s = oracle.compress(codec, d)
+    assert hs.call_dropin(codec.dname, s, len(d) - 1)[0] == 0  # outSize < uncompressed
+    assert hs.call_dropin(codec.dname, s[:-1], len(d))[0] == 0  # inSize < compressedLength
+
+
+def test_decode_reference_tail_flavours(hs, oracle):
+    """8 bit Packed: the decoder is ISA-invariant; golden streams of both encoder tail flavours decode."""
+    import json, os, base64
+
+    path = os.path.join(os.path.dirname(__file__), "golden", "rle8_packed_tails.json")
+    if not os.path.exists(path):
+        pytest.skip("golden file not minted")
+    for case in json.load(open(path)):
+        data = base64.b64decode(case["input"])
+        for k in ("sse2", "avx2"):
+            stream = base64.b64decode(case[k])
+            size, dec = hs.call_dropin("rle8_packed_decompress", stream, len(data))
+            assert size == len(data) and dec == data
+
+
+def test_malformed_block_reports_error(hs):
+    import torch
+
+    data = bytes(range(256)) * 64
+    container, info = hs.compress("rle8_packed_multi", _to_dev(data), block_size=1024)
+    bad = container.clone()
+    # corrupt the first block's stream header (uncompressedLength)
+    p0 = info.payload_start
+    bad[p0] = 0x55
+    with pytest.raises(hs.HsrleError):
+        hs.decompress(bad)
+    # corrupt the container magic
+    bad2 = container.clone()
+    bad2[0] = 0
+    with pytest.raises(hs.HsrleError):
+        hs.decompress(bad2)
+
+
+def test_partial_block_range(hs):
+    import torch
+
+    rng = random.Random(5)
+    data = mixed_runs(rng, 50000)
+    container, info = hs.compress("rle16_byte_packed", _to_dev(data), block_size=512)
+    out = torch.zeros(len(data), dtype=torch.uint8, device="cuda")
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    first, count = 10, 33
+    hs.decompress_async(container, info, out, status, first_block=first, block_count=count)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    got = out.cpu().numpy().tobytes()
+    lo, hi = first * 512, (first + count) * 512
+    assert got[lo:hi] == data[lo:hi]
+    assert got[:lo] == bytes(lo) and got[hi:] == bytes(len(data) - hi)  # nothing outside the range is written
