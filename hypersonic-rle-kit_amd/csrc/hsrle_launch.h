@@ -32,7 +32,14 @@ typedef hipError_t (*DecodeLaunch)(const DecodeArgs &, hipStream_t);
 typedef hipError_t (*EncodeLaunch)(const EncodeArgs &, hipStream_t);
 
 constexpr int kCodecCount = 50;
-constexpr int kDecodeTile = 128; // bytes produced per lane and round (k_decode_blocks T)
+#ifndef HSRLE_DECODE_TILE
+#define HSRLE_DECODE_TILE 128
+#endif
+#ifndef HSRLE_DECODE_RING
+#define HSRLE_DECODE_RING 256
+#endif
+constexpr int kDecodeTile = HSRLE_DECODE_TILE; // bytes produced per lane and round (k_decode_blocks T)
+constexpr int kDecodeRing = HSRLE_DECODE_RING; // per-lane stream ring in LDS (k_decode_blocks R)
 
 void register_w8(DecodeLaunch *dec, EncodeLaunch *enc);
 void register_w16(DecodeLaunch *dec, EncodeLaunch *enc);

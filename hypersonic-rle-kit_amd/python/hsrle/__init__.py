@@ -12,7 +12,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_DIR = os.path.dirname(os.path.dirname(_HERE))
-LIB_PATH = os.path.join(PKG_DIR, "libhsrle_hip.so")
+LIB_PATH = os.environ.get("HSRLE_LIB", os.path.join(PKG_DIR, "libhsrle_hip.so"))  # HSRLE_LIB: developer override for A/B builds
 
 OK, ERR_ARGUMENT, ERR_CAPACITY, ERR_FORMAT, ERR_DEVICE, ERR_UNSUPPORTED = range(6)
 SYNTH_RUNS, SYNTH_VIDEO = 0, 1

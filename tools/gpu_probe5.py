@@ -1,0 +1,19 @@
+# in-kernel phase stamps (diagnostic build): HSRLE_LIB=variants/libhsrle_stamps.so python tools/gpu_probe5.py
+import sys, os
+sys.path.insert(0,'tests'); sys.path.insert(0,'hypersonic-rle-kit_amd/python')
+import torch, hsrle
+size=(int(sys.argv[1]) if len(sys.argv)>1 else 1024)<<20
+bs=int(sys.argv[2]) if len(sys.argv)>2 else 4096
+codec=sys.argv[3] if len(sys.argv)>3 else 'rle8_packed_multi'
+src=hsrle.synth(0,1,2,size)
+cont,info=hsrle.compress(codec,src,block_size=bs)
+out=torch.empty(size,dtype=torch.uint8,device='cuda'); st=torch.zeros(64,dtype=torch.int32,device='cuda')
+hsrle.decompress_async(cont,info,out,st); torch.cuda.synchronize()
+st.zero_()
+hsrle.decompress_async(cont,info,out,st); torch.cuda.synchronize()
+d=st[16:].view(torch.int64).cpu().tolist()
+tI,tD,tF,tL,nR,nIt,nW=d[:7]
+tot=tI+tD+tF+tL
+print('waves',nW,'rounds/wave',nR/nW,'iters/round',nIt/nR)
+print('cycles per round: issue %.0f decode %.0f flush %.0f land %.0f total %.0f'%(tI/nR,tD/nR,tF/nR,tL/nR,tot/nR))
+print('ok', int(st[0].item())==0 and torch.equal(out,src))
