@@ -53,8 +53,7 @@ __global__ __launch_bounds__(64) void k_decode8_blocks(const uint8_t *__restrict
   static_assert(T == 64 || T == 128, "tile rows are flushed as whole 64/128-byte pieces");
 
   __shared__ __attribute__((aligned(16))) uint8_t tile[64 * TS];
-  __shared__ __attribute__((aligned(16))) uint8_t ring[64 * RS];
-  __shared__ __attribute__((aligned(16))) uint8_t dump[64 * 16];    // where predicated-off LDS stores go
+  __shared__ __attribute__((aligned(16))) uint8_t ring[64 * RS + 64 * 16]; // + 64 dump slots where predicated-off stores go
   __shared__ uint64_t rowBase[64];                                  // stream start of every row, relative to `payload`
   __shared__ uint64_t rowReq[64];                                   // per round: (chunks to load << 32) | loaded end
   __shared__ uint32_t rowStart[64], rowLen[64];                     // slow flush path only
@@ -116,23 +115,21 @@ __global__ __launch_bounds__(64) void k_decode8_blocks(const uint8_t *__restrict
       const uint64_t req = rowReq[r];
       const uint32_t e = (uint32_t)req, n = (uint32_t)(req >> 32);
       const bool valid = c < n;
-      const uint32_t pos = e + (valid ? c : 0u) * 16u;                 // predicated-off lanes re-read the row's first chunk
+      const uint32_t pos = e + c * 16u;
       const uint32_t ro = pos & RMASK;
-      pf[q] = ld128(payload + rowBase[r] + pos);
+      pf[q] = ld128(payload + rowBase[r] + (valid ? pos : 0u));        // predicated-off lanes re-read the stream start
       pfAt[q] = valid ? (r * (uint32_t)RS + ro) : (64u * (uint32_t)RS + lane * 16u);          // ring slot or dump slot
       pfMirror[q] = (valid && ro == 0u) ? (r * (uint32_t)RS + (uint32_t)R) : (64u * (uint32_t)RS + lane * 16u);
     }
   };
 
-  // ring and dump are adjacent in one array so that a plain offset selects either
+  // the dump slots sit behind the ring rows in the same array, so a plain offset selects either
   auto land = [&]() {
 #pragma unroll
     for (int q = 0; q < 8; q++)
     {
-      uint8_t *p0 = (pfAt[q] < 64u * (uint32_t)RS) ? ring + pfAt[q] : dump + (pfAt[q] - 64u * (uint32_t)RS);
-      uint8_t *p1 = (pfMirror[q] < 64u * (uint32_t)RS) ? ring + pfMirror[q] : dump + (pfMirror[q] - 64u * (uint32_t)RS);
-      st128(p0, pf[q]);
-      st128(p1, pf[q]);
+      st128(ring + pfAt[q], pf[q]);
+      st128(ring + pfMirror[q], pf[q]);
     }
   };
 
@@ -165,8 +162,12 @@ __global__ __launch_bounds__(64) void k_decode8_blocks(const uint8_t *__restrict
   if constexpr (TR::kLut)
     lutw = (TR::K == 3) ? 0x0000000000FF7F00ull : 0x00FE807E01FF7F00ull; // 0x00,0x7F,0xFF(,0x01,0x7E,0x80,0xFE): rleX_Xsl.h:533-543
 
+  // every spin is bounded: a malformed stream (or a bug) ends as DEC_ERR_STREAM, never as a hang
+  uint32_t roundsLeft = B / (uint32_t)T + B / 16u + 64u; // output rounds + worst-case starved rounds (>= 16 stream bytes each)
+
   while (__ballot(!done && o < blen) != 0ull)
   {
+    if (roundsLeft-- == 0u) { err |= DEC_ERR_STREAM | (0x100u << 0); break; }
     // ---- top-up for the NEXT round: the loads fly while this round decodes from the ring ----
     const uint32_t avail0 = E;                                         // bytes [.., avail0) are readable during this round
     issue();
@@ -174,15 +175,17 @@ __global__ __launch_bounds__(64) void k_decode8_blocks(const uint8_t *__restrict
     const uint32_t base = o;                                           // this round's tile row holds block bytes [base, ...)
     const uint32_t target = umin((o / (uint32_t)T + 1u) * (uint32_t)T, blen);
     uint32_t fin = (done || o >= target) ? 1u : 0u;
+    uint32_t stepsLeft = 2u * (uint32_t)T + 64u;
 
     while (__ballot(!fin) != 0ull)
     {
+      if (stepsLeft-- == 0u) { err |= DEC_ERR_STREAM | (0x100u << 1); done = 1; break; }
       // ================= one step, identical straight-line code for every lane =================
       const uint32_t resident = (avail0 > sp) ? avail0 - sp : 0u;
       const bool idle = (lit | run) == 0u;
       if (idle && last) done = 1;
       const bool streamOk = sp + 2u <= slen;
-      if (idle && !done && !streamOk) { err |= DEC_ERR_STREAM; done = 1; }
+      if (idle && !done && !streamOk) { err |= DEC_ERR_STREAM | (0x100u << 2); done = 1; }
       const bool parse = idle && !done && !fin && (resident >= MAXHDR || avail0 >= lim);
       bool starved = idle && !done && !parse;
 
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(64) void k_decode8_blocks(const uint8_t *__restrict
         range = (r7 == 0u) ? rext : (r7 == 1u ? (rext & 0xFFFFu) : r7);
         used = pos + ((r7 == 0u) ? 4u : (r7 == 1u ? 2u : 0u));
         endNow = (r7 == 1u && range == 0u) ? 1u : 0u;
-        if (parse && !endNow && range < 2u) { err |= DEC_ERR_STREAM; done = 1; }
+        if (parse && !endNow && range < 2u) { err |= DEC_ERR_STREAM | (0x100u << 3); done = 1; }
         range = (range >= 2u) ? range - 1u : 0u;                        // literal count + 1, like the other families
       }
       else
@@ -277,8 +280,8 @@ __global__ __launch_bounds__(64) void k_decode8_blocks(const uint8_t *__restrict
         run = (cnt == 0u || endNow) ? 0u : cnt + shortv - (TR::kLut ? 2u : 1u);
         last = (endNow || cnt == 0u) ? 1u : 0u;
         const uint32_t nsp = sp + used;
-        if (nsp > slen || lit > slen - nsp) { err |= DEC_ERR_STREAM; done = 1; }
-        if (lit == 0u && run == 0u && !last) { err |= DEC_ERR_STREAM; done = 1; }
+        if (nsp > slen || lit > slen - nsp) { err |= DEC_ERR_STREAM | (0x100u << 4); done = 1; }
+        if (lit == 0u && run == 0u && !last) { err |= DEC_ERR_STREAM | (0x100u << 5); done = 1; }
       }
 
       const uint32_t usedNow = parse ? used : 0u;
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(64) void k_decode8_blocks(const uint8_t *__restrict
       run -= isLit ? 0u : n;
       o += n;
       if ((lit | run) == 0u && last && !done && !starved) done = 1;
-      fin = (done || o >= target || starved) ? 1u : 0u;
+      fin |= (done || o >= target || starved) ? 1u : 0u;                // sticky for the rest of the round
     }
 
     // ---- flush ----
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(64) void k_decode8_blocks(const uint8_t *__restrict
   }
 
   if (active && o != blen)
-    err |= DEC_ERR_STREAM;
+    err |= DEC_ERR_STREAM | (0x100u << 6);
 
   if (err != 0 && status != nullptr)
     atomicOr(status, err);
