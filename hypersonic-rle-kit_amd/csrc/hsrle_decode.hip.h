@@ -6,19 +6,23 @@
 //   24/48 bit               src/rle{24,48}_extreme_cpu_decode.h
 //   128 bit                 src/rle128_extreme_cpu.h:499-802
 //   3/7 symbol LUT          src/rleX_Xsl.h:530-1881
-//   MEMCPY_* / MEMSET_*     src/rleX_extreme_common.h:32-312  (-> ring-to-tile copies / fill_run below)
+//   MEMCPY_* / MEMSET_*     src/rleX_extreme_common.h:32-312  (-> copy_literals / fill_run below)
 //
 // One lane decodes one block (= one complete reference stream); a 64-lane workgroup owns 64 consecutive blocks, i.e.
 // one contiguous 64 * blockSize slice of the output.  Data path per workgroup:
 //
-//   HBM --(16-byte vector loads, every lane streaming its own block, issued one round ahead)--> LDS ring [64][R + 16]
-//   LDS ring --(per-lane packet walk: header fields, 16-byte literal vectors)--> LDS tile [64][T + 16]
-//   LDS tile --(8 lanes x 16 B per row: whole 128-byte lines)--> HBM
+//   HBM --(top-up: T/16 adjacent lanes read T contiguous bytes of ONE stream, issued one round ahead)--> LDS ring [64][R]
+//   LDS ring --(per-lane packet walk: header fields, 16-byte literal vectors)--> LDS tile [64][T]
+//   LDS tile --(flush: T/16 adjacent lanes write T contiguous bytes of one row)--> HBM
 //
 // so the packet-to-packet dependency chain (the next header's position is known only after the previous packet's literal
-// length, reference: src/rleX_extreme_cpu_decode.h:129-162) only ever waits on LDS, never on HBM, and it is walked
-// by 64 lanes at once.  Nothing outside [0, uncompressedSize) is written (the reference scribbles up to 128 bytes past
-// the end).
+// length, reference: src/rleX_extreme_cpu_decode.h:129-162) only ever waits on LDS, never on HBM, and it is walked by
+// 64 lanes at once.  Measured facts of gfx950 that shape the code (tools/ubench/):
+//   * 16-byte loads by 64 lanes at 64 different streams run at ~1 TB/s chip-wide; grouped loads read whole lines.
+//   * an LDS access whose address is not a multiple of 4 is executed one lane at a time (64 cycles per wave instruction);
+//     dword aligned 16-byte accesses take 11-24 cycles.  So every LDS access here is DWORD ALIGNED and the byte
+//     granularity of the format is restored in registers (v_alignbyte / v_bfi).
+// Nothing outside [0, uncompressedSize) is written (the reference scribbles up to 128 bytes past the end, A.5 q7).
 #pragma once
 
 #include "hsrle_common.hip.h"
@@ -32,23 +36,23 @@ enum DecodeError : uint32_t
   DEC_ERR_MODE = 4u      // unknown 8 bit mode byte (reference: rle8_extreme_cpu.h:759-760)
 };
 
-// 32-byte per-lane fill pattern in LDS: pat[k] = sym[k % S].  `v` holds the symbol in its low S bytes.
+// 48-byte per-lane fill pattern in LDS: pat[k] = sym[k % S] (S > 1).  `v` holds the symbol in its low S bytes.
 template <int S>
 __device__ __forceinline__ void set_pattern(uint8_t *pat, u32x4 v)
 {
-  u32x4 a, b;
+  u32x4 a, b, c;
 
-  if constexpr (S == 1) { const uint32_t d = (v.x & 0xFFu) * 0x01010101u; a = u32x4{ d, d, d, d }; b = a; }
-  else if constexpr (S == 2) { const uint32_t h = v.x & 0xFFFFu; const uint32_t d = h | (h << 16); a = u32x4{ d, d, d, d }; b = a; }
-  else if constexpr (S == 4) { a = u32x4{ v.x, v.x, v.x, v.x }; b = a; }
-  else if constexpr (S == 8) { a = u32x4{ v.x, v.y, v.x, v.y }; b = a; }
-  else if constexpr (S == 16) { a = v; b = v; }
+  if constexpr (S == 2) { const uint32_t h = v.x & 0xFFFFu; const uint32_t d = h | (h << 16); a = u32x4{ d, d, d, d }; b = a; c = a; }
+  else if constexpr (S == 4) { a = u32x4{ v.x, v.x, v.x, v.x }; b = a; c = a; }
+  else if constexpr (S == 8) { a = u32x4{ v.x, v.y, v.x, v.y }; b = a; c = a; }
+  else if constexpr (S == 16) { a = v; b = v; c = v; }
   else if constexpr (S == 3)
   {
     const uint32_t t = v.x & 0xFFFFFFu;
     const uint32_t d0 = t | (t << 24), d1 = (t >> 8) | (t << 16), d2 = (t >> 16) | (t << 8);
     a = u32x4{ d0, d1, d2, d0 };
     b = u32x4{ d1, d2, d0, d1 };
+    c = u32x4{ d2, d0, d1, d2 };
   }
   else // S == 6
   {
@@ -56,30 +60,12 @@ __device__ __forceinline__ void set_pattern(uint8_t *pat, u32x4 v)
     const uint32_t d0 = lo, d1 = hi | (lo << 16), d2 = (lo >> 16) | (hi << 16);
     a = u32x4{ d0, d1, d2, d0 };
     b = u32x4{ d1, d2, d0, d1 };
+    c = u32x4{ d2, d0, d1, d2 };
   }
 
   st128(pat, a);
   st128(pat + 16, b);
-}
-
-// Write m bytes of the run pattern starting at pattern phase `phase` (0..S-1); may write 15 bytes beyond dst + m.
-template <int S>
-__device__ __forceinline__ void fill_run(uint8_t *dst, const uint8_t *pat, uint32_t m, uint32_t phase)
-{
-  if constexpr (16 % S == 0)
-  {
-    const u32x4 v = ld128(pat + phase);
-    for (uint32_t k = 0; k < m; k += 16)
-      st128(dst + k, v);
-  }
-  else
-  {
-    for (uint32_t k = 0; k < m; k += 16)
-    {
-      st128(dst + k, ld128(pat + phase));
-      phase = (phase + 16u) % (uint32_t)S;
-    }
-  }
+  st128(pat + 32, c);
 }
 
 template <int S>
@@ -94,6 +80,28 @@ __device__ __forceinline__ u32x4 mask_symbol(u32x4 v)
   else return v;
 }
 
+// 16 bytes starting at byte `p` of a buffer, using only dword aligned LDS reads (20 bytes) and a byte funnel
+__device__ __forceinline__ u32x4 lds_read16(const uint8_t *base, uint32_t p)
+{
+  const uint8_t *src = base + (p & ~3u);
+  const u32x4 x = ld128(src);
+  const uint32_t x4 = ld32(src + 16);
+  const uint32_t bs = p & 3u;
+  return u32x4{ alignbyte(x.y, x.x, bs), alignbyte(x.z, x.y, bs), alignbyte(x.w, x.z, bs), alignbyte(x4, x.w, bs) };
+}
+
+// 32 bits at byte offset pos (0..12) of the 16-byte little-endian value hi:lo
+__device__ __forceinline__ uint32_t ex32(uint64_t lo, uint64_t hi, uint32_t pos)
+{
+  const uint32_t sh = pos * 8u;
+  const uint64_t a = (lo >> (sh & 63u)) | ((hi << 1) << (63u - (sh & 63u)));
+  const uint64_t b = hi >> (sh & 63u);
+  return (uint32_t)(sh < 64u ? a : b);
+}
+
+// (mask & a) | (~mask & b)  -> v_bfi_b32
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (mask & a) | (~mask & b); }
+
 // FAM in {PLAIN, PACKED, LUT3, LUT7}; the 8 bit PLAIN / PACKED kernels also decode the Single modes (mode byte 1),
 // exactly like rle8_decompress / rle8_packed_decompress do.
 //   T = output bytes per lane and round (LDS tile row), R = per-lane stream ring size in LDS (power of two).
@@ -103,21 +111,24 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
                                                       uint32_t B, uint32_t firstBlock, uint32_t blockCount, uint32_t *__restrict__ status)
 {
   using TR = Traits<FAM, S, AL>;
-  constexpr int TS = T + 16;                 // tile row stride: 16 bytes of over-write slack
-  constexpr int RS = R + 16;                 // ring row stride: bytes [R, R+16) mirror [0, 16) so 16-byte reads never wrap
-  constexpr int CPR = T / 16;                // 16-byte chunks per tile row
-  constexpr int RPI = 64 / CPR;              // tile rows covered by one flush instruction
+  constexpr int TS = T + 16 + 4;             // tile row stride: 16 bytes of over-write slack; stride/4 odd (bank spread)
+  constexpr int RS = R + 32 + 4;             // ring row stride: bytes [R, R+32) mirror [0, 32) so a 20-byte read never wraps
+  constexpr int CPR = T / 16;                // 16-byte chunks per tile row == lanes that serve one row in top-up / flush
+  constexpr int RPI = 64 / CPR;              // rows covered by one top-up / flush instruction
   constexpr uint32_t RMASK = (uint32_t)R - 1u;
-  constexpr uint32_t MAXHDR = 1u + 4u + (uint32_t)S + 4u + 2u; // longest packet header of any family
-  constexpr int NPF = T / 16 + 1;            // 16-byte chunks one top-up can carry per lane
-  constexpr bool kPatInLds = (S != 1);       // 8 bit: the fill pattern is one broadcast register
-  static_assert((R & (R - 1)) == 0 && R >= 128, "ring size must be a power of two");
-  static_assert(T % 64 == 0 && T <= 256, "tile rows are flushed as 64/128-byte pieces");
+  constexpr uint32_t MAXHDR = 1u + 4u + (uint32_t)S + 4u + 2u; // longest packet header of any family (+ slack)
+  constexpr uint32_t DUMP = 64u * (uint32_t)RS; // offset of the 64 dump slots behind the ring rows
+  constexpr bool kPat = (S != 1);            // 8 bit: the fill pattern is one broadcast register
+  static_assert((R & (R - 1)) == 0 && R >= 128 && R % T == 0, "ring size must be a power of two and a multiple of T");
+  static_assert(T == 64 || T == 128, "tile rows are flushed as whole 64/128-byte pieces");
+  static_assert((TS / 4) % 2 == 1 && (RS / 4) % 2 == 1, "row strides are an odd number of dwords");
 
   __shared__ __attribute__((aligned(16))) uint8_t tile[64 * TS];
-  __shared__ __attribute__((aligned(16))) uint8_t ring[64 * RS];
-  __shared__ __attribute__((aligned(16))) uint8_t pats[kPatInLds ? 64 * 32 : 16];
-  __shared__ uint32_t rowStart[64], rowLen[64]; // slow flush path: block offset / length of what the row holds in the tile
+  __shared__ __attribute__((aligned(16))) uint8_t ring[64 * RS + 64 * 16]; // + 64 dump slots where predicated-off stores go
+  __shared__ __attribute__((aligned(16))) uint8_t pats[kPat ? 64 * 52 : 16];
+  __shared__ uint64_t rowBase[64];                                  // stream start of every row, relative to `payload`
+  __shared__ uint64_t rowReq[64];                                   // per round: (chunks to load << 32) | loaded end
+  __shared__ uint32_t rowStart[64], rowLen[64];                     // slow flush path only
 
   const uint32_t lane = threadIdx.x;
   const uint32_t wgFirst = firstBlock + blockIdx.x * 64u;
@@ -127,76 +138,88 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 
   uint8_t *const row = tile + lane * TS;
   uint8_t *const rng = ring + lane * RS;
-  uint8_t *const pat = pats + (kPatInLds ? lane * 32 : 0);
+  uint8_t *const pat = pats + (kPat ? lane * 52 : 0);
 
   // ---- per-lane stream state ----
-  const uint8_t *s = payload;   // this lane's stream (global)
   uint32_t slen = 0, blen = 0;
   uint32_t sp = 0;        // read position in the stream
   uint32_t E = 0;         // stream bytes [.., E) are in the ring (multiple of 16)
   uint32_t lim = 0;       // E never exceeds lim (loadable bytes of this stream incl. the payload tail pad)
   uint32_t lit = 0;       // literal bytes of the current packet still to copy
   uint32_t run = 0;       // run bytes of the current packet still to write
-  uint32_t phase = 0;     // pattern phase of the next run byte
+  uint32_t phase = 0;     // S > 1: pattern phase of the next run byte
   uint32_t o = 0;         // bytes of this block produced so far
-  uint32_t sym1 = 0;      // S == 1: current symbol, byte-broadcast
+  uint32_t sym4 = 0;      // S == 1: current symbol, byte-broadcast
+  uint32_t pd = 0;        // the dword of the tile row that contains the write position (its low (q & 3) bytes are valid)
   bool last = false;      // the stream ends after the current packet's literals
   bool done = true;
   bool single = false;
   uint32_t err = 0;
   [[maybe_unused]] uint32_t lut[TR::kLut ? TR::K : 1][TR::SW];
 
-  if (active)
   {
-    const uint64_t off0 = offsets[b];
-    s = payload + off0;
-    slen = (uint32_t)(offsets[b + 1] - off0);
-    const uint64_t start = (uint64_t)b * B;
-    blen = (uint32_t)((U - start) < (uint64_t)B ? (U - start) : (uint64_t)B);
-    const uint64_t room = (uint64_t)(payloadEnd - s);
-    lim = (uint32_t)(room > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : room) & ~15u;
-    done = false;
+    uint64_t off0 = 0;
+    if (active)
+    {
+      off0 = offsets[b];
+      slen = (uint32_t)(offsets[b + 1] - off0);
+      const uint64_t start = (uint64_t)b * B;
+      blen = (uint32_t)((U - start) < (uint64_t)B ? (U - start) : (uint64_t)B);
+      const uint64_t room = (uint64_t)(payloadEnd - payload) - off0;
+      lim = (uint32_t)(room > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : room) & ~15u;
+      done = false;
+    }
+    rowBase[lane] = off0;
   }
 
   auto set_sym = [&](u32x4 v) {
-    if constexpr (S == 1) sym1 = (v.x & 0xFFu) * 0x01010101u;
+    if constexpr (S == 1) sym4 = (v.x & 0xFFu) * 0x01010101u;
     else set_pattern<S>(pat, v);
   };
 
-  // ---- ring top-up: every lane streams its own block; loads are issued one round before their bytes are needed ----
-  u32x4 pf[NPF];
-  uint32_t want = 0;
+  // ---- ring top-up.  issue(): CPR loads; in load q, lanes CPR*g .. CPR*g+CPR-1 read T contiguous bytes of row RPI*q+g ----
+  u32x4 pf[CPR];
+  uint32_t pfAt[CPR], pfMirror[CPR];
 
   auto issue = [&]() {
     const uint32_t resident = E - (sp & ~15u);
-    want = umin(umin(((uint32_t)R - resident) >> 4, (uint32_t)NPF), (lim - E) >> 4);
+    uint32_t want = umin(umin(((uint32_t)R - resident) >> 4, (uint32_t)CPR), (lim - E) >> 4);
     if (done) want = 0;
+    rowReq[lane] = ((uint64_t)want << 32) | E;
+    E += want << 4;
+    __syncthreads();
 #pragma unroll
-    for (int q = 0; q < NPF; q++)
-      if ((uint32_t)q < want)
-        pf[q] = ld128(s + E + 16u * q);
+    for (int q = 0; q < CPR; q++)
+    {
+      const uint32_t r = (uint32_t)q * RPI + lane / CPR, c = lane % CPR;
+      const uint64_t req = rowReq[r];
+      const uint32_t e = (uint32_t)req, n = (uint32_t)(req >> 32);
+      const bool valid = c < n;
+      const uint32_t pos = e + c * 16u;
+      const uint32_t ro = pos & RMASK;
+      pf[q] = ld128(payload + rowBase[r] + (valid ? pos : 0u));        // predicated-off lanes re-read the stream start
+      pfAt[q] = valid ? (r * (uint32_t)RS + ro) : (DUMP + lane * 16u);  // ring slot or dump slot
+      pfMirror[q] = (valid && ro < 32u) ? (r * (uint32_t)RS + (uint32_t)R + ro) : (DUMP + lane * 16u);
+    }
   };
 
   auto land = [&]() {
 #pragma unroll
-    for (int q = 0; q < NPF; q++)
-      if ((uint32_t)q < want)
-      {
-        const uint32_t ro = (E + 16u * q) & RMASK;
-        st128(rng + ro, pf[q]);
-        if (ro == 0u)
-          st128(rng + R, pf[q]); // mirror of the first 16 ring bytes
-      }
-    E += want << 4;
+    for (int q = 0; q < CPR; q++)
+    {
+      st128(ring + pfAt[q], pf[q]);
+      st128(ring + pfMirror[q], pf[q]);
+    }
   };
 
   // prologue: fill the ring, then read the stream header from it
-  for (int k = 0; k < (R / 16 + NPF - 1) / NPF; k++)
+  __syncthreads();
+  for (int k = 0; k < R / T; k++)
   {
     issue();
     land();
+    __syncthreads();
   }
-  __syncthreads();
 
   if (active)
   {
@@ -234,6 +257,9 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     set_sym(u32x4{ 0, 0, 0, 0 }); // Packed decoders start with symbol 0 (rleX_extreme_cpu_decode.h:31-37, q5)
   }
 
+  // every spin is bounded: a malformed stream (or a bug) ends as DEC_ERR_STREAM, never as a hang
+  uint32_t roundsLeft = B / (uint32_t)T + B / 16u + 64u; // output rounds + worst-case starved rounds (>= 16 stream bytes each)
+
 #ifdef HSRLE_STAMPS
   unsigned long long tIssue = 0, tDecode = 0, tFlush = 0, tLand = 0, nRounds = 0, nIter = 0, t0, t1;
 #define HS_STAMP(acc) { t1 = __builtin_readcyclecounter(); acc += t1 - t0; t0 = t1; }
@@ -243,9 +269,11 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 
   while (__ballot(!done && o < blen) != 0ull)
   {
+    if (roundsLeft-- == 0u) { err |= DEC_ERR_STREAM; break; }
 #ifdef HSRLE_STAMPS
     t0 = __builtin_readcyclecounter(); nRounds++;
 #endif
+
     // ---- top-up for the NEXT round: the loads fly while this round decodes from the ring ----
     const uint32_t avail0 = E;                                         // bytes [.., avail0) are readable during this round
     issue();
@@ -253,12 +281,15 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 
     const uint32_t base = o;                                           // this round's tile row holds block bytes [base, ...)
     const uint32_t target = umin((o / (uint32_t)T + 1u) * (uint32_t)T, blen);
+    uint32_t itersLeft = 2u * (uint32_t)T + 16u;
 
     while (!done && o < target)
     {
+      if (itersLeft-- == 0u) { err |= DEC_ERR_STREAM; done = true; break; }
 #ifdef HSRLE_STAMPS
       nIter++;
 #endif
+
       if (lit == 0 && run == 0)
       {
         if (last) { done = true; break; }
@@ -268,153 +299,231 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
         // ---------------- packet header ----------------
         uint32_t cnt, range, used;
         bool endNow = false;
-#define HS_H(off) (rng + ((sp + (off)) & RMASK))
 
-        if constexpr (TR::kLut)
+        if constexpr (S == 1)
         {
-          const uint32_t v = ld16(HS_H(0));
-          used = 2;
-          const uint32_t idx = v >> (FAM == LUT3 ? 14 : 13);
-          cnt = (v >> TR::RB) & 0x7Fu;
-          range = v & ((1u << TR::RB) - 1u);
-
-          if (idx != 0)
-          {
-            uint32_t tmp[TR::SW];
-            if (idx == (uint32_t)TR::K)
-            {
-              const u32x4 nv = mask_symbol<S>(ld128(HS_H(used)));
-              used += S;
-#pragma unroll
-              for (int w = 0; w < TR::SW; w++) tmp[w] = nv[w];
-            }
-            else
-            {
-#pragma unroll
-              for (int w = 0; w < TR::SW; w++) tmp[w] = lut[0][w];
-#pragma unroll
-              for (int k = 1; k < TR::K; k++)
-                if (idx == (uint32_t)k)
-                {
-#pragma unroll
-                  for (int w = 0; w < TR::SW; w++) tmp[w] = lut[k][w];
-                }
-            }
-            const uint32_t limit = (idx == (uint32_t)TR::K) ? (uint32_t)TR::K - 1u : idx;
-#pragma unroll
-            for (int k = TR::K - 1; k >= 1; k--)
-              if ((uint32_t)k <= limit)
-              {
-#pragma unroll
-                for (int w = 0; w < TR::SW; w++) lut[k][w] = lut[k - 1][w];
-              }
-            u32x4 pv = u32x4{ 0, 0, 0, 0 };
-#pragma unroll
-            for (int w = 0; w < TR::SW; w++) { lut[0][w] = tmp[w]; pv[w] = tmp[w]; }
-            set_sym(pv);
-          }
-
-          if (cnt == 0) { cnt = ld32(HS_H(used)); used += 4; }
-          else if (cnt == 1) { cnt = ld16(HS_H(used)); used += 2; }
-
-          if (range == 0) { range = ld32(HS_H(used)); used += 4; }
-          else if (range == 1) { range = ld16(HS_H(used)); used += 2; endNow = (range == 0); }
-
-          if (!endNow && range < 2u) { err |= DEC_ERR_STREAM; done = true; break; }
-          lit = endNow ? 0u : range - 2u;
-          run = (cnt == 0) ? 0u : (TR::kAligned ? (cnt + 3u / (uint32_t)S - 2u) * (uint32_t)S : cnt + 1u);
-        }
-        else if constexpr (S == 1)
-        {
-          // 8 bit: the whole header (<= 10 bytes) comes from ONE 16-byte ring read; fields are picked with shifts
-          const u32x4 hv = ld128(HS_H(0));
+          // 8 bit: the whole header (<= 11 bytes) comes from ONE 16-byte ring read; fields are picked with shifts
+          const u32x4 hv = lds_read16(rng, sp & RMASK);
           const uint64_t lo = (uint64_t)hv.x | ((uint64_t)hv.y << 32), hi = (uint64_t)hv.z | ((uint64_t)hv.w << 32);
           uint32_t pos;
 
-          if (single)
+          if constexpr (TR::kLut)
           {
-            cnt = hv.x & 0xFFu;
-            pos = 1;
-            if (cnt == 0) { cnt = (uint32_t)(lo >> 8); pos = 5; }
-          }
-          else if constexpr (!TR::kPacked)
-          {
-            sym1 = (hv.x & 0xFFu) * 0x01010101u;
-            cnt = (hv.x >> 8) & 0xFFu;
+            const uint32_t w16 = hv.x & 0xFFFFu;
+            const uint32_t idx = w16 >> (FAM == LUT3 ? 14 : 13);
+            const uint32_t c7 = (w16 >> TR::RB) & 0x7Fu;
+            const uint32_t r7 = w16 & ((1u << TR::RB) - 1u);
             pos = 2;
-            if (cnt == 0) { cnt = (uint32_t)(lo >> 16); pos = 6; }
-          }
-          else
-          {
-            const uint32_t x = hv.x & 0xFFu;
-            cnt = x & 0x7Fu;
-            pos = 1;
-            if (cnt == 0) { cnt = (uint32_t)(lo >> 8); pos = 5; }
-            if (!(x & 0x80u)) { sym1 = ((uint32_t)(lo >> (8u * pos)) & 0xFFu) * 0x01010101u; pos += 1; }
-          }
 
-          const uint32_t w = (uint32_t)((lo >> (8u * pos)) | (hi << (64u - 8u * pos))); // pos in 1..7
-          const uint32_t r0 = w & 0xFFu;
-
-          if (TR::kRange7 && !single)
-          {
-            if (r0 & 1u) { range = w >> 1; used = pos + 4; endNow = (range == 0); }
-            else { range = r0 >> 1; used = pos + 1; }
-          }
-          else
-          {
-            range = r0; used = pos + 1;
-            if (r0 == 0)
+            if (idx != 0)
             {
-              const uint32_t pos2 = pos + 1; // 2..8
-              range = (pos2 < 8u) ? (uint32_t)((lo >> (8u * pos2)) | (hi << (64u - 8u * pos2))) : (uint32_t)hi;
-              used = pos + 5;
-              endNow = (range == 0);
+              // lut[k][0] holds entry k (one byte each); move entry idx (or the new symbol) to the front
+              uint32_t sb;
+              if (idx == (uint32_t)TR::K) { sb = (hv.x >> 16) & 0xFFu; pos = 3; }
+              else
+              {
+                sb = lut[0][0];
+#pragma unroll
+                for (int k = 1; k < TR::K; k++)
+                  if (idx == (uint32_t)k) sb = lut[k][0];
+              }
+              const uint32_t limit = (idx == (uint32_t)TR::K) ? (uint32_t)TR::K - 1u : idx;
+#pragma unroll
+              for (int k = TR::K - 1; k >= 1; k--)
+                if ((uint32_t)k <= limit) lut[k][0] = lut[k - 1][0];
+              lut[0][0] = sb;
+              sym4 = sb * 0x01010101u;
             }
+
+            cnt = c7;
+            if (c7 == 0u) { cnt = ex32(lo, hi, pos); pos += 4; }
+            else if (c7 == 1u) { cnt = ex32(lo, hi, pos) & 0xFFFFu; pos += 2; }
+
+            range = r7;
+            if (r7 == 0u) { range = ex32(lo, hi, pos); pos += 4; }
+            else if (r7 == 1u) { range = ex32(lo, hi, pos) & 0xFFFFu; pos += 2; endNow = (range == 0u); }
+            used = pos;
+
+            if (!endNow && range < 2u) { err |= DEC_ERR_STREAM; done = true; break; }
+            lit = endNow ? 0u : range - 2u;
+            run = (cnt == 0u) ? 0u : cnt + 1u;
           }
+          else
+          {
+            if (single)
+            {
+              cnt = hv.x & 0xFFu;
+              pos = 1;
+              if (cnt == 0) { cnt = (uint32_t)(lo >> 8); pos = 5; }
+            }
+            else if constexpr (!TR::kPacked)
+            {
+              sym4 = (hv.x & 0xFFu) * 0x01010101u;
+              cnt = (hv.x >> 8) & 0xFFu;
+              pos = 2;
+              if (cnt == 0) { cnt = (uint32_t)(lo >> 16); pos = 6; }
+            }
+            else
+            {
+              const uint32_t x = hv.x & 0xFFu;
+              cnt = x & 0x7Fu;
+              pos = 1;
+              if (cnt == 0) { cnt = (uint32_t)(lo >> 8); pos = 5; }
+              if (!(x & 0x80u)) { sym4 = (ex32(lo, hi, pos) & 0xFFu) * 0x01010101u; pos += 1; }
+            }
 
-          lit = (range == 0) ? 0u : range - 1u; // a 7 bit range byte of 0x00 carries no literals (A.5 q11)
+            const uint32_t w = ex32(lo, hi, pos);
+            const uint32_t r0 = w & 0xFFu;
 
-          if (cnt == 0) run = 0;
-          else if (single) run = cnt + ((FAM == PACKED) ? 2u : 4u) - 1u;
-          else run = cnt + TR::SHORT - 1u;
+            if (TR::kRange7 && !single)
+            {
+              if (r0 & 1u) { range = w >> 1; used = pos + 4; endNow = (range == 0); }
+              else { range = r0 >> 1; used = pos + 1; }
+            }
+            else
+            {
+              range = r0; used = pos + 1;
+              if (r0 == 0) { range = ex32(lo, hi, pos + 1u); used = pos + 5; endNow = (range == 0); }
+            }
+
+            lit = (range == 0) ? 0u : range - 1u; // a 7 bit range byte of 0x00 carries no literals (A.5 q11)
+
+            if (cnt == 0) run = 0;
+            else if (single) run = cnt + ((FAM == PACKED) ? 2u : 4u) - 1u;
+            else run = cnt + TR::SHORT - 1u;
+          }
         }
         else
         {
-          used = 0;
+#define HS_RD16(off) lds_read16(rng, (sp + (off)) & RMASK)
+#define HS_RD8(off) (uint32_t)(*(rng + ((sp + (off)) & RMASK)))
+          // S > 1: the first 16 header bytes in one read; the (rare) fields behind them with a second read
+          const u32x4 hv = HS_RD16(0);
+          const uint64_t lo = (uint64_t)hv.x | ((uint64_t)hv.y << 32), hi = (uint64_t)hv.z | ((uint64_t)hv.w << 32);
 
-          if constexpr (!TR::kPacked)
+          if constexpr (TR::kLut)
           {
-            set_sym(ld128(HS_H(0)));
-            used = S;
-            cnt = *HS_H(used); used += 1;
-            if (cnt == 0) { cnt = ld32(HS_H(used)); used += 4; }
+            const uint32_t w16 = hv.x & 0xFFFFu;
+            used = 2;
+            const uint32_t idx = w16 >> (FAM == LUT3 ? 14 : 13);
+            cnt = (w16 >> TR::RB) & 0x7Fu;
+            range = w16 & ((1u << TR::RB) - 1u);
+
+            if (idx != 0)
+            {
+              uint32_t tmp[TR::SW];
+              if (idx == (uint32_t)TR::K)
+              {
+                const u32x4 nv = mask_symbol<S>(HS_RD16(2));
+                used += S;
+#pragma unroll
+                for (int w = 0; w < TR::SW; w++) tmp[w] = nv[w];
+              }
+              else
+              {
+#pragma unroll
+                for (int w = 0; w < TR::SW; w++) tmp[w] = lut[0][w];
+#pragma unroll
+                for (int k = 1; k < TR::K; k++)
+                  if (idx == (uint32_t)k)
+                  {
+#pragma unroll
+                    for (int w = 0; w < TR::SW; w++) tmp[w] = lut[k][w];
+                  }
+              }
+              const uint32_t limit = (idx == (uint32_t)TR::K) ? (uint32_t)TR::K - 1u : idx;
+#pragma unroll
+              for (int k = TR::K - 1; k >= 1; k--)
+                if ((uint32_t)k <= limit)
+                {
+#pragma unroll
+                  for (int w = 0; w < TR::SW; w++) lut[k][w] = lut[k - 1][w];
+                }
+              u32x4 pv = u32x4{ 0, 0, 0, 0 };
+#pragma unroll
+              for (int w = 0; w < TR::SW; w++) { lut[0][w] = tmp[w]; pv[w] = tmp[w]; }
+              set_sym(pv);
+            }
+
+            // the extension fields sit at most at byte 2 + 8 + 4: re-read behind the symbol
+            const u32x4 ev = (used > 2u) ? HS_RD16(used) : u32x4{ (uint32_t)(lo >> 16), (uint32_t)(lo >> 48) | ((uint32_t)hi << 16), (uint32_t)(hi >> 16), (uint32_t)(hi >> 48) };
+            const uint64_t elo = (uint64_t)ev.x | ((uint64_t)ev.y << 32);
+            uint32_t ep = 0;
+            if (cnt == 0) { cnt = (uint32_t)elo; ep = 4; }
+            else if (cnt == 1) { cnt = (uint32_t)elo & 0xFFFFu; ep = 2; }
+            const uint32_t rext32 = (ep == 0u) ? (uint32_t)elo : ((ep == 2u) ? (uint32_t)(elo >> 16) : (uint32_t)(elo >> 32));
+            if (range == 0) { range = rext32; ep += 4; }
+            else if (range == 1) { range = rext32 & 0xFFFFu; ep += 2; endNow = (range == 0); }
+            used += ep;
+
+            if (!endNow && range < 2u) { err |= DEC_ERR_STREAM; done = true; break; }
+            lit = endNow ? 0u : range - 2u;
+            run = (cnt == 0) ? 0u : (TR::kAligned ? (cnt + 3u / (uint32_t)S - 2u) * (uint32_t)S : cnt + 1u);
           }
           else
           {
-            const uint32_t x = *HS_H(0);
-            used = 1;
-            cnt = x & 0x7Fu;
-            if (cnt == 0) { cnt = ld32(HS_H(used)); used += 4; }
-            if (!(x & 0x80u)) { set_sym(ld128(HS_H(used))); used += S; }
-          }
+            uint32_t x = 0;
+            if constexpr (!TR::kPacked)
+            {
+              set_sym(hv);
+              used = S;
+            }
+            else
+            {
+              x = hv.x & 0xFFu;
+              used = 1;
+            }
 
-          if constexpr (TR::kRange7)
-          {
-            const uint32_t r0 = *HS_H(used);
-            if (r0 & 1u) { range = ld32(HS_H(used)) >> 1; used += 4; endNow = (range == 0); }
-            else { range = r0 >> 1; used += 1; }
-          }
-          else
-          {
-            range = *HS_H(used); used += 1;
-            if (range == 0) { range = ld32(HS_H(used)); used += 4; endNow = (range == 0); }
-          }
+            // count byte (+ u32), optional symbol, range: everything behind `used` comes from one more read
+            const u32x4 tv = HS_RD16(used);
+            const uint64_t tlo = (uint64_t)tv.x | ((uint64_t)tv.y << 32), thi = (uint64_t)tv.z | ((uint64_t)tv.w << 32);
+            uint32_t tp;
 
-          lit = (range == 0) ? 0u : range - 1u;
-          run = (cnt == 0) ? 0u : (TR::kAligned ? (cnt + TR::SHORT / (uint32_t)S - 1u) * (uint32_t)S : cnt + TR::SHORT - 1u);
+            if constexpr (!TR::kPacked)
+            {
+              cnt = tv.x & 0xFFu; tp = 1;
+              if (cnt == 0) { cnt = (uint32_t)(tlo >> 8); tp = 5; }
+            }
+            else
+            {
+              cnt = x & 0x7Fu; tp = 0;
+              if (cnt == 0) { cnt = tv.x; tp = 4; }
+              if (!(x & 0x80u))
+              {
+                set_sym(lds_read16(rng, (sp + used + tp) & RMASK));
+                tp += S;
+              }
+            }
+
+            // range field: for S == 16 it can start beyond the 16 bytes of tv
+            uint32_t w;
+            if (tp <= 12u) w = ex32(tlo, thi, tp);
+            else w = lds_read16(rng, (sp + used + tp) & RMASK).x;
+            const uint32_t r0 = w & 0xFFu;
+
+            if constexpr (TR::kRange7)
+            {
+              if (r0 & 1u) { range = w >> 1; tp += 4; endNow = (range == 0); }
+              else { range = r0 >> 1; tp += 1; }
+            }
+            else
+            {
+              range = r0; tp += 1;
+              if (r0 == 0)
+              {
+                range = (tp <= 12u) ? ex32(tlo, thi, tp) : lds_read16(rng, (sp + used + tp) & RMASK).x;
+                tp += 4;
+                endNow = (range == 0);
+              }
+            }
+            used += tp;
+
+            lit = (range == 0) ? 0u : range - 1u;
+            run = (cnt == 0) ? 0u : (TR::kAligned ? (cnt + TR::SHORT / (uint32_t)S - 1u) * (uint32_t)S : cnt + TR::SHORT - 1u);
+          }
+#undef HS_RD16
+#undef HS_RD8
         }
-#undef HS_H
 
         sp += used;
         phase = 0;
@@ -423,51 +532,70 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 
         if (sp > slen || lit > slen - sp) { err |= DEC_ERR_STREAM; done = true; break; }
         if (lit == 0 && run == 0 && !last) { err |= DEC_ERR_STREAM; done = true; break; }
-        continue;
       }
 
+      // ---- literals: tile chunks at the dword aligned positions A + 16k receive ring bytes [sp - c + 16k, +16) ----
       if (lit != 0)
       {
         const uint32_t resident = (avail0 > sp) ? avail0 - sp : 0u;
         const uint32_t n = umin(umin(lit, target - o), resident);
         if (n == 0) break;                                             // literals not resident yet: continue next round
 
-        // loads may over-read (harmless, stays inside this lane's ring row); stores are bounded by n
-        uint8_t *dst = row + (o - base);
-        for (uint32_t k = 0; k < n; k += 64)
+        const uint32_t q = o - base, c = q & 3u;
+        uint8_t *dst = row + (q & ~3u);
+        const uint32_t srcp = sp - c;
+        const uint32_t total = c + n;                                  // bytes from dst that must end up valid
+        u32x4 w = lds_read16(rng, srcp & RMASK);
+        w.x = bfi((1u << (8u * c)) - 1u, pd, w.x);                     // keep the c valid bytes of the straddled dword
+        st128(dst, w);
+        for (uint32_t k = 16; k < total; k += 16)
         {
-          const u32x4 v0 = ld128(rng + ((sp + k) & RMASK));
-          const u32x4 v1 = ld128(rng + ((sp + k + 16) & RMASK));
-          const u32x4 v2 = ld128(rng + ((sp + k + 32) & RMASK));
-          const u32x4 v3 = ld128(rng + ((sp + k + 48) & RMASK));
-          st128(dst + k, v0);
-          if (k + 16 < n) st128(dst + k + 16, v1);
-          if (k + 32 < n) st128(dst + k + 32, v2);
-          if (k + 48 < n) st128(dst + k + 48, v3);
+          w = lds_read16(rng, (srcp + k) & RMASK);
+          st128(dst + k, w);
+        }
+        // new straddled dword: dword ((total & 15) >> 2) of the last chunk (if total is a multiple of 16: unknown -> 0 valid bytes)
+        {
+          const uint32_t idx = (total >> 2) & 3u;
+          pd = (idx == 0u) ? w.x : (idx == 1u ? w.y : (idx == 2u ? w.z : w.w));
         }
         sp += n;
         lit -= n;
         o += n;
       }
 
+      // ---- run: the same aligned chunks filled with the symbol pattern ----
       if (lit == 0 && run != 0 && o < target)
       {
         const uint32_t m = umin(run, target - o);
+        const uint32_t q = o - base, c = q & 3u;
+        uint8_t *dst = row + (q & ~3u);
+        const uint32_t total = c + m;
+
         if constexpr (S == 1)
         {
-          const u32x4 v = u32x4{ sym1, sym1, sym1, sym1 };
-          uint8_t *dst = row + (o - base);
-          for (uint32_t k = 0; k < m; k += 64)
-          {
+          const u32x4 v = u32x4{ sym4, sym4, sym4, sym4 };
+          u32x4 w = v;
+          w.x = bfi((1u << (8u * c)) - 1u, pd, sym4);
+          st128(dst, w);
+          for (uint32_t k = 16; k < total; k += 16)
             st128(dst + k, v);
-            if (k + 16 < m) st128(dst + k + 16, v);
-            if (k + 32 < m) st128(dst + k + 32, v);
-            if (k + 48 < m) st128(dst + k + 48, v);
-          }
+          pd = (total < 4u) ? w.x : sym4;
         }
         else
         {
-          fill_run<S>(row + (o - base), pat, m, phase);
+          // pattern byte for tile byte (A + j) is pat[(phase - c + j) mod S]; pat holds 48 bytes of the periodic pattern
+          uint32_t ph = (phase + (uint32_t)S - c % (uint32_t)S) % (uint32_t)S;
+          u32x4 w = lds_read16(pat, ph);
+          w.x = bfi((1u << (8u * c)) - 1u, pd, w.x);
+          st128(dst, w);
+          for (uint32_t k = 16; k < total; k += 16)
+          {
+            if constexpr (16 % S != 0) ph = (ph + 16u) % (uint32_t)S;
+            w = lds_read16(pat, ph);
+            st128(dst + k, w);
+          }
+          const uint32_t idx = (total >> 2) & 3u;
+          pd = (idx == 0u) ? w.x : (idx == 1u ? w.y : (idx == 2u ? w.z : w.w));
           phase = (phase + m) % (uint32_t)S;
         }
         run -= m;
@@ -483,7 +611,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 
     if (uniform)
     {
-      // fast path: all 64 rows hold T bytes of the same round: every store instruction writes RPI x T bytes = whole lines
+      // fast path: all 64 rows hold T bytes of the same round: every store instruction writes RPI x T contiguous bytes
       const uint32_t ubase = __builtin_amdgcn_readfirstlane(base);
       u32x4 fv[CPR];
 #pragma unroll
@@ -527,7 +655,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   }
 
 #ifdef HSRLE_STAMPS
-  // diagnostic build only: per-phase cycle sums of every workgroup's lane 0, appended behind the status word
+  // diagnostic build only (never shipped): per-phase cycle sums of every workgroup's lane 0, appended behind the status word
   if (status != nullptr)
   {
     unsigned long long *dbg = (unsigned long long *)(status + 16);

@@ -2,16 +2,15 @@
 // (reference: src/rle.h:101-103, :173-175, :199-208).  rle8_decompress / rle8_packed_decompress decode both the multi
 // and the single mode, so the Single codec ids share the multi decode kernels.
 #include "hsrle_decode.hip.h"
-#include "hsrle_decode8.hip.h"
 #include "hsrle_encode.hip.h"
 #include "hsrle_launch.h"
 
 namespace hsrle {
 
-static hipError_t dec_plain(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode8_blocks<PLAIN, kDecodeTile, kDecodeRing>, a, st); }
-static hipError_t dec_packed(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode8_blocks<PACKED, kDecodeTile, kDecodeRing>, a, st); }
-static hipError_t dec_lut3(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode8_blocks<LUT3, kDecodeTile, kDecodeRing>, a, st); }
-static hipError_t dec_lut7(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode8_blocks<LUT7, kDecodeTile, kDecodeRing>, a, st); }
+static hipError_t dec_plain(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PLAIN, 1, 0, kDecodeTile, kDecodeRing>, a, st); }
+static hipError_t dec_packed(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PACKED, 1, 0, kDecodeTile, kDecodeRing>, a, st); }
+static hipError_t dec_lut3(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<LUT3, 1, 0, kDecodeTile, kDecodeRing>, a, st); }
+static hipError_t dec_lut7(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<LUT7, 1, 0, kDecodeTile, kDecodeRing>, a, st); }
 
 static hipError_t enc_plain(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<PLAIN, 1, 0>, a, st); }
 static hipError_t enc_packed(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<PACKED, 1, 0>, a, st); }
