@@ -54,6 +54,13 @@ __device__ __forceinline__ void st32(uint8_t *p, uint32_t v) { __builtin_memcpy(
 __device__ __forceinline__ void st64(uint8_t *p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
 __device__ __forceinline__ void st128(uint8_t *p, u32x4 v) { __builtin_memcpy(p, &v, 16); }
 
+// 16-byte LDS accesses at DWORD aligned addresses.  gfx950 executes ds_read_b128 / ds_write_b128 at any dword aligned address
+// at full speed (tools/ubench/lds_widths.hip), but the compiler only emits them when it believes the address is 16-byte
+// aligned (otherwise it splits into ds_read2_b32 pairs); the alignment claim below is what selects the single instruction.
+__device__ __forceinline__ u32x4 lds_ld128(const uint8_t *p) { return *(const u32x4 *)__builtin_assume_aligned(p, 16); }
+__device__ __forceinline__ void lds_st128(uint8_t *p, u32x4 v) { *(u32x4 *)__builtin_assume_aligned(p, 16) = v; }
+__device__ __forceinline__ uint32_t lds_ld32(const uint8_t *p) { return *(const uint32_t *)__builtin_assume_aligned(p, 4); }
+
 // bytes [1..4] of the 8-byte value hi:lo, i.e. (hi:lo) >> (8*n), n in 0..3 (v_alignbyte_b32)
 __device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t n) { return __builtin_amdgcn_alignbyte(hi, lo, n); }
 

@@ -63,9 +63,9 @@ __device__ __forceinline__ void set_pattern(uint8_t *pat, u32x4 v)
     c = u32x4{ d2, d0, d1, d2 };
   }
 
-  st128(pat, a);
-  st128(pat + 16, b);
-  st128(pat + 32, c);
+  lds_st128(pat, a);
+  lds_st128(pat + 16, b);
+  lds_st128(pat + 32, c);
 }
 
 template <int S>
@@ -84,8 +84,8 @@ __device__ __forceinline__ u32x4 mask_symbol(u32x4 v)
 __device__ __forceinline__ u32x4 lds_read16(const uint8_t *base, uint32_t p)
 {
   const uint8_t *src = base + (p & ~3u);
-  const u32x4 x = ld128(src);
-  const uint32_t x4 = ld32(src + 16);
+  const u32x4 x = lds_ld128(src);
+  const uint32_t x4 = lds_ld32(src + 16);
   const uint32_t bs = p & 3u;
   return u32x4{ alignbyte(x.y, x.x, bs), alignbyte(x.z, x.y, bs), alignbyte(x.w, x.z, bs), alignbyte(x4, x.w, bs) };
 }
@@ -180,6 +180,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   // ---- ring top-up.  issue(): CPR loads; in load q, lanes CPR*g .. CPR*g+CPR-1 read T contiguous bytes of row RPI*q+g ----
   u32x4 pf[CPR];
   uint32_t pfAt[CPR], pfMirror[CPR];
+  uint64_t myBase[CPR];                                             // stream starts of the CPR rows this lane helps to load
 
   auto issue = [&]() {
     const uint32_t resident = E - (sp & ~15u);
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
       const bool valid = c < n;
       const uint32_t pos = e + c * 16u;
       const uint32_t ro = pos & RMASK;
-      pf[q] = ld128(payload + rowBase[r] + (valid ? pos : 0u));        // predicated-off lanes re-read the stream start
+      pf[q] = ld128(payload + myBase[q] + (valid ? pos : 0u));         // predicated-off lanes re-read the stream start
       pfAt[q] = valid ? (r * (uint32_t)RS + ro) : (DUMP + lane * 16u);  // ring slot or dump slot
       pfMirror[q] = (valid && ro < 32u) ? (r * (uint32_t)RS + (uint32_t)R + ro) : (DUMP + lane * 16u);
     }
@@ -207,13 +208,16 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 #pragma unroll
     for (int q = 0; q < CPR; q++)
     {
-      st128(ring + pfAt[q], pf[q]);
-      st128(ring + pfMirror[q], pf[q]);
+      lds_st128(ring + pfAt[q], pf[q]);
+      lds_st128(ring + pfMirror[q], pf[q]);
     }
   };
 
   // prologue: fill the ring, then read the stream header from it
   __syncthreads();
+#pragma unroll
+  for (int q = 0; q < CPR; q++)
+    myBase[q] = rowBase[(uint32_t)q * RPI + lane / CPR];
   for (int k = 0; k < R / T; k++)
   {
     issue();
@@ -547,11 +551,11 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
         const uint32_t total = c + n;                                  // bytes from dst that must end up valid
         u32x4 w = lds_read16(rng, srcp & RMASK);
         w.x = bfi((1u << (8u * c)) - 1u, pd, w.x);                     // keep the c valid bytes of the straddled dword
-        st128(dst, w);
+        lds_st128(dst, w);
         for (uint32_t k = 16; k < total; k += 16)
         {
           w = lds_read16(rng, (srcp + k) & RMASK);
-          st128(dst + k, w);
+          lds_st128(dst + k, w);
         }
         // new straddled dword: dword ((total & 15) >> 2) of the last chunk (if total is a multiple of 16: unknown -> 0 valid bytes)
         {
@@ -576,9 +580,9 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
           const u32x4 v = u32x4{ sym4, sym4, sym4, sym4 };
           u32x4 w = v;
           w.x = bfi((1u << (8u * c)) - 1u, pd, sym4);
-          st128(dst, w);
+          lds_st128(dst, w);
           for (uint32_t k = 16; k < total; k += 16)
-            st128(dst + k, v);
+            lds_st128(dst + k, v);
           pd = (total < 4u) ? w.x : sym4;
         }
         else
@@ -587,12 +591,12 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
           uint32_t ph = (phase + (uint32_t)S - c % (uint32_t)S) % (uint32_t)S;
           u32x4 w = lds_read16(pat, ph);
           w.x = bfi((1u << (8u * c)) - 1u, pd, w.x);
-          st128(dst, w);
+          lds_st128(dst, w);
           for (uint32_t k = 16; k < total; k += 16)
           {
             if constexpr (16 % S != 0) ph = (ph + 16u) % (uint32_t)S;
             w = lds_read16(pat, ph);
-            st128(dst + k, w);
+            lds_st128(dst + k, w);
           }
           const uint32_t idx = (total >> 2) & 3u;
           pd = (idx == 0u) ? w.x : (idx == 1u ? w.y : (idx == 2u ? w.z : w.w));
@@ -604,10 +608,15 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     }
 
     HS_STAMP(tDecode)
+    __syncthreads();                                                   // every lane is done reading the ring and writing its row
+
+    // ---- the loads issued before the decode step have had the whole round to arrive: move them into the ring first,
+    //      so that this wait never includes the flush stores below (vmcnt counts loads and stores in order) ----
+    land();
+    HS_STAMP(tLand)
     // ---- flush ----
     const uint32_t produced = o - base;
     const bool uniform = __ballot(active && produced == (uint32_t)T && base == __builtin_amdgcn_readfirstlane(base)) == ~0ull;
-    __syncthreads();
 
     if (uniform)
     {
@@ -616,7 +625,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
       u32x4 fv[CPR];
 #pragma unroll
       for (int q = 0; q < CPR; q++)
-        fv[q] = ld128(tile + ((uint32_t)q * RPI + lane / CPR) * TS + (lane % CPR) * 16u);
+        fv[q] = lds_ld128(tile + ((uint32_t)q * RPI + lane / CPR) * TS + (lane % CPR) * 16u);
 #pragma unroll
       for (int q = 0; q < CPR; q++)
         st128(out + (uint64_t)(wgFirst + (uint32_t)q * RPI + lane / CPR) * B + ubase + (lane % CPR) * 16u, fv[q]);
@@ -647,11 +656,8 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
       }
     }
 
-    HS_STAMP(tFlush)
-    // ---- the loads issued before the decode step have had the whole round to arrive ----
-    land();
     __syncthreads();
-    HS_STAMP(tLand)
+    HS_STAMP(tFlush)
   }
 
 #ifdef HSRLE_STAMPS
