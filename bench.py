@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline benchmark of BASELINE.json on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size-gib G] [--block B] [--codec NAME]
+
+Workload (N = 1): `rle8_packed_multi` -- 8 bit Packed, the north-star codec -- on an 8 GiB run-distributed(8) synthetic buffer
+(BASELINE.json: "8-bit Packed decode of an 8 GiB synthetic buffer at 1 GPU"), cut into 4 KiB blocks that are each a
+complete reference stream.  A STEP is one decode of the whole container, device resident (compressed container and output both in
+HBM).  `value` = uncompressed GiB decoded per second (the reference's own unit, src/main.c:875,:1014); the encode throughput of
+the same buffer is reported next to it ("encode").  For N > 1 every rank owns its own 8 GiB shard (weak scaling, block-sharded,
+no data-path collective: SURVEY.md §8e); the RCCL gather of the compressed segments into one stream is timed separately
+("gather_ms") because it is not part of the decode path.
+
+The JSON line also carries
+  roofline      HBM roofline of the decode kernel: algorithmic bytes (compressed + uncompressed) / average kernel
+                duration measured with HIP events on the launch stream, against the 8 TB/s peak
+  cpu_baseline  the same decode on the host CPU, one thread, on a bounded sample of the same workload: the compiled reference
+                (oracle/_ref, kind "reference") when it is present, else the oracle's restatement (kind "port")
+  bit_exact     block streams of a sample equal the CPU codec's streams and the full decode equals the input
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, "hypersonic-rle-kit_amd", "python"))
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+def cpu_baseline(container_prefix, n_blocks, block_size, codec_key, expect):
+    """Decode the first n_blocks of the container on the host (bounded sample), single thread."""
+    import numpy as np
+    from hsrle_testlib import CODEC_BY_KEY, REF_SO, Oracle
+
+    codec = CODEC_BY_KEY[codec_key]
+    raw = container_prefix
+    offs = np.frombuffer(raw, dtype=np.uint64, count=n_blocks + 1, offset=64).copy()
+    p0 = 64 + 8 * (int(np.frombuffer(raw, dtype=np.uint32, count=1, offset=28)[0]) + 1)
+    payload = np.frombuffer(raw, dtype=np.uint8, offset=p0)
+    usize = n_blocks * block_size
+    out = np.zeros(usize + 256, dtype=np.uint8)
+
+    if os.path.exists(REF_SO):
+        kind = "reference"
+        lib = ctypes.CDLL(REF_SO)
+        fn = ctypes.cast(getattr(lib, codec.dname), ctypes.c_void_p)
+        lib.hsrle_ref_decode_blocks.restype = ctypes.c_uint64
+        lib.hsrle_ref_decode_blocks.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64]
+        run = lambda: lib.hsrle_ref_decode_blocks(fn, payload.ctypes.data, offs.ctypes.data, n_blocks, block_size, out.ctypes.data, usize)
+    else:
+        kind = "port"
+        ora = Oracle()
+        ora.lib.hso_decompress_blocks.restype = ctypes.c_uint64
+        ora.lib.hso_decompress_blocks.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64]
+        run = lambda: ora.lib.hso_decompress_blocks(codec.family, codec.S, codec.aligned, payload.ctypes.data, offs.ctypes.data, n_blocks, block_size, out.ctypes.data, usize)
+
+    assert run() == usize  # warm-up run, discarded (reference protocol: src/main.c:822-887)
+    best, total, reps = None, 0.0, 0
+    t_end = time.time() + 12.0
+    while reps < 3 or (time.time() < t_end and reps < 40):
+        t0 = time.perf_counter()
+        got = run()
+        dt = time.perf_counter() - t0
+        assert got == usize
+        total += dt
+        reps += 1
+        best = dt if best is None else min(best, dt)
+    ok = out[:usize].tobytes() == expect
+    return {"value": round(usize / 2**30 / (total / reps), 3), "best": round(usize / 2**30 / best, 3), "unit": "GiB/s", "cores": 1, "kind": kind,
+            "sample": f"decode of the first {usize >> 20} MiB ({n_blocks} blocks) of the same container, {reps} runs, mean", "matches_gpu_input": bool(ok)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size-gib", type=float, default=8.0, help="uncompressed bytes per GPU")
+    ap.add_argument("--block", type=int, default=4096)
+    ap.add_argument("--codec", default="rle8_packed_multi")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the library has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import hsrle
+
+    hsrle.lib()
+    from hsrle_testlib import CODEC_BY_KEY, Oracle
+
+    codec = CODEC_BY_KEY[args.codec]
+    size = int(args.size_gib * (1 << 30)) // args.block * args.block
+    seed = 2 if not distributed else 100 + rank  # config 2 seed 2; sharded config seeds 100 + rank
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- setup (untimed): synthetic input generated on the device, compressed once ----
+    src = hsrle.synth(hsrle.SYNTH_RUNS, codec.S, seed, size, device=dev)
+    dst = torch.empty(hsrle.container_bound(size, args.block), dtype=torch.uint8, device=dev)
+    ws = torch.empty(hsrle.workspace_size(size, args.block), dtype=torch.uint8, device=dev)
+    hsrle.compress_async(args.codec, src, dst, args.block, workspace=ws)
+    torch.cuda.synchronize()
+    info = hsrle.container_info(dst)
+    container = dst[: info.totalSize]
+    out = torch.empty(size, dtype=torch.uint8, device=dev)
+    status = torch.zeros(16, dtype=torch.int32, device=dev)
+
+    def step():
+        hsrle.decompress_async(container, info, out, status)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+
+    # ---- timed region: exactly K steps, bracketed by barrier + synchronize; HIP events on the launch stream ----
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    barrier()
+    wall = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps
+
+    if distributed:
+        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+
+    # ---- correctness (untimed) ----
+    ok = int(status[0].item()) == 0 and torch.equal(out, src)
+    sample_blocks = min(info.blockCount, (16 << 20) // args.block)
+    ora = Oracle()
+    host_sample = src[: sample_blocks * args.block].cpu().numpy()
+    table = container[64 : 64 + 8 * (sample_blocks + 1)].view(torch.int64).cpu().numpy()
+    p0 = info.payload_start
+    pay = container[p0 : p0 + int(table[sample_blocks])].cpu().numpy().tobytes()
+    gpu_streams = [pay[int(table[i]) : int(table[i + 1])] for i in range(sample_blocks)]
+    ok = ok and gpu_streams == ora.compress_blocks(codec, host_sample, args.block)
+
+    # ---- encode throughput of the same buffer (untimed for `value`) ----
+    for _ in range(2):
+        hsrle.compress_async(args.codec, src, dst, args.block, workspace=ws)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    enc_steps = max(3, args.steps // 4)
+    e0.record()
+    for _ in range(enc_steps):
+        hsrle.compress_async(args.codec, src, dst, args.block, workspace=ws)
+    e1.record()
+    torch.cuda.synchronize()
+    enc_ms = e0.elapsed_time(e1) / enc_steps
+
+    # ---- the one exchange step of the sharded path: gather the per-rank compressed segments into one stream ----
+    gather_ms = None
+    if distributed:
+        from hsrle import dist as hd
+
+        barrier()
+        g0 = time.perf_counter()
+        full = hd.gather_container(container, size * world, root=0)
+        barrier()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        del full
+
+    if rank == 0:
+        total_units = size * world
+        alg_bytes = size + info.totalSize
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "rle8_extreme Packed decode throughput, uncompressed bytes (device resident block container)",
+            "value": round(total_units / 2**30 / (wall / args.steps), 2),
+            "unit": "GiB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(wall / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": f"{args.codec} decode, {size / 2**30:g} GiB run-distributed(8) synthetic per GPU (seed {seed}), {args.block} B blocks, "
+                                   f"ratio {info.totalSize / size:.4f}", "codec": args.codec, "block_size": args.block, "blocks_per_gpu": info.blockCount, "sharding": f"blocks x{world}"},
+            "bit_exact": bool(ok),
+            "encode": {"value": round(size / 2**30 / (enc_ms * 1e-3), 2), "unit": "GiB/s", "ms": round(enc_ms, 4), "note": "same buffer, encode kernel + size scan + compaction"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": None, "kernel": "k_decode_blocks<PACKED,1>", "kernel_ms": round(kernel_ms, 4),
+                         "algorithmic_bytes": int(alg_bytes), "note": "algorithmic bytes = container (compressed) + uncompressed output per launch; PMC traffic in profiles/"},
+        }
+        if gather_ms is not None:
+            line["gather_ms"] = round(gather_ms, 3)
+        if not args.no_cpu and world == 1:
+            nb = min(info.blockCount, (1 << 30) // args.block)
+            prefix_end = p0 + int(container[64 + 8 * nb : 64 + 8 * nb + 8].view(torch.int64).item()) + 64
+            prefix = container[: min(prefix_end, container.numel())].cpu().numpy().tobytes()
+            expect = src[: nb * args.block].cpu().numpy().tobytes()
+            line["cpu_baseline"] = cpu_baseline(prefix, nb, args.block, args.codec, expect)
+        print(json.dumps(line), flush=True)
+
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

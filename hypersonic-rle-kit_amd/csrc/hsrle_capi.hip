@@ -254,12 +254,12 @@ __global__ __launch_bounds__(64) void k_synth(int kind, int S, uint64_t seed, ui
     while (at < len)
     {
       uint64_t r = splitmix64(st);
-      const uint32_t Z = 8u + (uint32_t)(r % 120u);
+      const uint32_t Z = (((r >> 32) & 3u) == 0u) ? 40u + (uint32_t)(r % 120u) : 10u + (uint32_t)(r % 16u);
       for (uint32_t k = 0; k < Z && at + k < len; k++) o[at + k] = 0;
       at += Z;
       r = splitmix64(st);
-      const uint32_t Bn = 1u + (uint32_t)(r % 6u);
-      for (uint32_t k = 0; k < Bn && at + k < len; k++) o[at + k] = vals[(r >> (8 + 8 * k)) % 6u];
+      const uint32_t Bn = 1u + (uint32_t)(r % 9u);
+      for (uint32_t k = 0; k < Bn && at + k < len; k++) o[at + k] = vals[(r >> (8 + 4 * k)) % 6u];
       at += Bn;
     }
   }

@@ -1,0 +1,189 @@
+"""Multi-GPU sharding of the block container: one process per GPU, torch.distributed (backend "nccl" = RCCL
+over xGMI on the GPU node, "gloo" in the CPU tests).
+
+The path shards by INDEPENDENT UNITS: every block is a complete reference stream, so rank r simply owns the contiguous block
+range [r*n/W, (r+1)*n/W) -- encode and decode need no data-path collective at all.  The only exchange step is assembling ONE
+container from the per-rank segments (or cutting one container into per-rank segments):
+
+    gather_container():  all_gather of the per-rank payload sizes (W x int64)  ->  every rank knows every payload offset
+                         point-to-point send (ranks) / recv (root) of [offset table | payload]  =  gatherv over xGMI:
+                         the root receives on its W-1 distinct links at the same time, which is why a direct gatherv
+                         beats a ring for this one-to-one-root pattern
+    scatter_container(): the inverse (root -> ranks), so that a container produced elsewhere can be decoded by W GPUs
+
+Both are codec agnostic: they move bytes and fix up the offset table.  The reference has nothing comparable (it is single
+threaded and single device; its only sharded format, rle8m, is decoded by one OpenCL device: src/rle8_ocl.c:265-404).
+"""
+import struct
+
+import torch
+import torch.distributed as dist
+
+HEADER_SIZE = 64
+TAIL_PAD = 32
+MAGIC = b"HSRLEKIT"
+
+
+def shard_blocks(block_count, world_size, rank):
+    """Contiguous block range of `rank`: (first, count)."""
+    first = rank * block_count // world_size
+    last = (rank + 1) * block_count // world_size
+    return first, last - first
+
+
+def shard_bytes(total_size, block_size, world_size, rank):
+    """Byte range of the uncompressed buffer that `rank` owns: (offset, size)."""
+    nb = (total_size + block_size - 1) // block_size
+    first, count = shard_blocks(nb, world_size, rank)
+    lo = first * block_size
+    hi = min((first + count) * block_size, total_size)
+    return lo, max(hi - lo, 0)
+
+
+def pack_header(codec, uncompressed_size, block_size, block_count, payload_size):
+    total = HEADER_SIZE + 8 * (block_count + 1) + payload_size + TAIL_PAD
+    return MAGIC + struct.pack("<IIQIIQQ", 1, codec, uncompressed_size, block_size, block_count, payload_size, total) + bytes(16)
+
+
+def unpack_header(raw):
+    raw = bytes(raw[:HEADER_SIZE])
+    if raw[:8] != MAGIC:
+        raise ValueError("not an hsrle container")
+    version, codec, usize, bsize, bcount, psize, total = struct.unpack_from("<IIQIIQQ", raw, 8)
+    return {"version": version, "codec": codec, "uncompressedSize": usize, "blockSize": bsize, "blockCount": bcount, "payloadSize": psize, "totalSize": total}
+
+
+def _header_of(container):
+    return unpack_header(container[:HEADER_SIZE].cpu().numpy().tobytes())
+
+
+def _p2p(ops):
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+
+def gather_container(local_container, total_uncompressed_size, root=0, group=None):
+    """Assemble ONE container on `root` from the containers every rank produced for its own block range.
+
+    local_container: uint8 tensor (device of the backend) holding this rank's container (may be None / empty if the rank
+    owns no blocks).  Returns the assembled container on root, None on the other ranks.
+    """
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    dev = local_container.device if local_container is not None else torch.device("cpu")
+
+    if local_container is not None and local_container.numel() >= HEADER_SIZE:
+        h = _header_of(local_container)
+        mine = [h["codec"], h["blockSize"], h["blockCount"], h["payloadSize"]]
+    else:
+        h, mine = None, [-1, 0, 0, 0]
+
+    # exchange step 1: everybody learns everybody's block count and payload size
+    info = torch.tensor(mine, dtype=torch.int64, device=dev)
+    infos = [torch.zeros_like(info) for _ in range(world)]
+    dist.all_gather(infos, info, group=group)
+    infos = [t.cpu().tolist() for t in infos]
+    codec = max(i[0] for i in infos)
+    block_size = max(i[1] for i in infos)
+    counts = [i[2] for i in infos]
+    psizes = [i[3] for i in infos]
+    nblocks, payload = sum(counts), sum(psizes)
+    table_at, payload_at = HEADER_SIZE, HEADER_SIZE + 8 * (nblocks + 1)
+
+    if rank != root:
+        if h is not None and counts[rank] > 0:
+            lt = HEADER_SIZE
+            lp = HEADER_SIZE + 8 * (counts[rank] + 1)
+            _p2p([dist.P2POp(dist.isend, local_container[lt : lt + 8 * counts[rank]].contiguous(), root, group),
+                  dist.P2POp(dist.isend, local_container[lp : lp + psizes[rank]].contiguous(), root, group)])
+        return None
+
+    out = torch.zeros(payload_at + payload + TAIL_PAD, dtype=torch.uint8, device=dev)
+    out[:HEADER_SIZE] = torch.frombuffer(bytearray(pack_header(codec, total_uncompressed_size, block_size, nblocks, payload)), dtype=torch.uint8).to(dev)
+
+    # exchange step 2: gatherv of [offset table | payload] straight into their final places
+    ops, blk, pay = [], 0, 0
+    for r in range(world):
+        if counts[r] > 0:
+            tdst = out[table_at + 8 * blk : table_at + 8 * (blk + counts[r])]
+            pdst = out[payload_at + pay : payload_at + pay + psizes[r]]
+            if r == root:
+                lt, lp = HEADER_SIZE, HEADER_SIZE + 8 * (counts[r] + 1)
+                tdst.copy_(local_container[lt : lt + 8 * counts[r]])
+                pdst.copy_(local_container[lp : lp + psizes[r]])
+            else:
+                ops += [dist.P2POp(dist.irecv, tdst, r, group), dist.P2POp(dist.irecv, pdst, r, group)]
+        blk += counts[r]
+        pay += psizes[r]
+    _p2p(ops)
+
+    # offsets were relative to each rank's payload: add the payload prefix of the owning rank
+    table = out[table_at : table_at + 8 * (nblocks + 1)].view(torch.int64)
+    blk, pay = 0, 0
+    for r in range(world):
+        if counts[r] > 0:
+            table[blk : blk + counts[r]] += pay
+        blk += counts[r]
+        pay += psizes[r]
+    table[nblocks] = payload
+    return out
+
+
+def scatter_container(container, root=0, device=None, group=None):
+    """Inverse of gather_container: cut the root's container into one container per rank (contiguous block ranges).
+
+    Returns this rank's container (its blocks renumbered from 0, uncompressedSize = its byte range), or None if it owns no block.
+    """
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if rank == root:
+        dev = container.device
+        h = _header_of(container)
+        meta = torch.tensor([h["codec"], h["blockSize"], h["blockCount"], h["uncompressedSize"]], dtype=torch.int64, device=dev)
+    else:
+        dev = device if device is not None else torch.device("cpu")
+        meta = torch.zeros(4, dtype=torch.int64, device=dev)
+    dist.broadcast(meta, root, group=group)
+    codec, block_size, nblocks, usize = meta.cpu().tolist()
+    table_at, payload_at = HEADER_SIZE, HEADER_SIZE + 8 * (nblocks + 1)
+
+    # the root tells every rank the payload range of its blocks
+    ranges = torch.zeros(2 * world, dtype=torch.int64, device=dev)
+    if rank == root:
+        table = container[table_at : table_at + 8 * (nblocks + 1)].view(torch.int64).cpu()
+        for r in range(world):
+            first, count = shard_blocks(nblocks, world, r)
+            ranges[2 * r] = int(table[first])
+            ranges[2 * r + 1] = int(table[first + count])
+    dist.broadcast(ranges, root, group=group)
+    ranges = ranges.cpu().tolist()
+
+    first, count = shard_blocks(nblocks, world, rank)
+    p0, p1 = ranges[2 * rank], ranges[2 * rank + 1]
+    lo, size = shard_bytes(usize, block_size, world, rank)
+    local = None
+    if count > 0:
+        local = torch.zeros(HEADER_SIZE + 8 * (count + 1) + (p1 - p0) + TAIL_PAD, dtype=torch.uint8, device=dev)
+        local[:HEADER_SIZE] = torch.frombuffer(bytearray(pack_header(codec, size, block_size, count, p1 - p0)), dtype=torch.uint8).to(dev)
+
+    ops = []
+    if rank == root:
+        for r in range(world):
+            f, c = shard_blocks(nblocks, world, r)
+            if c == 0:
+                continue
+            tsrc = container[table_at + 8 * f : table_at + 8 * (f + c + 1)]
+            psrc = container[payload_at + ranges[2 * r] : payload_at + ranges[2 * r + 1]]
+            if r == root:
+                local[HEADER_SIZE : HEADER_SIZE + 8 * (c + 1)].copy_(tsrc)
+                local[HEADER_SIZE + 8 * (c + 1) : HEADER_SIZE + 8 * (c + 1) + (p1 - p0)].copy_(psrc)
+            else:
+                ops += [dist.P2POp(dist.isend, tsrc.contiguous(), r, group), dist.P2POp(dist.isend, psrc.contiguous(), r, group)]
+    elif count > 0:
+        ops += [dist.P2POp(dist.irecv, local[HEADER_SIZE : HEADER_SIZE + 8 * (count + 1)], root, group),
+                dist.P2POp(dist.irecv, local[HEADER_SIZE + 8 * (count + 1) : HEADER_SIZE + 8 * (count + 1) + (p1 - p0)], root, group)]
+    _p2p(ops)
+
+    if local is not None:
+        t = local[HEADER_SIZE : HEADER_SIZE + 8 * (count + 1)].view(torch.int64)
+        t -= p0
+    return local

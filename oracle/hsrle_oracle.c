@@ -1154,3 +1154,25 @@ uint32_t hso_compress_blocks(int family, int S, int aligned, const uint8_t *pIn,
 
   return (uint32_t)nBlocks;
 }
+
+/* Decode `nBlocks` block streams (payload + offsets[i] .. offsets[i+1]) into pOut + i * blockSize.  Returns the number of
+ * bytes produced, 0 on any failure.  Used by tests and by bench.py's cpu_baseline leg ("port"). */
+uint64_t hso_decompress_blocks(int family, int S, int aligned, const uint8_t *payload, const uint64_t *offsets, uint64_t nBlocks,
+                               uint32_t blockSize, uint8_t *pOut, uint64_t outSize)
+{
+  uint64_t produced = 0;
+
+  for (uint64_t b = 0; b < nBlocks; b++)
+  {
+    const uint64_t at = b * blockSize;
+    if (at >= outSize)
+      return 0;
+    const uint32_t room = (uint32_t)((outSize - at) < blockSize ? (outSize - at) : blockSize);
+    const uint32_t got = hso_decompress(family, S, aligned, payload + offsets[b], (uint32_t)(offsets[b + 1] - offsets[b]), pOut + at, room);
+    if (got == 0)
+      return 0;
+    produced += got;
+  }
+
+  return produced;
+}

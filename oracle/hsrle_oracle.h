@@ -64,6 +64,13 @@ uint32_t hso_compress_blocks(int family, int symbolBytes, int symAligned,
                              const uint8_t *pIn, uint64_t inSize, uint32_t blockSize,
                              uint8_t *pOut, uint32_t stride, uint32_t *pSizes);
 
+/* Decode nBlocks block streams (payload + offsets[i] .. offsets[i+1]) into pOut + i * blockSize; returns bytes produced. */
+uint64_t hso_decompress_blocks(int family, int symbolBytes, int symAligned, const uint8_t *payload, const uint64_t *offsets,
+                               uint64_t nBlocks, uint32_t blockSize, uint8_t *pOut, uint64_t outSize);
+
+/* oracle/hsrle_synth.c: bytes [offset, offset + size) of a deterministic synthetic workload (offset multiple of 64 KiB) */
+int hso_synth(int kind, int symbolBytes, uint64_t seed, uint64_t offset, uint8_t *out, uint64_t size);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,3 +39,39 @@ int hsrle_ref_has_avx2(void)
   _DetectCPUFeatures();
   return avx2Supported ? 1 : 0;
 }
+
+/* Run one of the reference's decompress functions (passed by address) over a sequence of block streams: what bench.py's
+ * cpu_baseline leg times as kind "reference".  The reference decoders write up to 128 bytes past a block's end
+ * (rle_decompress_additional_size); blocks are decoded in order so the next block repairs that, and the caller gives the
+ * output buffer 256 bytes of slack for the last one. */
+#include <stdint.h>
+typedef uint32_t (*hsrle_ref_codec_fn)(const uint8_t *, uint32_t, uint8_t *, uint32_t);
+
+uint64_t hsrle_ref_decode_blocks(hsrle_ref_codec_fn fn, const uint8_t *payload, const uint64_t *offsets, uint64_t nBlocks, uint32_t blockSize,
+                                 uint8_t *pOut, uint64_t outSize)
+{
+  uint64_t produced = 0;
+  for (uint64_t b = 0; b < nBlocks; b++)
+  {
+    const uint64_t at = b * blockSize;
+    const uint32_t room = (uint32_t)((outSize - at) < blockSize ? (outSize - at) : blockSize);
+    const uint32_t got = fn(payload + offsets[b], (uint32_t)(offsets[b + 1] - offsets[b]), pOut + at, room);
+    if (got == 0) return 0;
+    produced += got;
+  }
+  return produced;
+}
+
+uint64_t hsrle_ref_encode_blocks(hsrle_ref_codec_fn fn, const uint8_t *pIn, uint64_t inSize, uint32_t blockSize, uint8_t *pOut, uint32_t stride, uint32_t *pSizes)
+{
+  const uint64_t nBlocks = (inSize + blockSize - 1) / blockSize;
+  for (uint64_t b = 0; b < nBlocks; b++)
+  {
+    const uint64_t off = b * blockSize;
+    const uint32_t len = (uint32_t)((inSize - off) < blockSize ? (inSize - off) : blockSize);
+    const uint32_t c = fn(pIn + off, len, pOut + b * stride, stride);
+    if (c == 0) return 0;
+    pSizes[b] = c;
+  }
+  return nBlocks;
+}

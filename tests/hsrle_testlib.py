@@ -84,8 +84,32 @@ class Oracle:
         L.hso_call.restype = ctypes.c_uint32
         L.hso_call.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]
 
+        L.hso_synth.restype = ctypes.c_int
+        L.hso_synth.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]
+        L.hso_compress_blocks.restype = ctypes.c_uint32
+        L.hso_compress_blocks.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+
     def bounds(self, n):
         return self.lib.hso_compress_bounds(n)
+
+    def synth(self, kind, symbol_bytes, seed, size, offset=0):
+        """Bytes [offset, offset + size) of a synthetic workload (offset multiple of 64 KiB); numpy uint8 array."""
+        out = np.empty(size, dtype=np.uint8)
+        ok = self.lib.hso_synth(kind, symbol_bytes, seed, offset, out.ctypes.data, size)
+        assert ok
+        return out
+
+    def compress_blocks(self, codec, data, block_size):
+        """Encode every block of `data` (numpy uint8) independently; returns the list of block streams."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        n = data.size
+        nb = (n + block_size - 1) // block_size
+        stride = (self.bounds(block_size) + 15) & ~15
+        out = np.empty(nb * stride, dtype=np.uint8)
+        sizes = np.empty(nb, dtype=np.uint32)
+        got = self.lib.hso_compress_blocks(codec.family, codec.S, codec.aligned, data.ctypes.data, n, block_size, out.ctypes.data, stride, sizes.ctypes.data)
+        assert got == nb
+        return [out[i * stride : i * stride + int(sizes[i])].tobytes() for i in range(nb)]
 
     def compress(self, codec, data):
         data = bytes(data)
@@ -274,10 +298,28 @@ def synth_chunk_py(kind, S, seed, chunk_index, size=SYNTH_CHUNK):
         vals = bytes([0x01, 0x02, 0x03, 0xFF, 0xFE, 0x04])
         while len(out) < size:
             st, r = splitmix64(st)
-            Z = 8 + r % 120
+            Z = 40 + r % 120 if ((r >> 32) & 3) == 0 else 10 + r % 16
             out += bytes(Z)
             st, r = splitmix64(st)
-            B = 1 + r % 6
+            B = 1 + r % 9
             for k in range(B):
-                out.append(vals[(r >> (8 + 8 * k)) % 6])
+                out.append(vals[(r >> (8 + 4 * k)) % 6])
     return bytes(out[:size])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# host-side statement of the block container (include/hsrle.h), used by the CPU tests of the sharding logic
+
+
+def build_container(codec_index, uncompressed_size, block_size, streams):
+    """Assemble a container exactly as the device does (header, u64 offset table, payload, 32 zero bytes)."""
+    import struct
+
+    nb = len(streams)
+    payload = b"".join(streams)
+    offs = [0]
+    for s in streams:
+        offs.append(offs[-1] + len(s))
+    total = 64 + 8 * (nb + 1) + len(payload) + 32
+    head = b"HSRLEKIT" + struct.pack("<IIQIIQQ", 1, codec_index, uncompressed_size, block_size, nb, len(payload), total) + bytes(16)
+    return head + struct.pack(f"<{nb + 1}Q", *offs) + payload + bytes(32)

@@ -1,0 +1,74 @@
+"""The C-ABI library loads (no GPU needed) and exports every symbol include/hsrle.h declares; no compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(REPO, "hypersonic-rle-kit_amd", "libhsrle_hip.so")
+HEADER = os.path.join(REPO, "include", "hsrle.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    names = set(re.findall(r"\b((?:hsrle|rle)[A-Za-z0-9_]*)\s*\(", re.sub(r"/\*.*?\*/", "", text, flags=re.S)))
+    # macro-declared drop-in pairs
+    pairs = ["rle8_3symlut", "rle8_7symlut", "rle128_sym", "rle128_sym_packed", "rle128_byte", "rle128_byte_packed"]
+    for W in (16, 24, 32, 48, 64):
+        pairs += [f"rle{W}_{v}" for v in ("sym", "sym_packed", "byte", "byte_packed", "3symlut_sym", "7symlut_sym", "3symlut_byte", "7symlut_byte")]
+    for p in pairs:
+        names.add(p + "_compress")
+        names.add(p + "_decompress")
+    return sorted(n for n in names if not n.endswith("_t"))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(LIB):
+        import subprocess
+
+        subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(REPO, "hypersonic-rle-kit_amd")])
+    return ctypes.CDLL(LIB)
+
+
+def test_all_declared_symbols_are_exported(lib):
+    syms = declared_symbols()
+    assert len(syms) >= 2 + 100 + 15  # helpers + 50 drop-in pairs + hsrle_* API
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, f"not exported: {missing}"
+
+
+def test_reference_names_present(lib):
+    """Exactly the names of the reference's rle.h for the hot path (src/rle.h:100-394)."""
+    for s in ("rle_compress_bounds", "rle_decompress_additional_size", "rle8_multi_compress", "rle8_single_compress", "rle8_decompress",
+              "rle8_packed_multi_compress", "rle8_packed_single_compress", "rle8_packed_decompress", "rle64_3symlut_byte_compress",
+              "rle64_3symlut_byte_decompress", "rle24_sym_packed_compress", "rle128_byte_packed_decompress"):
+        assert hasattr(lib, s)
+
+
+def test_pure_host_helpers(lib):
+    """Helpers that need no device."""
+    lib.rle_compress_bounds.restype = ctypes.c_uint32
+    assert lib.rle_compress_bounds(ctypes.c_uint32(1000)) == 1193
+    assert lib.rle_compress_bounds(ctypes.c_uint32((1 << 30) + 1)) == 0
+    lib.rle_decompress_additional_size.restype = ctypes.c_uint32
+    assert lib.rle_decompress_additional_size() == 128
+    lib.hsrle_codec_from_name.restype = ctypes.c_int
+    lib.hsrle_codec_name.restype = ctypes.c_char_p
+    for i in range(50):
+        name = lib.hsrle_codec_name(i)
+        assert lib.hsrle_codec_from_name(name) == i
+    assert lib.hsrle_codec_from_name(b"rle8_packed_multi") == 1 and lib.hsrle_codec_from_name(b"rle64_3symlut_byte") == 44
+    assert lib.hsrle_codec_from_name(b"nope") == -1
+    lib.hsrle_container_bound.restype = ctypes.c_uint64
+    lib.hsrle_container_bound.argtypes = [ctypes.c_uint64, ctypes.c_uint32]
+    assert lib.hsrle_container_bound(1 << 20, 4096) > (1 << 20)
+    assert lib.hsrle_container_bound(1 << 20, 4000) == 0  # block size must be a multiple of 128
+
+
+def test_codec_table_matches_tests_table(lib):
+    from hsrle_testlib import CODECS
+
+    lib.hsrle_codec_name.restype = ctypes.c_char_p
+    assert [lib.hsrle_codec_name(i).decode() for i in range(50)] == [c.key for c in CODECS]

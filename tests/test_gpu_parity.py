@@ -133,3 +133,70 @@ def test_partial_block_range(hs):
     lo, hi = first * 512, (first + count) * 512
     assert got[lo:hi] == data[lo:hi]
     assert got[:lo] == bytes(lo) and got[hi:] == bytes(len(data) - hi)  # nothing outside the range is written
+
+
+def test_golden_vectors_through_the_c_abi(hs):
+    """Committed golden vectors minted from the compiled reference: drop-in compress must reproduce size + sha256."""
+    import base64, hashlib, json, os
+
+    vec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "vectors.json")))
+    for entry in vec["inputs"]:
+        data = base64.b64decode(entry["input"])
+        for c in CODECS:
+            g = entry["codecs"][c.key]
+            size, stream = hs.call_dropin(c.cname, data, hs.compress_bounds(len(data)))
+            assert size == g["size"] and hashlib.sha256(stream).hexdigest() == g["sha256"], f"{c.key} on {entry['name']}"
+
+
+def test_synthetic_generator_matches_cpu(hs, oracle):
+    for kind, S, size in ((0, 1, 3 * 65536 + 777), (0, 8, 2 * 65536), (0, 3, 70000), (1, 1, 200000), (0, 16, 65536 + 5)):
+        dev = hs.synth(kind, S, 9, size).cpu().numpy().tobytes()
+        assert dev == oracle.synth(kind, S, 9, size).tobytes()
+
+
+def test_synthetic_manifest_blocks_and_mono(hs):
+    """1 MiB synthetic workloads: 64 KiB block streams and the monolithic stream equal the REFERENCE's (sha256 manifest)."""
+    import hashlib, json, os
+
+    man = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "synth_manifest.json")))
+    for key, e in man["entries"].items():
+        ckey, kind = key.split("/kind")
+        c = CODEC_BY_KEY[ckey]
+        src = hs.synth(int(kind), c.S, man["seed"], man["size"])
+        container, info = hs.compress(ckey, src, block_size=man["block"])
+        _, streams = hs.split_container(container.cpu().numpy().tobytes())
+        assert [(len(s), hashlib.sha256(s).hexdigest()) for s in streams] == [(b["size"], b["sha256"]) for b in e["blocks"]], key
+        assert hs.decompress(container).equal(src)
+    # the monolithic (drop-in) stream of the two headline codecs
+    for key in ("rle8_packed_multi/kind0", "rle64_3symlut_byte/kind1"):
+        ckey, kind = key.split("/kind")
+        c = CODEC_BY_KEY[ckey]
+        data = hs.synth(int(kind), c.S, man["seed"], man["size"]).cpu().numpy().tobytes()
+        size, stream = hs.call_dropin(c.cname, data, hs.compress_bounds(len(data)))
+        assert (size, hashlib.sha256(stream).hexdigest()) == (man["entries"][key]["mono"]["size"], man["entries"][key]["mono"]["sha256"])
+        size, dec = hs.call_dropin(c.dname, stream, len(data))
+        assert size == len(data) and dec == data
+
+
+@pytest.mark.parametrize("key,kind,size,block", [("rle8_packed_multi", 0, (1 << 30) + 4096 * 3 + 100, 4096), ("rle64_3symlut_byte", 1, 88473600, 4096),
+                                                 ("rle8_packed_multi", 0, 1 << 28, 128), ("rle128_byte_packed", 0, 1 << 27, 1024)])
+def test_full_size_round_trip_properties(hs, oracle, key, kind, size, block):
+    """BASELINE-size buffers: encode -> decode round trip is the identity, the status word stays 0, a sample of block
+    streams equals the oracle's, and the container header is consistent (size-independent properties)."""
+    import torch
+
+    c = CODEC_BY_KEY[key]
+    src = hs.synth(kind, c.S, 3, size)
+    container, info = hs.compress(key, src, block_size=block)
+    assert info.uncompressedSize == size and info.blockCount == (size + block - 1) // block and info.totalSize == container.numel()
+    out = hs.decompress(container)
+    assert torch.equal(out, src)
+    # sample: first 256 blocks and last 64 blocks against the oracle
+    table = container[64 : 64 + 8 * (info.blockCount + 1)].view(torch.int64).cpu().numpy()
+    p0 = info.payload_start
+    for first, count in ((0, 256), (info.blockCount - 64, 64)):
+        pay = container[p0 + int(table[first]) : p0 + int(table[first + count])].cpu().numpy().tobytes()
+        base = int(table[first])
+        got = [pay[int(table[first + i]) - base : int(table[first + i + 1]) - base] for i in range(count)]
+        host = src[first * block : min((first + count) * block, size)].cpu().numpy()
+        assert got == oracle.compress_blocks(c, host, block)
