@@ -99,6 +99,12 @@ __device__ __forceinline__ uint32_t ex32(uint64_t lo, uint64_t hi, uint32_t pos)
   return (uint32_t)(sh < 64u ? a : b);
 }
 
+// The workgroup IS one wavefront (64 threads): LDS instructions of one wave execute in order, so lanes see each other's
+// LDS writes without an s_barrier and without the `s_waitcnt vmcnt(0)` that __syncthreads() implies (which would stall
+// every round until the round's global stores have completed).  This only stops the compiler from moving LDS accesses
+// across the point.
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+
 // (mask & a) | (~mask & b)  -> v_bfi_b32
 __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (mask & a) | (~mask & b); }
 
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     if (done) want = 0;
     rowReq[lane] = ((uint64_t)want << 32) | E;
     E += want << 4;
-    __syncthreads();
+    wave_sync();
 #pragma unroll
     for (int q = 0; q < CPR; q++)
     {
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   };
 
   // prologue: fill the ring, then read the stream header from it
-  __syncthreads();
+  wave_sync();
 #pragma unroll
   for (int q = 0; q < CPR; q++)
     myBase[q] = rowBase[(uint32_t)q * RPI + lane / CPR];
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   {
     issue();
     land();
-    __syncthreads();
+    wave_sync();
   }
 
   if (active)
@@ -287,6 +293,176 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     const uint32_t target = umin((o / (uint32_t)T + 1u) * (uint32_t)T, blen);
     uint32_t itersLeft = 2u * (uint32_t)T + 16u;
 
+    if constexpr (S == 1)
+    {
+      // ================= 8 bit: flat loop, header parse with selects (no data-dependent branches in the parse) =================
+      constexpr uint32_t SHORT_SINGLE = TR::kPacked ? 2u : 4u;
+      bool stall = false;                                              // this lane waits for the next round's ring bytes
+
+      for (;;)
+      {
+        const bool act = !done && !stall && o < target;
+        if (__ballot(act) == 0ull) break;
+        if (itersLeft-- == 0u) { err |= DEC_ERR_STREAM; done = true; break; }
+
+        const bool idle = (lit | run) == 0u;
+        const bool fin = act && idle && last;
+        const bool bad = act && idle && !last && (sp + 2u > slen);
+        const bool hungry = act && idle && !last && !bad && (avail0 - sp < MAXHDR) && (avail0 < lim);
+        const bool parse = act && idle && !last && !bad && !hungry;
+        if (bad) err |= DEC_ERR_STREAM;
+        done = done || fin || bad;
+        stall = stall || hungry;
+
+        // ---------------- packet header: one 16-byte ring read, fields picked with shifts ----------------
+        const u32x4 hv = lds_read16(rng, sp & RMASK);
+        const uint64_t lo = (uint64_t)hv.x | ((uint64_t)hv.y << 32), hi = (uint64_t)hv.z | ((uint64_t)hv.w << 32);
+        uint32_t cnt, pos, nsym = sym4, range, used, endNow = 0, hbad = 0;
+
+        if constexpr (TR::kLut)
+        {
+          const uint32_t w16 = hv.x & 0xFFFFu;
+          const uint32_t idx = w16 >> (FAM == LUT3 ? 14 : 13);
+          const uint32_t c7 = (w16 >> TR::RB) & 0x7Fu;
+          const uint32_t r7 = w16 & ((1u << TR::RB) - 1u);
+          const bool isNew = idx == (uint32_t)TR::K;
+          pos = isNew ? 3u : 2u;
+          // the move-to-front list lives in lut[k][0], one byte per entry
+          uint32_t sb = (hv.x >> 16) & 0xFFu;
+#pragma unroll
+          for (int k = 0; k < TR::K; k++)
+            if (idx == (uint32_t)k) sb = lut[k][0];
+          const uint32_t limit = isNew ? (uint32_t)TR::K - 1u : idx;
+          if (parse)
+          {
+#pragma unroll
+            for (int k = TR::K - 1; k >= 1; k--)
+              if ((uint32_t)k <= limit) lut[k][0] = lut[k - 1][0];
+            lut[0][0] = sb;
+          }
+          nsym = sb * 0x01010101u;
+          const uint32_t cext = ex32(lo, hi, pos);
+          cnt = (c7 == 0u) ? cext : (c7 == 1u ? (cext & 0xFFFFu) : c7);
+          pos += (c7 == 0u) ? 4u : (c7 == 1u ? 2u : 0u);
+          const uint32_t rext = ex32(lo, hi, pos);
+          range = (r7 == 0u) ? rext : (r7 == 1u ? (rext & 0xFFFFu) : r7);
+          used = pos + ((r7 == 0u) ? 4u : (r7 == 1u ? 2u : 0u));
+          endNow = (r7 == 1u && range == 0u) ? 1u : 0u;
+          hbad = (!endNow && range < 2u) ? 1u : 0u;
+          range = (range >= 2u) ? range - 1u : 0u;                      // literal count + 1, like the other families
+        }
+        else
+        {
+          const uint32_t b0 = hv.x & 0xFFu;
+
+          if constexpr (!TR::kPacked)
+          {
+            cnt = single ? b0 : ((hv.x >> 8) & 0xFFu);                  // multi: sym, cnt ...   single: cnt ...
+            pos = single ? 1u : 2u;
+            nsym = single ? sym4 : b0 * 0x01010101u;
+            const uint32_t c32 = ex32(lo, hi, pos);
+            const bool longc = cnt == 0u;
+            cnt = longc ? c32 : cnt;
+            pos += longc ? 4u : 0u;
+          }
+          else
+          {
+            cnt = single ? b0 : (b0 & 0x7Fu);
+            const uint32_t c32 = (uint32_t)(lo >> 8);
+            const bool longc = cnt == 0u;
+            cnt = longc ? c32 : cnt;
+            pos = longc ? 5u : 1u;
+            const bool newSym = !single && !(b0 & 0x80u);
+            const uint32_t sb = (uint32_t)(lo >> (8u * pos)) & 0xFFu;
+            nsym = newSym ? sb * 0x01010101u : sym4;
+            pos += newSym ? 1u : 0u;
+          }
+
+          const uint32_t w = ex32(lo, hi, pos);
+          const uint32_t r0 = w & 0xFFu;
+
+          if (TR::kPacked && !single)
+          {
+            const bool longr = (r0 & 1u) != 0u;                         // 7-bit-or-4-byte range (rle8_extreme_cpu.h:1883-1899)
+            range = longr ? (w >> 1) : (r0 >> 1);
+            used = pos + (longr ? 4u : 1u);
+            endNow = (longr && range == 0u) ? 1u : 0u;
+          }
+          else
+          {
+            const bool longr = r0 == 0u;
+            const uint32_t r32 = ex32(lo, hi, pos + 1u);
+            range = longr ? r32 : r0;
+            used = pos + (longr ? 5u : 1u);
+            endNow = (longr && range == 0u) ? 1u : 0u;
+          }
+        }
+
+        if (parse)
+        {
+          const uint32_t shortv = single ? SHORT_SINGLE : TR::SHORT;
+          sym4 = nsym;
+          lit = (range == 0u || endNow) ? 0u : range - 1u;               // a 7 bit range byte of 0x00 carries no literals (q11)
+          run = (cnt == 0u || endNow) ? 0u : cnt + shortv - (TR::kLut ? 2u : 1u);
+          last = endNow || cnt == 0u;
+          sp += used;
+          const bool sbad = hbad || sp > slen || lit > slen - sp || (lit == 0u && run == 0u && !last);
+          if (sbad) { err |= DEC_ERR_STREAM; done = true; }
+        }
+
+        const bool go = act && !done && !stall;
+
+        // ---- literals: tile chunks at the dword aligned positions A + 16k receive ring bytes [sp - c + 16k, +16) ----
+        {
+          const uint32_t resident = (avail0 > sp) ? avail0 - sp : 0u;
+          const uint32_t n = (go && lit != 0u) ? umin(umin(lit, target - o), resident) : 0u;
+          if (go && lit != 0u && n == 0u) stall = true;                  // literals not resident yet: continue next round
+
+          if (n != 0u)
+          {
+            const uint32_t q = o - base, c = q & 3u;
+            uint8_t *dst = row + (q & ~3u);
+            const uint32_t srcp = sp - c;
+            const uint32_t total = c + n;
+            u32x4 w = lds_read16(rng, srcp & RMASK);
+            w.x = bfi((1u << (8u * c)) - 1u, pd, w.x);                   // keep the c valid bytes of the straddled dword
+            lds_st128(dst, w);
+            for (uint32_t k = 16; k < total; k += 16)
+            {
+              w = lds_read16(rng, (srcp + k) & RMASK);
+              lds_st128(dst + k, w);
+            }
+            const uint32_t idx = (total >> 2) & 3u;
+            pd = (idx == 0u) ? w.x : (idx == 1u ? w.y : (idx == 2u ? w.z : w.w));
+            sp += n;
+            lit -= n;
+            o += n;
+          }
+        }
+
+        // ---- run: the same aligned chunks filled with the byte-broadcast symbol ----
+        {
+          const uint32_t m = (go && !stall && lit == 0u && run != 0u) ? umin(run, target - o) : 0u;
+
+          if (m != 0u)
+          {
+            const uint32_t q = o - base, c = q & 3u;
+            uint8_t *dst = row + (q & ~3u);
+            const uint32_t total = c + m;
+            const u32x4 v = u32x4{ sym4, sym4, sym4, sym4 };
+            u32x4 w = v;
+            w.x = bfi((1u << (8u * c)) - 1u, pd, sym4);
+            lds_st128(dst, w);
+            for (uint32_t k = 16; k < total; k += 16)
+              lds_st128(dst + k, v);
+            pd = (total < 4u) ? w.x : sym4;
+            run -= m;
+            o += m;
+          }
+        }
+      }
+    }
+    else
     while (!done && o < target)
     {
       if (itersLeft-- == 0u) { err |= DEC_ERR_STREAM; done = true; break; }
@@ -608,7 +784,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     }
 
     HS_STAMP(tDecode)
-    __syncthreads();                                                   // every lane is done reading the ring and writing its row
+    wave_sync();                                                   // every lane is done reading the ring and writing its row
 
     // ---- the loads issued before the decode step have had the whole round to arrive: move them into the ring first,
     //      so that this wait never includes the flush stores below (vmcnt counts loads and stores in order) ----
@@ -634,7 +810,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     {
       rowStart[lane] = base;
       rowLen[lane] = produced;
-      __syncthreads();
+      wave_sync();
 #pragma unroll 1
       for (int q = 0; q < CPR; q++)
       {
@@ -656,7 +832,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
       }
     }
 
-    __syncthreads();
+    wave_sync();
     HS_STAMP(tFlush)
   }
 

@@ -51,6 +51,12 @@ def _lib():
     global _LIB
     if _LIB is not None:
         return _LIB
+    try:
+        # torch ships its own HIP runtime; load it first so that this library binds to the SAME runtime instance
+        # (two runtimes in one process do not see each other's allocations)
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C {PKG_DIR}` (hipcc, gfx950); there is no fallback codec")
     L = ctypes.CDLL(LIB_PATH)

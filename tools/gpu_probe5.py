@@ -7,13 +7,15 @@ bs=int(sys.argv[2]) if len(sys.argv)>2 else 4096
 codec=sys.argv[3] if len(sys.argv)>3 else 'rle8_packed_multi'
 src=hsrle.synth(0,1,2,size)
 cont,info=hsrle.compress(codec,src,block_size=bs)
-out=torch.empty(size,dtype=torch.uint8,device='cuda'); st=torch.zeros(64,dtype=torch.int32,device='cuda')
+out=torch.empty(size,dtype=torch.uint8,device='cuda'); st=torch.zeros(128,dtype=torch.int32,device='cuda')
 hsrle.decompress_async(cont,info,out,st); torch.cuda.synchronize()
 st.zero_()
 hsrle.decompress_async(cont,info,out,st); torch.cuda.synchronize()
-d=st[16:].view(torch.int64).cpu().tolist()
+d=st[16:].view(torch.int64).cpu().tolist()+[0]*12
 tI,tD,tF,tL,nR,nIt,nW=d[:7]
 tot=tI+tD+tF+tL
 print('waves',nW,'rounds/wave',nR/nW,'iters/round',nIt/nR)
 print('cycles per round: issue %.0f decode %.0f flush %.0f land %.0f total %.0f'%(tI/nR,tD/nR,tF/nR,tL/nR,tot/nR))
+if len(d)>11 and d[11]:
+    print('wave-level iterations/round %.2f ; per lane-iteration cycles: parse %.0f lit %.0f run %.0f (lane-iterations %d)'%(d[7]/nR, d[8]/d[11], d[9]/d[11], d[10]/d[11], d[11]))
 print('ok', int(st[0].item())==0 and torch.equal(out,src))

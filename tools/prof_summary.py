@@ -1,7 +1,7 @@
 import sys, os, csv, glob, collections
 O=sys.argv[1]
 # kernel stats
-for f in glob.glob(O+'/trace/**/*kernel_stats.csv', recursive=True):
+for f in glob.glob(O+'/trace/**/*kernel_stats.csv', recursive=True)+glob.glob(O+'/stats/**/*kernel_stats.csv', recursive=True):
     print('== kernel stats', os.path.basename(f))
     for r in csv.DictReader(open(f)):
         print('  %-90s calls %4s avg_ns %12s total_ns %14s pct %s'%(r['Name'][:90], r['Calls'], r.get('AverageNs',r.get('Average')), r.get('TotalDurationNs',''), r.get('Percentage','')))
