@@ -80,14 +80,33 @@ __device__ __forceinline__ u32x4 mask_symbol(u32x4 v)
   else return v;
 }
 
-// 16 bytes starting at byte `p` of a buffer, using only dword aligned LDS reads (20 bytes) and a byte funnel
+// 16 bytes starting at byte offset `sh` (0..15) of the 32-byte value [x | y]: dword select + v_alignbyte
+__device__ __forceinline__ u32x4 funnel16(u32x4 x, u32x4 y, uint32_t sh)
+{
+  const bool d2 = (sh & 8u) != 0u, d1 = (sh & 4u) != 0u;
+  const uint32_t t0 = d2 ? x.z : x.x, t1 = d2 ? x.w : x.y, t2 = d2 ? y.x : x.z, t3 = d2 ? y.y : x.w, t4 = d2 ? y.z : y.x, t5 = d2 ? y.w : y.y;
+  const uint32_t z0 = d1 ? t1 : t0, z1 = d1 ? t2 : t1, z2 = d1 ? t3 : t2, z3 = d1 ? t4 : t3, z4 = d1 ? t5 : t4;
+  const uint32_t b = sh & 3u;
+  return u32x4{ alignbyte(z1, z0, b), alignbyte(z2, z1, b), alignbyte(z3, z2, b), alignbyte(z4, z3, b) };
+}
+
+// 16 bytes starting at byte `p` of an LDS buffer whose base is 16-byte aligned, using two NATURALLY ALIGNED 16-byte reads
+// (gfx950 executes an LDS access that is not naturally aligned one lane at a time: 64 cycles instead of ~15, measured in
+// tools/ubench/lds_align.hip) and a byte funnel in registers.
 __device__ __forceinline__ u32x4 lds_read16(const uint8_t *base, uint32_t p)
 {
-  const uint8_t *src = base + (p & ~3u);
-  const u32x4 x = lds_ld128(src);
-  const uint32_t x4 = lds_ld32(src + 16);
-  const uint32_t bs = p & 3u;
-  return u32x4{ alignbyte(x.y, x.x, bs), alignbyte(x.z, x.y, bs), alignbyte(x.w, x.z, bs), alignbyte(x4, x.w, bs) };
+  const uint8_t *src = base + (p & ~15u);
+  return funnel16(lds_ld128(src), lds_ld128(src + 16), p & 15u);
+}
+
+// low c bytes (c in 0..15) from `keep`, the rest from `fresh`
+__device__ __forceinline__ u32x4 merge_low(u32x4 keep, u32x4 fresh, uint32_t c)
+{
+  const uint64_t ones = ~0ull;
+  const uint64_t mlo = (c >= 8u) ? ones : ~(ones << (8u * c));
+  const uint64_t mhi = (c <= 8u) ? 0ull : ~(ones << (8u * (c - 8u)));
+  const uint32_t m0 = (uint32_t)mlo, m1 = (uint32_t)(mlo >> 32), m2 = (uint32_t)mhi, m3 = (uint32_t)(mhi >> 32);
+  return u32x4{ (keep.x & m0) | (fresh.x & ~m0), (keep.y & m1) | (fresh.y & ~m1), (keep.z & m2) | (fresh.z & ~m2), (keep.w & m3) | (fresh.w & ~m3) };
 }
 
 // 32 bits at byte offset pos (0..12) of the 16-byte little-endian value hi:lo
@@ -117,8 +136,8 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
                                                       uint32_t B, uint32_t firstBlock, uint32_t blockCount, uint32_t *__restrict__ status)
 {
   using TR = Traits<FAM, S, AL>;
-  constexpr int TS = T + 16 + 4;             // tile row stride: 16 bytes of over-write slack; stride/4 odd (bank spread)
-  constexpr int RS = R + 32 + 4;             // ring row stride: bytes [R, R+32) mirror [0, 32) so a 20-byte read never wraps
+  constexpr int TS = T + 16;                 // tile row stride: 16 bytes of over-write slack; an odd multiple of 16 (bank spread)
+  constexpr int RS = R + 48;                 // ring row stride: bytes [R, R+32) mirror [0, 32) so a 32-byte read never wraps
   constexpr int CPR = T / 16;                // 16-byte chunks per tile row == lanes that serve one row in top-up / flush
   constexpr int RPI = 64 / CPR;              // rows covered by one top-up / flush instruction
   constexpr uint32_t RMASK = (uint32_t)R - 1u;
@@ -127,11 +146,11 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   constexpr bool kPat = (S != 1);            // 8 bit: the fill pattern is one broadcast register
   static_assert((R & (R - 1)) == 0 && R >= 128 && R % T == 0, "ring size must be a power of two and a multiple of T");
   static_assert(T == 64 || T == 128, "tile rows are flushed as whole 64/128-byte pieces");
-  static_assert((TS / 4) % 2 == 1 && (RS / 4) % 2 == 1, "row strides are an odd number of dwords");
+  static_assert((TS / 16) % 2 == 1 && (RS / 16) % 2 == 1 && TS % 16 == 0 && RS % 16 == 0, "row strides are odd multiples of 16 bytes");
 
   __shared__ __attribute__((aligned(16))) uint8_t tile[64 * TS];
   __shared__ __attribute__((aligned(16))) uint8_t ring[64 * RS + 64 * 16]; // + 64 dump slots where predicated-off stores go
-  __shared__ __attribute__((aligned(16))) uint8_t pats[kPat ? 64 * 52 : 16];
+  __shared__ __attribute__((aligned(16))) uint8_t pats[kPat ? 64 * 48 : 16];
   __shared__ uint64_t rowBase[64];                                  // stream start of every row, relative to `payload`
   __shared__ uint64_t rowReq[64];                                   // per round: (chunks to load << 32) | loaded end
   __shared__ uint32_t rowStart[64], rowLen[64];                     // slow flush path only
@@ -144,7 +163,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 
   uint8_t *const row = tile + lane * TS;
   uint8_t *const rng = ring + lane * RS;
-  uint8_t *const pat = pats + (kPat ? lane * 52 : 0);
+  uint8_t *const pat = pats + (kPat ? lane * 48 : 0);
 
   // ---- per-lane stream state ----
   uint32_t slen = 0, blen = 0;
@@ -156,7 +175,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   uint32_t phase = 0;     // S > 1: pattern phase of the next run byte
   uint32_t o = 0;         // bytes of this block produced so far
   uint32_t sym4 = 0;      // S == 1: current symbol, byte-broadcast
-  uint32_t pd = 0;        // the dword of the tile row that contains the write position (its low (q & 3) bytes are valid)
+  u32x4 acc = u32x4{ 0, 0, 0, 0 }; // the 16-byte chunk of the tile row that contains the write position (its low (q & 15) bytes are valid)
   bool last = false;      // the stream ends after the current packet's literals
   bool done = true;
   bool single = false;
@@ -420,20 +439,23 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 
           if (n != 0u)
           {
-            const uint32_t q = o - base, c = q & 3u;
-            uint8_t *dst = row + (q & ~3u);
+            const uint32_t q = o - base, c = q & 15u;
+            uint8_t *dst = row + (q & ~15u);
             const uint32_t srcp = sp - c;
             const uint32_t total = c + n;
-            u32x4 w = lds_read16(rng, srcp & RMASK);
-            w.x = bfi((1u << (8u * c)) - 1u, pd, w.x);                   // keep the c valid bytes of the straddled dword
+            const uint8_t *src = rng + ((srcp & ~15u) & RMASK);
+            const uint32_t sh = srcp & 15u;
+            u32x4 x = lds_ld128(src), y = lds_ld128(src + 16);
+            u32x4 w = merge_low(acc, funnel16(x, y, sh), c);             // keep the c valid bytes of the straddled chunk
             lds_st128(dst, w);
             for (uint32_t k = 16; k < total; k += 16)
             {
-              w = lds_read16(rng, (srcp + k) & RMASK);
+              x = y;
+              y = lds_ld128(rng + (((srcp & ~15u) + k + 16u) & RMASK));
+              w = funnel16(x, y, sh);
               lds_st128(dst + k, w);
             }
-            const uint32_t idx = (total >> 2) & 3u;
-            pd = (idx == 0u) ? w.x : (idx == 1u ? w.y : (idx == 2u ? w.z : w.w));
+            acc = w;
             sp += n;
             lit -= n;
             o += n;
@@ -446,16 +468,15 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 
           if (m != 0u)
           {
-            const uint32_t q = o - base, c = q & 3u;
-            uint8_t *dst = row + (q & ~3u);
+            const uint32_t q = o - base, c = q & 15u;
+            uint8_t *dst = row + (q & ~15u);
             const uint32_t total = c + m;
             const u32x4 v = u32x4{ sym4, sym4, sym4, sym4 };
-            u32x4 w = v;
-            w.x = bfi((1u << (8u * c)) - 1u, pd, sym4);
+            const u32x4 w = merge_low(acc, v, c);
             lds_st128(dst, w);
             for (uint32_t k = 16; k < total; k += 16)
               lds_st128(dst + k, v);
-            pd = (total < 4u) ? w.x : sym4;
+            acc = (total <= 16u) ? w : v;
             run -= m;
             o += m;
           }
@@ -721,23 +742,22 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
         const uint32_t n = umin(umin(lit, target - o), resident);
         if (n == 0) break;                                             // literals not resident yet: continue next round
 
-        const uint32_t q = o - base, c = q & 3u;
-        uint8_t *dst = row + (q & ~3u);
+        const uint32_t q = o - base, c = q & 15u;
+        uint8_t *dst = row + (q & ~15u);
         const uint32_t srcp = sp - c;
         const uint32_t total = c + n;                                  // bytes from dst that must end up valid
-        u32x4 w = lds_read16(rng, srcp & RMASK);
-        w.x = bfi((1u << (8u * c)) - 1u, pd, w.x);                     // keep the c valid bytes of the straddled dword
+        const uint32_t sh = srcp & 15u;
+        u32x4 x = lds_ld128(rng + ((srcp & ~15u) & RMASK)), y = lds_ld128(rng + (((srcp & ~15u) + 16u) & RMASK));
+        u32x4 w = merge_low(acc, funnel16(x, y, sh), c);               // keep the c valid bytes of the straddled chunk
         lds_st128(dst, w);
         for (uint32_t k = 16; k < total; k += 16)
         {
-          w = lds_read16(rng, (srcp + k) & RMASK);
+          x = y;
+          y = lds_ld128(rng + (((srcp & ~15u) + k + 16u) & RMASK));
+          w = funnel16(x, y, sh);
           lds_st128(dst + k, w);
         }
-        // new straddled dword: dword ((total & 15) >> 2) of the last chunk (if total is a multiple of 16: unknown -> 0 valid bytes)
-        {
-          const uint32_t idx = (total >> 2) & 3u;
-          pd = (idx == 0u) ? w.x : (idx == 1u ? w.y : (idx == 2u ? w.z : w.w));
-        }
+        acc = w;
         sp += n;
         lit -= n;
         o += n;
@@ -747,26 +767,24 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
       if (lit == 0 && run != 0 && o < target)
       {
         const uint32_t m = umin(run, target - o);
-        const uint32_t q = o - base, c = q & 3u;
-        uint8_t *dst = row + (q & ~3u);
+        const uint32_t q = o - base, c = q & 15u;
+        uint8_t *dst = row + (q & ~15u);
         const uint32_t total = c + m;
 
         if constexpr (S == 1)
         {
           const u32x4 v = u32x4{ sym4, sym4, sym4, sym4 };
-          u32x4 w = v;
-          w.x = bfi((1u << (8u * c)) - 1u, pd, sym4);
+          const u32x4 w = merge_low(acc, v, c);
           lds_st128(dst, w);
           for (uint32_t k = 16; k < total; k += 16)
             lds_st128(dst + k, v);
-          pd = (total < 4u) ? w.x : sym4;
+          acc = (total <= 16u) ? w : v;
         }
         else
         {
           // pattern byte for tile byte (A + j) is pat[(phase - c + j) mod S]; pat holds 48 bytes of the periodic pattern
-          uint32_t ph = (phase + (uint32_t)S - c % (uint32_t)S) % (uint32_t)S;
-          u32x4 w = lds_read16(pat, ph);
-          w.x = bfi((1u << (8u * c)) - 1u, pd, w.x);
+          uint32_t ph = (phase + 16u * (uint32_t)S - c) % (uint32_t)S;
+          u32x4 w = merge_low(acc, lds_read16(pat, ph), c);
           lds_st128(dst, w);
           for (uint32_t k = 16; k < total; k += 16)
           {
@@ -774,8 +792,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
             w = lds_read16(pat, ph);
             lds_st128(dst + k, w);
           }
-          const uint32_t idx = (total >> 2) & 3u;
-          pd = (idx == 0u) ? w.x : (idx == 1u ? w.y : (idx == 2u ? w.z : w.w));
+          acc = w;
           phase = (phase + m) % (uint32_t)S;
         }
         run -= m;
