@@ -152,7 +152,8 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   __shared__ __attribute__((aligned(16))) uint8_t ring[64 * RS + 64 * 16]; // + 64 dump slots where predicated-off stores go
   __shared__ __attribute__((aligned(16))) uint8_t pats[kPat ? 64 * 48 : 16];
   __shared__ uint64_t rowBase[64];                                  // stream start of every row, relative to `payload`
-  __shared__ uint64_t rowReq[64];                                   // per round: (chunks to load << 32) | loaded end
+  __shared__ uint64_t rowReq[64];                                   // per round: (chunks requested << 32) | loaded end
+  __shared__ uint32_t rowTake[64];                                  // per round: chunks that fit into the ring when they land
   __shared__ uint32_t rowStart[64], rowLen[64];                     // slow flush path only
 
   const uint32_t lane = threadIdx.x;
@@ -207,12 +208,14 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   uint32_t pfAt[CPR], pfMirror[CPR];
   uint64_t myBase[CPR];                                             // stream starts of the CPR rows this lane helps to load
 
+  uint32_t wantReq = 0;                                             // chunks this row requested in issue()
+
   auto issue = [&]() {
-    const uint32_t resident = E - (sp & ~15u);
-    uint32_t want = umin(umin(((uint32_t)R - resident) >> 4, (uint32_t)CPR), (lim - E) >> 4);
-    if (done) want = 0;
-    rowReq[lane] = ((uint64_t)want << 32) | E;
-    E += want << 4;
+    // request up to CPR chunks behind E.  Whether they FIT is decided when they land (after this round's decode has
+    // freed ring space), so the ring only has to hold one round of consumption, not two.
+    wantReq = umin((uint32_t)CPR, (lim - E) >> 4);
+    if (done) wantReq = 0;
+    rowReq[lane] = ((uint64_t)wantReq << 32) | E;
     wave_sync();
 #pragma unroll
     for (int q = 0; q < CPR; q++)
@@ -224,17 +227,25 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
       const uint32_t pos = e + c * 16u;
       const uint32_t ro = pos & RMASK;
       pf[q] = ld128(payload + myBase[q] + (valid ? pos : 0u));         // predicated-off lanes re-read the stream start
-      pfAt[q] = valid ? (r * (uint32_t)RS + ro) : (DUMP + lane * 16u);  // ring slot or dump slot
-      pfMirror[q] = (valid && ro < 32u) ? (r * (uint32_t)RS + (uint32_t)R + ro) : (DUMP + lane * 16u);
+      pfAt[q] = r * (uint32_t)RS + ro;                                  // ring slot of this chunk
+      pfMirror[q] = (ro < 32u) ? (r * (uint32_t)RS + (uint32_t)R + ro) : (DUMP + lane * 16u);
     }
   };
 
   auto land = [&]() {
+    // chunks that fit now: the ring may hold bytes [floor16(sp), floor16(sp) + R)
+    const uint32_t fit = ((uint32_t)R - (E - (sp & ~15u))) >> 4;
+    const uint32_t take = umin(wantReq, fit);
+    rowTake[lane] = take;
+    E += take << 4;
+    wave_sync();
 #pragma unroll
     for (int q = 0; q < CPR; q++)
     {
-      lds_st128(ring + pfAt[q], pf[q]);
-      lds_st128(ring + pfMirror[q], pf[q]);
+      const uint32_t r = (uint32_t)q * RPI + lane / CPR, c = lane % CPR;
+      const bool valid = c < rowTake[r];
+      lds_st128(ring + (valid ? pfAt[q] : DUMP + lane * 16u), pf[q]);
+      lds_st128(ring + (valid ? pfMirror[q] : DUMP + lane * 16u), pf[q]);
     }
   };
 
@@ -811,6 +822,9 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     const uint32_t produced = o - base;
     const bool uniform = __ballot(active && produced == (uint32_t)T && base == __builtin_amdgcn_readfirstlane(base)) == ~0ull;
 
+#ifdef HSRLE_STAMPS
+    if (!uniform) nIter++;   // diagnostic: rounds that took the slow flush path
+#endif
     if (uniform)
     {
       // fast path: all 64 rows hold T bytes of the same round: every store instruction writes RPI x T contiguous bytes
@@ -821,6 +835,9 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
         fv[q] = lds_ld128(tile + ((uint32_t)q * RPI + lane / CPR) * TS + (lane % CPR) * 16u);
 #pragma unroll
       for (int q = 0; q < CPR; q++)
+#ifdef HSRLE_ABLATE_STORES  // timing-only diagnostic build: only one lane in 64 stores (output is wrong)
+        if (lane == 0)
+#endif
         st128(out + (uint64_t)(wgFirst + (uint32_t)q * RPI + lane / CPR) * B + ubase + (lane % CPR) * 16u, fv[q]);
     }
     else

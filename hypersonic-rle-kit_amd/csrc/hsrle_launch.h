@@ -33,10 +33,10 @@ typedef hipError_t (*EncodeLaunch)(const EncodeArgs &, hipStream_t);
 
 constexpr int kCodecCount = 50;
 #ifndef HSRLE_DECODE_TILE
-#define HSRLE_DECODE_TILE 128
+#define HSRLE_DECODE_TILE 64
 #endif
 #ifndef HSRLE_DECODE_RING
-#define HSRLE_DECODE_RING 256
+#define HSRLE_DECODE_RING 128
 #endif
 constexpr int kDecodeTile = HSRLE_DECODE_TILE; // bytes produced per lane and round (k_decode_blocks T)
 constexpr int kDecodeRing = HSRLE_DECODE_RING; // per-lane stream ring in LDS (k_decode_blocks R)
