@@ -183,19 +183,26 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   uint32_t err = 0;
   [[maybe_unused]] uint32_t lut[TR::kLut ? TR::K : 1][TR::SW];
 
+  // Stream positions (sp, E, slen, lim) are VIRTUAL: position 0 is the T-byte aligned global address at or below the
+  // stream start, the stream itself begins at virtual position g0.  Top-up loads then fetch T-byte aligned pieces, so
+  // every 64/128-byte sector of the container is requested exactly once by this workgroup.
+  uint32_t g0 = 0;
   {
-    uint64_t off0 = 0;
+    uint64_t base0 = 0;
     if (active)
     {
-      off0 = offsets[b];
-      slen = (uint32_t)(offsets[b + 1] - off0);
+      const uint64_t off0 = offsets[b];
+      g0 = (uint32_t)((uintptr_t)(payload + off0) & (uintptr_t)(T - 1));
+      g0 = umin(g0, (uint32_t)(off0 < 0xFFFFFFFFull ? off0 : 0xFFFFFFFFull) + 64u) & ~15u; // never reach in front of the container (>= 64 header bytes precede the payload)
+      base0 = off0 - g0;                                               // may be "negative" for block 0: wraps, added to `payload` again below
+      slen = (uint32_t)(offsets[b + 1] - off0) + g0;
       const uint64_t start = (uint64_t)b * B;
       blen = (uint32_t)((U - start) < (uint64_t)B ? (U - start) : (uint64_t)B);
-      const uint64_t room = (uint64_t)(payloadEnd - payload) - off0;
+      const uint64_t room = (uint64_t)(payloadEnd - payload) - base0;
       lim = (uint32_t)(room > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : room) & ~15u;
       done = false;
     }
-    rowBase[lane] = off0;
+    rowBase[lane] = base0;
   }
 
   auto set_sym = [&](u32x4 v) {
@@ -263,17 +270,18 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 
   if (active)
   {
-    sp = TR::kHeaderSize;
+    sp = g0 + TR::kHeaderSize;
+    const uint8_t *hd = rng + g0;                                      // g0 is a multiple of 16 and < R
 
-    if (slen < TR::kHeaderSize + 2u || ld32(rng) != blen || ld32(rng + 4) != slen)
+    if (slen < g0 + TR::kHeaderSize + 2u || ld32(hd) != blen || ld32(hd + 4) != slen - g0)
     {
       err |= DEC_ERR_HEADER;
       done = true;
     }
     else if constexpr (S == 1 && !TR::kLut)
     {
-      const uint32_t mode = rng[8];
-      if (mode == 1u) { single = true; set_sym(u32x4{ rng[9], 0, 0, 0 }); sp = 10; }
+      const uint32_t mode = hd[8];
+      if (mode == 1u) { single = true; set_sym(u32x4{ hd[9], 0, 0, 0 }); sp = g0 + 10; }
       else if (mode != 0u) { err |= DEC_ERR_MODE; done = true; }
     }
   }
