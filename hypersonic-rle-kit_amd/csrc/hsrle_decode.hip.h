@@ -137,24 +137,21 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 {
   using TR = Traits<FAM, S, AL>;
   constexpr int TS = T + 16;                 // tile row stride: 16 bytes of over-write slack; an odd multiple of 16 (bank spread)
-  constexpr int RS = R + 48;                 // ring row stride: bytes [R, R+32) mirror [0, 32) so a 32-byte read never wraps
+  constexpr int RS = R + 32;                 // ring row stride: bytes [R, R+32) mirror [0, 32) so a 32-byte read never wraps
   constexpr int CPR = T / 16;                // 16-byte chunks per tile row == lanes that serve one row in top-up / flush
   constexpr int RPI = 64 / CPR;              // rows covered by one top-up / flush instruction
   constexpr uint32_t RMASK = (uint32_t)R - 1u;
   constexpr uint32_t MAXHDR = 1u + 4u + (uint32_t)S + 4u + 2u; // longest packet header of any family (+ slack)
-  constexpr uint32_t DUMP = 64u * (uint32_t)RS; // offset of the 64 dump slots behind the ring rows
   constexpr bool kPat = (S != 1);            // 8 bit: the fill pattern is one broadcast register
   static_assert((R & (R - 1)) == 0 && R >= 128 && R % T == 0, "ring size must be a power of two and a multiple of T");
   static_assert(T == 64 || T == 128, "tile rows are flushed as whole 64/128-byte pieces");
-  static_assert((TS / 16) % 2 == 1 && (RS / 16) % 2 == 1 && TS % 16 == 0 && RS % 16 == 0, "row strides are odd multiples of 16 bytes");
+  static_assert((TS / 16) % 2 == 1 && TS % 16 == 0 && RS % 16 == 0, "rows are 16-byte aligned; the tile stride is an odd multiple of 16 bytes");
 
   __shared__ __attribute__((aligned(16))) uint8_t tile[64 * TS];
-  __shared__ __attribute__((aligned(16))) uint8_t ring[64 * RS + 64 * 16]; // + 64 dump slots where predicated-off stores go
+  __shared__ __attribute__((aligned(16))) uint8_t ring[64 * RS];
   __shared__ __attribute__((aligned(16))) uint8_t pats[kPat ? 64 * 48 : 16];
-  __shared__ uint64_t rowBase[64];                                  // stream start of every row, relative to `payload`
-  __shared__ uint64_t rowReq[64];                                   // per round: (chunks requested << 32) | loaded end
-  __shared__ uint32_t rowTake[64];                                  // per round: chunks that fit into the ring when they land
-  __shared__ uint32_t rowStart[64], rowLen[64];                     // slow flush path only
+  // per-row scalars (stream base, top-up requests, flush extents) are exchanged between lanes with wave shuffles
+  // (ds_bpermute: no LDS allocation), so the whole LDS budget is ring + tile: 15 KB per wave -> 10 waves per CU
 
   const uint32_t lane = threadIdx.x;
   const uint32_t wgFirst = firstBlock + blockIdx.x * 64u;
@@ -187,6 +184,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   // stream start, the stream itself begins at virtual position g0.  Top-up loads then fetch T-byte aligned pieces, so
   // every 64/128-byte sector of the container is requested exactly once by this workgroup.
   uint32_t g0 = 0;
+  uint64_t myBase0 = 0;                                             // this row's (virtual) stream start, relative to `payload`
   {
     uint64_t base0 = 0;
     if (active)
@@ -202,7 +200,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
       lim = (uint32_t)(room > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : room) & ~15u;
       done = false;
     }
-    rowBase[lane] = base0;
+    myBase0 = base0;
   }
 
   auto set_sym = [&](u32x4 v) {
@@ -212,7 +210,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 
   // ---- ring top-up.  issue(): CPR loads; in load q, lanes CPR*g .. CPR*g+CPR-1 read T contiguous bytes of row RPI*q+g ----
   u32x4 pf[CPR];
-  uint32_t pfAt[CPR], pfMirror[CPR];
+  uint32_t pfAt[CPR];
   uint64_t myBase[CPR];                                             // stream starts of the CPR rows this lane helps to load
 
   uint32_t wantReq = 0;                                             // chunks this row requested in issue()
@@ -222,20 +220,15 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     // freed ring space), so the ring only has to hold one round of consumption, not two.
     wantReq = umin((uint32_t)CPR, (lim - E) >> 4);
     if (done) wantReq = 0;
-    rowReq[lane] = ((uint64_t)wantReq << 32) | E;
-    wave_sync();
 #pragma unroll
     for (int q = 0; q < CPR; q++)
     {
       const uint32_t r = (uint32_t)q * RPI + lane / CPR, c = lane % CPR;
-      const uint64_t req = rowReq[r];
-      const uint32_t e = (uint32_t)req, n = (uint32_t)(req >> 32);
+      const uint32_t e = (uint32_t)__shfl((int)E, (int)r, 64), n = (uint32_t)__shfl((int)wantReq, (int)r, 64);
       const bool valid = c < n;
       const uint32_t pos = e + c * 16u;
-      const uint32_t ro = pos & RMASK;
       pf[q] = ld128(payload + myBase[q] + (valid ? pos : 0u));         // predicated-off lanes re-read the stream start
-      pfAt[q] = r * (uint32_t)RS + ro;                                  // ring slot of this chunk
-      pfMirror[q] = (ro < 32u) ? (r * (uint32_t)RS + (uint32_t)R + ro) : (DUMP + lane * 16u);
+      pfAt[q] = r * (uint32_t)RS + (pos & RMASK);                       // ring slot of this chunk
     }
   };
 
@@ -243,16 +236,18 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     // chunks that fit now: the ring may hold bytes [floor16(sp), floor16(sp) + R)
     const uint32_t fit = ((uint32_t)R - (E - (sp & ~15u))) >> 4;
     const uint32_t take = umin(wantReq, fit);
-    rowTake[lane] = take;
     E += take << 4;
-    wave_sync();
 #pragma unroll
     for (int q = 0; q < CPR; q++)
     {
       const uint32_t r = (uint32_t)q * RPI + lane / CPR, c = lane % CPR;
-      const bool valid = c < rowTake[r];
-      lds_st128(ring + (valid ? pfAt[q] : DUMP + lane * 16u), pf[q]);
-      lds_st128(ring + (valid ? pfMirror[q] : DUMP + lane * 16u), pf[q]);
+      const uint32_t tk = (uint32_t)__shfl((int)take, (int)r, 64);
+      if (c < tk)
+      {
+        lds_st128(ring + pfAt[q], pf[q]);
+        if ((pfAt[q] - r * (uint32_t)RS) < 32u)
+          lds_st128(ring + pfAt[q] + (uint32_t)R, pf[q]);              // mirror of the first 32 ring bytes
+      }
     }
   };
 
@@ -260,7 +255,11 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   wave_sync();
 #pragma unroll
   for (int q = 0; q < CPR; q++)
-    myBase[q] = rowBase[(uint32_t)q * RPI + lane / CPR];
+  {
+    const int r = (int)((uint32_t)q * RPI + lane / CPR);
+    const uint32_t lo32 = (uint32_t)__shfl((int)(uint32_t)myBase0, r, 64), hi32 = (uint32_t)__shfl((int)(uint32_t)(myBase0 >> 32), r, 64);
+    myBase[q] = ((uint64_t)hi32 << 32) | lo32;
+  }
   for (int k = 0; k < R / T; k++)
   {
     issue();
@@ -850,24 +849,22 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     }
     else
     {
-      rowStart[lane] = base;
-      rowLen[lane] = produced;
-      wave_sync();
 #pragma unroll 1
       for (int q = 0; q < CPR; q++)
       {
         const uint32_t r = (uint32_t)q * RPI + lane / CPR, c = lane % CPR;
         const uint32_t rb = wgFirst + r;
-        const uint32_t valid = rowLen[r];
+        const uint32_t valid = (uint32_t)__shfl((int)produced, (int)r, 64);
+        const uint32_t rstart = (uint32_t)__shfl((int)base, (int)r, 64);
         const uint32_t co = c * 16u;
         if (rb >= lastBlockExcl || co >= valid)
           continue;
 
-        uint8_t *g = out + (uint64_t)rb * B + rowStart[r] + co;
+        uint8_t *g = out + (uint64_t)rb * B + rstart + co;
         const uint8_t *l = tile + r * TS + co;
 
         if (co + 16u <= valid)
-          st128(g, ld128(l));
+          st128(g, lds_ld128(l));
         else
           for (uint32_t k = 0; k < valid - co; k++)
             g[k] = l[k];
