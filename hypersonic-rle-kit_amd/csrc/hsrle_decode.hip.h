@@ -129,8 +129,9 @@ __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
 
 // FAM in {PLAIN, PACKED, LUT3, LUT7}; the 8 bit PLAIN / PACKED kernels also decode the Single modes (mode byte 1),
 // exactly like rle8_decompress / rle8_packed_decompress do.
-//   T = output bytes per lane and round (LDS tile row), R = per-lane stream ring size in LDS (power of two).
-template <int FAM, int S, int AL, int T, int R>
+//   T = output bytes per lane and flush (LDS tile row), Q = output bytes per lane and decode/top-up step (T % Q == 0),
+//   R = per-lane stream ring size in LDS (power of two).
+template <int FAM, int S, int AL, int T, int R, int Q = T>
 __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict__ payload, const uint64_t *__restrict__ offsets,
                                                       const uint8_t *__restrict__ payloadEnd, uint8_t *__restrict__ out, uint64_t U,
                                                       uint32_t B, uint32_t firstBlock, uint32_t blockCount, uint32_t *__restrict__ status)
@@ -139,11 +140,13 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   constexpr int TS = T + 16;                 // tile row stride: 16 bytes of over-write slack; an odd multiple of 16 (bank spread)
   constexpr int RS = R + 32;                 // ring row stride: bytes [R, R+32) mirror [0, 32) so a 32-byte read never wraps
   constexpr int CPR = T / 16;                // 16-byte chunks per tile row == lanes that serve one row in top-up / flush
-  constexpr int RPI = 64 / CPR;              // rows covered by one top-up / flush instruction
+  constexpr int RPI = 64 / CPR;              // rows covered by one flush instruction
+  constexpr int LPR = Q / 16;                // lanes that serve one row in a top-up (Q contiguous stream bytes)
+  constexpr int RPL = 64 / LPR;              // rows covered by one top-up instruction
   constexpr uint32_t RMASK = (uint32_t)R - 1u;
   constexpr uint32_t MAXHDR = 1u + 4u + (uint32_t)S + 4u + 2u; // longest packet header of any family (+ slack)
   constexpr bool kPat = (S != 1);            // 8 bit: the fill pattern is one broadcast register
-  static_assert((R & (R - 1)) == 0 && R >= 128 && R % T == 0, "ring size must be a power of two and a multiple of T");
+  static_assert((R & (R - 1)) == 0 && R >= 128 && R % Q == 0 && T % Q == 0 && (Q == 64 || Q == 128), "ring size must be a power of two and a multiple of Q");
   static_assert(T == 64 || T == 128, "tile rows are flushed as whole 64/128-byte pieces");
   static_assert((TS / 16) % 2 == 1 && TS % 16 == 0 && RS % 16 == 0, "rows are 16-byte aligned; the tile stride is an odd multiple of 16 bytes");
 
@@ -208,22 +211,22 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     else set_pattern<S>(pat, v);
   };
 
-  // ---- ring top-up.  issue(): CPR loads; in load q, lanes CPR*g .. CPR*g+CPR-1 read T contiguous bytes of row RPI*q+g ----
-  u32x4 pf[CPR];
-  uint32_t pfAt[CPR];
-  uint64_t myBase[CPR];                                             // stream starts of the CPR rows this lane helps to load
+  // ---- ring top-up.  issue(): LPR loads; in load q, lanes LPR*g .. LPR*g+LPR-1 read Q contiguous bytes of row RPL*q+g ----
+  u32x4 pf[LPR];
+  uint32_t pfAt[LPR];
+  uint64_t myBase[LPR];                                             // stream starts of the LPR rows this lane helps to load
 
   uint32_t wantReq = 0;                                             // chunks this row requested in issue()
 
   auto issue = [&]() {
-    // request up to CPR chunks behind E.  Whether they FIT is decided when they land (after this round's decode has
+    // request up to LPR chunks behind E.  Whether they FIT is decided when they land (after this round's decode has
     // freed ring space), so the ring only has to hold one round of consumption, not two.
-    wantReq = umin((uint32_t)CPR, (lim - E) >> 4);
+    wantReq = umin((uint32_t)LPR, (lim - E) >> 4);
     if (done) wantReq = 0;
 #pragma unroll
-    for (int q = 0; q < CPR; q++)
+    for (int q = 0; q < LPR; q++)
     {
-      const uint32_t r = (uint32_t)q * RPI + lane / CPR, c = lane % CPR;
+      const uint32_t r = (uint32_t)q * RPL + lane / LPR, c = lane % LPR;
       const uint32_t e = (uint32_t)__shfl((int)E, (int)r, 64), n = (uint32_t)__shfl((int)wantReq, (int)r, 64);
       const bool valid = c < n;
       const uint32_t pos = e + c * 16u;
@@ -238,9 +241,9 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     const uint32_t take = umin(wantReq, fit);
     E += take << 4;
 #pragma unroll
-    for (int q = 0; q < CPR; q++)
+    for (int q = 0; q < LPR; q++)
     {
-      const uint32_t r = (uint32_t)q * RPI + lane / CPR, c = lane % CPR;
+      const uint32_t r = (uint32_t)q * RPL + lane / LPR, c = lane % LPR;
       const uint32_t tk = (uint32_t)__shfl((int)take, (int)r, 64);
       if (c < tk)
       {
@@ -254,13 +257,13 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   // prologue: fill the ring, then read the stream header from it
   wave_sync();
 #pragma unroll
-  for (int q = 0; q < CPR; q++)
+  for (int q = 0; q < LPR; q++)
   {
-    const int r = (int)((uint32_t)q * RPI + lane / CPR);
+    const int r = (int)((uint32_t)q * RPL + lane / LPR);
     const uint32_t lo32 = (uint32_t)__shfl((int)(uint32_t)myBase0, r, 64), hi32 = (uint32_t)__shfl((int)(uint32_t)(myBase0 >> 32), r, 64);
     myBase[q] = ((uint64_t)hi32 << 32) | lo32;
   }
-  for (int k = 0; k < R / T; k++)
+  for (int k = 0; k < R / Q; k++)
   {
     issue();
     land();
@@ -304,6 +307,8 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     set_sym(u32x4{ 0, 0, 0, 0 }); // Packed decoders start with symbol 0 (rleX_extreme_cpu_decode.h:31-37, q5)
   }
 
+  uint32_t base = 0;      // block offset of the first byte of the tile row (multiple of 16); the row holds [base, o)
+
   // every spin is bounded: a malformed stream (or a bug) ends as DEC_ERR_STREAM, never as a hang
   uint32_t roundsLeft = B / (uint32_t)T + B / 16u + 64u; // output rounds + worst-case starved rounds (>= 16 stream bytes each)
 
@@ -321,14 +326,18 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     t0 = __builtin_readcyclecounter(); nRounds++;
 #endif
 
-    // ---- top-up for the NEXT round: the loads fly while this round decodes from the ring ----
-    const uint32_t avail0 = E;                                         // bytes [.., avail0) are readable during this round
+    const uint32_t flushTarget = umin((o / (uint32_t)T + 1u) * (uint32_t)T, blen);
+
+#pragma unroll 1
+    for (int step = 0; step < T / Q; step++)
+    {
+    // ---- top-up for the NEXT step: the loads fly while this step decodes from the ring ----
+    const uint32_t avail0 = E;                                         // bytes [.., avail0) are readable during this step
     issue();
     HS_STAMP(tIssue)
 
-    const uint32_t base = o;                                           // this round's tile row holds block bytes [base, ...)
-    const uint32_t target = umin((o / (uint32_t)T + 1u) * (uint32_t)T, blen);
-    uint32_t itersLeft = 2u * (uint32_t)T + 16u;
+    const uint32_t target = umin((o / (uint32_t)Q + 1u) * (uint32_t)Q, flushTarget);
+    uint32_t itersLeft = 2u * (uint32_t)Q + 16u;
 
     if constexpr (S == 1)
     {
@@ -350,6 +359,9 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
         if (bad) err |= DEC_ERR_STREAM;
         done = done || fin || bad;
         stall = stall || hungry;
+#ifdef HSRLE_STAMPS
+        if (hungry) tLand += 1ull << 40;   // diagnostic: header-starved events in the top bits
+#endif
 
         // ---------------- packet header: one 16-byte ring read, fields picked with shifts ----------------
         const u32x4 hv = lds_read16(rng, sp & RMASK);
@@ -454,6 +466,9 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
           const uint32_t resident = (avail0 > sp) ? avail0 - sp : 0u;
           const uint32_t n = (go && lit != 0u) ? umin(umin(lit, target - o), resident) : 0u;
           if (go && lit != 0u && n == 0u) stall = true;                  // literals not resident yet: continue next round
+#ifdef HSRLE_STAMPS
+          if (go && lit != 0u && n == 0u) tFlush += 1ull << 40;   // diagnostic: literal-starved events in the top bits
+#endif
 
           if (n != 0u)
           {
@@ -825,51 +840,46 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     //      so that this wait never includes the flush stores below (vmcnt counts loads and stores in order) ----
     land();
     HS_STAMP(tLand)
-    // ---- flush ----
-    const uint32_t produced = o - base;
-    const bool uniform = __ballot(active && produced == (uint32_t)T && base == __builtin_amdgcn_readfirstlane(base)) == ~0ull;
-
-#ifdef HSRLE_STAMPS
-    if (!uniform) nIter++;   // diagnostic: rounds that took the slow flush path
-#endif
-    if (uniform)
-    {
-      // fast path: all 64 rows hold T bytes of the same round: every store instruction writes RPI x T contiguous bytes
-      const uint32_t ubase = __builtin_amdgcn_readfirstlane(base);
-      u32x4 fv[CPR];
-#pragma unroll
-      for (int q = 0; q < CPR; q++)
-        fv[q] = lds_ld128(tile + ((uint32_t)q * RPI + lane / CPR) * TS + (lane % CPR) * 16u);
-#pragma unroll
-      for (int q = 0; q < CPR; q++)
-#ifdef HSRLE_ABLATE_STORES  // timing-only diagnostic build: only one lane in 64 stores (output is wrong)
-        if (lane == 0)
-#endif
-        st128(out + (uint64_t)(wgFirst + (uint32_t)q * RPI + lane / CPR) * B + ubase + (lane % CPR) * 16u, fv[q]);
+    wave_sync();
     }
-    else
+
+    // ---- flush: whole 16-byte chunks only.  A row that ends inside a chunk (lane starved, or the block tail) keeps that
+    //      chunk in `acc` and re-writes it at tile offset 0 in the next round, so there is no byte-granular path ----
+    const uint32_t produced = o - base;
+    const bool tailNow = active && o == blen && (produced & 15u) != 0u;   // only the last block of a buffer can have one
+    const uint32_t chunks = active ? (produced >> 4) : 0u;
+#ifdef HSRLE_STAMPS
+    if (active && produced != (uint32_t)T) tIssue += 1ull << 40;          // diagnostic: partial rows
+#endif
     {
-#pragma unroll 1
+      u32x4 fv[CPR];
+      uint32_t fAt[CPR];
+#pragma unroll
       for (int q = 0; q < CPR; q++)
       {
         const uint32_t r = (uint32_t)q * RPI + lane / CPR, c = lane % CPR;
-        const uint32_t rb = wgFirst + r;
-        const uint32_t valid = (uint32_t)__shfl((int)produced, (int)r, 64);
-        const uint32_t rstart = (uint32_t)__shfl((int)base, (int)r, 64);
-        const uint32_t co = c * 16u;
-        if (rb >= lastBlockExcl || co >= valid)
-          continue;
-
-        uint8_t *g = out + (uint64_t)rb * B + rstart + co;
-        const uint8_t *l = tile + r * TS + co;
-
-        if (co + 16u <= valid)
-          st128(g, lds_ld128(l));
-        else
-          for (uint32_t k = 0; k < valid - co; k++)
-            g[k] = l[k];
+        const uint32_t nch = (uint32_t)__shfl((int)chunks, (int)r, 64);
+        const uint32_t rst = (uint32_t)__shfl((int)base, (int)r, 64);
+        fv[q] = lds_ld128(tile + r * TS + c * 16u);
+        fAt[q] = (c < nch) ? rst + c * 16u : 0xFFFFFFFFu;
+      }
+#pragma unroll
+      for (int q = 0; q < CPR; q++)
+      {
+#ifdef HSRLE_ABLATE_STORES  // timing-only diagnostic build: only one lane in 64 stores (output is wrong)
+        if (lane == 0)
+#endif
+        if (fAt[q] != 0xFFFFFFFFu)
+          st128(out + (uint64_t)(wgFirst + (uint32_t)q * RPI + lane / CPR) * B + fAt[q], fv[q]);
       }
     }
+    if (tailNow)
+    {
+      const uint32_t at = chunks << 4;
+      for (uint32_t k = 0; k < (produced & 15u); k++)
+        out[(uint64_t)b * B + base + at + k] = row[at + k];
+    }
+    base += chunks << 4;
 
     wave_sync();
     HS_STAMP(tFlush)

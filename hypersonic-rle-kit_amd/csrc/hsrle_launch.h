@@ -33,11 +33,15 @@ typedef hipError_t (*EncodeLaunch)(const EncodeArgs &, hipStream_t);
 
 constexpr int kCodecCount = 50;
 #ifndef HSRLE_DECODE_TILE
-#define HSRLE_DECODE_TILE 64
+#define HSRLE_DECODE_TILE 128
 #endif
 #ifndef HSRLE_DECODE_RING
 #define HSRLE_DECODE_RING 128
 #endif
+#ifndef HSRLE_DECODE_STEP
+#define HSRLE_DECODE_STEP 64
+#endif
+constexpr int kDecodeStep = HSRLE_DECODE_STEP; // output bytes per lane and decode/top-up step (k_decode_blocks Q)
 constexpr int kDecodeTile = HSRLE_DECODE_TILE; // bytes produced per lane and round (k_decode_blocks T)
 constexpr int kDecodeRing = HSRLE_DECODE_RING; // per-lane stream ring in LDS (k_decode_blocks R)
 

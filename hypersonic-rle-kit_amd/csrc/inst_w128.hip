@@ -5,10 +5,10 @@
 
 namespace hsrle {
 
-static hipError_t dec_sym(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PLAIN, 16, 1, kDecodeTile, kDecodeRing>, a, st); }
-static hipError_t dec_sym_packed(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PACKED, 16, 1, kDecodeTile, kDecodeRing>, a, st); }
-static hipError_t dec_byte(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PLAIN, 16, 0, kDecodeTile, kDecodeRing>, a, st); }
-static hipError_t dec_byte_packed(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PACKED, 16, 0, kDecodeTile, kDecodeRing>, a, st); }
+static hipError_t dec_sym(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PLAIN, 16, 1, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
+static hipError_t dec_sym_packed(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PACKED, 16, 1, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
+static hipError_t dec_byte(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PLAIN, 16, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
+static hipError_t dec_byte_packed(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PACKED, 16, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
 
 static hipError_t enc_sym(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<PLAIN, 16, 1>, a, st); }
 static hipError_t enc_sym_packed(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<PACKED, 16, 1>, a, st); }

@@ -7,10 +7,10 @@
 
 namespace hsrle {
 
-static hipError_t dec_plain(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PLAIN, 1, 0, kDecodeTile, kDecodeRing>, a, st); }
-static hipError_t dec_packed(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PACKED, 1, 0, kDecodeTile, kDecodeRing>, a, st); }
-static hipError_t dec_lut3(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<LUT3, 1, 0, kDecodeTile, kDecodeRing>, a, st); }
-static hipError_t dec_lut7(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<LUT7, 1, 0, kDecodeTile, kDecodeRing>, a, st); }
+static hipError_t dec_plain(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PLAIN, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
+static hipError_t dec_packed(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PACKED, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
+static hipError_t dec_lut3(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<LUT3, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
+static hipError_t dec_lut7(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<LUT7, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
 
 static hipError_t enc_plain(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<PLAIN, 1, 0>, a, st); }
 static hipError_t enc_packed(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<PACKED, 1, 0>, a, st); }

@@ -13,6 +13,8 @@ st.zero_()
 hsrle.decompress_async(cont,info,out,st); torch.cuda.synchronize()
 d=st[16:].view(torch.int64).cpu().tolist()+[0]*12
 tI,tD,tF,tL,nR,nIt,nW=d[:7]
+print('lane0 events: partial rows',tI>>40,'literal-starved',tF>>40,'header-starved',tL>>40)
+tI&=(1<<40)-1; tF&=(1<<40)-1; tL&=(1<<40)-1
 tot=tI+tD+tF+tL
 print('waves',nW,'rounds/wave',nR/nW,'iters/round',nIt/nR)
 print('cycles per round: issue %.0f decode %.0f flush %.0f land %.0f total %.0f'%(tI/nR,tD/nR,tF/nR,tL/nR,tot/nR))
