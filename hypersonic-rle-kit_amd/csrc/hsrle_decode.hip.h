@@ -873,13 +873,14 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
           st128(out + (uint64_t)(wgFirst + (uint32_t)q * RPI + lane / CPR) * B + fAt[q], fv[q]);
       }
     }
+    base += chunks << 4;
     if (tailNow)
     {
       const uint32_t at = chunks << 4;
       for (uint32_t k = 0; k < (produced & 15u); k++)
-        out[(uint64_t)b * B + base + at + k] = row[at + k];
+        out[(uint64_t)b * B + base + k] = row[at + k];
+      base = o;                                                        // written exactly once
     }
-    base += chunks << 4;
 
     wave_sync();
     HS_STAMP(tFlush)
