@@ -319,6 +319,8 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 #define HS_STAMP(acc)
 #endif
 
+  issue();                                                            // loads for the first step fly during its decode
+
   while (__ballot(!done && o < blen) != 0ull)
   {
     if (roundsLeft-- == 0u) { err |= DEC_ERR_STREAM; break; }
@@ -331,10 +333,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 #pragma unroll 1
     for (int step = 0; step < T / Q; step++)
     {
-    // ---- top-up for the NEXT step: the loads fly while this step decodes from the ring ----
     const uint32_t avail0 = E;                                         // bytes [.., avail0) are readable during this step
-    issue();
-    HS_STAMP(tIssue)
 
     const uint32_t target = umin((o / (uint32_t)Q + 1u) * (uint32_t)Q, flushTarget);
     uint32_t itersLeft = 2u * (uint32_t)Q + 16u;
@@ -841,6 +840,12 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     land();
     HS_STAMP(tLand)
     wave_sync();
+
+    // ---- top-up for the step after the next decode: issued right after landing and BEFORE the flush stores, so that the
+    //      prefetch registers are live across the flush (the flush data then cannot share registers with them, which would
+    //      force a full `s_waitcnt vmcnt(0)` drain of the stores before every top-up) ----
+    issue();
+    HS_STAMP(tIssue)
     }
 
     // ---- flush: whole 16-byte chunks only.  A row that ends inside a chunk (lane starved, or the block tail) keeps that

@@ -5,7 +5,9 @@ import torch, hsrle
 size=(int(sys.argv[1]) if len(sys.argv)>1 else 1024)<<20
 bs=int(sys.argv[2]) if len(sys.argv)>2 else 4096
 codec=sys.argv[3] if len(sys.argv)>3 else 'rle8_packed_multi'
-src=hsrle.synth(0,1,2,size)
+S={'8':1,'16':2,'24':3,'32':4,'48':6,'64':8,'128':16}[codec.split('_')[0][3:]]
+kind=int(sys.argv[4]) if len(sys.argv)>4 else 0
+src=hsrle.synth(kind,S,2,size)
 cont,info=hsrle.compress(codec,src,block_size=bs)
 out=torch.empty(size,dtype=torch.uint8,device='cuda'); st=torch.zeros(128,dtype=torch.int32,device='cuda')
 hsrle.decompress_async(cont,info,out,st); torch.cuda.synchronize()
