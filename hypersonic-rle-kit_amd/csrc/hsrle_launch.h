@@ -64,14 +64,14 @@ inline hipError_t launch_decode(KERNEL k, const DecodeArgs &a, hipStream_t st)
 }
 
 template <typename KERNEL>
-inline hipError_t launch_encode(KERNEL k, const EncodeArgs &a, hipStream_t st)
+inline hipError_t launch_encode(KERNEL k, const EncodeArgs &a, hipStream_t st, int capResidency = 1)
 {
   const uint32_t grid = (a.nBlocks + 63u) / 64u;
   // The encoder keeps one 128-byte line per lane open on the read side and one on the write side.  With the full 32 waves per CU
   // those open lines (32 CUs x 32 waves x 64 lanes x 2 x 128 B = 16 MiB per XCD) thrash the 4 MiB L2 and every line is fetched /
   // written several times (measured: 6.8x read, 5.9x write amplification).  A dynamic LDS reservation caps the residency.
   static const uint32_t ldsCap = [] { const char *e = getenv("HSRLE_ENCODE_LDS_CAP"); return e ? (uint32_t)atoi(e) : kEncodeLdsCap; }();
-  hipLaunchKernelGGL(k, dim3(grid), dim3(64), ldsCap, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(64), capResidency ? ldsCap : 0u, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes);
   return hipGetLastError();
 }
 

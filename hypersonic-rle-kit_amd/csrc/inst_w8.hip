@@ -3,6 +3,7 @@
 // and the single mode, so the Single codec ids share the multi decode kernels.
 #include "hsrle_decode.hip.h"
 #include "hsrle_encode.hip.h"
+#include "hsrle_encode8.hip.h"
 #include "hsrle_launch.h"
 
 namespace hsrle {
@@ -12,10 +13,10 @@ static hipError_t dec_packed(const DecodeArgs &a, hipStream_t st) { return launc
 static hipError_t dec_lut3(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<LUT3, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
 static hipError_t dec_lut7(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<LUT7, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
 
-static hipError_t enc_plain(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<PLAIN, 1, 0>, a, st); }
-static hipError_t enc_packed(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<PACKED, 1, 0>, a, st); }
-static hipError_t enc_lut3(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<LUT3, 1, 0>, a, st); }
-static hipError_t enc_lut7(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<LUT7, 1, 0>, a, st); }
+static hipError_t enc_plain(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode8_blocks<PLAIN>, a, st, 0); }
+static hipError_t enc_packed(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode8_blocks<PACKED>, a, st, 0); }
+static hipError_t enc_lut3(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode8_blocks<LUT3>, a, st, 0); }
+static hipError_t enc_lut7(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode8_blocks<LUT7>, a, st, 0); }
 static hipError_t enc_single(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<SINGLE, 1, 0>, a, st); }
 static hipError_t enc_packed_single(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<PACKED_SINGLE, 1, 0>, a, st); }
 
