@@ -61,7 +61,6 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
   // ---- per-lane encoder state ----
   uint32_t avail = 0;        // input bytes [.., avail) are (or were) in the ring; the ring holds [avail - H, avail)
   uint32_t cb = 0;           // base of the 16-position chunk scanned next (multiple of 16)
-  uint32_t posbit = 0;       // first position of that chunk still to look at
   bool inRun = false;
   uint32_t runStart = 0, sym = 0;
   uint32_t lastRLE = 0;
@@ -72,6 +71,9 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
   uint32_t pend = 0;         // bytes in the output row
   uint32_t rowBase = 0;      // stream offset of row byte 0 (multiple of 16)
   bool reported = false;     // the stream size has been written
+  uint64_t winStarts = 0, pendingEnds = 0;   // current window: run-start bits, run-end bits not yet handled
+  bool windowOpen = false, winOpenAtEnd = false;
+  uint32_t winW = 0;
 
   // ---- output row primitives ----
   auto ob = [&](uint32_t v) { orow[pend] = (uint8_t)v; pend += 1; };
@@ -334,64 +336,90 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
     issue();
 
     // ---------------- scan what is in the ring ----------------
+    // Phase A (uniform): equality mask of up to 64 positions -> bit masks of run starts and run ends.
+    // Phase B (per lane): one handle_run per run END -- a lane's trip count is the number of runs that end in its window.
     if (!finished)
     {
+      if (pendingEnds == 0ull && !windowOpen)
+      {
+        // window [cb, cb + W): every position needs its successor byte (or the end of the input)
+        const uint32_t lastStep = (avail >= n) ? 1u : 0u;
+        uint32_t W = lastStep ? umin(64u, n - cb) : umin(64u, ((avail - 1u - cb) >> 4) << 4);
+        if (cb >= n) W = 0;
+        if (W != 0u)
+        {
+          uint64_t e64 = 0;
+#pragma unroll
+          for (uint32_t j = 0; j < 4u; j++)
+          {
+            if (j * 16u < W)
+            {
+              const u32x4 x = lds_ld128(hrow + ((cb + j * 16u) & HM));
+              const uint32_t x4 = lds_ld32(hrow + ((cb + j * 16u + 16u) & HM));
+              const uint32_t z0 = zero_bytes(x.x ^ alignbyte(x.y, x.x, 1)), z1 = zero_bytes(x.y ^ alignbyte(x.z, x.y, 1));
+              const uint32_t z2 = zero_bytes(x.z ^ alignbyte(x.w, x.z, 1)), z3 = zero_bytes(x.w ^ alignbyte(x4, x.w, 1));
+              // 0x80 flags -> 4 bits per dword
+              const uint32_t b0 = (((z0 >> 7) * 0x00204081u) >> 21) & 0xFu, b1 = (((z1 >> 7) * 0x00204081u) >> 21) & 0xFu;
+              const uint32_t b2 = (((z2 >> 7) * 0x00204081u) >> 21) & 0xFu, b3 = (((z3 >> 7) * 0x00204081u) >> 21) & 0xFu;
+              e64 |= (uint64_t)(b0 | (b1 << 4) | (b2 << 8) | (b3 << 12)) << (16u * j);
+            }
+          }
+          // position i is a match only if cb + i + 1 < n (bytes at or beyond n never match)
+          const uint32_t validBits = (n - cb > W) ? W : (n - cb - 1u);
+          e64 &= (validBits >= 64u) ? ~0ull : ((1ull << validBits) - 1ull);
+          const uint64_t wmask = (W >= 64u) ? ~0ull : ((1ull << W) - 1ull);
+          const uint64_t prev = (e64 << 1) | (inRun ? 1ull : 0ull);      // "the position before me matched"
+          winStarts = e64 & ~prev;
+          pendingEnds = ~e64 & prev & wmask;                            // bit i: a run ends with position i (exclusive end cb + i + 1)
+          winOpenAtEnd = ((e64 >> (W - 1u)) & 1ull) != 0ull;             // the last position matches its successor: run goes on
+          winW = W;
+          windowOpen = true;
+        }
+      }
+
       bool stall = false;
 
-      while (!stall)
+      while (pendingEnds != 0ull)
       {
-        if (cb >= n)
+        const uint32_t i = (uint32_t)__builtin_ctzll(pendingEnds);
+        const uint64_t sBelow = winStarts & ((2ull << i) - 1ull);
+        uint32_t st = runStart, sy = sym;
+        if (sBelow != 0ull)
         {
-          // end of input: a run that reaches the end is judged now; then the literal terminator unless the stream ended
-          if (inRun) { if (!handle_run(runStart, n)) { stall = true; break; } inRun = false; }
-          if (!ended) { if (!finish_literals()) { stall = true; break; } ended = true; }
-          finished = true;
-          break;
+          st = cb + (63u - (uint32_t)__builtin_clzll(sBelow));
+          sy = hrow[st & HM];
         }
-        if (cb + 17u > avail && avail < n)
-          break;                                                        // the chunk's look-ahead byte has not arrived yet
+        sym = sy;
+        if (!handle_run(st, cb + i + 1u)) { stall = true; break; }
+        pendingEnds &= pendingEnds - 1ull;
+      }
 
-        // e16 bit i: input[cb + i] == input[cb + i + 1]   (positions at or beyond n never match)
-        const u32x4 x = lds_ld128(hrow + (cb & HM));
-        const uint32_t x4 = lds_ld32(hrow + ((cb + 16u) & HM));
-        const uint32_t z0 = zero_bytes(x.x ^ alignbyte(x.y, x.x, 1)), z1 = zero_bytes(x.y ^ alignbyte(x.z, x.y, 1));
-        const uint32_t z2 = zero_bytes(x.z ^ alignbyte(x.w, x.z, 1)), z3 = zero_bytes(x.w ^ alignbyte(x4, x.w, 1));
-        // 0x80 flags -> 4 bits per dword
-        const uint32_t b0 = (((z0 >> 7) * 0x00204081u) >> 21) & 0xFu, b1 = (((z1 >> 7) * 0x00204081u) >> 21) & 0xFu;
-        const uint32_t b2 = (((z2 >> 7) * 0x00204081u) >> 21) & 0xFu, b3 = (((z3 >> 7) * 0x00204081u) >> 21) & 0xFu;
-        uint32_t e16 = b0 | (b1 << 4) | (b2 << 8) | (b3 << 12);
-        const uint32_t validBits = (n - cb > 16u) ? 16u : (n - cb - 1u);  // position i is valid if cb + i + 1 < n
-        e16 &= (validBits >= 16u) ? 0xFFFFu : ((1u << validBits) - 1u);
-
-        for (;;)
+      if (!stall && windowOpen)
+      {
+        // the window is done: remember a run that is still open at its end
+        if (winOpenAtEnd)
         {
-          const uint32_t above = ~((1u << posbit) - 1u);
-          if (inRun)
+          // the open run is the last one that started in this window; with no start at all the carried run goes on
+          if (winStarts != 0ull)
           {
-            const uint32_t zero = (~e16 & 0xFFFFu) & above;              // first position whose successor differs
-            if (zero == 0u) { posbit = 16; break; }
-            const uint32_t i = (uint32_t)__builtin_ctz(zero);
-            if (!handle_run(runStart, cb + i + 1u)) { posbit = i; stall = true; break; }
-            inRun = false;
-            posbit = i + 1u;
+            runStart = cb + (63u - (uint32_t)__builtin_clzll(winStarts));
+            sym = hrow[runStart & HM];
           }
-          else
-          {
-            const uint32_t one = e16 & above;
-            if (one == 0u) { posbit = 16; break; }
-            const uint32_t i = (uint32_t)__builtin_ctz(one);
-            runStart = cb + i;
-            const uint32_t dw = (i < 4u) ? x.x : (i < 8u ? x.y : (i < 12u ? x.z : x.w));
-            sym = (dw >> (8u * (i & 3u))) & 0xFFu;
-            inRun = true;
-            posbit = i + 1u;
-          }
-          if (posbit >= 16u) break;
+          inRun = true;
         }
+        else
+          inRun = false;
+        cb += winW;
+        windowOpen = false;
+      }
 
-        if (stall) break;
-        cb += 16u;
-        posbit = 0;
+      if (!stall && !windowOpen && cb >= n && avail >= n)
+      {
+        // end of input: a run that reaches the end is judged now; then the literal terminator unless the stream ended
+        bool ok = true;
+        if (inRun) { ok = handle_run(runStart, n); if (ok) inRun = false; }
+        if (ok && !ended) { ok = finish_literals(); if (ok) ended = true; }
+        if (ok) finished = true;
       }
     }
 
