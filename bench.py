@@ -32,6 +32,19 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
 
+def measured_traffic(codec, size, block):
+    """HBM bytes per decode launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json: FETCH_SIZE and
+    WRITE_SIZE, one counter per pass, KiB units as rocprofv3 reports them; uncorrected -- see DESIGN.md §5).  None when the
+    workload is not the one that was profiled."""
+    try:
+        t = json.load(open(os.path.join(REPO, "profiles", "r01_traffic.json")))
+        if t["codec"] == codec and t["size"] == size and t["block"] == block:
+            return int(t["fetch_bytes"] + t["write_bytes"])
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(container_prefix, n_blocks, block_size, codec_key, expect):
     """Decode the first n_blocks of the container on the host (bounded sample), single thread."""
     import numpy as np
@@ -94,7 +107,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the library has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("HSRLE_FORCE_DIST") == "1"   # the env switch lets a 1-GPU box exercise the RCCL code path
     if distributed:
         import torch.distributed as dist
 
@@ -207,7 +220,7 @@ def main():
             "bit_exact": bool(ok),
             "encode": {"value": round(size / 2**30 / (enc_ms * 1e-3), 2), "unit": "GiB/s", "ms": round(enc_ms, 4), "note": "same buffer, encode kernel + size scan + compaction"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None, "kernel": "k_decode_blocks<PACKED,1>", "kernel_ms": round(kernel_ms, 4),
+                         "traffic": measured_traffic(args.codec, size, args.block), "kernel": "k_decode_blocks<PACKED,1>", "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes": int(alg_bytes), "note": "algorithmic bytes = container (compressed) + uncompressed output per launch; PMC traffic in profiles/"},
         }
         if gather_ms is not None:

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 {
   using TR = Traits<FAM, S, AL>;
   constexpr int TS = T + 16;                 // tile row stride: 16 bytes of over-write slack; an odd multiple of 16 (bank spread)
-  constexpr int RS = R + 32;                 // ring row stride: bytes [R, R+32) mirror [0, 32) so a 32-byte read never wraps
+  constexpr int RS = R + 16;                 // ring row stride: bytes [R, R+16) mirror [0, 16) so a 32-byte aligned window never wraps
   constexpr int CPR = T / 16;                // 16-byte chunks per tile row == lanes that serve one row in top-up / flush
   constexpr int RPI = 64 / CPR;              // rows covered by one flush instruction
   constexpr int LPR = Q / 16;                // lanes that serve one row in a top-up (Q contiguous stream bytes)
@@ -248,8 +248,8 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
       if (c < tk)
       {
         lds_st128(ring + pfAt[q], pf[q]);
-        if ((pfAt[q] - r * (uint32_t)RS) < 32u)
-          lds_st128(ring + pfAt[q] + (uint32_t)R, pf[q]);              // mirror of the first 32 ring bytes
+        if ((pfAt[q] - r * (uint32_t)RS) < 16u)
+          lds_st128(ring + pfAt[q] + (uint32_t)R, pf[q]);              // mirror of the first 16 ring bytes
       }
     }
   };
