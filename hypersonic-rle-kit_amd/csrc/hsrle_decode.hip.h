@@ -146,7 +146,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   constexpr uint32_t RMASK = (uint32_t)R - 1u;
   constexpr uint32_t MAXHDR = 1u + 4u + (uint32_t)S + 4u + 2u; // longest packet header of any family (+ slack)
   constexpr bool kPat = (S != 1);            // 8 bit: the fill pattern is one broadcast register
-  static_assert((R & (R - 1)) == 0 && R >= 128 && R % Q == 0 && T % Q == 0 && (Q == 64 || Q == 128), "ring size must be a power of two and a multiple of Q");
+  static_assert((R & (R - 1)) == 0 && R >= 64 && R >= T && R % Q == 0 && T % Q == 0 && (Q == 32 || Q == 64 || Q == 128), "ring size must be a power of two and a multiple of Q");
   static_assert(T == 64 || T == 128, "tile rows are flushed as whole 64/128-byte pieces");
   static_assert((TS / 16) % 2 == 1 && TS % 16 == 0 && RS % 16 == 0, "rows are 16-byte aligned; the tile stride is an odd multiple of 16 bytes");
 
@@ -333,10 +333,17 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 #pragma unroll 1
     for (int step = 0; step < T / Q; step++)
     {
-    const uint32_t avail0 = E;                                         // bytes [.., avail0) are readable during this step
-
     const uint32_t target = umin((o / (uint32_t)Q + 1u) * (uint32_t)Q, flushTarget);
     uint32_t itersLeft = 2u * (uint32_t)Q + 16u;
+
+    // Pass 0 decodes with the ring as it stands.  A lane whose packet needs bytes that were not resident (the ring holds
+    // < R bytes behind a misaligned sp; literal-heavy stretches consume more than that per step) stops early; the top-up that
+    // lands after pass 0 holds what it waits for, so pass 1 lets exactly those lanes finish the step.  No lane ever falls
+    // a step behind, and every row stays T-aligned in the output.
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++)
+    {
+    const uint32_t avail0 = E;                                         // bytes [.., avail0) are readable during this pass
 
     if constexpr (S == 1)
     {
@@ -834,6 +841,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 
     HS_STAMP(tDecode)
     wave_sync();                                                   // every lane is done reading the ring and writing its row
+    if (pass != 0) break;
 
     // ---- the loads issued before the decode step have had the whole round to arrive: move them into the ring first,
     //      so that this wait never includes the flush stores below (vmcnt counts loads and stores in order) ----
@@ -846,6 +854,8 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     //      force a full `s_waitcnt vmcnt(0)` drain of the stores before every top-up) ----
     issue();
     HS_STAMP(tIssue)
+    if (__ballot(!done && o < target) == 0ull) break;                // nobody starved (the common case)
+    }
     }
 
     // ---- flush: whole 16-byte chunks only.  A row that ends inside a chunk (lane starved, or the block tail) keeps that

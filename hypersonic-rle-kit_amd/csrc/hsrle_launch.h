@@ -41,7 +41,7 @@ constexpr uint32_t kEncodeLdsCap = 20000;       // bytes of dynamic LDS per enco
 #define HSRLE_DECODE_RING 128
 #endif
 #ifndef HSRLE_DECODE_STEP
-#define HSRLE_DECODE_STEP 64
+#define HSRLE_DECODE_STEP 128
 #endif
 constexpr int kDecodeStep = HSRLE_DECODE_STEP; // output bytes per lane and decode/top-up step (k_decode_blocks Q)
 constexpr int kDecodeTile = HSRLE_DECODE_TILE; // bytes produced per lane and round (k_decode_blocks T)
