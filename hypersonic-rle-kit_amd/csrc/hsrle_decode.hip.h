@@ -99,6 +99,25 @@ __device__ __forceinline__ u32x4 lds_read16(const uint8_t *base, uint32_t p)
   return funnel16(lds_ld128(src), lds_ld128(src + 16), p & 15u);
 }
 
+// Same result from three NATURALLY ALIGNED 8-byte reads (24-byte window at p & ~7): one dword-select stage instead of two.
+// `base` is 16-byte aligned and readable up to (p & ~7) + 24.
+__device__ __forceinline__ uint64_t lds_ld64(const uint8_t *p) { return *(const uint64_t *)__builtin_assume_aligned(p, 8); }
+
+__device__ __forceinline__ u32x4 funnel24(uint64_t a, uint64_t b, uint64_t c, uint32_t sh)
+{
+  const bool d1 = (sh & 4u) != 0u;
+  const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32), c0 = (uint32_t)c, c1 = (uint32_t)(c >> 32);
+  const uint32_t z0 = d1 ? a1 : a0, z1 = d1 ? b0 : a1, z2 = d1 ? b1 : b0, z3 = d1 ? c0 : b1, z4 = d1 ? c1 : c0;
+  const uint32_t n = sh & 3u;
+  return u32x4{ alignbyte(z1, z0, n), alignbyte(z2, z1, n), alignbyte(z3, z2, n), alignbyte(z4, z3, n) };
+}
+
+__device__ __forceinline__ u32x4 lds_read16_w8(const uint8_t *base, uint32_t p)
+{
+  const uint8_t *src = base + (p & ~7u);
+  return funnel24(lds_ld64(src), lds_ld64(src + 8), lds_ld64(src + 16), p & 7u);
+}
+
 // low c bytes (c in 0..15) from `keep`, the rest from `fresh`
 __device__ __forceinline__ u32x4 merge_low(u32x4 keep, u32x4 fresh, uint32_t c)
 {
@@ -146,13 +165,17 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   constexpr uint32_t RMASK = (uint32_t)R - 1u;
   constexpr uint32_t MAXHDR = 1u + 4u + (uint32_t)S + 4u + 2u; // longest packet header of any family (+ slack)
   constexpr bool kPat = (S != 1);            // 8 bit: the fill pattern is one broadcast register
-  static_assert((R & (R - 1)) == 0 && R >= 64 && R >= T && R % Q == 0 && T % Q == 0 && (Q == 32 || Q == 64 || Q == 128), "ring size must be a power of two and a multiple of Q");
+  static_assert((R & (R - 1)) == 0 && R >= 64 && R % Q == 0 && T % Q == 0 && (Q == 32 || Q == 64 || Q == 128), "ring size must be a power of two and a multiple of Q");
   static_assert(T == 64 || T == 128, "tile rows are flushed as whole 64/128-byte pieces");
   static_assert((TS / 16) % 2 == 1 && TS % 16 == 0 && RS % 16 == 0, "rows are 16-byte aligned; the tile stride is an odd multiple of 16 bytes");
 
   __shared__ __attribute__((aligned(16))) uint8_t tile[64 * TS];
   __shared__ __attribute__((aligned(16))) uint8_t ring[64 * RS];
   __shared__ __attribute__((aligned(16))) uint8_t pats[kPat ? 64 * 48 : 16];
+#ifdef HSRLE_LDS_BALLAST  // occupancy experiment only: extra LDS so that fewer waves fit on a CU
+  __shared__ uint8_t ballast[HSRLE_LDS_BALLAST];
+  if (U == 0x7FFFFFFFFFFFFFFFull) ballast[threadIdx.x] = 1;
+#endif
   // per-row scalars (stream base, top-up requests, flush extents) are exchanged between lanes with wave shuffles
   // (ds_bpermute: no LDS allocation), so the whole LDS budget is ring + tile: 15 KB per wave -> 10 waves per CU
 
@@ -183,8 +206,8 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   uint32_t err = 0;
   [[maybe_unused]] uint32_t lut[TR::kLut ? TR::K : 1][TR::SW];
 
-  // Stream positions (sp, E, slen, lim) are VIRTUAL: position 0 is the T-byte aligned global address at or below the
-  // stream start, the stream itself begins at virtual position g0.  Top-up loads then fetch T-byte aligned pieces, so
+  // Stream positions (sp, E, slen, lim) are VIRTUAL: position 0 is the Q-byte aligned global address at or below the
+  // stream start, the stream itself begins at virtual position g0.  Top-up loads then fetch Q-byte aligned pieces, so
   // every 64/128-byte sector of the container is requested exactly once by this workgroup.
   uint32_t g0 = 0;
   uint64_t myBase0 = 0;                                             // this row's (virtual) stream start, relative to `payload`
@@ -193,7 +216,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     if (active)
     {
       const uint64_t off0 = offsets[b];
-      g0 = (uint32_t)((uintptr_t)(payload + off0) & (uintptr_t)(T - 1));
+      g0 = (uint32_t)((uintptr_t)(payload + off0) & (uintptr_t)(Q - 1));
       g0 = umin(g0, (uint32_t)(off0 < 0xFFFFFFFFull ? off0 : 0xFFFFFFFFull) + 64u) & ~15u; // never reach in front of the container (>= 64 header bytes precede the payload)
       base0 = off0 - g0;                                               // may be "negative" for block 0: wraps, added to `payload` again below
       slen = (uint32_t)(offsets[b + 1] - off0) + g0;
@@ -347,166 +370,169 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 
     if constexpr (S == 1)
     {
-      // ================= 8 bit: flat loop, header parse with selects (no data-dependent branches in the parse) =================
+      // ================= 8 bit: one packet per loop trip; lane flags live in one VGPR =================
       constexpr uint32_t SHORT_SINGLE = TR::kPacked ? 2u : 4u;
-      bool stall = false;                                              // this lane waits for the next round's ring bytes
+      constexpr uint32_t F_DONE = 1u, F_STALL = 2u, F_LAST = 4u;        // F_STALL: waits for the next pass's ring bytes
+      uint32_t fl = (done ? F_DONE : 0u) | (last ? F_LAST : 0u);
+      // a header may be parsed at sp iff sp <= spOK: MAXHDR bytes resident (or the stream completely loaded) and >= 2 bytes left
+      const uint32_t spOK = umin((avail0 < lim) ? avail0 - MAXHDR : 0xFFFFFFFFu, slen - 2u);
 
       for (;;)
       {
-        const bool act = !done && !stall && o < target;
+        const bool act = (fl & (F_DONE | F_STALL)) == 0u && o < target;
         if (__ballot(act) == 0ull) break;
-        if (itersLeft-- == 0u) { err |= DEC_ERR_STREAM; done = true; break; }
+        if (itersLeft-- == 0u) { err |= DEC_ERR_STREAM; fl |= F_DONE; break; }
 
-        const bool idle = (lit | run) == 0u;
-        const bool fin = act && idle && last;
-        const bool bad = act && idle && !last && (sp + 2u > slen);
-        const bool hungry = act && idle && !last && !bad && (avail0 - sp < MAXHDR) && (avail0 < lim);
-        const bool parse = act && idle && !last && !bad && !hungry;
-        if (bad) err |= DEC_ERR_STREAM;
-        done = done || fin || bad;
-        stall = stall || hungry;
-#ifdef HSRLE_STAMPS
-        if (hungry) tLand += 1ull << 40;   // diagnostic: header-starved events in the top bits
-#endif
-
-        // ---------------- packet header: one 16-byte ring read, fields picked with shifts ----------------
-        const u32x4 hv = lds_read16(rng, sp & RMASK);
-        const uint64_t lo = (uint64_t)hv.x | ((uint64_t)hv.y << 32), hi = (uint64_t)hv.z | ((uint64_t)hv.w << 32);
-        uint32_t cnt, pos, nsym = sym4, range, used, endNow = 0, hbad = 0;
-
-        if constexpr (TR::kLut)
+        if (act && (lit | run) == 0u)
         {
-          const uint32_t w16 = hv.x & 0xFFFFu;
-          const uint32_t idx = w16 >> (FAM == LUT3 ? 14 : 13);
-          const uint32_t c7 = (w16 >> TR::RB) & 0x7Fu;
-          const uint32_t r7 = w16 & ((1u << TR::RB) - 1u);
-          const bool isNew = idx == (uint32_t)TR::K;
-          pos = isNew ? 3u : 2u;
-          // the move-to-front list lives in lut[k][0], one byte per entry
-          uint32_t sb = (hv.x >> 16) & 0xFFu;
-#pragma unroll
-          for (int k = 0; k < TR::K; k++)
-            if (idx == (uint32_t)k) sb = lut[k][0];
-          const uint32_t limit = isNew ? (uint32_t)TR::K - 1u : idx;
-          if (parse)
+          if ((fl & F_LAST) != 0u || sp > spOK)
           {
-#pragma unroll
-            for (int k = TR::K - 1; k >= 1; k--)
-              if ((uint32_t)k <= limit) lut[k][0] = lut[k - 1][0];
-            lut[0][0] = sb;
-          }
-          nsym = sb * 0x01010101u;
-          const uint32_t cext = ex32(lo, hi, pos);
-          cnt = (c7 == 0u) ? cext : (c7 == 1u ? (cext & 0xFFFFu) : c7);
-          pos += (c7 == 0u) ? 4u : (c7 == 1u ? 2u : 0u);
-          const uint32_t rext = ex32(lo, hi, pos);
-          range = (r7 == 0u) ? rext : (r7 == 1u ? (rext & 0xFFFFu) : r7);
-          used = pos + ((r7 == 0u) ? 4u : (r7 == 1u ? 2u : 0u));
-          endNow = (r7 == 1u && range == 0u) ? 1u : 0u;
-          hbad = (!endNow && range < 2u) ? 1u : 0u;
-          range = (range >= 2u) ? range - 1u : 0u;                      // literal count + 1, like the other families
-        }
-        else
-        {
-          const uint32_t b0 = hv.x & 0xFFu;
-
-          if constexpr (!TR::kPacked)
-          {
-            cnt = single ? b0 : ((hv.x >> 8) & 0xFFu);                  // multi: sym, cnt ...   single: cnt ...
-            pos = single ? 1u : 2u;
-            nsym = single ? sym4 : b0 * 0x01010101u;
-            const uint32_t c32 = ex32(lo, hi, pos);
-            const bool longc = cnt == 0u;
-            cnt = longc ? c32 : cnt;
-            pos += longc ? 4u : 0u;
+            // rare: end of the stream, header not resident yet, or a truncated stream
+            if ((fl & F_LAST) != 0u) fl |= F_DONE;
+            else if (sp + 2u > slen) { err |= DEC_ERR_STREAM; fl |= F_DONE; }
+            else fl |= F_STALL;
           }
           else
           {
-            cnt = single ? b0 : (b0 & 0x7Fu);
-            const uint32_t c32 = (uint32_t)(lo >> 8);
-            const bool longc = cnt == 0u;
-            cnt = longc ? c32 : cnt;
-            pos = longc ? 5u : 1u;
-            const bool newSym = !single && !(b0 & 0x80u);
-            const uint32_t sb = (uint32_t)(lo >> (8u * pos)) & 0xFFu;
-            nsym = newSym ? sb * 0x01010101u : sym4;
-            pos += newSym ? 1u : 0u;
-          }
+            // ---------------- packet header: 16 stream bytes at sp, fields picked with shifts ----------------
+            const u32x4 hv = lds_read16_w8(rng, sp & RMASK);
+            [[maybe_unused]] const uint64_t lo = (uint64_t)hv.x | ((uint64_t)hv.y << 32), hi = (uint64_t)hv.z | ((uint64_t)hv.w << 32);
+            uint32_t cnt, pos, nsym = sym4, range, used, endNow = 0, hbad = 0;
 
-          const uint32_t w = ex32(lo, hi, pos);
-          const uint32_t r0 = w & 0xFFu;
-
-          if (TR::kPacked && !single)
-          {
-            const bool longr = (r0 & 1u) != 0u;                         // 7-bit-or-4-byte range (rle8_extreme_cpu.h:1883-1899)
-            range = longr ? (w >> 1) : (r0 >> 1);
-            used = pos + (longr ? 4u : 1u);
-            endNow = (longr && range == 0u) ? 1u : 0u;
-          }
-          else
-          {
-            const bool longr = r0 == 0u;
-            const uint32_t r32 = ex32(lo, hi, pos + 1u);
-            range = longr ? r32 : r0;
-            used = pos + (longr ? 5u : 1u);
-            endNow = (longr && range == 0u) ? 1u : 0u;
-          }
-        }
-
-        if (parse)
-        {
-          const uint32_t shortv = single ? SHORT_SINGLE : TR::SHORT;
-          sym4 = nsym;
-          lit = (range == 0u || endNow) ? 0u : range - 1u;               // a 7 bit range byte of 0x00 carries no literals (q11)
-          run = (cnt == 0u || endNow) ? 0u : cnt + shortv - (TR::kLut ? 2u : 1u);
-          last = endNow || cnt == 0u;
-          sp += used;
-          const bool sbad = hbad || sp > slen || lit > slen - sp || (lit == 0u && run == 0u && !last);
-          if (sbad) { err |= DEC_ERR_STREAM; done = true; }
-        }
-
-        const bool go = act && !done && !stall;
-
-        // ---- literals: tile chunks at the dword aligned positions A + 16k receive ring bytes [sp - c + 16k, +16) ----
-        {
-          const uint32_t resident = (avail0 > sp) ? avail0 - sp : 0u;
-          const uint32_t n = (go && lit != 0u) ? umin(umin(lit, target - o), resident) : 0u;
-          if (go && lit != 0u && n == 0u) stall = true;                  // literals not resident yet: continue next round
-#ifdef HSRLE_STAMPS
-          if (go && lit != 0u && n == 0u) tFlush += 1ull << 40;   // diagnostic: literal-starved events in the top bits
-#endif
-
-          if (n != 0u)
-          {
-            const uint32_t q = o - base, c = q & 15u;
-            uint8_t *dst = row + (q & ~15u);
-            const uint32_t srcp = sp - c;
-            const uint32_t total = c + n;
-            const uint8_t *src = rng + ((srcp & ~15u) & RMASK);
-            const uint32_t sh = srcp & 15u;
-            u32x4 x = lds_ld128(src), y = lds_ld128(src + 16);
-            u32x4 w = merge_low(acc, funnel16(x, y, sh), c);             // keep the c valid bytes of the straddled chunk
-            lds_st128(dst, w);
-            for (uint32_t k = 16; k < total; k += 16)
+            if constexpr (TR::kLut)
             {
-              x = y;
-              y = lds_ld128(rng + (((srcp & ~15u) + k + 16u) & RMASK));
-              w = funnel16(x, y, sh);
-              lds_st128(dst + k, w);
+              const uint32_t w16 = hv.x & 0xFFFFu;
+              const uint32_t idx = w16 >> (FAM == LUT3 ? 14 : 13);
+              const uint32_t c7 = (w16 >> TR::RB) & 0x7Fu;
+              const uint32_t r7 = w16 & ((1u << TR::RB) - 1u);
+              const bool isNew = idx == (uint32_t)TR::K;
+              pos = isNew ? 3u : 2u;
+              // the move-to-front list lives in lut[k][0], one byte per entry
+              uint32_t sb = (hv.x >> 16) & 0xFFu;
+#pragma unroll
+              for (int k = 0; k < TR::K; k++)
+                if (idx == (uint32_t)k) sb = lut[k][0];
+              const uint32_t limit = isNew ? (uint32_t)TR::K - 1u : idx;
+#pragma unroll
+              for (int k = TR::K - 1; k >= 1; k--)
+                if ((uint32_t)k <= limit) lut[k][0] = lut[k - 1][0];
+              lut[0][0] = sb;
+              nsym = sb * 0x01010101u;
+              const uint32_t cext = ex32(lo, hi, pos);
+              cnt = (c7 == 0u) ? cext : (c7 == 1u ? (cext & 0xFFFFu) : c7);
+              pos += (c7 == 0u) ? 4u : (c7 == 1u ? 2u : 0u);
+              const uint32_t rext = ex32(lo, hi, pos);
+              range = (r7 == 0u) ? rext : (r7 == 1u ? (rext & 0xFFFFu) : r7);
+              used = pos + ((r7 == 0u) ? 4u : (r7 == 1u ? 2u : 0u));
+              endNow = (r7 == 1u && range == 0u) ? 1u : 0u;
+              hbad = (!endNow && range < 2u) ? 1u : 0u;
+              range = (range >= 2u) ? range - 1u : 0u;                    // literal count + 1, like the other families
             }
-            acc = w;
-            sp += n;
-            lit -= n;
-            o += n;
+            else
+            {
+              const uint32_t b0 = hv.x & 0xFFu;
+
+              if constexpr (!TR::kPacked)
+              {
+                cnt = single ? b0 : ((hv.x >> 8) & 0xFFu);                // multi: sym, cnt ...   single: cnt ...
+                pos = single ? 1u : 2u;
+                nsym = single ? sym4 : __builtin_amdgcn_perm(hv.x, hv.x, 0u); // byte 0 broadcast
+                const uint32_t c32 = ex32(lo, hi, pos);
+                const bool longc = cnt == 0u;
+                cnt = longc ? c32 : cnt;
+                pos += longc ? 4u : 0u;
+
+                const uint32_t w = ex32(lo, hi, pos);
+                const uint32_t r0 = w & 0xFFu;
+                const bool longr = r0 == 0u;
+                const uint32_t r32 = ex32(lo, hi, pos + 1u);
+                range = longr ? r32 : r0;
+                used = pos + (longr ? 5u : 1u);
+                endNow = (longr && range == 0u) ? 1u : 0u;
+              }
+              else
+              {
+                // Packed: [cnt7 | same-flag] [cnt32 if cnt7 == 0] [symbol unless same] [range7 | long-flag, or range32]
+                // everything sits in the 8 bytes A:Bd that start at byte 0 (short count) or byte 4 (long count)
+                const uint32_t c7 = single ? b0 : (b0 & 0x7Fu);
+                const bool longc = c7 == 0u;
+                cnt = longc ? alignbyte(hv.y, hv.x, 1u) : c7;
+                const uint32_t A = longc ? hv.y : hv.x, Bd = longc ? hv.z : hv.y;
+                const bool newSym = !single && !(b0 & 0x80u);
+                nsym = newSym ? __builtin_amdgcn_perm(A, A, 0x01010101u) : sym4;   // byte 1 of A, broadcast
+                const uint32_t posr = newSym ? 2u : 1u;                   // the range field, relative to A
+                pos = (longc ? 4u : 0u) + posr;
+                const uint32_t w = alignbyte(Bd, A, posr);
+                const uint32_t r0 = w & 0xFFu;
+
+                if (!single)
+                {
+                  const bool longr = (r0 & 1u) != 0u;                     // 7-bit-or-4-byte range (rle8_extreme_cpu.h:1883-1899)
+                  range = longr ? (w >> 1) : (r0 >> 1);
+                  used = pos + (longr ? 4u : 1u);
+                  endNow = (longr && range == 0u) ? 1u : 0u;
+                }
+                else
+                {
+                  const bool longr = r0 == 0u;
+                  const uint32_t r32 = alignbyte(Bd, A, posr + 1u);
+                  range = longr ? r32 : r0;
+                  used = pos + (longr ? 5u : 1u);
+                  endNow = (longr && range == 0u) ? 1u : 0u;
+                }
+              }
+            }
+
+            const uint32_t shortv = single ? SHORT_SINGLE : TR::SHORT;
+            const bool lastNow = endNow || cnt == 0u;
+            sym4 = nsym;
+            lit = (range == 0u || endNow) ? 0u : range - 1u;             // a 7 bit range byte of 0x00 carries no literals (q11)
+            run = lastNow ? 0u : cnt + shortv - (TR::kLut ? 2u : 1u);
+            if (lastNow) fl |= F_LAST;
+            sp += used;
+            if (hbad || sp > slen || lit > slen - sp || (lit == 0u && run == 0u && !lastNow)) { err |= DEC_ERR_STREAM; fl |= F_DONE; }
           }
         }
 
-        // ---- run: the same aligned chunks filled with the byte-broadcast symbol ----
+        if (act && (fl & (F_DONE | F_STALL)) == 0u)
         {
-          const uint32_t m = (go && !stall && lit == 0u && run != 0u) ? umin(run, target - o) : 0u;
-
-          if (m != 0u)
+          // ---- literals: tile chunks at the aligned positions A + 16k receive ring bytes [sp - c + 16k, +16) ----
+          if (lit != 0u)
           {
+            const uint32_t resident = (avail0 > sp) ? avail0 - sp : 0u;
+            const uint32_t n = umin(umin(lit, target - o), resident);
+            if (n == 0u) fl |= F_STALL;                                   // literals not resident yet: continue next pass
+            else
+            {
+              const uint32_t q = o - base, c = q & 15u;
+              uint8_t *dst = row + (q & ~15u);
+              const uint32_t srcp = sp - c;
+              const uint32_t total = c + n;
+              const uint32_t s8 = srcp & ~7u, sh = srcp & 7u;
+              const uint8_t *src = rng + (s8 & RMASK);
+              uint64_t xa = lds_ld64(src), xb = lds_ld64(src + 8), xc = lds_ld64(src + 16);
+              u32x4 w = merge_low(acc, funnel24(xa, xb, xc, sh), c);     // keep the c valid bytes of the straddled chunk
+              lds_st128(dst, w);
+              for (uint32_t k = 16; k < total; k += 16)
+              {
+                const uint8_t *nx = rng + ((s8 + k + 8u) & RMASK);         // the next 16 window bytes (8-byte aligned, mirror covers the wrap)
+                xa = xc;
+                xb = lds_ld64(nx);
+                xc = lds_ld64(nx + 8);
+                w = funnel24(xa, xb, xc, sh);
+                lds_st128(dst + k, w);
+              }
+              acc = w;
+              sp += n;
+              lit -= n;
+              o += n;
+            }
+          }
+
+          // ---- run: the same aligned chunks filled with the byte-broadcast symbol ----
+          if (lit == 0u && run != 0u && o < target)
+          {
+            const uint32_t m = umin(run, target - o);
             const uint32_t q = o - base, c = q & 15u;
             uint8_t *dst = row + (q & ~15u);
             const uint32_t total = c + m;
@@ -521,6 +547,9 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
           }
         }
       }
+
+      done = (fl & F_DONE) != 0u;
+      last = (fl & F_LAST) != 0u;
     }
     else
     while (!done && o < target)
