@@ -36,36 +36,26 @@ enum DecodeError : uint32_t
   DEC_ERR_MODE = 4u      // unknown 8 bit mode byte (reference: rle8_extreme_cpu.h:759-760)
 };
 
-// 48-byte per-lane fill pattern in LDS: pat[k] = sym[k % S] (S > 1).  `v` holds the symbol in its low S bytes.
+// Per-lane fill pattern of a run, in registers (S > 1).  `v` holds the symbol in its low S bytes.
+//   S in {2,4,8,16}: the symbol replicated to 16 bytes (the pattern has period 16)
+//   S in {3,6}:      three dwords d0 d1 d2 = one 12-byte period (lcm(S, 4) == 12); w is unused
 template <int S>
-__device__ __forceinline__ void set_pattern(uint8_t *pat, u32x4 v)
+__device__ __forceinline__ u32x4 make_pattern(u32x4 v)
 {
-  u32x4 a, b, c;
-
-  if constexpr (S == 2) { const uint32_t h = v.x & 0xFFFFu; const uint32_t d = h | (h << 16); a = u32x4{ d, d, d, d }; b = a; c = a; }
-  else if constexpr (S == 4) { a = u32x4{ v.x, v.x, v.x, v.x }; b = a; c = a; }
-  else if constexpr (S == 8) { a = u32x4{ v.x, v.y, v.x, v.y }; b = a; c = a; }
-  else if constexpr (S == 16) { a = v; b = v; c = v; }
+  if constexpr (S == 2) { const uint32_t h = v.x & 0xFFFFu; const uint32_t d = h | (h << 16); return u32x4{ d, d, d, d }; }
+  else if constexpr (S == 4) return u32x4{ v.x, v.x, v.x, v.x };
+  else if constexpr (S == 8) return u32x4{ v.x, v.y, v.x, v.y };
+  else if constexpr (S == 16) return v;
   else if constexpr (S == 3)
   {
     const uint32_t t = v.x & 0xFFFFFFu;
-    const uint32_t d0 = t | (t << 24), d1 = (t >> 8) | (t << 16), d2 = (t >> 16) | (t << 8);
-    a = u32x4{ d0, d1, d2, d0 };
-    b = u32x4{ d1, d2, d0, d1 };
-    c = u32x4{ d2, d0, d1, d2 };
+    return u32x4{ t | (t << 24), (t >> 8) | (t << 16), (t >> 16) | (t << 8), 0 };
   }
   else // S == 6
   {
     const uint32_t lo = v.x, hi = v.y & 0xFFFFu;
-    const uint32_t d0 = lo, d1 = hi | (lo << 16), d2 = (lo >> 16) | (hi << 16);
-    a = u32x4{ d0, d1, d2, d0 };
-    b = u32x4{ d1, d2, d0, d1 };
-    c = u32x4{ d2, d0, d1, d2 };
+    return u32x4{ lo, hi | (lo << 16), (lo >> 16) | (hi << 16), 0 };
   }
-
-  lds_st128(pat, a);
-  lds_st128(pat + 16, b);
-  lds_st128(pat + 32, c);
 }
 
 template <int S>
@@ -97,6 +87,21 @@ __device__ __forceinline__ u32x4 lds_read16(const uint8_t *base, uint32_t p)
 {
   const uint8_t *src = base + (p & ~15u);
   return funnel16(lds_ld128(src), lds_ld128(src + 16), p & 15u);
+}
+
+// 16 bytes of the periodic run pattern starting at pattern phase ph (0 <= ph < S), S in {2,4,8,16}
+__device__ __forceinline__ u32x4 pattern_chunk16(u32x4 pv, uint32_t ph) { return funnel16(pv, pv, ph); }
+
+// S in {3,6}: the three distinct dwords e0 e1 e2 of the pattern stream that starts at phase ph; 16-byte chunk number k of
+// that stream is { e[k%3], e[(k+1)%3], e[(k+2)%3], e[k%3] } (16 bytes ahead == one dword further in the 12-byte period)
+__device__ __forceinline__ void pattern_dwords12(u32x4 pv, uint32_t ph, uint32_t &e0, uint32_t &e1, uint32_t &e2)
+{
+  const bool j = ph >= 4u;                                           // ph <= 5
+  const uint32_t r0 = j ? pv.y : pv.x, r1 = j ? pv.z : pv.y, r2 = j ? pv.x : pv.z;
+  const uint32_t b = ph & 3u;
+  e0 = alignbyte(r1, r0, b);
+  e1 = alignbyte(r2, r1, b);
+  e2 = alignbyte(r0, r2, b);
 }
 
 // Same result from three NATURALLY ALIGNED 8-byte reads (24-byte window at p & ~7): one dword-select stage instead of two.
@@ -164,14 +169,12 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   constexpr int RPL = 64 / LPR;              // rows covered by one top-up instruction
   constexpr uint32_t RMASK = (uint32_t)R - 1u;
   constexpr uint32_t MAXHDR = 1u + 4u + (uint32_t)S + 4u + 2u; // longest packet header of any family (+ slack)
-  constexpr bool kPat = (S != 1);            // 8 bit: the fill pattern is one broadcast register
   static_assert((R & (R - 1)) == 0 && R >= 64 && R % Q == 0 && T % Q == 0 && (Q == 32 || Q == 64 || Q == 128), "ring size must be a power of two and a multiple of Q");
   static_assert(T == 64 || T == 128, "tile rows are flushed as whole 64/128-byte pieces");
   static_assert((TS / 16) % 2 == 1 && TS % 16 == 0 && RS % 16 == 0, "rows are 16-byte aligned; the tile stride is an odd multiple of 16 bytes");
 
   __shared__ __attribute__((aligned(16))) uint8_t tile[64 * TS];
   __shared__ __attribute__((aligned(16))) uint8_t ring[64 * RS];
-  __shared__ __attribute__((aligned(16))) uint8_t pats[kPat ? 64 * 48 : 16];
 #ifdef HSRLE_LDS_BALLAST  // occupancy experiment only: extra LDS so that fewer waves fit on a CU
   __shared__ uint8_t ballast[HSRLE_LDS_BALLAST];
   if (U == 0x7FFFFFFFFFFFFFFFull) ballast[threadIdx.x] = 1;
@@ -187,7 +190,6 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 
   uint8_t *const row = tile + lane * TS;
   uint8_t *const rng = ring + lane * RS;
-  uint8_t *const pat = pats + (kPat ? lane * 48 : 0);
 
   // ---- per-lane stream state ----
   uint32_t slen = 0, blen = 0;
@@ -199,6 +201,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   uint32_t phase = 0;     // S > 1: pattern phase of the next run byte
   uint32_t o = 0;         // bytes of this block produced so far
   uint32_t sym4 = 0;      // S == 1: current symbol, byte-broadcast
+  [[maybe_unused]] u32x4 patv = u32x4{ 0, 0, 0, 0 }; // S > 1: run pattern (make_pattern)
   u32x4 acc = u32x4{ 0, 0, 0, 0 }; // the 16-byte chunk of the tile row that contains the write position (its low (q & 15) bytes are valid)
   bool last = false;      // the stream ends after the current packet's literals
   bool done = true;
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 
   auto set_sym = [&](u32x4 v) {
     if constexpr (S == 1) sym4 = (v.x & 0xFFu) * 0x01010101u;
-    else set_pattern<S>(pat, v);
+    else patv = make_pattern<S>(v);
   };
 
   // ---- ring top-up.  issue(): LPR loads; in load q, lanes LPR*g .. LPR*g+LPR-1 read Q contiguous bytes of row RPL*q+g ----
@@ -664,7 +667,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
         }
         else
         {
-#define HS_RD16(off) lds_read16(rng, (sp + (off)) & RMASK)
+#define HS_RD16(off) lds_read16_w8(rng, (sp + (off)) & RMASK)
 #define HS_RD8(off) (uint32_t)(*(rng + ((sp + (off)) & RMASK)))
           // S > 1: the first 16 header bytes in one read; the (rare) fields behind them with a second read
           const u32x4 hv = HS_RD16(0);
@@ -759,7 +762,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
               if (cnt == 0) { cnt = tv.x; tp = 4; }
               if (!(x & 0x80u))
               {
-                set_sym(lds_read16(rng, (sp + used + tp) & RMASK));
+                set_sym(lds_read16_w8(rng, (sp + used + tp) & RMASK));
                 tp += S;
               }
             }
@@ -767,7 +770,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
             // range field: for S == 16 it can start beyond the 16 bytes of tv
             uint32_t w;
             if (tp <= 12u) w = ex32(tlo, thi, tp);
-            else w = lds_read16(rng, (sp + used + tp) & RMASK).x;
+            else w = lds_read16_w8(rng, (sp + used + tp) & RMASK).x;
             const uint32_t r0 = w & 0xFFu;
 
             if constexpr (TR::kRange7)
@@ -780,7 +783,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
               range = r0; tp += 1;
               if (r0 == 0)
               {
-                range = (tp <= 12u) ? ex32(tlo, thi, tp) : lds_read16(rng, (sp + used + tp) & RMASK).x;
+                range = (tp <= 12u) ? ex32(tlo, thi, tp) : lds_read16_w8(rng, (sp + used + tp) & RMASK).x;
                 tp += 4;
                 endNow = (range == 0);
               }
@@ -814,15 +817,18 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
         uint8_t *dst = row + (q & ~15u);
         const uint32_t srcp = sp - c;
         const uint32_t total = c + n;                                  // bytes from dst that must end up valid
-        const uint32_t sh = srcp & 15u;
-        u32x4 x = lds_ld128(rng + ((srcp & ~15u) & RMASK)), y = lds_ld128(rng + (((srcp & ~15u) + 16u) & RMASK));
-        u32x4 w = merge_low(acc, funnel16(x, y, sh), c);               // keep the c valid bytes of the straddled chunk
+        const uint32_t s8 = srcp & ~7u, sh = srcp & 7u;
+        const uint8_t *src = rng + (s8 & RMASK);
+        uint64_t xa = lds_ld64(src), xb = lds_ld64(src + 8), xc = lds_ld64(src + 16);
+        u32x4 w = merge_low(acc, funnel24(xa, xb, xc, sh), c);         // keep the c valid bytes of the straddled chunk
         lds_st128(dst, w);
         for (uint32_t k = 16; k < total; k += 16)
         {
-          x = y;
-          y = lds_ld128(rng + (((srcp & ~15u) + k + 16u) & RMASK));
-          w = funnel16(x, y, sh);
+          const uint8_t *nx = rng + ((s8 + k + 8u) & RMASK);
+          xa = xc;
+          xb = lds_ld64(nx);
+          xc = lds_ld64(nx + 8);
+          w = funnel24(xa, xb, xc, sh);
           lds_st128(dst + k, w);
         }
         acc = w;
@@ -850,17 +856,31 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
         }
         else
         {
-          // pattern byte for tile byte (A + j) is pat[(phase - c + j) mod S]; pat holds 48 bytes of the periodic pattern
-          uint32_t ph = (phase + 16u * (uint32_t)S - c) % (uint32_t)S;
-          u32x4 w = merge_low(acc, lds_read16(pat, ph), c);
-          lds_st128(dst, w);
-          for (uint32_t k = 16; k < total; k += 16)
+          // the pattern byte for tile byte (A + j) is sym[(phase - c + j) mod S]
+          const uint32_t ph = (phase + 16u * (uint32_t)S - c) % (uint32_t)S;
+          if constexpr (16 % S == 0)
           {
-            if constexpr (16 % S != 0) ph = (ph + 16u) % (uint32_t)S;
-            w = lds_read16(pat, ph);
-            lds_st128(dst + k, w);
+            const u32x4 v = pattern_chunk16(patv, ph);                    // every chunk of the run holds the same 16 bytes
+            const u32x4 w = merge_low(acc, v, c);
+            lds_st128(dst, w);
+            for (uint32_t k = 16; k < total; k += 16)
+              lds_st128(dst + k, v);
+            acc = (total <= 16u) ? w : v;
           }
-          acc = w;
+          else
+          {
+            uint32_t e0, e1, e2;
+            pattern_dwords12(patv, ph, e0, e1, e2);
+            u32x4 w = merge_low(acc, u32x4{ e0, e1, e2, e0 }, c);
+            lds_st128(dst, w);
+            for (uint32_t k = 16; k < total; k += 16)
+            {
+              const uint32_t t = e0; e0 = e1; e1 = e2; e2 = t;
+              w = u32x4{ e0, e1, e2, e0 };
+              lds_st128(dst + k, w);
+            }
+            acc = w;
+          }
           phase = (phase + m) % (uint32_t)S;
         }
         run -= m;
