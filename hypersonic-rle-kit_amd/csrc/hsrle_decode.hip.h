@@ -29,6 +29,8 @@
 
 namespace hsrle {
 
+typedef u32x4 u32x4_unaligned __attribute__((aligned(1)));   // `out` is a caller pointer: no alignment promise
+
 enum DecodeError : uint32_t
 {
   DEC_ERR_HEADER = 1u,   // block stream header does not match the container table
@@ -934,7 +936,8 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
         if (lane == 0)
 #endif
         if (fAt[q] != 0xFFFFFFFFu)
-          st128(out + (uint64_t)(wgFirst + (uint32_t)q * RPI + lane / CPR) * B + fAt[q], fv[q]);
+          // streaming store: the output is written once and never read here, keep it from evicting the compressed lines in L2
+          __builtin_nontemporal_store(fv[q], (u32x4_unaligned *)(out + (uint64_t)(wgFirst + (uint32_t)q * RPI + lane / CPR) * B + fAt[q]));
       }
     }
     base += chunks << 4;

@@ -1,11 +1,29 @@
-# Full codec sweep (BASELINE config 5 shape): python tools/sweep.py [size_mib] [block] -> markdown table on stdout
-import sys, os, json
+# Full codec sweep (BASELINE config 5 shape): python tools/sweep.py [size_mib] [block] [video] -> markdown table on stdout
+# GPU columns: device-resident encode / decode of the whole buffer.  CPU columns: the compiled reference (oracle/_ref) when it is
+# present, else the oracle's restatement, single thread, on the first 16 MiB of the same buffer / container (block by block).
+import sys, os, json, time, ctypes
 sys.path.insert(0,'tests'); sys.path.insert(0,'hypersonic-rle-kit_amd/python')
+import numpy as np
 import torch, hsrle
-from hsrle_testlib import CODECS
+from hsrle_testlib import CODECS, REF_SO, Oracle, Reference
 size=(int(sys.argv[1]) if len(sys.argv)>1 else 1024)<<20
 bs=int(sys.argv[2]) if len(sys.argv)>2 else 4096
 kinds=[('runs',0)] + ([('video',1)] if len(sys.argv)>3 else [])
+CPU_SAMPLE=min(size,16<<20)
+have_ref=os.path.exists(REF_SO)
+CPU=Reference() if have_ref else Oracle()
+if have_ref:
+    ref=ctypes.CDLL(REF_SO)
+    ref.hsrle_ref_decode_blocks.restype=ctypes.c_uint64
+    ref.hsrle_ref_decode_blocks.argtypes=[ctypes.c_void_p]*3+[ctypes.c_uint64,ctypes.c_uint32,ctypes.c_void_p,ctypes.c_uint64]
+    ref.hsrle_ref_encode_blocks.restype=ctypes.c_uint64
+    ref.hsrle_ref_encode_blocks.argtypes=[ctypes.c_void_p,ctypes.c_void_p,ctypes.c_uint64,ctypes.c_uint32,ctypes.c_void_p,ctypes.c_uint32,ctypes.c_void_p]
+else:
+    ora=Oracle()
+    ora.lib.hso_decompress_blocks.restype=ctypes.c_uint64
+    ora.lib.hso_decompress_blocks.argtypes=[ctypes.c_int]*3+[ctypes.c_void_p,ctypes.c_void_p,ctypes.c_uint64,ctypes.c_uint32,ctypes.c_void_p,ctypes.c_uint64]
+    ora.lib.hso_compress_blocks.restype=ctypes.c_uint32
+    ora.lib.hso_compress_blocks.argtypes=[ctypes.c_int]*3+[ctypes.c_void_p,ctypes.c_uint64,ctypes.c_uint32,ctypes.c_void_p,ctypes.c_uint32,ctypes.c_void_p]
 def bench(fn, n=3):
     fn(); torch.cuda.synchronize()
     e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
@@ -13,8 +31,35 @@ def bench(fn, n=3):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1)/n/1e3
-rows=[]
-print('| codec | data | ratio | encode GiB/s | decode GiB/s | decode % of 8 TB/s (C+U) | round trip |'); print('|---|---|---:|---:|---:|---:|---|')
+def best(fn,n=2):
+    b=1e9
+    for _ in range(n):
+        t=time.perf_counter(); r=fn(); b=min(b,time.perf_counter()-t)
+    return b,r
+def cpu_cols(c, src, cont, info):
+    nb=CPU_SAMPLE//bs
+    raw=cont[:64+8*(info.blockCount+1)].cpu().numpy()
+    offs=np.frombuffer(raw.tobytes(),dtype=np.uint64,count=nb+1,offset=64).copy()
+    p0=64+8*(info.blockCount+1)
+    payload=cont[p0:p0+int(offs[nb])+64].cpu().numpy().copy()
+    inp=np.concatenate([src[:CPU_SAMPLE].cpu().numpy(), np.full(64,0xA5,dtype=np.uint8)])   # guard pad behind the sample (reads past a block end see the next block anyway)
+    out=np.zeros(CPU_SAMPLE+256,dtype=np.uint8)
+    stride=bs+256
+    enc=np.zeros(nb*stride+64,dtype=np.uint8); sizes=np.zeros(nb,dtype=np.uint32)
+    if have_ref:
+        fd=ctypes.cast(getattr(ref,c.dname),ctypes.c_void_p); fe=ctypes.cast(getattr(ref,c.cname),ctypes.c_void_p)
+        td,got=best(lambda: ref.hsrle_ref_decode_blocks(fd,payload.ctypes.data,offs.ctypes.data,nb,bs,out.ctypes.data,CPU_SAMPLE))
+        te,_=best(lambda: ref.hsrle_ref_encode_blocks(fe,inp.ctypes.data,CPU_SAMPLE,bs,enc.ctypes.data,stride,sizes.ctypes.data))
+    else:
+        td,got=best(lambda: ora.lib.hso_decompress_blocks(c.family,c.S,c.aligned,payload.ctypes.data,offs.ctypes.data,nb,bs,out.ctypes.data,CPU_SAMPLE))
+        te,_=best(lambda: ora.lib.hso_compress_blocks(c.family,c.S,c.aligned,inp.ctypes.data,CPU_SAMPLE,bs,enc.ctypes.data,stride,sizes.ctypes.data))
+    okd=got==CPU_SAMPLE and bool((out[:CPU_SAMPLE]==inp[:CPU_SAMPLE]).all())
+    # the CPU's block streams must equal the GPU's: sampled blocks, each encoded alone behind a guard pad (the reference's wide
+    # encoders peek past the block end; "bytes beyond the end never match" is the container's rule)
+    same=all(CPU.compress(c, bytes(inp[i*bs:(i+1)*bs]))==bytes(payload[int(offs[i]):int(offs[i+1])]) for i in range(0,nb,max(1,nb//61)))
+    return CPU_SAMPLE/te/2**30, CPU_SAMPLE/td/2**30, okd and same
+print('GPU: whole %d MiB buffer, %d B blocks, device resident.  CPU: %s, 1 thread, first %d MiB.'%(size>>20,bs,'compiled reference (oracle/_ref)' if have_ref else "oracle restatement ('port')",CPU_SAMPLE>>20)); print()
+print('| codec | data | ratio | GPU encode GiB/s | GPU decode GiB/s | decode % of 8 TB/s (C+U) | CPU encode GiB/s | CPU decode GiB/s | round trip + streams == CPU |'); print('|---|---|---:|---:|---:|---:|---:|---:|---|')
 for kname,kind in kinds:
     cache={}
     for c in CODECS:
@@ -26,5 +71,6 @@ for kname,kind in kinds:
         out=torch.empty(size,dtype=torch.uint8,device='cuda'); st=torch.zeros(16,dtype=torch.int32,device='cuda')
         td=bench(lambda: hsrle.decompress_async(dst,info,out,st)); te=bench(lambda: hsrle.compress_async(c.key,src,dst,bs,workspace=ws),2)
         ok=int(st[0].item())==0 and torch.equal(out,src)
-        print('| %s | %s | %.4f | %.0f | %.0f | %.1f | %s |'%(c.key,kname,info.totalSize/size,size/te/2**30,size/td/2**30,(size+info.totalSize)/td/8e10,'ok' if ok else 'FAIL'),flush=True)
+        ce,cd,cok=cpu_cols(c,src,dst,info)
+        print('| %s | %s | %.4f | %.0f | %.0f | %.1f | %.2f | %.2f | %s |'%(c.key,kname,info.totalSize/size,size/te/2**30,size/td/2**30,(size+info.totalSize)/td/8e10,ce,cd,'ok' if (ok and cok) else 'FAIL'),flush=True)
         del dst,ws,out
