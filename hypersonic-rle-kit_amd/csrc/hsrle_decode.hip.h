@@ -163,17 +163,21 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
                                                       uint32_t B, uint32_t firstBlock, uint32_t blockCount, uint32_t *__restrict__ status)
 {
   using TR = Traits<FAM, S, AL>;
-  constexpr int TS = T + 16;                 // tile row stride: 16 bytes of over-write slack; an odd multiple of 16 (bank spread)
+  constexpr int TS = T;                      // tile row stride: no pad -- the 16-byte chunks of a row are XOR-swizzled by the row index instead (TSW)
   constexpr int RS = R + 16;                 // ring row stride: bytes [R, R+16) mirror [0, 16) so a 32-byte aligned window never wraps
   constexpr int CPR = T / 16;                // 16-byte chunks per tile row == lanes that serve one row in top-up / flush
   constexpr int RPI = 64 / CPR;              // rows covered by one flush instruction
+#ifndef HSRLE_FLUSH_GROUP
+#define HSRLE_FLUSH_GROUP 4
+#endif
+  constexpr int FH = CPR < HSRLE_FLUSH_GROUP ? CPR : HSRLE_FLUSH_GROUP; // flush instructions in flight together
   constexpr int LPR = Q / 16;                // lanes that serve one row in a top-up (Q contiguous stream bytes)
   constexpr int RPL = 64 / LPR;              // rows covered by one top-up instruction
   constexpr uint32_t RMASK = (uint32_t)R - 1u;
   constexpr uint32_t MAXHDR = 1u + 4u + (uint32_t)S + 4u + 2u; // longest packet header of any family (+ slack)
   static_assert((R & (R - 1)) == 0 && R >= 64 && R % Q == 0 && T % Q == 0 && (Q == 32 || Q == 64 || Q == 128), "ring size must be a power of two and a multiple of Q");
   static_assert(T == 64 || T == 128, "tile rows are flushed as whole 64/128-byte pieces");
-  static_assert((TS / 16) % 2 == 1 && TS % 16 == 0 && RS % 16 == 0, "rows are 16-byte aligned; the tile stride is an odd multiple of 16 bytes");
+  static_assert(TS % 16 == 0 && RS % 16 == 0 && (RS / 16) % 2 == 1, "rows are 16-byte aligned; the ring stride is an odd multiple of 16 bytes");
 
   __shared__ __attribute__((aligned(16))) uint8_t tile[64 * TS];
   __shared__ __attribute__((aligned(16))) uint8_t ring[64 * RS];
@@ -191,6 +195,11 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   const bool active = b < lastBlockExcl;
 
   uint8_t *const row = tile + lane * TS;
+  // Tile swizzle: chunk k of row r lives at chunk slot k ^ f(r), so that 8 neighbouring rows touch 8 different bank groups
+  // when they access the same chunk index (what the pad did before, without its 1 KB per wave).  T = 128: f = r & 7;
+  // T = 64: f = (r >> 1) & 3 (two rows share a 128-byte bank line).
+  auto tsw_of = [](uint32_t r) -> uint32_t { return (T == 128 ? (r & 7u) : ((r >> 1) & 3u)) << 4; };
+  const uint32_t tsw = tsw_of(lane);
   uint8_t *const rng = ring + lane * RS;
 
   // ---- per-lane stream state ----
@@ -510,14 +519,14 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
             else
             {
               const uint32_t q = o - base, c = q & 15u;
-              uint8_t *dst = row + (q & ~15u);
+              const uint32_t d0 = q & ~15u;
               const uint32_t srcp = sp - c;
               const uint32_t total = c + n;
               const uint32_t s8 = srcp & ~7u, sh = srcp & 7u;
               const uint8_t *src = rng + (s8 & RMASK);
               uint64_t xa = lds_ld64(src), xb = lds_ld64(src + 8), xc = lds_ld64(src + 16);
               u32x4 w = merge_low(acc, funnel24(xa, xb, xc, sh), c);     // keep the c valid bytes of the straddled chunk
-              lds_st128(dst, w);
+              lds_st128(row + (d0 ^ tsw), w);
               for (uint32_t k = 16; k < total; k += 16)
               {
                 const uint8_t *nx = rng + ((s8 + k + 8u) & RMASK);         // the next 16 window bytes (8-byte aligned, mirror covers the wrap)
@@ -525,7 +534,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
                 xb = lds_ld64(nx);
                 xc = lds_ld64(nx + 8);
                 w = funnel24(xa, xb, xc, sh);
-                lds_st128(dst + k, w);
+                lds_st128(row + ((d0 + k) ^ tsw), w);
               }
               acc = w;
               sp += n;
@@ -539,13 +548,13 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
           {
             const uint32_t m = umin(run, target - o);
             const uint32_t q = o - base, c = q & 15u;
-            uint8_t *dst = row + (q & ~15u);
+            const uint32_t d0 = q & ~15u;
             const uint32_t total = c + m;
             const u32x4 v = u32x4{ sym4, sym4, sym4, sym4 };
             const u32x4 w = merge_low(acc, v, c);
-            lds_st128(dst, w);
+            lds_st128(row + (d0 ^ tsw), w);
             for (uint32_t k = 16; k < total; k += 16)
-              lds_st128(dst + k, v);
+              lds_st128(row + ((d0 + k) ^ tsw), v);
             acc = (total <= 16u) ? w : v;
             run -= m;
             o += m;
@@ -816,14 +825,14 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
         if (n == 0) break;                                             // literals not resident yet: continue next round
 
         const uint32_t q = o - base, c = q & 15u;
-        uint8_t *dst = row + (q & ~15u);
+        const uint32_t d0 = q & ~15u;
         const uint32_t srcp = sp - c;
         const uint32_t total = c + n;                                  // bytes from dst that must end up valid
         const uint32_t s8 = srcp & ~7u, sh = srcp & 7u;
         const uint8_t *src = rng + (s8 & RMASK);
         uint64_t xa = lds_ld64(src), xb = lds_ld64(src + 8), xc = lds_ld64(src + 16);
         u32x4 w = merge_low(acc, funnel24(xa, xb, xc, sh), c);         // keep the c valid bytes of the straddled chunk
-        lds_st128(dst, w);
+        lds_st128(row + (d0 ^ tsw), w);
         for (uint32_t k = 16; k < total; k += 16)
         {
           const uint8_t *nx = rng + ((s8 + k + 8u) & RMASK);
@@ -831,7 +840,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
           xb = lds_ld64(nx);
           xc = lds_ld64(nx + 8);
           w = funnel24(xa, xb, xc, sh);
-          lds_st128(dst + k, w);
+          lds_st128(row + ((d0 + k) ^ tsw), w);
         }
         acc = w;
         sp += n;
@@ -844,16 +853,16 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
       {
         const uint32_t m = umin(run, target - o);
         const uint32_t q = o - base, c = q & 15u;
-        uint8_t *dst = row + (q & ~15u);
+        const uint32_t d0 = q & ~15u;
         const uint32_t total = c + m;
 
         if constexpr (S == 1)
         {
           const u32x4 v = u32x4{ sym4, sym4, sym4, sym4 };
           const u32x4 w = merge_low(acc, v, c);
-          lds_st128(dst, w);
+          lds_st128(row + (d0 ^ tsw), w);
           for (uint32_t k = 16; k < total; k += 16)
-            lds_st128(dst + k, v);
+            lds_st128(row + ((d0 + k) ^ tsw), v);
           acc = (total <= 16u) ? w : v;
         }
         else
@@ -864,9 +873,9 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
           {
             const u32x4 v = pattern_chunk16(patv, ph);                    // every chunk of the run holds the same 16 bytes
             const u32x4 w = merge_low(acc, v, c);
-            lds_st128(dst, w);
+            lds_st128(row + (d0 ^ tsw), w);
             for (uint32_t k = 16; k < total; k += 16)
-              lds_st128(dst + k, v);
+              lds_st128(row + ((d0 + k) ^ tsw), v);
             acc = (total <= 16u) ? w : v;
           }
           else
@@ -874,12 +883,12 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
             uint32_t e0, e1, e2;
             pattern_dwords12(patv, ph, e0, e1, e2);
             u32x4 w = merge_low(acc, u32x4{ e0, e1, e2, e0 }, c);
-            lds_st128(dst, w);
+            lds_st128(row + (d0 ^ tsw), w);
             for (uint32_t k = 16; k < total; k += 16)
             {
               const uint32_t t = e0; e0 = e1; e1 = e2; e2 = t;
               w = u32x4{ e0, e1, e2, e0 };
-              lds_st128(dst + k, w);
+              lds_st128(row + ((d0 + k) ^ tsw), w);
             }
             acc = w;
           }
@@ -917,27 +926,31 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 #ifdef HSRLE_STAMPS
     if (active && produced != (uint32_t)T) tIssue += 1ull << 40;          // diagnostic: partial rows
 #endif
-    {
-      u32x4 fv[CPR];
-      uint32_t fAt[CPR];
 #pragma unroll
-      for (int q = 0; q < CPR; q++)
+    for (int h = 0; h < CPR; h += FH)                                  // FH rows-groups at a time bounds the live registers
+    {
+      u32x4 fv[FH];
+      uint32_t fAt[FH];
+#pragma unroll
+      for (int k = 0; k < FH; k++)
       {
+        const int q = h + k;
         const uint32_t r = (uint32_t)q * RPI + lane / CPR, c = lane % CPR;
         const uint32_t nch = (uint32_t)__shfl((int)chunks, (int)r, 64);
         const uint32_t rst = (uint32_t)__shfl((int)base, (int)r, 64);
-        fv[q] = lds_ld128(tile + r * TS + c * 16u);
-        fAt[q] = (c < nch) ? rst + c * 16u : 0xFFFFFFFFu;
+        fv[k] = lds_ld128(tile + r * TS + ((c * 16u) ^ tsw_of(r)));
+        fAt[k] = (c < nch) ? rst + c * 16u : 0xFFFFFFFFu;
       }
 #pragma unroll
-      for (int q = 0; q < CPR; q++)
+      for (int k = 0; k < FH; k++)
       {
+        const int q = h + k;
 #ifdef HSRLE_ABLATE_STORES  // timing-only diagnostic build: only one lane in 64 stores (output is wrong)
         if (lane == 0)
 #endif
-        if (fAt[q] != 0xFFFFFFFFu)
+        if (fAt[k] != 0xFFFFFFFFu)
           // streaming store: the output is written once and never read here, keep it from evicting the compressed lines in L2
-          __builtin_nontemporal_store(fv[q], (u32x4_unaligned *)(out + (uint64_t)(wgFirst + (uint32_t)q * RPI + lane / CPR) * B + fAt[q]));
+          __builtin_nontemporal_store(fv[k], (u32x4_unaligned *)(out + (uint64_t)(wgFirst + (uint32_t)q * RPI + lane / CPR) * B + fAt[k]));
       }
     }
     base += chunks << 4;
@@ -945,7 +958,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     {
       const uint32_t at = chunks << 4;
       for (uint32_t k = 0; k < (produced & 15u); k++)
-        out[(uint64_t)b * B + base + k] = row[at + k];
+        out[(uint64_t)b * B + base + k] = row[(at ^ tsw) + k];
       base = o;                                                        // written exactly once
     }
 
