@@ -164,7 +164,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 {
   using TR = Traits<FAM, S, AL>;
   constexpr int TS = T;                      // tile row stride: no pad -- the 16-byte chunks of a row are XOR-swizzled by the row index instead (TSW)
-  constexpr int RS = R + 16;                 // ring row stride: bytes [R, R+16) mirror [0, 16) so a 32-byte aligned window never wraps
+  constexpr int RS = R;                      // ring row stride: no pad, no mirror -- chunks are XOR-swizzled by the row index (rowx), every 8-byte piece is addressed on its own
   constexpr int CPR = T / 16;                // 16-byte chunks per tile row == lanes that serve one row in top-up / flush
   constexpr int RPI = 64 / CPR;              // rows covered by one flush instruction
 #ifndef HSRLE_FLUSH_GROUP
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   constexpr uint32_t MAXHDR = 1u + 4u + (uint32_t)S + 4u + 2u; // longest packet header of any family (+ slack)
   static_assert((R & (R - 1)) == 0 && R >= 64 && R % Q == 0 && T % Q == 0 && (Q == 32 || Q == 64 || Q == 128), "ring size must be a power of two and a multiple of Q");
   static_assert(T == 64 || T == 128, "tile rows are flushed as whole 64/128-byte pieces");
-  static_assert(TS % 16 == 0 && RS % 16 == 0 && (RS / 16) % 2 == 1, "rows are 16-byte aligned; the ring stride is an odd multiple of 16 bytes");
+  static_assert(TS % 16 == 0 && RS % 16 == 0, "rows are 16-byte aligned");
 
   __shared__ __attribute__((aligned(16))) uint8_t tile[64 * TS];
   __shared__ __attribute__((aligned(16))) uint8_t ring[64 * RS];
@@ -200,7 +200,15 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   // T = 64: f = (r >> 1) & 3 (two rows share a 128-byte bank line).
   auto tsw_of = [](uint32_t r) -> uint32_t { return (T == 128 ? (r & 7u) : ((r >> 1) & 3u)) << 4; };
   const uint32_t tsw = tsw_of(lane);
-  uint8_t *const rng = ring + lane * RS;
+  // Ring swizzle, same idea as the tile's: ring byte x (0 <= x < R) of row r lives at ring[(r * R) ^ rsw_of(r) ^ x]; the XOR only
+  // touches the chunk-index bits, so bytes inside a 16-byte chunk (and 8-byte halves) stay in place.
+  auto rsw_of = [](uint32_t r) -> uint32_t { return (R >= 128 ? (r & 7u) : ((r >> 1) & 3u)) << 4; };
+  const uint32_t rowx = (lane * (uint32_t)RS) ^ rsw_of(lane);
+  // 16 stream bytes at virtual position p: three naturally aligned 8-byte reads (each wraps / swizzles on its own) + byte funnel
+  auto ring_win16 = [&](uint32_t p) -> u32x4 {
+    const uint32_t a = p & ~7u;
+    return funnel24(lds_ld64(ring + (rowx ^ (a & RMASK))), lds_ld64(ring + (rowx ^ ((a + 8u) & RMASK))), lds_ld64(ring + (rowx ^ ((a + 16u) & RMASK))), p & 7u);
+  };
 
   // ---- per-lane stream state ----
   uint32_t slen = 0, blen = 0;
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
       const bool valid = c < n;
       const uint32_t pos = e + c * 16u;
       pf[q] = ld128(payload + myBase[q] + (valid ? pos : 0u));         // predicated-off lanes re-read the stream start
-      pfAt[q] = r * (uint32_t)RS + (pos & RMASK);                       // ring slot of this chunk
+      pfAt[q] = (r * (uint32_t)RS) ^ rsw_of(r) ^ (pos & RMASK);         // ring slot of this chunk
     }
   };
 
@@ -285,8 +293,6 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
       if (c < tk)
       {
         lds_st128(ring + pfAt[q], pf[q]);
-        if ((pfAt[q] - r * (uint32_t)RS) < 16u)
-          lds_st128(ring + pfAt[q] + (uint32_t)R, pf[q]);              // mirror of the first 16 ring bytes
       }
     }
   };
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   if (active)
   {
     sp = g0 + TR::kHeaderSize;
-    const uint8_t *hd = rng + g0;                                      // g0 is a multiple of 16 and < R
+    const uint8_t *hd = ring + (rowx ^ g0);                            // g0 is a multiple of 16 and < R: one whole chunk
 
     if (slen < g0 + TR::kHeaderSize + 2u || ld32(hd) != blen || ld32(hd + 4) != slen - g0)
     {
@@ -409,7 +415,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
           else
           {
             // ---------------- packet header: 16 stream bytes at sp, fields picked with shifts ----------------
-            const u32x4 hv = lds_read16_w8(rng, sp & RMASK);
+            const u32x4 hv = ring_win16(sp);
             [[maybe_unused]] const uint64_t lo = (uint64_t)hv.x | ((uint64_t)hv.y << 32), hi = (uint64_t)hv.z | ((uint64_t)hv.w << 32);
             uint32_t cnt, pos, nsym = sym4, range, used, endNow = 0, hbad = 0;
 
@@ -523,16 +529,14 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
               const uint32_t srcp = sp - c;
               const uint32_t total = c + n;
               const uint32_t s8 = srcp & ~7u, sh = srcp & 7u;
-              const uint8_t *src = rng + (s8 & RMASK);
-              uint64_t xa = lds_ld64(src), xb = lds_ld64(src + 8), xc = lds_ld64(src + 16);
+              uint64_t xa = lds_ld64(ring + (rowx ^ (s8 & RMASK))), xb = lds_ld64(ring + (rowx ^ ((s8 + 8u) & RMASK))), xc = lds_ld64(ring + (rowx ^ ((s8 + 16u) & RMASK)));
               u32x4 w = merge_low(acc, funnel24(xa, xb, xc, sh), c);     // keep the c valid bytes of the straddled chunk
               lds_st128(row + (d0 ^ tsw), w);
               for (uint32_t k = 16; k < total; k += 16)
               {
-                const uint8_t *nx = rng + ((s8 + k + 8u) & RMASK);         // the next 16 window bytes (8-byte aligned, mirror covers the wrap)
                 xa = xc;
-                xb = lds_ld64(nx);
-                xc = lds_ld64(nx + 8);
+                xb = lds_ld64(ring + (rowx ^ ((s8 + k + 8u) & RMASK)));
+                xc = lds_ld64(ring + (rowx ^ ((s8 + k + 16u) & RMASK)));
                 w = funnel24(xa, xb, xc, sh);
                 lds_st128(row + ((d0 + k) ^ tsw), w);
               }
@@ -583,103 +587,8 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
         uint32_t cnt, range, used;
         bool endNow = false;
 
-        if constexpr (S == 1)
         {
-          // 8 bit: the whole header (<= 11 bytes) comes from ONE 16-byte ring read; fields are picked with shifts
-          const u32x4 hv = lds_read16(rng, sp & RMASK);
-          const uint64_t lo = (uint64_t)hv.x | ((uint64_t)hv.y << 32), hi = (uint64_t)hv.z | ((uint64_t)hv.w << 32);
-          uint32_t pos;
-
-          if constexpr (TR::kLut)
-          {
-            const uint32_t w16 = hv.x & 0xFFFFu;
-            const uint32_t idx = w16 >> (FAM == LUT3 ? 14 : 13);
-            const uint32_t c7 = (w16 >> TR::RB) & 0x7Fu;
-            const uint32_t r7 = w16 & ((1u << TR::RB) - 1u);
-            pos = 2;
-
-            if (idx != 0)
-            {
-              // lut[k][0] holds entry k (one byte each); move entry idx (or the new symbol) to the front
-              uint32_t sb;
-              if (idx == (uint32_t)TR::K) { sb = (hv.x >> 16) & 0xFFu; pos = 3; }
-              else
-              {
-                sb = lut[0][0];
-#pragma unroll
-                for (int k = 1; k < TR::K; k++)
-                  if (idx == (uint32_t)k) sb = lut[k][0];
-              }
-              const uint32_t limit = (idx == (uint32_t)TR::K) ? (uint32_t)TR::K - 1u : idx;
-#pragma unroll
-              for (int k = TR::K - 1; k >= 1; k--)
-                if ((uint32_t)k <= limit) lut[k][0] = lut[k - 1][0];
-              lut[0][0] = sb;
-              sym4 = sb * 0x01010101u;
-            }
-
-            cnt = c7;
-            if (c7 == 0u) { cnt = ex32(lo, hi, pos); pos += 4; }
-            else if (c7 == 1u) { cnt = ex32(lo, hi, pos) & 0xFFFFu; pos += 2; }
-
-            range = r7;
-            if (r7 == 0u) { range = ex32(lo, hi, pos); pos += 4; }
-            else if (r7 == 1u) { range = ex32(lo, hi, pos) & 0xFFFFu; pos += 2; endNow = (range == 0u); }
-            used = pos;
-
-            if (!endNow && range < 2u) { err |= DEC_ERR_STREAM; done = true; break; }
-            lit = endNow ? 0u : range - 2u;
-            run = (cnt == 0u) ? 0u : cnt + 1u;
-          }
-          else
-          {
-            if (single)
-            {
-              cnt = hv.x & 0xFFu;
-              pos = 1;
-              if (cnt == 0) { cnt = (uint32_t)(lo >> 8); pos = 5; }
-            }
-            else if constexpr (!TR::kPacked)
-            {
-              sym4 = (hv.x & 0xFFu) * 0x01010101u;
-              cnt = (hv.x >> 8) & 0xFFu;
-              pos = 2;
-              if (cnt == 0) { cnt = (uint32_t)(lo >> 16); pos = 6; }
-            }
-            else
-            {
-              const uint32_t x = hv.x & 0xFFu;
-              cnt = x & 0x7Fu;
-              pos = 1;
-              if (cnt == 0) { cnt = (uint32_t)(lo >> 8); pos = 5; }
-              if (!(x & 0x80u)) { sym4 = (ex32(lo, hi, pos) & 0xFFu) * 0x01010101u; pos += 1; }
-            }
-
-            const uint32_t w = ex32(lo, hi, pos);
-            const uint32_t r0 = w & 0xFFu;
-
-            if (TR::kRange7 && !single)
-            {
-              if (r0 & 1u) { range = w >> 1; used = pos + 4; endNow = (range == 0); }
-              else { range = r0 >> 1; used = pos + 1; }
-            }
-            else
-            {
-              range = r0; used = pos + 1;
-              if (r0 == 0) { range = ex32(lo, hi, pos + 1u); used = pos + 5; endNow = (range == 0); }
-            }
-
-            lit = (range == 0) ? 0u : range - 1u; // a 7 bit range byte of 0x00 carries no literals (A.5 q11)
-
-            if (cnt == 0) run = 0;
-            else if (single) run = cnt + ((FAM == PACKED) ? 2u : 4u) - 1u;
-            else run = cnt + TR::SHORT - 1u;
-          }
-        }
-        else
-        {
-#define HS_RD16(off) lds_read16_w8(rng, (sp + (off)) & RMASK)
-#define HS_RD8(off) (uint32_t)(*(rng + ((sp + (off)) & RMASK)))
+#define HS_RD16(off) ring_win16(sp + (off))
           // S > 1: the first 16 header bytes in one read; the (rare) fields behind them with a second read
           const u32x4 hv = HS_RD16(0);
           const uint64_t lo = (uint64_t)hv.x | ((uint64_t)hv.y << 32), hi = (uint64_t)hv.z | ((uint64_t)hv.w << 32);
@@ -773,7 +682,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
               if (cnt == 0) { cnt = tv.x; tp = 4; }
               if (!(x & 0x80u))
               {
-                set_sym(lds_read16_w8(rng, (sp + used + tp) & RMASK));
+                set_sym(ring_win16(sp + used + tp));
                 tp += S;
               }
             }
@@ -781,7 +690,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
             // range field: for S == 16 it can start beyond the 16 bytes of tv
             uint32_t w;
             if (tp <= 12u) w = ex32(tlo, thi, tp);
-            else w = lds_read16_w8(rng, (sp + used + tp) & RMASK).x;
+            else w = ring_win16(sp + used + tp).x;
             const uint32_t r0 = w & 0xFFu;
 
             if constexpr (TR::kRange7)
@@ -794,7 +703,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
               range = r0; tp += 1;
               if (r0 == 0)
               {
-                range = (tp <= 12u) ? ex32(tlo, thi, tp) : lds_read16_w8(rng, (sp + used + tp) & RMASK).x;
+                range = (tp <= 12u) ? ex32(tlo, thi, tp) : ring_win16(sp + used + tp).x;
                 tp += 4;
                 endNow = (range == 0);
               }
@@ -805,7 +714,6 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
             run = (cnt == 0) ? 0u : (TR::kAligned ? (cnt + TR::SHORT / (uint32_t)S - 1u) * (uint32_t)S : cnt + TR::SHORT - 1u);
           }
 #undef HS_RD16
-#undef HS_RD8
         }
 
         sp += used;
@@ -829,16 +737,14 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
         const uint32_t srcp = sp - c;
         const uint32_t total = c + n;                                  // bytes from dst that must end up valid
         const uint32_t s8 = srcp & ~7u, sh = srcp & 7u;
-        const uint8_t *src = rng + (s8 & RMASK);
-        uint64_t xa = lds_ld64(src), xb = lds_ld64(src + 8), xc = lds_ld64(src + 16);
+        uint64_t xa = lds_ld64(ring + (rowx ^ (s8 & RMASK))), xb = lds_ld64(ring + (rowx ^ ((s8 + 8u) & RMASK))), xc = lds_ld64(ring + (rowx ^ ((s8 + 16u) & RMASK)));
         u32x4 w = merge_low(acc, funnel24(xa, xb, xc, sh), c);         // keep the c valid bytes of the straddled chunk
         lds_st128(row + (d0 ^ tsw), w);
         for (uint32_t k = 16; k < total; k += 16)
         {
-          const uint8_t *nx = rng + ((s8 + k + 8u) & RMASK);
           xa = xc;
-          xb = lds_ld64(nx);
-          xc = lds_ld64(nx + 8);
+          xb = lds_ld64(ring + (rowx ^ ((s8 + k + 8u) & RMASK)));
+          xc = lds_ld64(ring + (rowx ^ ((s8 + k + 16u) & RMASK)));
           w = funnel24(xa, xb, xc, sh);
           lds_st128(row + ((d0 + k) ^ tsw), w);
         }
@@ -856,16 +762,6 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
         const uint32_t d0 = q & ~15u;
         const uint32_t total = c + m;
 
-        if constexpr (S == 1)
-        {
-          const u32x4 v = u32x4{ sym4, sym4, sym4, sym4 };
-          const u32x4 w = merge_low(acc, v, c);
-          lds_st128(row + (d0 ^ tsw), w);
-          for (uint32_t k = 16; k < total; k += 16)
-            lds_st128(row + ((d0 + k) ^ tsw), v);
-          acc = (total <= 16u) ? w : v;
-        }
-        else
         {
           // the pattern byte for tile byte (A + j) is sym[(phase - c + j) mod S]
           const uint32_t ph = (phase + 16u * (uint32_t)S - c) % (uint32_t)S;
