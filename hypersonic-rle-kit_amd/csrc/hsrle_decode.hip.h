@@ -181,6 +181,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 
   __shared__ __attribute__((aligned(16))) uint8_t tile[64 * TS];
   __shared__ __attribute__((aligned(16))) uint8_t ring[64 * RS];
+  __shared__ __attribute__((aligned(16))) uint32_t rinfo[64];           // per-row scalars for the serving lanes (publish())
 #ifdef HSRLE_LDS_BALLAST  // occupancy experiment only: extra LDS so that fewer waves fit on a CU
   __shared__ uint8_t ballast[HSRLE_LDS_BALLAST];
   if (U == 0x7FFFFFFFFFFFFFFFull) ballast[threadIdx.x] = 1;
@@ -263,16 +264,28 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 
   uint32_t wantReq = 0;                                             // chunks this row requested in issue()
 
+  // Per-row scalars travel between the row's owner lane and the lanes that serve the row through a 64-dword LDS array:
+  // the owner of row r writes slot (r % G) * P + r / G (P = lanes per row, G = 64 / P rows per instruction), so the P rows a
+  // lane serves (rows q * G + lane / P, q = 0 .. P-1) are P consecutive dwords: one or two broadcast ds_read_b128 instead of
+  // P (or 2 P) ds_bpermute.
+  auto publish = [&](uint32_t v, int P) { rinfo[(lane % (64u / (uint32_t)P)) * (uint32_t)P + lane / (64u / (uint32_t)P)] = v; };
+
   auto issue = [&]() {
     // request up to LPR chunks behind E.  Whether they FIT is decided when they land (after this round's decode has
     // freed ring space), so the ring only has to hold one round of consumption, not two.
     wantReq = umin((uint32_t)LPR, (lim - E) >> 4);
     if (done) wantReq = 0;
+    publish(E | wantReq, LPR);                                        // E is a multiple of 16, wantReq <= 8
+    wave_sync();
+    uint32_t ri[LPR];
+#pragma unroll
+    for (int q = 0; q < LPR; q++) ri[q] = rinfo[(lane / LPR) * LPR + q];
+    wave_sync();
 #pragma unroll
     for (int q = 0; q < LPR; q++)
     {
       const uint32_t r = (uint32_t)q * RPL + lane / LPR, c = lane % LPR;
-      const uint32_t e = (uint32_t)__shfl((int)E, (int)r, 64), n = (uint32_t)__shfl((int)wantReq, (int)r, 64);
+      const uint32_t e = ri[q] & ~15u, n = ri[q] & 15u;
       const bool valid = c < n;
       const uint32_t pos = e + c * 16u;
       pf[q] = ld128(payload + myBase[q] + (valid ? pos : 0u));         // predicated-off lanes re-read the stream start
@@ -285,15 +298,17 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     const uint32_t fit = ((uint32_t)R - (E - (sp & ~15u))) >> 4;
     const uint32_t take = umin(wantReq, fit);
     E += take << 4;
+    publish(take, LPR);
+    wave_sync();
+    uint32_t ri[LPR];
+#pragma unroll
+    for (int q = 0; q < LPR; q++) ri[q] = rinfo[(lane / LPR) * LPR + q];
+    wave_sync();
 #pragma unroll
     for (int q = 0; q < LPR; q++)
     {
-      const uint32_t r = (uint32_t)q * RPL + lane / LPR, c = lane % LPR;
-      const uint32_t tk = (uint32_t)__shfl((int)take, (int)r, 64);
-      if (c < tk)
-      {
+      if (lane % LPR < ri[q])
         lds_st128(ring + pfAt[q], pf[q]);
-      }
     }
   };
 
@@ -822,8 +837,13 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 #ifdef HSRLE_STAMPS
     if (active && produced != (uint32_t)T) tIssue += 1ull << 40;          // diagnostic: partial rows
 #endif
+    publish(chunks != 0u ? (base | chunks) : 0u, CPR);                  // base is a multiple of 16 while chunks are pending (after the tail bytes it is not), chunks <= 8
+    wave_sync();
+    uint32_t fi[CPR];
 #pragma unroll
-    for (int h = 0; h < CPR; h += FH)                                  // FH rows-groups at a time bounds the live registers
+    for (int q = 0; q < CPR; q++) fi[q] = rinfo[(lane / CPR) * CPR + q];
+#pragma unroll
+    for (int h = 0; h < CPR; h += FH)                                  // FH row-groups at a time bounds the live registers
     {
       u32x4 fv[FH];
       uint32_t fAt[FH];
@@ -832,10 +852,8 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
       {
         const int q = h + k;
         const uint32_t r = (uint32_t)q * RPI + lane / CPR, c = lane % CPR;
-        const uint32_t nch = (uint32_t)__shfl((int)chunks, (int)r, 64);
-        const uint32_t rst = (uint32_t)__shfl((int)base, (int)r, 64);
         fv[k] = lds_ld128(tile + r * TS + ((c * 16u) ^ tsw_of(r)));
-        fAt[k] = (c < nch) ? rst + c * 16u : 0xFFFFFFFFu;
+        fAt[k] = (c < (fi[q] & 15u)) ? (fi[q] & ~15u) + c * 16u : 0xFFFFFFFFu;
       }
 #pragma unroll
       for (int k = 0; k < FH; k++)

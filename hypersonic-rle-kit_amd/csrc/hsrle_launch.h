@@ -71,7 +71,8 @@ inline hipError_t launch_encode(KERNEL k, const EncodeArgs &a, hipStream_t st, i
   // those open lines (32 CUs x 32 waves x 64 lanes x 2 x 128 B = 16 MiB per XCD) thrash the 4 MiB L2 and every line is fetched /
   // written several times (measured: 6.8x read, 5.9x write amplification).  A dynamic LDS reservation caps the residency.
   static const uint32_t ldsCap = [] { const char *e = getenv("HSRLE_ENCODE_LDS_CAP"); return e ? (uint32_t)atoi(e) : kEncodeLdsCap; }();
-  hipLaunchKernelGGL(k, dim3(grid), dim3(64), capResidency ? ldsCap : 0u, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes);
+  static const uint32_t lds8 = [] { const char *e = getenv("HSRLE_ENCODE8_LDS"); return e ? (uint32_t)atoi(e) : 0u; }();   // experiment knob
+  hipLaunchKernelGGL(k, dim3(grid), dim3(64), capResidency ? ldsCap : lds8, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes);
   return hipGetLastError();
 }
 
