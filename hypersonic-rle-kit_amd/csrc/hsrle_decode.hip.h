@@ -585,17 +585,21 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
       last = (fl & F_LAST) != 0u;
     }
     else
-    while (!done && o < target)
     {
-      if (itersLeft-- == 0u) { err |= DEC_ERR_STREAM; done = true; break; }
+    // ================= wider symbols: per-lane loop; lane flags (done, last) live in one VGPR as in the 8 bit loop =================
+    constexpr uint32_t F_DONE = 1u, F_LAST = 4u;
+    uint32_t fl = (done ? F_DONE : 0u) | (last ? F_LAST : 0u);
+    while ((fl & F_DONE) == 0u && o < target)
+    {
+      if (itersLeft-- == 0u) { err |= DEC_ERR_STREAM; fl |= F_DONE; break; }
 #ifdef HSRLE_STAMPS
       nIter++;
 #endif
 
       if (lit == 0 && run == 0)
       {
-        if (last) { done = true; break; }
-        if (sp + 2u > slen) { err |= DEC_ERR_STREAM; done = true; break; }
+        if ((fl & F_LAST) != 0u) { fl |= F_DONE; break; }
+        if (sp + 2u > slen) { err |= DEC_ERR_STREAM; fl |= F_DONE; break; }
         if (avail0 - sp < MAXHDR && avail0 < lim) break;               // header not resident yet: continue next round
 
         // ---------------- packet header ----------------
@@ -663,7 +667,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
             else if (range == 1) { range = rext32 & 0xFFFFu; ep += 2; endNow = (range == 0); }
             used += ep;
 
-            if (!endNow && range < 2u) { err |= DEC_ERR_STREAM; done = true; break; }
+            if (!endNow && range < 2u) { err |= DEC_ERR_STREAM; fl |= F_DONE; break; }
             lit = endNow ? 0u : range - 2u;
             run = (cnt == 0) ? 0u : (TR::kAligned ? (cnt + 3u / (uint32_t)S - 2u) * (uint32_t)S : cnt + 1u);
           }
@@ -733,11 +737,11 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 
         sp += used;
         phase = 0;
-        last = endNow || (cnt == 0);
+        if (endNow || cnt == 0u) fl |= F_LAST;
         if (endNow) { lit = 0; run = 0; }
 
-        if (sp > slen || lit > slen - sp) { err |= DEC_ERR_STREAM; done = true; break; }
-        if (lit == 0 && run == 0 && !last) { err |= DEC_ERR_STREAM; done = true; break; }
+        if (sp > slen || lit > slen - sp) { err |= DEC_ERR_STREAM; fl |= F_DONE; break; }
+        if (lit == 0 && run == 0 && (fl & F_LAST) == 0u) { err |= DEC_ERR_STREAM; fl |= F_DONE; break; }
       }
 
       // ---- literals: tile chunks at the dword aligned positions A + 16k receive ring bytes [sp - c + 16k, +16) ----
@@ -808,6 +812,9 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
         run -= m;
         o += m;
       }
+    }
+    done = (fl & F_DONE) != 0u;
+    last = (fl & F_LAST) != 0u;
     }
 
     HS_STAMP(tDecode)
