@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--size-gib", type=float, default=8.0, help="uncompressed bytes per GPU")
     ap.add_argument("--block", type=int, default=4096)
     ap.add_argument("--codec", default="rle8_packed_multi")
+    ap.add_argument("--synth", choices=["runs", "video"], default="runs", help="synthetic generator: run-distributed (headline) or video-shaped (BASELINE config 3)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
 
@@ -123,13 +124,15 @@ def main():
     size = int(args.size_gib * (1 << 30)) // args.block * args.block
     seed = 2 if not distributed else 100 + rank  # config 2 seed 2; sharded config seeds 100 + rank
 
+    synth_name = "run-distributed(%d)" % (8 * codec.S) if args.synth == "runs" else "video-shaped"
+
     def barrier():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
     # ---- setup (untimed): synthetic input generated on the device, compressed once ----
-    src = hsrle.synth(hsrle.SYNTH_RUNS, codec.S, seed, size, device=dev)
+    src = hsrle.synth(hsrle.SYNTH_RUNS if args.synth == "runs" else hsrle.SYNTH_VIDEO, codec.S, seed, size, device=dev)
     dst = torch.empty(hsrle.container_bound(size, args.block), dtype=torch.uint8, device=dev)
     ws = torch.empty(hsrle.workspace_size(size, args.block), dtype=torch.uint8, device=dev)
     hsrle.compress_async(args.codec, src, dst, args.block, workspace=ws)
@@ -215,7 +218,7 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": f"{args.codec} decode, {size / 2**30:g} GiB run-distributed(8) synthetic per GPU (seed {seed}), {args.block} B blocks, "
+            "config": {"workload": f"{args.codec} decode, {size / 2**30:g} GiB {synth_name} synthetic per GPU (seed {seed}), {args.block} B blocks, "
                                    f"ratio {info.totalSize / size:.4f}", "codec": args.codec, "block_size": args.block, "blocks_per_gpu": info.blockCount, "sharding": f"blocks x{world}"},
             "bit_exact": bool(ok),
             "encode": {"value": round(size / 2**30 / (enc_ms * 1e-3), 2), "unit": "GiB/s", "ms": round(enc_ms, 4), "note": "same buffer, encode kernel + size scan + compaction"},

@@ -1,19 +1,20 @@
 // hsrle_encode8.hip.h -- the 8 bit multi-symbol encoders (rle8_multi, rle8_packed_multi, rle8_{3,7}symlut) with the block's
-// input and output staged through LDS.
+// input staged through LDS and the output assembled in registers.
 //
 // Replaces: src/rle8_extreme_cpu.h:86-344 (wrapper, scalar tail, final block), :936-1099 (canonical AVX2 body),
 //           src/rleX_Xsl.h:114-264 (process_symbol), :269-346, :421-485 (TYPE_SIZE 8 instantiation).
 //
 // Same execution model as everything else here: one lane = one block = one reference stream, 64 blocks per wavefront, the
-// emit decisions run as the sequential state machine they are.  What this kernel adds over the generic
-// k_encode_blocks is the DATA PATH (the generic kernel reads and writes global memory per lane, which costs 6-7x HBM traffic
-// amplification, measured):
+// emit decisions run as the sequential state machine they are.  Data path:
 //   HBM --(top-up: 4 adjacent lanes read 64 contiguous, aligned input bytes of ONE block per step)--> LDS history ring [64][256]
-//   ring --(run detection: 16 positions per step from one aligned 16-byte read: x ^ (x >> 8) == 0, the GPU form of the
-//           reference's cmpeq + movemask + ctz scan, rle8_extreme_cpu.h:952-1084; events = run starts / run ends)-->
-//   packets (header bytes + literal bytes copied ring -> row with a 128-bit byte funnel) --> LDS output row [64][160]
-//   row --(flush: 4 adjacent lanes write whole 16-byte chunks of one row)--> HBM staging slot
-// Literal gaps longer than the ring can serve (incompressible stretches) take a direct global-to-global path.
+//   ring --(run detection: 64 positions per step: x ^ (x >> 8) == 0 on aligned 16-byte reads, the GPU form of the
+//           reference's cmpeq + movemask + ctz scan, rle8_extreme_cpu.h:952-1084; bit masks of run starts / run ends)-->
+//   packets: header bytes are assembled in registers, literal bytes come from the ring through a 128-bit byte funnel; both are
+//           appended to a 16-byte output accumulator, and every completed 16-byte chunk goes straight to the block's staging
+//           slot in HBM (the compressed side is the small side, so per-lane stores are not what limits the kernel).
+// The kernel is latency bound like the decoder (throughput scales linearly with waves per CU), so LDS is spent on nothing but
+// the ring: 16 KB per wave (XOR-swizzled rows, no pad, no mirror) = 9 waves per CU.
+// Literal gaps that have left the ring (long runs, incompressible stretches) are read from global memory instead.
 #pragma once
 
 #include "hsrle_common.hip.h"
@@ -27,26 +28,25 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
 {
   using TR = Traits<FAM, 1, 0>;
   constexpr int Q = 64;                      // input bytes per lane and step
-  constexpr int H = 256;                     // history ring per lane (power of two)
-  constexpr int HS = H + 48;                 // ring row stride (32 mirror bytes; odd multiple of 16)
-  constexpr int OC = 160;                    // output row capacity
-  constexpr int OS = OC + 16;                // output row stride (16 bytes of over-write slack; odd multiple of 16)
+#ifndef HSRLE_ENC8_RING
+#define HSRLE_ENC8_RING 256
+#endif
+  constexpr int H = HSRLE_ENC8_RING;         // history ring per lane (power of two)
   constexpr int LPR = Q / 16, RPL = 64 / LPR;
   constexpr uint32_t HM = (uint32_t)H - 1u;
-  constexpr uint32_t LMAX = 96u;             // longest literal gap served from the ring
-  constexpr uint32_t HDRMAX = 12u;           // longest packet header + slack
   constexpr int K = TR::K;
 
-  __shared__ __attribute__((aligned(16))) uint8_t hist[64 * HS];
-  __shared__ __attribute__((aligned(16))) uint8_t outr[64 * OS];
+  __shared__ __attribute__((aligned(16))) uint8_t hist[64 * H];
+  __shared__ __attribute__((aligned(16))) uint32_t rinfo[64];
 
   const uint32_t lane = threadIdx.x;
   const uint32_t wgFirst = blockIdx.x * 64u;
   const uint32_t b = wgFirst + lane;
   const bool active = b < nBlocks;
 
-  uint8_t *const hrow = hist + lane * HS;
-  uint8_t *const orow = outr + lane * OS;
+  // ring byte x of row r lives at hist[(r * H) ^ hsw(r) ^ (x & HM)]: chunks XOR-swizzled by the row index (bank spread without pad)
+  auto hsw_of = [](uint32_t r) -> uint32_t { return (r & 7u) << 4; };
+  const uint32_t hbase = (lane * (uint32_t)H) ^ hsw_of(lane);
 
   uint32_t n = 0;
   if (active)
@@ -54,85 +54,111 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
     const uint64_t start = (uint64_t)b * B;
     n = (uint32_t)((U - start) < (uint64_t)B ? (U - start) : (uint64_t)B);
   }
-  const uint8_t *const d = in + (uint64_t)b * B;
+  const uint64_t blockAt = (uint64_t)b * B;
   uint8_t *const slot = slots + (uint64_t)b * slotStride;
-  const uint8_t *const inEnd = in + U;
 
   // ---- per-lane encoder state ----
   uint32_t avail = 0;        // input bytes [.., avail) are (or were) in the ring; the ring holds [avail - H, avail)
-  uint32_t cb = 0;           // base of the 16-position chunk scanned next (multiple of 16)
+  uint32_t cb = 0;           // base of the window scanned next (multiple of 16)
   bool inRun = false;
   uint32_t runStart = 0, sym = 0;
   uint32_t lastRLE = 0;
   uint32_t lastSym = 0;      // Packed: lastSymbol (starts 0, A.5 q5)
   [[maybe_unused]] uint64_t lutw = (K == 3) ? 0x0000000000FF7F00ull : 0x00FE807E01FF7F00ull; // LUT: MTF list, entry k in byte k
   bool ended = false;        // the end terminator has been written
-  bool finished = !active;   // the whole stream is in the row / slot
-  uint32_t pend = 0;         // bytes in the output row
-  uint32_t rowBase = 0;      // stream offset of row byte 0 (multiple of 16)
-  bool reported = false;     // the stream size has been written
-  uint64_t winStarts = 0, pendingEnds = 0;   // current window: run-start bits, run-end bits not yet handled
-  bool windowOpen = false, winOpenAtEnd = false;
-  uint32_t winW = 0;
+  bool finished = !active;   // the whole stream is in the slot
+  uint64_t winStarts = 0;    // current window: run-start bits
 
-  // ---- output row primitives ----
-  auto ob = [&](uint32_t v) { orow[pend] = (uint8_t)v; pend += 1; };
-  auto o16 = [&](uint32_t v) { ob(v); ob(v >> 8); };
-  auto o32 = [&](uint32_t v) { ob(v); ob(v >> 8); ob(v >> 16); ob(v >> 24); };
+  // ---- output: 16-byte accumulator + stream position; completed chunks go to the slot ----
+  const u32x4 zero4 = u32x4{ 0, 0, 0, 0 };
+  u32x4 oacc = zero4;        // the chunk that contains stream position opos (its low opos & 15 bytes are valid)
+  uint32_t opos = 0;         // stream bytes produced so far
 
-  // literal bytes [from, from + len) of the input, served from the ring
-  auto lit_from_ring = [&](uint32_t from, uint32_t len) {
-    if (len == 0) return;
-    const uint32_t c = pend & 15u;
-    uint8_t *dst = orow + (pend & ~15u);
+  // append the low nb (<= 12) bytes of hv
+  auto append = [&](u32x4 hv, uint32_t nb) {
+    const uint32_t c = opos & 15u;
+    const u32x4 lowp = (c == 0u) ? hv : funnel16(zero4, hv, 16u - c);   // hv << c bytes
+    const u32x4 w = merge_low(oacc, lowp, c);
+    if (c + nb >= 16u)
+    {
+      st128(slot + (opos & ~15u), w);
+      oacc = (c == 0u) ? zero4 : funnel16(hv, zero4, 16u - c);          // hv >> (16 - c) bytes
+    }
+    else
+      oacc = w;
+    opos += nb;
+  };
+
+  // packet header under construction: up to 12 bytes, little endian
+  uint64_t hlo = 0;
+  uint32_t hhi = 0, hn = 0;
+  auto hpush = [&](uint32_t v, uint32_t k) {                            // the low k (1, 2 or 4) bytes of v
+    const uint32_t sh = hn * 8u;
+    if (hn < 8u)
+    {
+      hlo |= (uint64_t)v << sh;
+      if (hn + k > 8u) hhi |= v >> (64u - sh);
+    }
+    else
+      hhi |= v << (sh - 64u);
+    hn += k;
+  };
+  auto hb = [&](uint32_t v) { hpush(v & 0xFFu, 1u); };
+  auto h16 = [&](uint32_t v) { hpush(v & 0xFFFFu, 2u); };
+  auto h32 = [&](uint32_t v) { hpush(v, 4u); };
+  auto hflush = [&]() {
+    append(u32x4{ (uint32_t)hlo, (uint32_t)(hlo >> 32), hhi, 0u }, hn);
+    hlo = 0; hhi = 0; hn = 0;
+  };
+
+  // 16 input bytes at block position p (p may reach below 0 or beyond the input: those bytes are never used)
+  auto ring_win = [&](uint32_t p) -> u32x4 {
+    const uint32_t a0 = p & ~15u;
+    return funnel16(lds_ld128(hist + (hbase ^ (a0 & HM))), lds_ld128(hist + (hbase ^ ((a0 + 16u) & HM))), p & 15u);
+  };
+  auto glob_win = [&](uint32_t p) -> u32x4 {
+    const int64_t g = (int64_t)blockAt + (int64_t)(int32_t)p;
+    if (g >= 0 && (uint64_t)g + 16u <= U)
+      return ld128(in + g);
+    uint32_t t[4] = { 0, 0, 0, 0 };
+    for (uint32_t k = 0; k < 16u; k++)
+    {
+      const int64_t gk = g + (int64_t)k;
+      if (gk >= 0 && (uint64_t)gk < U) t[k >> 2] |= (uint32_t)in[gk] << (8u * (k & 3u));
+    }
+    return u32x4{ t[0], t[1], t[2], t[3] };
+  };
+
+  // literal bytes [from, from + len) of the block: from the ring while they are still there, else from global memory
+  auto emit_literals = [&](uint32_t from, uint32_t len) {
+    if (len == 0u) return;
+    const bool viaRing = from + (uint32_t)H >= avail + 16u;
+    const uint32_t c = opos & 15u, total = c + len;
     const uint32_t srcp = from - c;
-    const uint32_t sh = srcp & 15u, a0 = srcp & ~15u;
-    u32x4 x = lds_ld128(hrow + (a0 & HM)), y = lds_ld128(hrow + ((a0 + 16u) & HM));
-    u32x4 w = merge_low(lds_ld128(dst), funnel16(x, y, sh), c);
-    lds_st128(dst, w);
-    const uint32_t total = c + len;
-    for (uint32_t k = 16; k < total; k += 16)
+    uint8_t *const dst = slot + (opos & ~15u);
+    u32x4 w = merge_low(oacc, viaRing ? ring_win(srcp) : glob_win(srcp), c);
+    uint32_t k = 0;
+    while (k + 16u <= total)
     {
-      x = y;
-      y = lds_ld128(hrow + ((a0 + k + 16u) & HM));
-      lds_st128(dst + k, funnel16(x, y, sh));
+      st128(dst + k, w);
+      k += 16u;
+      if (k < total) w = viaRing ? ring_win(srcp + k) : glob_win(srcp + k);
     }
-    pend += len;
-  };
-
-  // long literal gap: everything for this packet goes straight to the slot in global memory
-  auto direct_flush_row = [&]() {
-    for (uint32_t k = 0; k < pend; k += 16)
-      st128(slot + rowBase + k, lds_ld128(orow + k));
-  };
-  auto direct_literals = [&](uint32_t gpos, uint32_t from, uint32_t len) {
-    copy_over(slot + gpos, d + from, len, inEnd);
-  };
-  // After a direct packet the row continues at stream offset `end`; its first chunk must hold the (end & 15) stream bytes
-  // that precede it.  Those are the tail of [old row bytes .. header | literals]: bytes below `litAt` are still in the old
-  // row (which started at oldBase), the others are input bytes starting at `from`.
-  auto restart_row = [&](uint32_t end, uint32_t oldBase, uint32_t litAt, uint32_t from) {
-    const uint32_t nb = end & ~15u, np = end & 15u;
-    uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-    for (uint32_t k = 0; k < np; k++)
-    {
-      const uint32_t sPos = nb + k;                                    // stream offset of this byte
-      const uint32_t v = (sPos < litAt) ? (uint32_t)orow[sPos - oldBase] : (uint32_t)d[from + (sPos - litAt)];
-      const uint32_t sh = 8u * (k & 3u);
-      if (k < 4u) t0 |= v << sh; else if (k < 8u) t1 |= v << sh; else if (k < 12u) t2 |= v << sh; else t3 |= v << sh;
-    }
-    lds_st128(orow, u32x4{ t0, t1, t2, t3 });
-    rowBase = nb;
-    pend = np;
+    oacc = w;
+    opos += len;
   };
 
   // ---- stream header ----
   if (active)
   {
-    o32(n);
-    o32(0);
-    if constexpr (!TR::kLut) ob(0); // mode = multi
+    h32(n);
+    h32(0);
+    if constexpr (!TR::kLut) hb(0); // mode = multi
+    hflush();
   }
+
+  // ---- per-row scalars for the lanes that serve a row (same scheme as the decoder's publish()) ----
+  auto publish = [&](uint32_t v) { rinfo[(lane % (uint32_t)RPL) * (uint32_t)LPR + lane / (uint32_t)RPL] = v; };
 
   // ---- input top-up (4 lanes per row read 64 contiguous bytes; the loads fly during the step's scan) ----
   u32x4 pf[LPR];
@@ -142,11 +168,17 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
   auto issue = [&]() {
     const uint32_t left = (n > avail) ? (n - avail + 15u) >> 4 : 0u;
     wantReq = umin((uint32_t)LPR, left);
+    publish(wantReq != 0u ? (avail | wantReq) : 0u);                   // avail is a multiple of 16 while chunks are left
+    wave_sync();
+    uint32_t ri[LPR];
+#pragma unroll
+    for (int q = 0; q < LPR; q++) ri[q] = rinfo[(lane / LPR) * LPR + q];
+    wave_sync();
 #pragma unroll
     for (int q = 0; q < LPR; q++)
     {
       const uint32_t r = (uint32_t)q * RPL + lane / LPR, c = lane % LPR;
-      const uint32_t e = (uint32_t)__shfl((int)avail, (int)r, 64), nreq = (uint32_t)__shfl((int)wantReq, (int)r, 64);
+      const uint32_t nreq = ri[q] & 15u, e = ri[q] & ~15u;
       const bool valid = c < nreq;
       const uint64_t g = (uint64_t)(wgFirst + r) * B + e + c * 16u;
       u32x4 v = u32x4{ 0, 0, 0, 0 };
@@ -163,7 +195,7 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
         }
       }
       pf[q] = v;
-      pfAt[q] = r * (uint32_t)HS + ((e + c * 16u) & HM);
+      pfAt[q] = (r * (uint32_t)H) ^ hsw_of(r) ^ ((e + c * 16u) & HM);
     }
   };
 
@@ -172,23 +204,21 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
     const uint32_t keep = (cb >= 16u) ? cb - 16u : 0u;
     const uint32_t fit = ((uint32_t)H - (avail - keep)) >> 4;
     const uint32_t take = umin(wantReq, fit);
+    publish(take);
+    wave_sync();
+    uint32_t ri[LPR];
+#pragma unroll
+    for (int q = 0; q < LPR; q++) ri[q] = rinfo[(lane / LPR) * LPR + q];
+    wave_sync();
 #pragma unroll
     for (int q = 0; q < LPR; q++)
-    {
-      const uint32_t r = (uint32_t)q * RPL + lane / LPR, c = lane % LPR;
-      const uint32_t tk = (uint32_t)__shfl((int)take, (int)r, 64);
-      if (c < tk)
-      {
+      if (lane % LPR < ri[q])
         lds_st128(hist + pfAt[q], pf[q]);
-        if ((pfAt[q] - r * (uint32_t)HS) < 32u)
-          lds_st128(hist + pfAt[q] + (uint32_t)H, pf[q]); // mirror of the first 32 ring bytes
-      }
-    }
     avail = umin(avail + (take << 4), n);
   };
 
-  // ---- one finished run [p, e): decide, and if emitted write the packet.  Returns false if the row is full (retry later) ----
-  auto handle_run = [&](uint32_t p, uint32_t e) -> bool {
+  // ---- one finished run [p, e): decide, and if emitted write the packet ----
+  auto handle_run = [&](uint32_t p, uint32_t e) {
     const uint32_t count = e - p;
     const uint32_t gap = p - lastRLE;
     bool same = false, body = false;
@@ -234,15 +264,7 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
     }
 
     if (!k)
-      return true;
-
-    const bool viaRing = gap <= LMAX && (gap == 0u || lastRLE + (uint32_t)H >= avail + 16u);
-    if (pend + HDRMAX + (viaRing ? gap + 16u : 0u) > (uint32_t)OC)
-      return false;                                                    // row full: flush first, then come back to this run end
-
-    if (!viaRing)
-      direct_flush_row();
-    const uint32_t pend0 = pend;
+      return;
 
     // ---- header ----
     if constexpr (TR::kLut)
@@ -251,76 +273,51 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
       const uint64_t keepHi = lutw & ~((1ull << (8u * (limit + 1u))) - 1ull);
       const uint64_t low = lutw & ((1ull << (8u * limit)) - 1ull);
       lutw = keepHi | (low << 8) | (uint64_t)sym;
-      o16((m << (K == 3 ? 14 : 13)) | (c7 << TR::RB) | r7);
-      if (m == (uint32_t)K) ob(sym);
-      if (cst != c7) { if (cst <= 0xFFFFu) o16(cst); else o32(cst); }
-      if (rng != r7) { if (rng <= 0xFFFFu) o16(rng); else o32(rng); }
+      h16((m << (K == 3 ? 14 : 13)) | (c7 << TR::RB) | r7);
+      if (m == (uint32_t)K) hb(sym);
+      if (cst != c7) { if (cst <= 0xFFFFu) h16(cst); else h32(cst); }
+      if (rng != r7) { if (rng <= 0xFFFFu) h16(rng); else h32(rng); }
     }
     else if constexpr (TR::kPacked)
     {
       if (body) lastSym = sym;                                          // only the body rule tracks lastSymbol (A.3)
       const uint32_t c = count - 3u + 1u, sm = same ? 0x80u : 0u;
-      if (c <= 127u) ob(c | sm); else { ob(sm); o32(c); }
-      if (!same) ob(sym);
-      if (k == 1) ob((rng << 1) & 0xFFu); else o32((rng << 1) | 1u);
+      if (c <= 127u) hb(c | sm); else { hb(sm); h32(c); }
+      if (!same) hb(sym);
+      if (k == 1) hb(rng << 1); else h32((rng << 1) | 1u);
     }
     else
     {
       const uint32_t c = count - 6u + 1u;
-      ob(sym);
-      if (c <= 255u) ob(c); else { ob(0); o32(c); }
-      if (k == 1) ob(rng); else { ob(0); o32(rng); }
+      hb(sym);
+      if (c <= 255u) hb(c); else { hb(0); h32(c); }
+      if (k == 1) hb(rng); else { hb(0); h32(rng); }
     }
+    hflush();
 
     // ---- literals ----
-    if (viaRing)
-      lit_from_ring(lastRLE, gap);
-    else
-    {
-      // header bytes were appended to the row behind the directly flushed part: move them out, then the literals
-      const uint32_t hdr = pend - pend0;
-      for (uint32_t j = 0; j < hdr; j++)
-        slot[rowBase + pend0 + j] = orow[pend0 + j];
-      direct_literals(rowBase + pend, lastRLE, gap);
-      restart_row(rowBase + pend + gap, rowBase, rowBase + pend, lastRLE);
-    }
-
+    emit_literals(lastRLE, gap);
     lastRLE = e;
 
     if (e >= n)
     {
       // end terminator (rle8_extreme_cpu.h:203-338; rleX_Xsl.h:319-338)
-      if constexpr (TR::kLut) { o16((1u << TR::RB) | 1u); o16(0); o16(0); }
-      else if constexpr (TR::kPacked) { ob(0x80); o32(0); o32(1); }
-      else { ob(0); ob(0); o32(0); ob(0); o32(0); }
+      if constexpr (TR::kLut) { h16((1u << TR::RB) | 1u); h16(0); h16(0); }
+      else if constexpr (TR::kPacked) { hb(0x80); h32(0); h32(1); }
+      else { hb(0); hb(0); h32(0); hb(0); h32(0); }
+      hflush();
       ended = true;
     }
-    return true;
   };
 
   // literal terminator carrying the bytes behind the last emitted run
-  auto finish_literals = [&]() -> bool {
+  auto finish_literals = [&]() {
     const uint32_t kLit = n - lastRLE;
-    const bool viaRing = kLit <= LMAX && (kLit == 0u || lastRLE + (uint32_t)H >= avail + 16u);
-    if (pend + HDRMAX + (viaRing ? kLit + 16u : 0u) > (uint32_t)OC)
-      return false;
-    if (!viaRing)
-      direct_flush_row();
-    const uint32_t pend0 = pend;
-    if constexpr (TR::kLut) { o16(1u << TR::RB); o16(0); o32(kLit + 2u); }
-    else if constexpr (TR::kPacked) { ob(0x80); o32(0); o32(((kLit + 1u) << 1) | 1u); }
-    else { ob(0); ob(0); o32(0); ob(0); o32(kLit + 1u); }
-    if (viaRing)
-      lit_from_ring(lastRLE, kLit);
-    else
-    {
-      const uint32_t hdr = pend - pend0;
-      for (uint32_t j = 0; j < hdr; j++)
-        slot[rowBase + pend0 + j] = orow[pend0 + j];
-      direct_literals(rowBase + pend, lastRLE, kLit);
-      restart_row(rowBase + pend + kLit, rowBase, rowBase + pend, lastRLE);
-    }
-    return true;
+    if constexpr (TR::kLut) { h16(1u << TR::RB); h16(0); h32(kLit + 2u); }
+    else if constexpr (TR::kPacked) { hb(0x80); h32(0); h32(((kLit + 1u) << 1) | 1u); }
+    else { hb(0); hb(0); h32(0); hb(0); h32(kLit + 1u); }
+    hflush();
+    emit_literals(lastRLE, kLit);
   };
 
   // ---- main loop ----
@@ -328,9 +325,9 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
   land();
   wave_sync();
 
-  uint32_t stepsLeft = 4u * (B / (uint32_t)Q) + B / 8u + 64u;           // bounded: every step scans or flushes something
+  uint32_t stepsLeft = 2u * (B / (uint32_t)Q) + 64u;                    // bounded: every step scans a window or lands input
 
-  while (__ballot(!finished || (active && !reported)) != 0ull)
+  while (__ballot(!finished) != 0ull)
   {
     if (stepsLeft-- == 0u) break;
     issue();
@@ -340,127 +337,84 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
     // Phase B (per lane): one handle_run per run END -- a lane's trip count is the number of runs that end in its window.
     if (!finished)
     {
-      if (pendingEnds == 0ull && !windowOpen)
+      // window [cb, cb + W): every position needs its successor byte (or the end of the input)
+      const uint32_t lastStep = (avail >= n) ? 1u : 0u;
+      uint32_t W = lastStep ? umin(64u, n - cb) : umin(64u, ((avail - 1u - cb) >> 4) << 4);
+      if (cb >= n) W = 0;
+      if (W != 0u)
       {
-        // window [cb, cb + W): every position needs its successor byte (or the end of the input)
-        const uint32_t lastStep = (avail >= n) ? 1u : 0u;
-        uint32_t W = lastStep ? umin(64u, n - cb) : umin(64u, ((avail - 1u - cb) >> 4) << 4);
-        if (cb >= n) W = 0;
-        if (W != 0u)
-        {
-          uint64_t e64 = 0;
+        uint64_t e64 = 0;
 #pragma unroll
-          for (uint32_t j = 0; j < 4u; j++)
-          {
-            if (j * 16u < W)
-            {
-              const u32x4 x = lds_ld128(hrow + ((cb + j * 16u) & HM));
-              const uint32_t x4 = lds_ld32(hrow + ((cb + j * 16u + 16u) & HM));
-              const uint32_t z0 = zero_bytes(x.x ^ alignbyte(x.y, x.x, 1)), z1 = zero_bytes(x.y ^ alignbyte(x.z, x.y, 1));
-              const uint32_t z2 = zero_bytes(x.z ^ alignbyte(x.w, x.z, 1)), z3 = zero_bytes(x.w ^ alignbyte(x4, x.w, 1));
-              // 0x80 flags -> 4 bits per dword
-              const uint32_t b0 = (((z0 >> 7) * 0x00204081u) >> 21) & 0xFu, b1 = (((z1 >> 7) * 0x00204081u) >> 21) & 0xFu;
-              const uint32_t b2 = (((z2 >> 7) * 0x00204081u) >> 21) & 0xFu, b3 = (((z3 >> 7) * 0x00204081u) >> 21) & 0xFu;
-              e64 |= (uint64_t)(b0 | (b1 << 4) | (b2 << 8) | (b3 << 12)) << (16u * j);
-            }
-          }
-          // position i is a match only if cb + i + 1 < n (bytes at or beyond n never match)
-          const uint32_t validBits = (n - cb > W) ? W : (n - cb - 1u);
-          e64 &= (validBits >= 64u) ? ~0ull : ((1ull << validBits) - 1ull);
-          const uint64_t wmask = (W >= 64u) ? ~0ull : ((1ull << W) - 1ull);
-          const uint64_t prev = (e64 << 1) | (inRun ? 1ull : 0ull);      // "the position before me matched"
-          winStarts = e64 & ~prev;
-          pendingEnds = ~e64 & prev & wmask;                            // bit i: a run ends with position i (exclusive end cb + i + 1)
-          winOpenAtEnd = ((e64 >> (W - 1u)) & 1ull) != 0ull;             // the last position matches its successor: run goes on
-          winW = W;
-          windowOpen = true;
-        }
-      }
-
-      bool stall = false;
-
-      while (pendingEnds != 0ull)
-      {
-        const uint32_t i = (uint32_t)__builtin_ctzll(pendingEnds);
-        const uint64_t sBelow = winStarts & ((2ull << i) - 1ull);
-        uint32_t st = runStart, sy = sym;
-        if (sBelow != 0ull)
+        for (uint32_t j = 0; j < 4u; j++)
         {
-          st = cb + (63u - (uint32_t)__builtin_clzll(sBelow));
-          sy = hrow[st & HM];
+          if (j * 16u < W)
+          {
+            const u32x4 x = lds_ld128(hist + (hbase ^ ((cb + j * 16u) & HM)));
+            const uint32_t x4 = lds_ld32(hist + (hbase ^ ((cb + j * 16u + 16u) & HM)));
+            const uint32_t z0 = zero_bytes(x.x ^ alignbyte(x.y, x.x, 1)), z1 = zero_bytes(x.y ^ alignbyte(x.z, x.y, 1));
+            const uint32_t z2 = zero_bytes(x.z ^ alignbyte(x.w, x.z, 1)), z3 = zero_bytes(x.w ^ alignbyte(x4, x.w, 1));
+            // 0x80 flags -> 4 bits per dword
+            const uint32_t b0 = (((z0 >> 7) * 0x00204081u) >> 21) & 0xFu, b1 = (((z1 >> 7) * 0x00204081u) >> 21) & 0xFu;
+            const uint32_t b2 = (((z2 >> 7) * 0x00204081u) >> 21) & 0xFu, b3 = (((z3 >> 7) * 0x00204081u) >> 21) & 0xFu;
+            e64 |= (uint64_t)(b0 | (b1 << 4) | (b2 << 8) | (b3 << 12)) << (16u * j);
+          }
         }
-        sym = sy;
-        if (!handle_run(st, cb + i + 1u)) { stall = true; break; }
-        pendingEnds &= pendingEnds - 1ull;
-      }
+        // position i is a match only if cb + i + 1 < n (bytes at or beyond n never match)
+        const uint32_t validBits = (n - cb > W) ? W : (n - cb - 1u);
+        e64 &= (validBits >= 64u) ? ~0ull : ((1ull << validBits) - 1ull);
+        const uint64_t wmask = (W >= 64u) ? ~0ull : ((1ull << W) - 1ull);
+        const uint64_t prev = (e64 << 1) | (inRun ? 1ull : 0ull);      // "the position before me matched"
+        winStarts = e64 & ~prev;
+        uint64_t pendingEnds = ~e64 & prev & wmask;                     // bit i: a run ends with position i (exclusive end cb + i + 1)
 
-      if (!stall && windowOpen)
-      {
-        // the window is done: remember a run that is still open at its end
-        if (winOpenAtEnd)
+        while (pendingEnds != 0ull)
+        {
+          const uint32_t i = (uint32_t)__builtin_ctzll(pendingEnds);
+          const uint64_t sBelow = winStarts & ((2ull << i) - 1ull);
+          uint32_t st = runStart, sy = sym;
+          if (sBelow != 0ull)
+          {
+            st = cb + (63u - (uint32_t)__builtin_clzll(sBelow));
+            sy = hist[hbase ^ (st & HM)];
+          }
+          sym = sy;
+          handle_run(st, cb + i + 1u);
+          pendingEnds &= pendingEnds - 1ull;
+        }
+
+        // the window is done: remember a run that is still open at its end (its last position matches its successor)
+        if (((e64 >> (W - 1u)) & 1ull) != 0ull)
         {
           // the open run is the last one that started in this window; with no start at all the carried run goes on
           if (winStarts != 0ull)
           {
             runStart = cb + (63u - (uint32_t)__builtin_clzll(winStarts));
-            sym = hrow[runStart & HM];
+            sym = hist[hbase ^ (runStart & HM)];
           }
           inRun = true;
         }
         else
           inRun = false;
-        cb += winW;
-        windowOpen = false;
+        cb += W;
       }
 
-      if (!stall && !windowOpen && cb >= n && avail >= n)
+      if (cb >= n && avail >= n)
       {
         // end of input: a run that reaches the end is judged now; then the literal terminator unless the stream ended
-        bool ok = true;
-        if (inRun) { ok = handle_run(runStart, n); if (ok) inRun = false; }
-        if (ok && !ended) { ok = finish_literals(); if (ok) ended = true; }
-        if (ok) finished = true;
+        if (inRun) { handle_run(runStart, n); inRun = false; }
+        if (!ended) { finish_literals(); ended = true; }
+        // the last partial chunk, then the stream size (header field compressedLength and the size table)
+        if ((opos & 15u) != 0u)
+          st128(slot + (opos & ~15u), oacc);
+        st32(slot + 4, opos);
+        sizes[b] = opos;
+        finished = true;
       }
     }
 
     wave_sync();
     land();
     wave_sync();
-
-    // ---------------- flush whole 16-byte chunks of every row (4 lanes per row; rows keep their ragged tail) ----------------
-    {
-      const uint32_t nch = reported ? 0u : (finished ? (pend + 15u) >> 4 : pend >> 4); // a finished stream flushes its last partial chunk too
-      for (uint32_t pass = 0; pass < (uint32_t)(OS / 16 + LPR - 1) / LPR; pass++)
-      {
-        if (__ballot(nch > pass * LPR) == 0ull) break;
-#pragma unroll
-        for (int q = 0; q < LPR; q++)
-        {
-          const uint32_t r = (uint32_t)q * RPL + lane / LPR, c = pass * LPR + lane % LPR;
-          const uint32_t rn = (uint32_t)__shfl((int)nch, (int)r, 64);
-          const uint32_t rb = (uint32_t)__shfl((int)rowBase, (int)r, 64);
-          if (c < rn)
-            st128(slots + (uint64_t)(wgFirst + r) * slotStride + rb + c * 16u, lds_ld128(outr + r * OS + c * 16u));
-        }
-      }
-      wave_sync();
-      if (!finished)
-      {
-        const uint32_t whole = pend & ~15u;
-        if (whole != 0u)
-          lds_st128(orow, lds_ld128(orow + whole));                    // the ragged tail moves to the row start
-        rowBase += whole;
-        pend &= 15u;
-      }
-      else if (active && !reported)
-      {
-        const uint32_t total = rowBase + pend;
-        st32(slot + 4, total);                                         // compressedLength (patched behind the flushed header)
-        sizes[b] = total;
-        reported = true;
-      }
-      wave_sync();
-    }
   }
 }
 

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$1; shift; mkdir -p $O; cd $R
 for grp in "$@"; do
   n=$(echo $grp | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/pmc_$n -- python3 bench.py --steps 3 --warmup 1 --no-cpu > $O/pmc_$n.log 2>&1 || tail -3 $O/pmc_$n.log
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/pmc_$n -- python3 bench.py --steps 3 --warmup 1 --no-cpu $BENCH_ARGS > $O/pmc_$n.log 2>&1 || tail -3 $O/pmc_$n.log
 done
 python3 tools/prof_summary.py $O > $O/summary.txt 2>&1
 grep -A40 "k_decode_blocks" $O/summary.txt | head -60
