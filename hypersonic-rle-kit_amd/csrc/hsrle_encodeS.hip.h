@@ -1,0 +1,453 @@
+// hsrle_encodeS.hip.h -- the multi-symbol encoders for 2/3/4/6/8-byte symbols (plain, Packed, 3/7-symbol LUT; sym- and
+// byte-aligned) with the block's input staged through LDS and the output assembled in registers: the data path of
+// k_encode8_blocks (hsrle_encode8.hip.h) with the run enumeration of the wide codecs.
+//
+// Replaces: src/rleX_extreme_cpu_encode.h:14-609 (16/32/64 bit), src/rle24_extreme_cpu_encode.h, src/rle48_extreme_cpu_encode.h
+//           (24/48 bit), src/rleX_Xsl_multibyte_encoder.h:18-370 + src/rleX_Xsl.h:114-264 (LUT).
+//
+// Run enumeration (restated by oracle/hsrle_oracle.c:runs_next): with the match bits m[j] = (d[j] == d[j + S])
+// (false at and beyond n - S), a run starts at the first p >= i with S consecutive set bits, i.e. at the start of a stretch of
+// L >= S set bits; it ends at e = p + S + S * floor(L / S) (whole symbols) plus, for the byte-aligned variants and only while a
+// whole further symbol would still fit in the input, the L mod S matching leading bytes.  The search continues at i = e
+// whether or not the run was emitted.  Here every lane computes the match bits of a 64-position window from the LDS ring
+// (SWAR compare of each 16-byte chunk with the bytes S further on) and walks the stretches of set bits; a stretch that is still
+// open at the window end is carried by its start position.
+#pragma once
+
+#include "hsrle_common.hip.h"
+#include "hsrle_decode.hip.h" // funnel16, merge_low, wave_sync
+
+namespace hsrle {
+
+template <int FAM, int S, int AL>
+__global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t nBlocks,
+                                                       uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes)
+{
+  using TR = Traits<FAM, S, AL>;
+  static_assert(S == 2 || S == 3 || S == 4 || S == 6 || S == 8, "8 bit and 128 bit symbols have their own kernels");
+  static_assert(FAM == PLAIN || FAM == PACKED || FAM == LUT3 || FAM == LUT7, "multi-symbol families only");
+  constexpr int Q = 64;                      // input bytes per lane and step
+  constexpr int H = 256;                     // history ring per lane (power of two)
+  constexpr int LPR = Q / 16, RPL = 64 / LPR;
+  constexpr uint32_t HM = (uint32_t)H - 1u;
+  constexpr int K = TR::K;
+  constexpr uint32_t SU = (uint32_t)S;
+
+  __shared__ __attribute__((aligned(16))) uint8_t hist[64 * H];
+  __shared__ __attribute__((aligned(16))) uint32_t rinfo[64];
+
+  const uint32_t lane = threadIdx.x;
+  const uint32_t wgFirst = blockIdx.x * 64u;
+  const uint32_t b = wgFirst + lane;
+  const bool active = b < nBlocks;
+
+  // ring byte x of row r lives at hist[(r * H) ^ hsw(r) ^ (x & HM)]: chunks XOR-swizzled by the row index (bank spread without pad)
+  auto hsw_of = [](uint32_t r) -> uint32_t { return (r & 7u) << 4; };
+  const uint32_t hbase = (lane * (uint32_t)H) ^ hsw_of(lane);
+
+  uint32_t n = 0;
+  if (active)
+  {
+    const uint64_t start = (uint64_t)b * B;
+    n = (uint32_t)((U - start) < (uint64_t)B ? (U - start) : (uint64_t)B);
+  }
+  const uint64_t blockAt = (uint64_t)b * B;
+  uint8_t *const slot = slots + (uint64_t)b * slotStride;
+
+  // ---- per-lane encoder state ----
+  uint32_t avail = 0;        // input bytes [.., avail) are (or were) in the ring; the ring holds [avail - H, avail)
+  uint32_t cb = 0;           // base of the window scanned next (multiple of 16)
+  uint32_t from = 0;         // run search position i: match bits below it are ignored
+  bool open = false;         // a stretch of set match bits is open ...
+  uint32_t sStart = 0;       // ... since this position
+  uint32_t sy0 = 0, sy1 = 0; // the symbol at sStart (low S bytes)
+  uint32_t lastRLE = 0;
+  [[maybe_unused]] uint32_t la0 = 0, la1 = 0;  // Packed: last emitted symbol (starts as zeros)
+  bool ended = false;        // the end terminator has been written
+  bool finished = !active;   // the whole stream is in the slot
+
+  [[maybe_unused]] uint32_t lut0[K ? K : 1], lut1[K ? K : 1];          // LUT: move-to-front list, entry k = {lut0[k], lut1[k]}
+  if constexpr (TR::kLut)
+  {
+    constexpr uint32_t init[7] = { 0x00u, 0x7Fu, 0xFFu, 0x01u, 0x7Eu, 0x80u, 0xFEu };
+#pragma unroll
+    for (int k = 0; k < K; k++)
+    {
+      const uint32_t b4 = init[k] * 0x01010101u;
+      lut0[k] = (S >= 4) ? b4 : (b4 & ((1u << (8 * (S & 3))) - 1u));
+      lut1[k] = (S == 8) ? b4 : (S == 6 ? (b4 & 0xFFFFu) : 0u);
+    }
+  }
+
+  // ---- output: 16-byte accumulator + stream position; completed chunks go to the slot ----
+  const u32x4 zero4 = u32x4{ 0, 0, 0, 0 };
+  u32x4 oacc = zero4;        // the chunk that contains stream position opos (its low opos & 15 bytes are valid)
+  uint32_t opos = 0;         // stream bytes produced so far
+
+  // append the low nb (<= 16) bytes of hv
+  auto append = [&](u32x4 hv, uint32_t nb) {
+    const uint32_t c = opos & 15u;
+    const u32x4 lowp = (c == 0u) ? hv : funnel16(zero4, hv, 16u - c);   // hv << c bytes
+    const u32x4 w = merge_low(oacc, lowp, c);
+    if (c + nb >= 16u)
+    {
+      st128(slot + (opos & ~15u), w);
+      oacc = (c == 0u) ? zero4 : funnel16(hv, zero4, 16u - c);          // hv >> (16 - c) bytes
+    }
+    else
+      oacc = w;
+    opos += nb;
+  };
+
+  // packet header under construction: up to 16 bytes, little endian (flushed early when a field would not fit)
+  uint64_t hlo = 0, hhi = 0;
+  uint32_t hn = 0;
+  auto hflush = [&]() {
+    if (hn != 0u)
+      append(u32x4{ (uint32_t)hlo, (uint32_t)(hlo >> 32), (uint32_t)hhi, (uint32_t)(hhi >> 32) }, hn);
+    hlo = 0; hhi = 0; hn = 0;
+  };
+  auto hpush = [&](uint64_t v, uint32_t k) {                            // the low k (1..8) bytes of v; v has no bits above them
+    if (hn + k > 16u) hflush();
+    if (hn < 8u)
+    {
+      const uint32_t sh = hn * 8u;
+      hlo |= v << sh;
+      if (hn + k > 8u) hhi |= v >> (64u - sh);                          // hn >= 1 here, so the shift is < 64
+    }
+    else
+      hhi |= v << ((hn - 8u) * 8u);
+    hn += k;
+  };
+  auto hb = [&](uint32_t v) { hpush((uint64_t)(v & 0xFFu), 1u); };
+  auto h16 = [&](uint32_t v) { hpush((uint64_t)(v & 0xFFFFu), 2u); };
+  auto h32 = [&](uint32_t v) { hpush((uint64_t)v, 4u); };
+  auto hsym = [&](uint32_t s0, uint32_t s1) { hpush((uint64_t)s0 | ((uint64_t)s1 << 32), SU); };
+
+  // 16 input bytes at block position p (p may reach below 0 or beyond the input: those bytes are never used)
+  auto ring_win = [&](uint32_t p) -> u32x4 {
+    const uint32_t a0 = p & ~15u;
+    return funnel16(lds_ld128(hist + (hbase ^ (a0 & HM))), lds_ld128(hist + (hbase ^ ((a0 + 16u) & HM))), p & 15u);
+  };
+  auto glob_win = [&](uint32_t p) -> u32x4 {
+    const int64_t g = (int64_t)blockAt + (int64_t)(int32_t)p;
+    if (g >= 0 && (uint64_t)g + 16u <= U)
+      return ld128(in + g);
+    uint32_t t[4] = { 0, 0, 0, 0 };
+    for (uint32_t k = 0; k < 16u; k++)
+    {
+      const int64_t gk = g + (int64_t)k;
+      if (gk >= 0 && (uint64_t)gk < U) t[k >> 2] |= (uint32_t)in[gk] << (8u * (k & 3u));
+    }
+    return u32x4{ t[0], t[1], t[2], t[3] };
+  };
+
+  // literal bytes [at, at + len) of the block: from the ring while they are still there, else from global memory
+  auto emit_literals = [&](uint32_t at, uint32_t len) {
+    if (len == 0u) return;
+    const bool viaRing = at + (uint32_t)H >= avail + 16u;
+    const uint32_t c = opos & 15u, total = c + len;
+    const uint32_t srcp = at - c;
+    uint8_t *const dst = slot + (opos & ~15u);
+    u32x4 w = merge_low(oacc, viaRing ? ring_win(srcp) : glob_win(srcp), c);
+    uint32_t k = 0;
+    while (k + 16u <= total)
+    {
+      st128(dst + k, w);
+      k += 16u;
+      if (k < total) w = viaRing ? ring_win(srcp + k) : glob_win(srcp + k);
+    }
+    oacc = w;
+    opos += len;
+  };
+
+  // ---- stream header ----
+  if (active)
+  {
+    h32(n);
+    h32(0);
+    hflush();
+  }
+
+  // ---- per-row scalars for the lanes that serve a row (same scheme as the decoder's publish()) ----
+  auto publish = [&](uint32_t v) { rinfo[(lane % (uint32_t)RPL) * (uint32_t)LPR + lane / (uint32_t)RPL] = v; };
+
+  // ---- input top-up (4 lanes per row read 64 contiguous bytes; the loads fly during the step's scan) ----
+  u32x4 pf[LPR];
+  uint32_t pfAt[LPR];
+  uint32_t wantReq = 0;
+
+  auto issue = [&]() {
+    const uint32_t left = (n > avail) ? (n - avail + 15u) >> 4 : 0u;
+    wantReq = umin((uint32_t)LPR, left);
+    publish(wantReq != 0u ? (avail | wantReq) : 0u);                   // avail is a multiple of 16 while chunks are left
+    wave_sync();
+    uint32_t ri[LPR];
+#pragma unroll
+    for (int q = 0; q < LPR; q++) ri[q] = rinfo[(lane / LPR) * LPR + q];
+    wave_sync();
+#pragma unroll
+    for (int q = 0; q < LPR; q++)
+    {
+      const uint32_t r = (uint32_t)q * RPL + lane / LPR, c = lane % LPR;
+      const uint32_t nreq = ri[q] & 15u, e = ri[q] & ~15u;
+      const bool valid = c < nreq;
+      const uint64_t g = (uint64_t)(wgFirst + r) * B + e + c * 16u;
+      u32x4 v = u32x4{ 0, 0, 0, 0 };
+      if (valid)
+      {
+        if (g + 16u <= U)
+          v = ld128(in + g);
+        else
+        {
+          uint32_t t[4] = { 0, 0, 0, 0 };
+          for (uint32_t k = 0; k < 16u && g + k < U; k++)
+            t[k >> 2] |= (uint32_t)in[g + k] << (8u * (k & 3u));
+          v = u32x4{ t[0], t[1], t[2], t[3] };
+        }
+      }
+      pf[q] = v;
+      pfAt[q] = (r * (uint32_t)H) ^ hsw_of(r) ^ ((e + c * 16u) & HM);
+    }
+  };
+
+  auto land = [&]() {
+    // the ring must keep the chunk being scanned (and one before it for the byte funnel)
+    const uint32_t keep = (cb >= 16u) ? cb - 16u : 0u;
+    const uint32_t fit = ((uint32_t)H - (avail - keep)) >> 4;
+    const uint32_t take = umin(wantReq, fit);
+    publish(take);
+    wave_sync();
+    uint32_t ri[LPR];
+#pragma unroll
+    for (int q = 0; q < LPR; q++) ri[q] = rinfo[(lane / LPR) * LPR + q];
+    wave_sync();
+#pragma unroll
+    for (int q = 0; q < LPR; q++)
+      if (lane % LPR < ri[q])
+        lds_st128(hist + pfAt[q], pf[q]);
+    avail = umin(avail + (take << 4), n);
+  };
+
+  // ---- one enumerated run [p, e) of the symbol {s0, s1}: decide, and if emitted write the packet ----
+  auto handle_run = [&](uint32_t p, uint32_t e, uint32_t s0, uint32_t s1) {
+    const uint32_t count = e - p;
+    const uint32_t gap = p - lastRLE;
+
+    if constexpr (TR::kLut)
+    {
+      // rleX_Xsl.h:116-195 (process_symbol); SURVEY.md A.3
+      constexpr uint32_t RB = TR::RB, MAXC = 127u, MAXR = (1u << RB) - 1u;
+      const uint32_t range = gap + 2u;
+      uint32_t m = (uint32_t)K;
+#pragma unroll
+      for (int k = K - 1; k >= 0; k--)
+        if (lut0[k] == s0 && lut1[k] == s1) m = (uint32_t)k;
+      const uint32_t c = TR::kAligned ? (count / SU - 3u / SU + 2u) : (count - 3u + 2u);
+      // the penalty uses 0xFFFFF where the writer uses 0xFFFF (A.5 q3; rleX_Xsl.h:130 vs :195)
+      uint32_t pen = (range <= 0xFFFFFu) ? (range <= MAXR ? 0u : 2u) : 4u;
+      pen += (c <= 0xFFFFFu) ? (c <= MAXC ? 0u : 2u) : 4u;
+      pen += (m == (uint32_t)K) ? 1u : 0u;
+      if (!(count >= SU + 10u || count >= 3u + pen))
+        return;
+
+      // move to front (rleX_Xsl.h:134-188)
+      const uint32_t limit = (m == (uint32_t)K) ? (uint32_t)K - 1u : m;
+#pragma unroll
+      for (int k = K - 1; k >= 1; k--)
+        if ((uint32_t)k <= limit) { lut0[k] = lut0[k - 1]; lut1[k] = lut1[k - 1]; }
+      lut0[0] = s0; lut1[0] = s1;
+
+      const uint32_t c7 = (c <= MAXC) ? c : (c <= 0xFFFFu ? 1u : 0u);
+      const uint32_t r7 = (range <= MAXR) ? range : (range <= 0xFFFFu ? 1u : 0u);
+      h16((m << (K == 3 ? 14 : 13)) | (c7 << RB) | r7);
+      if (m == (uint32_t)K) hsym(s0, s1);
+      if (c != c7) { if (c <= 0xFFFFu) h16(c); else h32(c); }
+      if (range != r7) { if (range <= 0xFFFFu) h16(range); else h32(range); }
+    }
+    else
+    {
+      // rleX_extreme_cpu_encode.h:165-313; thresholds SURVEY.md A.2
+      const uint32_t range = gap + 1u;
+      bool same = false;
+      if constexpr (TR::kPacked) same = (s0 == la0 && s1 == la1);
+      bool shortOk;
+      if constexpr (!TR::kPacked) shortOk = range <= TR::MAXRANGE && count >= TR::SHORT;
+      else shortOk = range <= TR::MAXRANGE && ((count >= TR::SHORT && same) || count >= TR::MEDIUM);
+      const int k = shortOk ? 1 : (count >= TR::LONG ? 2 : 0);
+      if (!k)
+        return;
+      if constexpr (TR::kPacked) { la0 = s0; la1 = s1; }
+
+      const uint32_t c = TR::kAligned ? (count / SU - TR::SHORT / SU + 1u) : (count - TR::SHORT + 1u);
+      if constexpr (!TR::kPacked)
+      {
+        hsym(s0, s1);
+        if (c <= 255u) hb(c); else { hb(0); h32(c); }
+      }
+      else
+      {
+        const uint32_t sm = same ? 0x80u : 0u;
+        if (c <= 127u) hb(c | sm); else { hb(sm); h32(c); }
+        if (!same) hsym(s0, s1);
+      }
+      if constexpr (TR::kRange7)
+      {
+        if (k == 1) hb(range << 1); else h32((range << 1) | 1u);
+      }
+      else
+      {
+        if (k == 1) hb(range); else { hb(0); h32(range); }
+      }
+    }
+    hflush();
+
+    // ---- literals ----
+    emit_literals(lastRLE, gap);
+    lastRLE = e;
+
+    if (e >= n)
+    {
+      // end terminator (rleX_extreme_cpu_encode.h:373-609; rleX_Xsl_multibyte_encoder.h:329-370)
+      if constexpr (TR::kLut) { h16((1u << TR::RB) | 1u); h16(0); h16(0); }
+      else
+      {
+        if constexpr (!TR::kPacked) { hsym(0, 0); hb(0); h32(0); } else { hb(0x80); h32(0); }
+        if constexpr (TR::kRange7) h32(1); else { hb(0); h32(0); }
+      }
+      hflush();
+      ended = true;
+    }
+  };
+
+  // literal terminator carrying the bytes behind the last emitted run
+  auto finish_literals = [&]() {
+    const uint32_t kLit = n - lastRLE;
+    if constexpr (TR::kLut) { h16(1u << TR::RB); h16(0); h32(kLit + 2u); }
+    else
+    {
+      if constexpr (!TR::kPacked) { hsym(0, 0); hb(0); h32(0); } else { hb(0x80); h32(0); }
+      if constexpr (TR::kRange7) h32(((kLit + 1u) << 1) | 1u); else { hb(0); h32(kLit + 1u); }
+    }
+    hflush();
+    emit_literals(lastRLE, kLit);
+  };
+
+  // a stretch of L set match bits that started at sStart has ended: if it is a run (L >= S), enumerate it
+  auto close_stretch = [&](uint32_t L) -> uint32_t {                    // returns the run end (the new search position), or 0
+    if (L < SU)
+      return 0u;
+    const uint32_t whole = sStart + SU + SU * (L / SU);
+    uint32_t e = whole;
+    if constexpr (!TR::kAligned)
+      if (whole + SU <= n) e = sStart + SU + L;
+    handle_run(sStart, e, sy0, sy1);
+    return e;
+  };
+
+  // ---- main loop ----
+  issue();
+  land();
+  wave_sync();
+
+  uint32_t stepsLeft = 2u * (B / (uint32_t)Q) + 64u;                    // bounded: every step scans a window or lands input
+
+  while (__ballot(!finished) != 0ull)
+  {
+    if (stepsLeft-- == 0u) break;
+    issue();
+
+    if (!finished)
+    {
+      // window [cb, cb + W): position j needs the bytes up to j + S (or the end of the input)
+      const bool lastStep = avail >= n;
+      uint32_t W = 0;
+      if (cb < n)
+      {
+        if (lastStep) W = umin(64u, n - cb);
+        else if (avail > cb + SU) W = umin(64u, ((avail - SU - cb) >> 4) << 4);
+      }
+
+      if (W != 0u)
+      {
+        uint64_t m = 0;
+        u32x4 x = lds_ld128(hist + (hbase ^ (cb & HM)));
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; j++)
+        {
+          if (j * 16u < W)
+          {
+            const u32x4 nx = lds_ld128(hist + (hbase ^ ((cb + j * 16u + 16u) & HM)));
+            const u32x4 y = funnel16(x, nx, SU);                         // the bytes S further on
+            const uint32_t z0 = zero_bytes(x.x ^ y.x), z1 = zero_bytes(x.y ^ y.y), z2 = zero_bytes(x.z ^ y.z), z3 = zero_bytes(x.w ^ y.w);
+            // 0x80 flags -> 4 bits per dword
+            const uint32_t b0 = (((z0 >> 7) * 0x00204081u) >> 21) & 0xFu, b1 = (((z1 >> 7) * 0x00204081u) >> 21) & 0xFu;
+            const uint32_t b2 = (((z2 >> 7) * 0x00204081u) >> 21) & 0xFu, b3 = (((z3 >> 7) * 0x00204081u) >> 21) & 0xFu;
+            m |= (uint64_t)(b0 | (b1 << 4) | (b2 << 8) | (b3 << 12)) << (16u * j);
+            x = nx;
+          }
+        }
+        // position j matches only if j + S < n (bytes at or beyond n never match) and lies inside the window
+        const uint32_t validBits = (n > cb + SU) ? umin(W, n - SU - cb) : 0u;
+        m &= (validBits >= 64u) ? ~0ull : ((1ull << validBits) - 1ull);
+        // positions below the search position are ignored
+        if (from > cb) m &= (from - cb >= 64u) ? 0ull : ~((1ull << (from - cb)) - 1ull);
+
+        uint32_t pos = 0;
+        for (;;)
+        {
+          if (!open)
+          {
+            const uint64_t rest = (pos < 64u) ? (m >> pos) : 0ull;
+            if (rest == 0ull) break;
+            pos += (uint32_t)__builtin_ctzll(rest);
+            sStart = cb + pos;
+            const u32x4 sv = ring_win(sStart);
+            sy0 = (S >= 4) ? sv.x : (sv.x & ((1u << (8 * (S & 3))) - 1u));
+            sy1 = (S == 8) ? sv.y : (S == 6 ? (sv.y & 0xFFFFu) : 0u);
+            open = true;
+          }
+          // the stretch ends at the first clear bit at or behind pos
+          const uint64_t inv = (pos < 64u) ? (~m >> pos) : 0ull;
+          const uint32_t z = (inv != 0ull) ? pos + (uint32_t)__builtin_ctzll(inv) : 64u;
+          if (z >= W && !(lastStep && cb + W >= n))
+            break;                                                       // still open at the window end: goes on in the next window
+          const uint32_t zc = umin(z, W);
+          open = false;
+          pos = zc;
+          const uint32_t e = close_stretch(cb + zc - sStart);
+          if (e != 0u)
+          {
+            from = e;
+            if (e > cb + zc)
+            {
+              const uint32_t cut = e - cb;
+              if (cut >= 64u) { m = 0; pos = 64u; }
+              else { m &= ~((1ull << cut) - 1ull); pos = cut; }
+            }
+          }
+          if (pos >= W) break;
+        }
+        cb += W;
+      }
+
+      if (cb >= n && avail >= n)
+      {
+        // end of input: the literal terminator unless the stream ended with a run
+        if (!ended) { finish_literals(); ended = true; }
+        // the last partial chunk, then the stream size (header field compressedLength and the size table)
+        if ((opos & 15u) != 0u)
+          st128(slot + (opos & ~15u), oacc);
+        st32(slot + 4, opos);
+        sizes[b] = opos;
+        finished = true;
+      }
+    }
+
+    wave_sync();
+    land();
+    wave_sync();
+  }
+}
+
+} // namespace hsrle
