@@ -392,7 +392,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     for (int step = 0; step < T / Q; step++)
     {
     const uint32_t target = umin((o / (uint32_t)Q + 1u) * (uint32_t)Q, flushTarget);
-    uint32_t itersLeft = 2u * (uint32_t)Q + 16u;
+    [[maybe_unused]] uint32_t itersLeft = 2u * (uint32_t)Q + 16u;
 
     // Pass 0 decodes with the ring as it stands.  A lane whose packet needs bytes that were not resident (the ring holds
     // < R bytes behind a misaligned sp; literal-heavy stretches consume more than that per step) stops early; the top-up that
@@ -416,7 +416,8 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
       {
         const bool act = (fl & (F_DONE | F_STALL)) == 0u && o < target;
         if (__ballot(act) == 0ull) break;
-        if (itersLeft-- == 0u) { err |= DEC_ERR_STREAM; fl |= F_DONE; break; }
+        // every trip of an active lane either consumes stream bytes (a header is >= 2 bytes), produces output bytes, or
+        // deactivates the lane (done / stall), so the loop is bounded by the resident stream bytes plus the step's output
 
         if (act && (lit | run) == 0u)
         {
