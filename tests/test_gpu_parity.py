@@ -3,6 +3,7 @@
 Bit-exact bar (integer / byte work): every block stream must equal the oracle's (= the reference's, see
 test_oracle_vs_ref.py / test_oracle_golden.py) stream for that block, and every decode must reproduce the input exactly.
 """
+import os
 import random
 import struct
 
@@ -200,3 +201,18 @@ def test_full_size_round_trip_properties(hs, oracle, key, kind, size, block):
         got = [pay[int(table[first + i]) - base : int(table[first + i + 1]) - base] for i in range(count)]
         host = src[first * block : min((first + count) * block, size)].cpu().numpy()
         assert got == oracle.compress_blocks(c, host, block)
+
+
+def test_native_cli_over_the_c_abi():
+    """hsrlekit_gpu (C++ host program, no python, no torch) drives the device container API and the drop-in functions of
+    rle.h through the C ABI: every codec must round trip a small synthetic buffer (exit code 0)."""
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hypersonic-rle-kit_amd", "hsrlekit_gpu")
+    if not os.path.exists(exe):
+        pytest.skip("hsrlekit_gpu not built (make -C hypersonic-rle-kit_amd tools)")
+    r = subprocess.run([exe, "--synth", "runs", "8", "--runs", "2", "--block", "1024"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("GiB/s") >= 4 * 50 and "all codecs round-tripped" in r.stdout
+    r = subprocess.run([exe, "--synth", "video", "1", "--runs", "1", "--codec", "rle8_packed_multi", "--host"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "drop-in" in r.stdout and "FAILED" not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
