@@ -259,7 +259,9 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 
   // ---- ring top-up.  issue(): LPR loads; in load q, lanes LPR*g .. LPR*g+LPR-1 read Q contiguous bytes of row RPL*q+g ----
   u32x4 pf[LPR];
-  uint32_t pfAt[LPR];
+  uint32_t pfAt[LPR], pfPos[LPR];                                   // ring slot / stream position of the chunk held in pf[q] (~0: none)
+#pragma unroll
+  for (int q = 0; q < LPR; q++) { pf[q] = u32x4{ 0, 0, 0, 0 }; pfAt[q] = 0; pfPos[q] = 0xFFFFFFFFu; }
   uint64_t myBase[LPR];                                             // stream starts of the LPR rows this lane helps to load
 
   uint32_t wantReq = 0;                                             // chunks this row requested in issue()
@@ -270,11 +272,15 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   // P (or 2 P) ds_bpermute.
   auto publish = [&](uint32_t v, int P) { rinfo[(lane % (64u / (uint32_t)P)) * (uint32_t)P + lane / (64u / (uint32_t)P)] = v; };
 
-  auto issue = [&]() {
-    // request up to LPR chunks behind E.  Whether they FIT is decided when they land (after this round's decode has
-    // freed ring space), so the ring only has to hold one round of consumption, not two.
-    wantReq = umin((uint32_t)LPR, (lim - E) >> 4);
-    if (done) wantReq = 0;
+  // topup(): one exchange per step.  The row owner first accounts for what LANDS -- of the chunks requested one step ago, those
+  // that fit now that this step's decode has freed ring space: the ring may hold bytes [floor16(sp), floor16(sp) + R) -- and
+  // then requests up to LPR chunks behind the new E.  Whether THOSE fit is decided when they land, so the ring only has to hold
+  // one step of consumption, not two.  The serving lanes get E | request in one dword: the chunk a lane holds lands iff its
+  // stream position is below the new E (chunks land in stream order).
+  auto topup = [&]() {
+    const uint32_t fit = ((uint32_t)R - (E - (sp & ~15u))) >> 4;
+    E += umin(wantReq, fit) << 4;
+    wantReq = done ? 0u : umin((uint32_t)LPR, (lim - E) >> 4);
     publish(E | wantReq, LPR);                                        // E is a multiple of 16, wantReq <= 8
     wave_sync();
     uint32_t ri[LPR];
@@ -283,32 +289,18 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     wave_sync();
 #pragma unroll
     for (int q = 0; q < LPR; q++)
+      if (pfPos[q] < (ri[q] & ~15u))
+        lds_st128(ring + pfAt[q], pf[q]);
+#pragma unroll
+    for (int q = 0; q < LPR; q++)
     {
       const uint32_t r = (uint32_t)q * RPL + lane / LPR, c = lane % LPR;
       const uint32_t e = ri[q] & ~15u, n = ri[q] & 15u;
       const bool valid = c < n;
       const uint32_t pos = e + c * 16u;
       pf[q] = ld128(payload + myBase[q] + (valid ? pos : 0u));         // predicated-off lanes re-read the stream start
+      pfPos[q] = valid ? pos : 0xFFFFFFFFu;
       pfAt[q] = (r * (uint32_t)RS) ^ rsw_of(r) ^ (pos & RMASK);         // ring slot of this chunk
-    }
-  };
-
-  auto land = [&]() {
-    // chunks that fit now: the ring may hold bytes [floor16(sp), floor16(sp) + R)
-    const uint32_t fit = ((uint32_t)R - (E - (sp & ~15u))) >> 4;
-    const uint32_t take = umin(wantReq, fit);
-    E += take << 4;
-    publish(take, LPR);
-    wave_sync();
-    uint32_t ri[LPR];
-#pragma unroll
-    for (int q = 0; q < LPR; q++) ri[q] = rinfo[(lane / LPR) * LPR + q];
-    wave_sync();
-#pragma unroll
-    for (int q = 0; q < LPR; q++)
-    {
-      if (lane % LPR < ri[q])
-        lds_st128(ring + pfAt[q], pf[q]);
     }
   };
 
@@ -321,11 +313,11 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     const uint32_t lo32 = (uint32_t)__shfl((int)(uint32_t)myBase0, r, 64), hi32 = (uint32_t)__shfl((int)(uint32_t)(myBase0 >> 32), r, 64);
     myBase[q] = ((uint64_t)hi32 << 32) | lo32;
   }
+  topup();                                                            // requests the first R bytes of every stream ...
   for (int k = 0; k < R / Q; k++)
   {
-    issue();
-    land();
-    wave_sync();
+    topup();                                                          // ... lands them (sp is still 0) and requests the next piece,
+    wave_sync();                                                      //     which flies during the first step's decode
   }
 
   if (active)
@@ -376,8 +368,6 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 #else
 #define HS_STAMP(acc)
 #endif
-
-  issue();                                                            // loads for the first step fly during its decode
 
   while (__ballot(!done && o < blen) != 0ull)
   {
@@ -822,17 +812,13 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     wave_sync();                                                   // every lane is done reading the ring and writing its row
     if (pass != 0) break;
 
-    // ---- the loads issued before the decode step have had the whole round to arrive: move them into the ring first,
-    //      so that this wait never includes the flush stores below (vmcnt counts loads and stores in order) ----
-    land();
+    // ---- top-up: the loads issued one step ago have had the whole decode to arrive; they move into the ring first (this wait
+    //      never includes the flush stores below: vmcnt counts loads and stores in order), then the next piece is requested --
+    //      BEFORE the flush stores, so that the prefetch registers are live across the flush (the flush data then cannot share
+    //      registers with them, which would force a full `s_waitcnt vmcnt(0)` drain of the stores before every top-up) ----
+    topup();
     HS_STAMP(tLand)
     wave_sync();
-
-    // ---- top-up for the step after the next decode: issued right after landing and BEFORE the flush stores, so that the
-    //      prefetch registers are live across the flush (the flush data then cannot share registers with them, which would
-    //      force a full `s_waitcnt vmcnt(0)` drain of the stores before every top-up) ----
-    issue();
-    HS_STAMP(tIssue)
     if (__ballot(!done && o < target) == 0ull) break;                // nobody starved (the common case)
     }
     }
