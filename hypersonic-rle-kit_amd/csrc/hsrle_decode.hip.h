@@ -128,10 +128,11 @@ __device__ __forceinline__ u32x4 lds_read16_w8(const uint8_t *base, uint32_t p)
 // low c bytes (c in 0..15) from `keep`, the rest from `fresh`
 __device__ __forceinline__ u32x4 merge_low(u32x4 keep, u32x4 fresh, uint32_t c)
 {
-  const uint64_t ones = ~0ull;
-  const uint64_t mlo = (c >= 8u) ? ones : ~(ones << (8u * c));
-  const uint64_t mhi = (c <= 8u) ? 0ull : ~(ones << (8u * (c - 8u)));
-  const uint32_t m0 = (uint32_t)mlo, m1 = (uint32_t)(mlo >> 32), m2 = (uint32_t)mhi, m3 = (uint32_t)(mhi >> 32);
+  // one 64-bit mask of the low (c & 7) bytes; it is the low half's mask for c < 8 and the high half's for c >= 8
+  const uint64_t part = ~(~0ull << (8u * (c & 7u)));
+  const bool hiHalf = c >= 8u;
+  const uint32_t p0 = (uint32_t)part, p1 = (uint32_t)(part >> 32);
+  const uint32_t m0 = hiHalf ? ~0u : p0, m1 = hiHalf ? ~0u : p1, m2 = hiHalf ? p0 : 0u, m3 = hiHalf ? p1 : 0u;
   return u32x4{ (keep.x & m0) | (fresh.x & ~m0), (keep.y & m1) | (fresh.y & ~m1), (keep.z & m2) | (fresh.z & ~m2), (keep.w & m3) | (fresh.w & ~m3) };
 }
 
