@@ -223,7 +223,7 @@ def main():
             "bit_exact": bool(ok),
             "encode": {"value": round(size / 2**30 / (enc_ms * 1e-3), 2), "unit": "GiB/s", "ms": round(enc_ms, 4), "note": "same buffer, encode kernel + size scan + compaction"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": measured_traffic(args.codec, size, args.block), "kernel": "k_decode_blocks<PACKED,1>", "kernel_ms": round(kernel_ms, 4),
+                         "traffic": measured_traffic(args.codec, size, args.block), "kernel": "k_decode_blocks<PACKED,1>", "waves_per_cu": hsrle.kernel_waves_per_cu(args.codec, True), "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes": int(alg_bytes), "note": "algorithmic bytes = container (compressed) + uncompressed output per launch; PMC traffic in profiles/"},
         }
         if gather_ms is not None:

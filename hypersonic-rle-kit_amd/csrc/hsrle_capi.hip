@@ -583,6 +583,17 @@ const char *hsrle_status_string(int s)
 
 const char *hsrle_version(void) { return "hsrle-hip 0.1 (gfx950)"; }
 
+int hsrle_kernel_waves_per_cu(int codec, int decode)
+{
+  if (codec < 0 || codec >= kCodecCount)
+    return 0;
+  init_tables();
+  int n = 0;
+  if (decode) { DecodeArgs a{}; a.residentWorkgroups = &n; if (g_dec[codec](a, nullptr) != hipSuccess) return 0; }
+  else { EncodeArgs a{}; a.residentWorkgroups = &n; if (g_enc[codec](a, nullptr) != hipSuccess) return 0; }
+  return n;
+}
+
 int hsrle_device_count(void)
 {
   int n = 0;

@@ -260,7 +260,9 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 
   // ---- ring top-up.  issue(): LPR loads; in load q, lanes LPR*g .. LPR*g+LPR-1 read Q contiguous bytes of row RPL*q+g ----
   u32x4 pf[LPR];
-  uint32_t pfAt[LPR], pfPos[LPR];                                   // ring slot / stream position of the chunk held in pf[q] (~0: none)
+  constexpr bool kKeepSlots = !(TR::kLut && S > 1);                   // the LUT kernels of the wide symbols are the register-hungry ones
+  [[maybe_unused]] uint32_t pfAt[LPR];
+  uint32_t pfPos[LPR];                                   // ring slot / stream position of the chunk held in pf[q] (~0: none)
 #pragma unroll
   for (int q = 0; q < LPR; q++) { pf[q] = u32x4{ 0, 0, 0, 0 }; pfAt[q] = 0; pfPos[q] = 0xFFFFFFFFu; }
   uint64_t myBase[LPR];                                             // stream starts of the LPR rows this lane helps to load
@@ -291,7 +293,13 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 #pragma unroll
     for (int q = 0; q < LPR; q++)
       if (pfPos[q] < (ri[q] & ~15u))
-        lds_st128(ring + pfAt[q], pf[q]);
+      {
+        // the chunk's ring slot: kept in a register, or -- where registers are what stands between 8 and 9 waves per CU --
+        // recomputed from its stream position
+        const uint32_t r = (uint32_t)q * RPL + lane / LPR;
+        const uint32_t slot = kKeepSlots ? pfAt[q] : ((r * (uint32_t)RS) ^ rsw_of(r) ^ (pfPos[q] & RMASK));
+        lds_st128(ring + slot, pf[q]);
+      }
 #pragma unroll
     for (int q = 0; q < LPR; q++)
     {
@@ -301,7 +309,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
       const uint32_t pos = e + c * 16u;
       pf[q] = ld128(payload + myBase[q] + (valid ? pos : 0u));         // predicated-off lanes re-read the stream start
       pfPos[q] = valid ? pos : 0xFFFFFFFFu;
-      pfAt[q] = (r * (uint32_t)RS) ^ rsw_of(r) ^ (pos & RMASK);         // ring slot of this chunk
+      if constexpr (kKeepSlots) pfAt[q] = (r * (uint32_t)RS) ^ rsw_of(r) ^ (pos & RMASK);   // ring slot of this chunk
     }
   };
 

@@ -17,6 +17,7 @@ struct DecodeArgs
   uint64_t U;
   uint32_t B, firstBlock, blockCount;
   uint32_t *status;
+  int *residentWorkgroups = nullptr; // query mode: no launch; receives the number of workgroups (= waves) of this kernel that fit on one CU
 };
 
 struct EncodeArgs
@@ -27,6 +28,7 @@ struct EncodeArgs
   uint8_t *slots;
   uint32_t slotStride;
   uint32_t *sizes;
+  int *residentWorkgroups = nullptr; // query mode, as in DecodeArgs
 };
 
 typedef hipError_t (*DecodeLaunch)(const DecodeArgs &, hipStream_t);
@@ -58,6 +60,8 @@ void register_w128(DecodeLaunch *dec, EncodeLaunch *enc);
 template <typename KERNEL>
 inline hipError_t launch_decode(KERNEL k, const DecodeArgs &a, hipStream_t st)
 {
+  if (a.residentWorkgroups != nullptr)
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(a.residentWorkgroups, k, 64, 0);
   const uint32_t grid = (a.blockCount + 63u) / 64u;
   hipLaunchKernelGGL(k, dim3(grid), dim3(64), 0, st, a.payload, a.offsets, a.payloadEnd, a.out, a.U, a.B, a.firstBlock, a.blockCount, a.status);
   return hipGetLastError();
@@ -72,6 +76,8 @@ inline hipError_t launch_encode(KERNEL k, const EncodeArgs &a, hipStream_t st, i
   // written several times (measured: 6.8x read, 5.9x write amplification).  A dynamic LDS reservation caps the residency.
   static const uint32_t ldsCap = [] { const char *e = getenv("HSRLE_ENCODE_LDS_CAP"); return e ? (uint32_t)atoi(e) : kEncodeLdsCap; }();
   static const uint32_t lds8 = [] { const char *e = getenv("HSRLE_ENCODE8_LDS"); return e ? (uint32_t)atoi(e) : 0u; }();   // experiment knob
+  if (a.residentWorkgroups != nullptr)
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(a.residentWorkgroups, k, 64, capResidency ? ldsCap : lds8);
   hipLaunchKernelGGL(k, dim3(grid), dim3(64), capResidency ? ldsCap : lds8, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes);
   return hipGetLastError();
 }

@@ -69,6 +69,8 @@ def _lib():
     L.hsrle_status_string.argtypes = [ci]
     L.hsrle_version.restype = ctypes.c_char_p
     L.hsrle_device_count.restype = ci
+    L.hsrle_kernel_waves_per_cu.restype = ci
+    L.hsrle_kernel_waves_per_cu.argtypes = [ci, ci]
     L.rle_compress_bounds.restype = u32
     L.rle_compress_bounds.argtypes = [u32]
     L.rle_decompress_additional_size.restype = u32
@@ -123,6 +125,11 @@ def codec_id(name_or_id):
     if cid < 0:
         raise KeyError(name_or_id)
     return cid
+
+
+def kernel_waves_per_cu(codec, decode=True):
+    """Wavefronts of the codec's decode / encode kernel resident on one CU (from the HIP runtime's occupancy calculation)."""
+    return int(_lib().hsrle_kernel_waves_per_cu(codec_id(codec), 1 if decode else 0))
 
 
 def compress_bounds(n):

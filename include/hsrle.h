@@ -210,6 +210,10 @@ int hsrle_synth_dev_async(int kind, int symbolBytes, uint64_t seed, void *dOut, 
 
 /* library / device introspection */
 int hsrle_device_count(void);
+/* Workgroups (= wavefronts: every kernel here runs one wave per workgroup) of the codec's decode (decode != 0) or encode kernel
+ * that are resident on one CU at a time, as the HIP runtime computes it from the kernel's LDS and register use; 0 on error.
+ * The kernels are latency bound, so this is the first number to look at when a build got slower. */
+int hsrle_kernel_waves_per_cu(int codec, int decode);
 const char *hsrle_version(void);
 
 #ifdef __cplusplus
