@@ -216,3 +216,12 @@ def test_native_cli_over_the_c_abi():
     assert r.stdout.count("GiB/s") >= 4 * 50 and "all codecs round-tripped" in r.stdout
     r = subprocess.run([exe, "--synth", "video", "1", "--runs", "1", "--codec", "rle8_packed_multi", "--host"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "drop-in" in r.stdout and "FAILED" not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_north_star_kernels_keep_their_occupancy(hs):
+    """The kernels are latency bound: throughput is proportional to the waves resident per CU.  A change that
+    pushes the 8 bit Packed kernels over 168 VGPRs or 17 KB of LDS silently costs 11 %: fail loudly instead."""
+    assert hs.kernel_waves_per_cu("rle8_packed_multi", decode=True) >= 9
+    assert hs.kernel_waves_per_cu("rle8_packed_multi", decode=False) >= 9
+    for c in CODECS:
+        assert hs.kernel_waves_per_cu(c.key, decode=True) >= 8 and hs.kernel_waves_per_cu(c.key, decode=False) >= 8, c.key
