@@ -583,6 +583,13 @@ const char *hsrle_status_string(int s)
 
 const char *hsrle_version(void) { return "hsrle-hip 0.1 (gfx950)"; }
 
+uint32_t hsrle_suggest_block_size(uint64_t inSize)
+{
+  if (inSize >= 65536ull * 4096ull) return 4096u;
+  if (inSize >= 65536ull * 2048ull) return 2048u;
+  return 1024u;
+}
+
 int hsrle_kernel_waves_per_cu(int codec, int decode)
 {
   if (codec < 0 || codec >= kCodecCount)

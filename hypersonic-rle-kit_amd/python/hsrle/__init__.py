@@ -69,6 +69,8 @@ def _lib():
     L.hsrle_status_string.argtypes = [ci]
     L.hsrle_version.restype = ctypes.c_char_p
     L.hsrle_device_count.restype = ci
+    L.hsrle_suggest_block_size.restype = u32
+    L.hsrle_suggest_block_size.argtypes = [u64]
     L.hsrle_kernel_waves_per_cu.restype = ci
     L.hsrle_kernel_waves_per_cu.argtypes = [ci, ci]
     L.rle_compress_bounds.restype = u32
@@ -125,6 +127,11 @@ def codec_id(name_or_id):
     if cid < 0:
         raise KeyError(name_or_id)
     return cid
+
+
+def suggest_block_size(n):
+    """Block size that gives a buffer of n bytes enough blocks to fill the GPU (hsrle_suggest_block_size)."""
+    return int(_lib().hsrle_suggest_block_size(n))
 
 
 def kernel_waves_per_cu(codec, decode=True):

@@ -156,6 +156,13 @@ typedef struct hsrle_container_info
   uint64_t payloadSize, totalSize;
 } hsrle_container_info_t;
 
+/* A block size for `inSize` input bytes that fills the GPU: the default (4096) when that gives at least 65536 blocks, else 2048
+ * or 1024.  One lane walks one block, so a buffer with few blocks is bound by the per-block latency (32 steps of ~8 us for 4 KiB),
+ * not by bandwidth: an 88 MB frame decodes at 250 GiB/s with 4 KiB blocks and at 770 GiB/s with 1 KiB blocks -- for 9 % more
+ * compressed bytes (every block carries its own stream header and terminator).  The choice is the caller's; nothing in the
+ * library calls this on its own. */
+uint32_t hsrle_suggest_block_size(uint64_t inSize);
+
 /* Upper bound of the container size for `inSize` input bytes cut into blocks of `blockSize` (0 = default). */
 uint64_t hsrle_container_bound(uint64_t inSize, uint32_t blockSize);
 /* Scratch the compressor needs in device memory (per-block staging streams, sizes, scan partials). */
