@@ -225,3 +225,22 @@ def test_north_star_kernels_keep_their_occupancy(hs):
     assert hs.kernel_waves_per_cu("rle8_packed_multi", decode=False) >= 9
     for c in CODECS:
         assert hs.kernel_waves_per_cu(c.key, decode=True) >= 8 and hs.kernel_waves_per_cu(c.key, decode=False) >= 8, c.key
+
+
+def test_reference_cli_runs_on_the_gpu_library(tmp_path):
+    """oracle/_ref/hsrlekit_dropin is the reference's own benchmark program (src/main.c, unmodified) linked against
+    libhsrle_hip.so in place of the reference's extreme-codec translation units (oracle/Makefile).  Its benchmark loop calls all
+    100 drop-in functions through codecCallbacks[] and validates every round trip itself; `--test` turns any failure into a
+    non-zero exit code.  Skipped where the binary was not built (no reference checkout on the build machine)."""
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "hsrlekit_dropin")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/hsrlekit_dropin not built")
+    rng = random.Random(7)
+    sample = tmp_path / "sample.bin"
+    sample.write_bytes(mixed_runs(rng, 120000) + bytes(rng.randrange(256) for _ in range(12000)) + mixed_runs(rng, 40000))
+    r = subprocess.run([exe, str(sample), "--extreme", "--not-short", "--runs", "1", "--min-time", "0", "--test"], capture_output=True, text=True, timeout=900)
+    out = r.stdout.replace("\r", "\n")
+    assert r.returncode == 0, out[-3000:] + r.stderr[-2000:]
+    assert "FAILED" not in out and "8 Bit Packed" in out and "128 Bit Packed (Byte)" in out and "64 Bit 3LUT (Byte)" in out
