@@ -1,0 +1,49 @@
+# differential stress test on the GPU: python tools/gpu_stress.py [seconds] [seed]
+# random inputs of many shapes x all 50 codecs x several block sizes: every block stream must equal the oracle's, the decode must
+# equal the input, the status word must be 0.  Prints the first mismatches and a summary; exit code 1 on any failure.
+import sys, os, time, random
+sys.path.insert(0,'tests'); sys.path.insert(0,'hypersonic-rle-kit_amd/python')
+import numpy as np, torch, hsrle
+from hsrle_testlib import CODECS, Oracle, fuzz_sections, mixed_runs, single_symbol_mix, FUZZ_LENGTHS
+budget=float(sys.argv[1]) if len(sys.argv)>1 else 120.0
+seed=int(sys.argv[2]) if len(sys.argv)>2 else 1
+rng=random.Random(seed); ora=Oracle()
+def long_runs(rng,n):
+    out=bytearray()
+    while len(out)<n:
+        S=rng.choice([1,2,3,4,6,8,16]); sym=bytes(rng.randrange(256) for _ in range(S))
+        k=rng.choice([40,200,1000,5000,70000,300000])
+        out+=(sym*(k//S+2))[:k]; out+=bytes(rng.randrange(256) for _ in range(rng.choice([0,1,2,7,100,300,70000])))
+    return bytes(out[:n])
+def near_period(rng,n):
+    # almost-periodic data: runs broken by single-byte flips every so often (stresses stretch handling across windows)
+    S=rng.choice([2,3,4,6,8,16]); sym=bytes(rng.randrange(4) for _ in range(S)); b=bytearray((sym*(n//S+1))[:n])
+    for _ in range(n//rng.choice([37,61,64,65,127,200])): b[rng.randrange(n)]^=rng.randrange(1,4)
+    return bytes(b)
+gens=[lambda r:b"".join(fuzz_sections(r,8,FUZZ_LENGTHS) for _ in range(6)), lambda r:mixed_runs(r,r.choice([3000,20000,70000])), lambda r:single_symbol_mix(r,r.choice([3000,30000])),
+      lambda r:long_runs(r,r.choice([20000,400000])), lambda r:near_period(r,r.choice([5000,50000])), lambda r:bytes(r.randrange(r.choice([2,3,256])) for _ in range(r.choice([1,100,5000,40000])))]
+t0=time.time(); cases=0; bad=0; blocks=0
+while time.time()-t0<budget:
+    data=rng.choice(gens)(rng)
+    if not data: continue
+    tail=rng.choice([0,0,1,5,17,127])
+    if tail and len(data)>tail: data=data[:len(data)-tail]
+    arr=np.frombuffer(data,dtype=np.uint8)
+    src=torch.from_numpy(arr.copy()).cuda()
+    for bs in rng.sample([128,256,384,1024,4096,65536],3):
+        for c in rng.sample(CODECS,10):
+            cont,info=hsrle.compress(c.key,src,block_size=bs)
+            _,streams=hsrle.split_container(cont.cpu().numpy().tobytes())
+            exp=ora.compress_blocks(c,arr,bs)
+            cases+=1; blocks+=len(exp)
+            if streams!=exp:
+                bad+=1
+                i=next(k for k in range(len(exp)) if streams[k]!=exp[k])
+                print('ENCODE MISMATCH',c.key,'block size',bs,'input len',len(data),'block',i,'gpu',len(streams[i]),'oracle',len(exp[i]),'seed',seed,flush=True)
+            out=torch.zeros(len(data),dtype=torch.uint8,device='cuda'); st=torch.zeros(16,dtype=torch.int32,device='cuda')
+            hsrle.decompress_async(cont,info,out,st); torch.cuda.synchronize()
+            if int(st[0].item())!=0 or not torch.equal(out,src):
+                bad+=1; print('DECODE MISMATCH',c.key,'block size',bs,'input len',len(data),'status',int(st[0].item()),'seed',seed,flush=True)
+    if bad>20: break
+print('stress: %d codec x block-size cases, %d block streams compared, %d failures, %.0f s'%(cases,blocks,bad,time.time()-t0))
+sys.exit(1 if bad else 0)
