@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_compact(const uint8_t *__restrict__ slo
                                                  uint8_t *__restrict__ payload, uint32_t nBlocks)
 {
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t b = blockIdx.x * 4u + (threadIdx.x >> 6);
+  const uint32_t b = xcd_tile(blockIdx.x, gridDim.x) * 4u + (threadIdx.x >> 6);   // XCD-aware tile order (hsrle_common.hip.h)
   if (b >= nBlocks)
     return;
 

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   // (ds_bpermute: no LDS allocation), so the whole LDS budget is ring + tile: 15 KB per wave -> 10 waves per CU
 
   const uint32_t lane = threadIdx.x;
-  const uint32_t wgFirst = firstBlock + blockIdx.x * 64u;
+  const uint32_t wgFirst = firstBlock + xcd_tile(blockIdx.x, gridDim.x) * 64u;   // XCD-aware tile order (hsrle_common.hip.h)
   const uint32_t lastBlockExcl = firstBlock + blockCount;
   const uint32_t b = wgFirst + lane;
   const bool active = b < lastBlockExcl;

@@ -848,7 +848,7 @@ template <int FAM, int S, int AL>
 __global__ __launch_bounds__(64) void k_encode_blocks(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t nBlocks,
                                                       uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes)
 {
-  const uint32_t b = blockIdx.x * 64u + threadIdx.x;
+  const uint32_t b = xcd_tile(blockIdx.x, gridDim.x) * 64u + threadIdx.x;   // XCD-aware tile order (hsrle_common.hip.h)
   if (b >= nBlocks)
     return;
 

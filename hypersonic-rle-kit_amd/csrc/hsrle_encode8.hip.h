@@ -40,7 +40,7 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
   __shared__ __attribute__((aligned(16))) uint32_t rinfo[64];
 
   const uint32_t lane = threadIdx.x;
-  const uint32_t wgFirst = blockIdx.x * 64u;
+  const uint32_t wgFirst = xcd_tile(blockIdx.x, gridDim.x) * 64u;    // XCD-aware tile order (hsrle_common.hip.h)
   const uint32_t b = wgFirst + lane;
   const bool active = b < nBlocks;
 
