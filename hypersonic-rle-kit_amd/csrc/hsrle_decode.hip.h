@@ -6,22 +6,25 @@
 //   24/48 bit               src/rle{24,48}_extreme_cpu_decode.h
 //   128 bit                 src/rle128_extreme_cpu.h:499-802
 //   3/7 symbol LUT          src/rleX_Xsl.h:530-1881
-//   MEMCPY_* / MEMSET_*     src/rleX_extreme_common.h:32-312  (-> copy_literals / fill_run below)
+//   MEMCPY_* / MEMSET_*     src/rleX_extreme_common.h:32-312  (-> the literal / run parts of the packet loop below)
 //
-// One lane decodes one block (= one complete reference stream); a 64-lane workgroup owns 64 consecutive blocks, i.e.
-// one contiguous 64 * blockSize slice of the output.  Data path per workgroup:
+// One lane decodes one block (= one complete reference stream); a 64-lane workgroup (one wavefront) owns 64 consecutive blocks,
+// i.e. one contiguous 64 * blockSize slice of the output.  Data path per workgroup and step of Q = T = 128 output bytes per lane:
 //
-//   HBM --(top-up: T/16 adjacent lanes read T contiguous bytes of ONE stream, issued one round ahead)--> LDS ring [64][R]
-//   LDS ring --(per-lane packet walk: header fields, 16-byte literal vectors)--> LDS tile [64][T]
-//   LDS tile --(flush: T/16 adjacent lanes write T contiguous bytes of one row)--> HBM
+//   HBM --(top-up: 8 adjacent lanes read 128 contiguous, aligned bytes of ONE stream, issued one step ahead)--> LDS ring [64][R]
+//   LDS ring --(per-lane packet walk: header fields, 16-byte literal / run chunks)--> LDS tile [64][T]
+//   LDS tile --(flush: 8 adjacent lanes write the 128 contiguous bytes of one row, non-temporal)--> HBM
 //
 // so the packet-to-packet dependency chain (the next header's position is known only after the previous packet's literal
 // length, reference: src/rleX_extreme_cpu_decode.h:129-162) only ever waits on LDS, never on HBM, and it is walked by
-// 64 lanes at once.  Measured facts of gfx950 that shape the code (tools/ubench/):
-//   * 16-byte loads by 64 lanes at 64 different streams run at ~1 TB/s chip-wide; grouped loads read whole lines.
-//   * an LDS access whose address is not a multiple of 4 is executed one lane at a time (64 cycles per wave instruction);
-//     dword aligned 16-byte accesses take 11-24 cycles.  So every LDS access here is DWORD ALIGNED and the byte
-//     granularity of the format is restored in registers (v_alignbyte / v_bfi).
+// 64 lanes at once.  Measured facts of gfx950 that shape the code (tools/ubench/, DESIGN.md 4.1):
+//   * 16-byte loads by 64 lanes at 64 different streams run at ~1 TB/s chip-wide; grouped loads read whole lines; rows must be
+//     written as whole aligned 128-byte lines (misaligned rows: 0.45x).
+//   * an LDS access that is not NATURALLY aligned (16/8/4-byte access at a multiple of its size) is executed one lane at a time
+//     (64 cycles per wave instruction instead of 11-22).  So every LDS access here is naturally aligned and the byte granularity
+//     of the format is restored in registers (v_alignbyte / v_bfi / v_cndmask: funnel16, funnel24, merge_low).
+//   * the kernel is instruction-issue / latency bound and its throughput is proportional to the resident waves, so ring and
+//     tile are unpadded (XOR-swizzled rows) and everything else lives in registers: 16.6 KB LDS, <= 168 VGPRs, 9 waves per CU.
 // Nothing outside [0, uncompressedSize) is written (the reference scribbles up to 128 bytes past the end, A.5 q7).
 #pragma once
 
