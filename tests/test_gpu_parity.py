@@ -244,3 +244,38 @@ def test_reference_cli_runs_on_the_gpu_library(tmp_path):
     out = r.stdout.replace("\r", "\n")
     assert r.returncode == 0, out[-3000:] + r.stderr[-2000:]
     assert "FAILED" not in out and "8 Bit Packed" in out and "128 Bit Packed (Byte)" in out and "64 Bit 3LUT (Byte)" in out
+
+
+def test_compress_and_decompress_are_graph_capturable(hs):
+    """With a caller-provided workspace the async entry points only enqueue kernels on the given stream (no allocation, no
+    synchronisation), so they can be captured into a HIP graph and replayed (include/hsrle.h)."""
+    import torch
+
+    size, block = (8 << 20) + 4096 * 3 + 77, 4096
+    key = "rle8_packed_multi"
+    src = hs.synth(hs.SYNTH_RUNS, 1, 9, size)
+    dst = torch.empty(hs.container_bound(size, block), dtype=torch.uint8, device="cuda")
+    ws = torch.empty(hs.workspace_size(size, block), dtype=torch.uint8, device="cuda")
+    out = torch.zeros(size, dtype=torch.uint8, device="cuda")
+    status = torch.zeros(16, dtype=torch.int32, device="cuda")
+    # eager run: fixes the container layout (sizes are data dependent, the data is not going to change its shape below)
+    hs.compress_async(key, src, dst, block, workspace=ws)
+    torch.cuda.synchronize()
+    info = hs.container_info(dst)
+    eager = dst[: info.totalSize].clone()
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            hs.compress_async(key, src, dst, block, workspace=ws)
+            hs.decompress_async(dst, info, out, status)
+    torch.cuda.current_stream().wait_stream(side)
+
+    for rep in range(3):
+        dst.zero_(); out.zero_(); status.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(dst[: info.totalSize], eager), f"replay {rep}: container differs from the eager run"
+        assert int(status[0].item()) == 0 and torch.equal(out, src), f"replay {rep}: decode differs from the input"
