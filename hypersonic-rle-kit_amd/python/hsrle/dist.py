@@ -57,6 +57,15 @@ def _header_of(container):
     return unpack_header(container[:HEADER_SIZE].cpu().numpy().tobytes())
 
 
+P2P_PIECE = 1 << 30  # bytes per point-to-point message: keeps every message count below 2^31 whatever the transport does with it
+
+
+def _pieces(op, tensor, peer, group):
+    """One P2POp per <= 1 GiB piece of a 1-D uint8 tensor (sender and receiver cut identically: both know the size)."""
+    n = tensor.numel()
+    return [dist.P2POp(op, tensor[at : min(at + P2P_PIECE, n)], peer, group) for at in range(0, n, P2P_PIECE)]
+
+
 def _p2p(ops):
     if ops:
         for w in dist.batch_isend_irecv(ops):
@@ -94,8 +103,8 @@ def gather_container(local_container, total_uncompressed_size, root=0, group=Non
         if h is not None and counts[rank] > 0:
             lt = HEADER_SIZE
             lp = HEADER_SIZE + 8 * (counts[rank] + 1)
-            _p2p([dist.P2POp(dist.isend, local_container[lt : lt + 8 * counts[rank]].contiguous(), root, group),
-                  dist.P2POp(dist.isend, local_container[lp : lp + psizes[rank]].contiguous(), root, group)])
+            _p2p(_pieces(dist.isend, local_container[lt : lt + 8 * counts[rank]], root, group)
+                 + _pieces(dist.isend, local_container[lp : lp + psizes[rank]], root, group))
         return None
 
     out = torch.zeros(payload_at + payload + TAIL_PAD, dtype=torch.uint8, device=dev)
@@ -112,7 +121,7 @@ def gather_container(local_container, total_uncompressed_size, root=0, group=Non
                 tdst.copy_(local_container[lt : lt + 8 * counts[r]])
                 pdst.copy_(local_container[lp : lp + psizes[r]])
             else:
-                ops += [dist.P2POp(dist.irecv, tdst, r, group), dist.P2POp(dist.irecv, pdst, r, group)]
+                ops += _pieces(dist.irecv, tdst, r, group) + _pieces(dist.irecv, pdst, r, group)
         blk += counts[r]
         pay += psizes[r]
     _p2p(ops)
@@ -177,10 +186,10 @@ def scatter_container(container, root=0, device=None, group=None):
                 local[HEADER_SIZE : HEADER_SIZE + 8 * (c + 1)].copy_(tsrc)
                 local[HEADER_SIZE + 8 * (c + 1) : HEADER_SIZE + 8 * (c + 1) + (p1 - p0)].copy_(psrc)
             else:
-                ops += [dist.P2POp(dist.isend, tsrc.contiguous(), r, group), dist.P2POp(dist.isend, psrc.contiguous(), r, group)]
+                ops += _pieces(dist.isend, tsrc, r, group) + _pieces(dist.isend, psrc, r, group)
     elif count > 0:
-        ops += [dist.P2POp(dist.irecv, local[HEADER_SIZE : HEADER_SIZE + 8 * (count + 1)], root, group),
-                dist.P2POp(dist.irecv, local[HEADER_SIZE + 8 * (count + 1) : HEADER_SIZE + 8 * (count + 1) + (p1 - p0)], root, group)]
+        ops += _pieces(dist.irecv, local[HEADER_SIZE : HEADER_SIZE + 8 * (count + 1)], root, group)
+        ops += _pieces(dist.irecv, local[HEADER_SIZE + 8 * (count + 1) : HEADER_SIZE + 8 * (count + 1) + (p1 - p0)], root, group)
     _p2p(ops)
 
     if local is not None:

@@ -30,6 +30,8 @@ def _worker(rank, world, port, codec_key, total, block, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from hsrle import dist as hd
+
+        hd.P2P_PIECE = 1000  # force the multi-piece path of the point-to-point transfers (1 GiB pieces in production)
         from hsrle_testlib import CODECS, CODEC_BY_KEY, Oracle, build_container
 
         ora = Oracle()
