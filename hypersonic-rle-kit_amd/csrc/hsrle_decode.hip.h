@@ -242,11 +242,15 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     uint64_t base0 = 0;
     if (active)
     {
-      const uint64_t off0 = offsets[b];
+      uint64_t off0 = offsets[b], off1 = offsets[b + 1];
+      // the offset table is data too: an entry outside the payload (or a negative / oversized stream length) must end as an error
+      // bit, never as a wild read -- the lane then sees an empty stream at offset 0, which fails the header check
+      const uint64_t payloadBytes = (uint64_t)(payloadEnd - payload);
+      if (off0 > off1 || off1 > payloadBytes || off1 - off0 > 0xFFFFFF00ull) { off0 = 0; off1 = 0; }   // -> DEC_ERR_HEADER below
       g0 = (uint32_t)((uintptr_t)(payload + off0) & (uintptr_t)(Q - 1));
       g0 = umin(g0, (uint32_t)(off0 < 0xFFFFFFFFull ? off0 : 0xFFFFFFFFull) + 64u) & ~15u; // never reach in front of the container (>= 64 header bytes precede the payload)
       base0 = off0 - g0;                                               // may be "negative" for block 0: wraps, added to `payload` again below
-      slen = (uint32_t)(offsets[b + 1] - off0) + g0;
+      slen = (uint32_t)(off1 - off0) + g0;
       const uint64_t start = (uint64_t)b * B;
       blen = (uint32_t)((U - start) < (uint64_t)B ? (U - start) : (uint64_t)B);
       const uint64_t room = (uint64_t)(payloadEnd - payload) - base0;

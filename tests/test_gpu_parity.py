@@ -111,6 +111,12 @@ def test_malformed_block_reports_error(hs):
     bad[p0] = 0x55
     with pytest.raises(hs.HsrleError):
         hs.decompress(bad)
+    # corrupt the offset table: entries beyond the payload, and a decreasing pair -- an error, not a wild read
+    for pos, value in ((3, 1 << 40), (5, 0)):
+        bad3 = container.clone()
+        bad3[64 + 8 * pos : 64 + 8 * pos + 8] = torch.frombuffer(bytearray(struct.pack("<Q", value)), dtype=torch.uint8).cuda()
+        with pytest.raises(hs.HsrleError):
+            hs.decompress(bad3)
     # corrupt the container magic
     bad2 = container.clone()
     bad2[0] = 0
