@@ -84,8 +84,32 @@ def cpu_baseline(container_prefix, n_blocks, block_size, codec_key, expect):
         reps += 1
         best = dt if best is None else min(best, dt)
     ok = out[:usize].tobytes() == expect
-    return {"value": round(usize / 2**30 / (total / reps), 3), "best": round(usize / 2**30 / best, 3), "unit": "GiB/s", "cores": 1, "kind": kind,
-            "sample": f"decode of the first {usize >> 20} MiB ({n_blocks} blocks) of the same container, {reps} runs, mean", "matches_gpu_input": bool(ok)}
+    res = {"value": round(usize / 2**30 / (total / reps), 3), "best": round(usize / 2**30 / best, 3), "unit": "GiB/s", "cores": 1, "kind": kind,
+           "sample": f"decode of the first {usize >> 20} MiB ({n_blocks} blocks) of the same container, {reps} runs, mean", "matches_gpu_input": bool(ok)}
+
+    # context, not the baseline: the same decode spread over all host cores by the shim's pthread loop (one contiguous block range
+    # per thread).  SURVEY.md §8d "CPU beside it": 1-thread and N-thread.
+    if kind == "reference" and hasattr(lib, "hsrle_ref_decode_blocks_mt"):
+        nthreads = max(1, min(os.cpu_count() or 1, 1024))
+        lib.hsrle_ref_decode_blocks_mt.restype = ctypes.c_uint64
+        lib.hsrle_ref_decode_blocks_mt.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int]
+        # the reference writes up to 128 bytes past a block's end: thread t's range sits at + 256 * t (own slack per range)
+        out2 = np.zeros(usize + 256 * (nthreads + 1), dtype=np.uint8)
+        runmt = lambda: lib.hsrle_ref_decode_blocks_mt(fn, payload.ctypes.data, offs.ctypes.data, n_blocks, block_size, out2.ctypes.data, nthreads)
+        if runmt() == usize:  # warm-up
+            tb, t_stop, runs = None, time.time() + 4.0, 0
+            while runs < 3 or (time.time() < t_stop and runs < 50):
+                t0 = time.perf_counter()
+                got = runmt()
+                dt = time.perf_counter() - t0
+                runs += 1
+                if got == usize:
+                    tb = dt if tb is None else min(tb, dt)
+            bounds = [n_blocks * t // nthreads for t in range(nthreads + 1)]
+            same = all(out2[bounds[t] * block_size + 256 * t : bounds[t + 1] * block_size + 256 * t].tobytes() == expect[bounds[t] * block_size : bounds[t + 1] * block_size] for t in range(nthreads))
+            if tb is not None and same:
+                res["all_cores"] = {"value": round(usize / 2**30 / tb, 2), "unit": "GiB/s", "cores": nthreads, "note": "best of %d runs, one block range per POSIX thread" % runs}
+    return res
 
 
 def main():

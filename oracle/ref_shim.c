@@ -75,3 +75,54 @@ uint64_t hsrle_ref_encode_blocks(hsrle_ref_codec_fn fn, const uint8_t *pIn, uint
   }
   return nBlocks;
 }
+
+/* The same over `nThreads` POSIX threads (one contiguous block range each): the "all host cores" context figure of bench.py.
+ * Thread t writes its range at pOut + firstBlock_t * blockSize + 256 * t, i.e. every range has its own 256 bytes of slack
+ * (neighbouring ranges would otherwise scribble over each other's first bytes); pOut needs outSize + 256 * (nThreads + 1) bytes.
+ * Returns the number of bytes produced. */
+#include <pthread.h>
+
+typedef struct
+{
+  hsrle_ref_codec_fn fn;
+  const uint8_t *payload;
+  const uint64_t *offsets;
+  uint64_t first, count;
+  uint32_t blockSize;
+  uint8_t *out;
+  uint64_t produced;
+} hsrle_ref_mt_job;
+
+static void *hsrle_ref_mt_worker(void *p)
+{
+  hsrle_ref_mt_job *j = (hsrle_ref_mt_job *)p;
+  j->produced = hsrle_ref_decode_blocks(j->fn, j->payload, j->offsets + j->first, j->count, j->blockSize, j->out, j->count * (uint64_t)j->blockSize);
+  return 0;
+}
+
+uint64_t hsrle_ref_decode_blocks_mt(hsrle_ref_codec_fn fn, const uint8_t *payload, const uint64_t *offsets, uint64_t nBlocks, uint32_t blockSize,
+                                    uint8_t *pOut, int nThreads)
+{
+  if (nThreads < 1) nThreads = 1;
+  if (nThreads > 1024) nThreads = 1024;
+  pthread_t th[1024];
+  hsrle_ref_mt_job jobs[1024];
+  uint64_t total = 0;
+
+  for (int t = 0; t < nThreads; t++)
+  {
+    const uint64_t b0 = nBlocks * (uint64_t)t / (uint64_t)nThreads, b1 = nBlocks * (uint64_t)(t + 1) / (uint64_t)nThreads;
+    jobs[t] = (hsrle_ref_mt_job){ fn, payload, offsets, b0, b1 - b0, blockSize, pOut + b0 * blockSize + 256u * (uint64_t)t, 0 };
+    if (pthread_create(&th[t], 0, hsrle_ref_mt_worker, &jobs[t]) != 0)
+    {
+      hsrle_ref_mt_worker(&jobs[t]);
+      th[t] = 0;
+    }
+  }
+  for (int t = 0; t < nThreads; t++)
+  {
+    if (th[t]) pthread_join(th[t], 0);
+    total += jobs[t].produced;
+  }
+  return total;
+}
