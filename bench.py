@@ -199,6 +199,10 @@ def main():
     pay = container[p0 : p0 + int(table[sample_blocks])].cpu().numpy().tobytes()
     gpu_streams = [pay[int(table[i]) : int(table[i + 1])] for i in range(sample_blocks)]
     ok = ok and gpu_streams == ora.compress_blocks(codec, host_sample, args.block)
+    if distributed:  # bit_exact is a statement about every rank's shard
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = bool(t.item())
 
     # ---- encode throughput of the same buffer (untimed for `value`) ----
     for _ in range(2):
