@@ -113,6 +113,12 @@ def cpu_baseline(container_prefix, n_blocks, block_size, codec_key, expect):
 
 
 def main():
+    # stdout carries exactly ONE line: the JSON result of rank 0.  Libraries print to fd 1 too (RCCL prints its version banner
+    # there when a communicator is created), so everything else is sent to stderr for the lifetime of the process.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -262,7 +268,8 @@ def main():
             prefix = container[: min(prefix_end, container.numel())].cpu().numpy().tobytes()
             expect = src[: nb * args.block].cpu().numpy().tobytes()
             line["cpu_baseline"] = cpu_baseline(prefix, nb, args.block, args.codec, expect)
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
 
     if distributed:
         dist.destroy_process_group()
