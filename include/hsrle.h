@@ -8,7 +8,8 @@
  *  1. DROP-IN entry points with exactly the names, signatures and error behaviour of the reference's public
  *     header (reference: src/rle.h:100-394; registered in src/codec_funcs.h:270-410).  Host pointers in, host
  *     pointers out, one monolithic reference stream.  A maintainer links libhsrle_hip.so instead of
- *     rle8_extreme_cpu.c / rleX_extreme_cpu.c / rle{24,48,128}_extreme_cpu.c / rleX_Xsl.c.
+ *     rle8_extreme_cpu.c / rleX_extreme_cpu.c / rle{24,48,128}_extreme_cpu.c / rleX_Xsl.c (INTEGRATION.md has the link recipe;
+ *     the reference's own `hsrlekit` built that way passes its `--test` run on the GPU, tests/test_gpu_parity.py).
  *
  *  2. Device-resident block API (`hsrle_*_dev`): the input is cut into fixed-size blocks, every block is encoded
  *     as an independent, self-terminating reference stream (bit-exact with what the reference encoder produces
