@@ -11,7 +11,8 @@
 // One lane decodes one block (= one complete reference stream); a 64-lane workgroup (one wavefront) owns 64 consecutive blocks,
 // i.e. one contiguous 64 * blockSize slice of the output.  Data path per workgroup and step of Q = T = 128 output bytes per lane:
 //
-//   HBM --(top-up: 8 adjacent lanes read 128 contiguous, aligned bytes of ONE stream, issued one step ahead)--> LDS ring [64][R]
+//   HBM --(top-up: 8 adjacent lanes hold the next 8 16-byte chunks of ONE stream in registers; a chunk moves into the ring when it
+//          fits and its lane then requests the chunk 128 bytes further on: every chunk is requested exactly once)--> LDS ring [64][R]
 //   LDS ring --(per-lane packet walk: header fields, 16-byte literal / run chunks)--> LDS tile [64][T]
 //   LDS tile --(flush: 8 adjacent lanes write the 128 contiguous bytes of one row, non-temporal)--> HBM
 //
@@ -22,9 +23,12 @@
 //     written as whole aligned 128-byte lines (misaligned rows: 0.45x).
 //   * an LDS access that is not NATURALLY aligned (16/8/4-byte access at a multiple of its size) is executed one lane at a time
 //     (64 cycles per wave instruction instead of 11-22).  So every LDS access here is naturally aligned and the byte granularity
-//     of the format is restored in registers (v_alignbyte / v_bfi / v_cndmask: funnel16, funnel24, merge_low).
-//   * the kernel is instruction-issue / latency bound and its throughput is proportional to the resident waves, so ring and
-//     tile are unpadded (XOR-swizzled rows) and everything else lives in registers: 16.6 KB LDS, <= 168 VGPRs, 9 waves per CU.
+//     of the format is restored in registers (v_alignbyte / v_bfi / v_cndmask: funnel16, funnel24, merge_low_m).
+//   * a wave on its own needs ~13.5 k cycles per 128-byte step (a serial chain of ~1 450 instructions), so throughput scales with
+//     the resident waves: ring and tile are unpadded (XOR-swizzled rows), everything else lives in registers: 16.9 KB LDS,
+//     <= 168 VGPRs, 9 waves per CU (LDS is allocated in 1 280-byte granules: 10 waves would need <= 15 360 bytes).
+//   * under full occupancy the vector-memory instructions of a step stall for ~10 k cycles (alone: 1.5 k): the L1's outstanding
+//     requests are the bound (TCP_PENDING_STALL 60 %, ~1 000 cycles per read request), hence the exactly-once top-up.
 // Nothing outside [0, uncompressedSize) is written (the reference scribbles up to 128 bytes past the end, A.5 q7).
 #pragma once
 
@@ -128,7 +132,7 @@ __device__ __forceinline__ u32x4 lds_read16_w8(const uint8_t *base, uint32_t p)
   return funnel24(lds_ld64(src), lds_ld64(src + 8), lds_ld64(src + 16), p & 7u);
 }
 
-// low c bytes (c in 0..15) from `keep`, the rest from `fresh`
+// low c bytes (c in 0..15) from `keep`, the rest from `fresh` (the encoders' accumulators; the decoder takes its mask from a LUT)
 __device__ __forceinline__ u32x4 merge_low(u32x4 keep, u32x4 fresh, uint32_t c)
 {
   // one 64-bit mask of the low (c & 7) bytes; it is the low half's mask for c < 8 and the high half's for c >= 8
@@ -137,6 +141,12 @@ __device__ __forceinline__ u32x4 merge_low(u32x4 keep, u32x4 fresh, uint32_t c)
   const uint32_t p0 = (uint32_t)part, p1 = (uint32_t)(part >> 32);
   const uint32_t m0 = hiHalf ? ~0u : p0, m1 = hiHalf ? ~0u : p1, m2 = hiHalf ? p0 : 0u, m3 = hiHalf ? p1 : 0u;
   return u32x4{ (keep.x & m0) | (fresh.x & ~m0), (keep.y & m1) | (fresh.y & ~m1), (keep.z & m2) | (fresh.z & ~m2), (keep.w & m3) | (fresh.w & ~m3) };
+}
+
+// the same with the mask given (bytes set in m come from `keep`)
+__device__ __forceinline__ u32x4 merge_low_m(u32x4 keep, u32x4 fresh, u32x4 m)
+{
+  return u32x4{ (keep.x & m.x) | (fresh.x & ~m.x), (keep.y & m.y) | (fresh.y & ~m.y), (keep.z & m.z) | (fresh.z & ~m.z), (keep.w & m.w) | (fresh.w & ~m.w) };
 }
 
 // 32 bits at byte offset pos (0..12) of the 16-byte little-endian value hi:lo
@@ -186,12 +196,22 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   __shared__ __attribute__((aligned(16))) uint8_t tile[64 * TS];
   __shared__ __attribute__((aligned(16))) uint8_t ring[64 * RS];
   __shared__ __attribute__((aligned(16))) uint32_t rinfo[64];           // per-row scalars for the serving lanes (publish())
+  // mlut[c] = 16-byte mask with the low c bytes set: the merge of a partial chunk takes its mask from here (one ds_read_b128; the 16
+  // entries cover all 64 banks exactly once, so lanes either share an address or hit different banks) instead of ~9 VALU
+  __shared__ __attribute__((aligned(16))) uint8_t mlut[16 * 16];
+  if (threadIdx.x < 16u)
+  {
+    const uint32_t c = threadIdx.x;
+    const uint64_t part = ~(~0ull << (8u * (c & 7u)));
+    const bool hiHalf = c >= 8u;
+    const uint32_t p0 = (uint32_t)part, p1 = (uint32_t)(part >> 32);
+    lds_st128(mlut + c * 16u, u32x4{ hiHalf ? ~0u : p0, hiHalf ? ~0u : p1, hiHalf ? p0 : 0u, hiHalf ? p1 : 0u });
+  }
+#define HS_MERGE_LOW(keep, fresh, c) merge_low_m(keep, fresh, lds_ld128(mlut + ((c) << 4)))
 #ifdef HSRLE_LDS_BALLAST  // occupancy experiment only: extra LDS so that fewer waves fit on a CU
   __shared__ uint8_t ballast[HSRLE_LDS_BALLAST];
   if (U == 0x7FFFFFFFFFFFFFFFull) ballast[threadIdx.x] = 1;
 #endif
-  // per-row scalars (stream base, top-up requests, flush extents) are exchanged between lanes with wave shuffles
-  // (ds_bpermute: no LDS allocation), so the whole LDS budget is ring + tile: 15 KB per wave -> 10 waves per CU
 
   const uint32_t lane = threadIdx.x;
   const uint32_t wgFirst = firstBlock + xcd_tile(blockIdx.x, gridDim.x) * 64u;   // XCD-aware tile order (hsrle_common.hip.h)
@@ -255,6 +275,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
       blen = (uint32_t)((U - start) < (uint64_t)B ? (U - start) : (uint64_t)B);
       const uint64_t room = (uint64_t)(payloadEnd - payload) - base0;
       lim = (uint32_t)(room > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : room) & ~15u;
+      lim = umin(lim, (slen + 15u) & ~15u);                            // nothing behind the stream's last chunk is ever requested
       done = false;
     }
     myBase0 = base0;
@@ -267,59 +288,71 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 
   // ---- ring top-up.  issue(): LPR loads; in load q, lanes LPR*g .. LPR*g+LPR-1 read Q contiguous bytes of row RPL*q+g ----
   u32x4 pf[LPR];
-  constexpr bool kKeepSlots = !(TR::kLut && S > 1);                   // the LUT kernels of the wide symbols are the register-hungry ones
-  [[maybe_unused]] uint32_t pfAt[LPR];
-  uint32_t pfPos[LPR];                                   // ring slot / stream position of the chunk held in pf[q] (~0: none)
+  uint32_t pfPos[LPR];                                              // stream position of the chunk held in / on its way to pf[q] (~0: none)
 #pragma unroll
-  for (int q = 0; q < LPR; q++) { pf[q] = u32x4{ 0, 0, 0, 0 }; pfAt[q] = 0; pfPos[q] = 0xFFFFFFFFu; }
+  for (int q = 0; q < LPR; q++) { pf[q] = u32x4{ 0, 0, 0, 0 }; pfPos[q] = 0xFFFFFFFFu; }
   uint64_t myBase[LPR];                                             // stream starts of the LPR rows this lane helps to load
-
-  uint32_t wantReq = 0;                                             // chunks this row requested in issue()
+  // whether a stream has a chunk left for a lane: from the row's lim kept in a register per served row, or -- where registers are
+  // what stands between 8 and 9 waves per CU (the LUT decoders of the wide symbols) -- from a 4-bit count the owner packs below E
+  constexpr bool kPackLim = TR::kLut && S > 1;
+  [[maybe_unused]] uint32_t limq[LPR];                              // lim of those rows
 
   // Per-row scalars travel between the row's owner lane and the lanes that serve the row through a 64-dword LDS array:
   // the owner of row r writes slot (r % G) * P + r / G (P = lanes per row, G = 64 / P rows per instruction), so the P rows a
   // lane serves (rows q * G + lane / P, q = 0 .. P-1) are P consecutive dwords: one or two broadcast ds_read_b128 instead of
   // P (or 2 P) ds_bpermute.
   auto publish = [&](uint32_t v, int P) { rinfo[(lane % (64u / (uint32_t)P)) * (uint32_t)P + lane / (64u / (uint32_t)P)] = v; };
+#define HS_EXCHANGE(dst, v, P) { publish(v, P); wave_sync(); _Pragma("unroll") for (int q_ = 0; q_ < (P); q_++) dst[q_] = rinfo[(lane / (P)) * (P) + q_]; }
 
-  // topup(): one exchange per step.  The row owner first accounts for what LANDS -- of the chunks requested one step ago, those
-  // that fit now that this step's decode has freed ring space: the ring may hold bytes [floor16(sp), floor16(sp) + R) -- and
-  // then requests up to LPR chunks behind the new E.  Whether THOSE fit is decided when they land, so the ring only has to hold
-  // one step of consumption, not two.  The serving lanes get E | request in one dword: the chunk a lane holds lands iff its
-  // stream position is below the new E (chunks land in stream order).
+#ifdef HSRLE_STAMPS
+  unsigned long long tx0 = 0, tx1 = 0, tx2 = 0, tx3 = 0, tx4 = 0, tq0, tq1;
+#define HS_XSTAMP(acc) { tq1 = __builtin_readcyclecounter(); acc += tq1 - tq0; tq0 = tq1; }
+#else
+#define HS_XSTAMP(acc)
+#endif
+  // topup(): one exchange per step.  The LPR lanes that serve a row keep the next LPR chunks behind E in flight / in registers,
+  // lane c the chunk whose index is c modulo LPR.  The row owner accounts for what LANDS now that this step's decode has freed
+  // ring space (the ring may hold [floor16(sp), floor16(sp) + R); whether a chunk fits is decided when it lands, so the ring only
+  // has to hold one step of consumption, not two) and publishes the new E; a serving lane whose chunk lies below it moves the
+  // chunk into the ring and requests its next one, Q bytes further on; a chunk that does not fit yet simply stays in its register.
+  // Every chunk of the container is requested exactly once -- no re-requests, no dummy loads of predicated-off lanes: the L1's
+  // outstanding-request slots are what bounds this kernel under full occupancy (TCP_PENDING_STALL 60 %), and the
+  // previous policy (request Q bytes behind E every step, drop what does not fit) spent 1.8x the compressed bytes on them.
+  static_assert(RPL % 8 == 0, "the ring swizzle of row q * RPL + g must not depend on q");
+  const uint32_t serveBase = ((lane / LPR) * (uint32_t)RS) ^ rsw_of(lane / LPR);   // ring row (swizzled) of the first row this lane serves
   auto topup = [&]() {
-    const uint32_t fit = ((uint32_t)R - (E - (sp & ~15u))) >> 4;
-    E += umin(wantReq, fit) << 4;
-    wantReq = done ? 0u : umin((uint32_t)LPR, (lim - E) >> 4);
-    publish(E | wantReq, LPR);                                        // E is a multiple of 16, wantReq <= 8
-    wave_sync();
+#ifdef HSRLE_STAMPS
+    tq0 = __builtin_readcyclecounter();
+#endif
+    if (!done) E += umin(umin((uint32_t)Q, lim - E), (uint32_t)R - (E - (sp & ~15u)));
     uint32_t ri[LPR];
-#pragma unroll
-    for (int q = 0; q < LPR; q++) ri[q] = rinfo[(lane / LPR) * LPR + q];
+    HS_EXCHANGE(ri, kPackLim ? (E | umin(15u, (lim - E) >> 4)) : E, LPR)      // E is a multiple of 16
     wave_sync();
-#pragma unroll
-    for (int q = 0; q < LPR; q++)
-      if (pfPos[q] < (ri[q] & ~15u))
-      {
-        // the chunk's ring slot: kept in a register, or -- where registers are what stands between 8 and 9 waves per CU --
-        // recomputed from its stream position
-        const uint32_t r = (uint32_t)q * RPL + lane / LPR;
-        const uint32_t slot = kKeepSlots ? pfAt[q] : ((r * (uint32_t)RS) ^ rsw_of(r) ^ (pfPos[q] & RMASK));
-        lds_st128(ring + slot, pf[q]);
-      }
+    HS_XSTAMP(tx0)
+    bool landed[LPR];
 #pragma unroll
     for (int q = 0; q < LPR; q++)
     {
-      const uint32_t r = (uint32_t)q * RPL + lane / LPR, c = lane % LPR;
-      const uint32_t e = ri[q] & ~15u, n = ri[q] & 15u;
-      const bool valid = c < n;
-      const uint32_t pos = e + c * 16u;
-      pf[q] = ld128(payload + myBase[q] + (valid ? pos : 0u));         // predicated-off lanes re-read the stream start
-      pfPos[q] = valid ? pos : 0xFFFFFFFFu;
-      if constexpr (kKeepSlots) pfAt[q] = (r * (uint32_t)RS) ^ rsw_of(r) ^ (pos & RMASK);   // ring slot of this chunk
+      landed[q] = pfPos[q] < (ri[q] & ~15u);
+      if (landed[q])                                                    // row q * RPL + lane / LPR: the q term is the instruction's offset field
+        lds_st128(ring + ((serveBase ^ (pfPos[q] & RMASK)) + (uint32_t)q * RPL * RS), pf[q]);
     }
+    HS_XSTAMP(tx1)
+#pragma unroll
+    for (int q = 0; q < LPR; q++)
+      if (landed[q])
+      {
+        // the chunk Q bytes further on exists iff it starts below lim
+        if (kPackLim ? (((pfPos[q] + (uint32_t)Q - (ri[q] & ~15u)) >> 4) < (ri[q] & 15u)) : (limq[q] - pfPos[q] > (uint32_t)Q))
+        {
+          pfPos[q] += (uint32_t)Q;
+          pf[q] = ld128(payload + myBase[q] + pfPos[q]);
+        }
+        else
+          pfPos[q] = 0xFFFFFFFFu;                                         // this lane's part of the stream is complete
+      }
+    HS_XSTAMP(tx2)
   };
-
   // prologue: fill the ring, then read the stream header from it
   wave_sync();
 #pragma unroll
@@ -329,11 +362,20 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     const uint32_t lo32 = (uint32_t)__shfl((int)(uint32_t)myBase0, r, 64), hi32 = (uint32_t)__shfl((int)(uint32_t)(myBase0 >> 32), r, 64);
     myBase[q] = ((uint64_t)hi32 << 32) | lo32;
   }
-  topup();                                                            // requests the first R bytes of every stream ...
+#pragma unroll
+  for (int q = 0; q < LPR; q++)
+  {
+    const int r = (int)((uint32_t)q * RPL + lane / LPR);
+    const uint32_t rowLim = (uint32_t)__shfl((int)lim, r, 64);
+    if constexpr (!kPackLim) limq[q] = rowLim;
+    pfPos[q] = (lane % LPR) * 16u;                                    // the first Q bytes of every stream ...
+    if (pfPos[q] < rowLim) pf[q] = ld128(payload + myBase[q] + pfPos[q]);
+    else pfPos[q] = 0xFFFFFFFFu;
+  }
   for (int k = 0; k < R / Q; k++)
   {
-    topup();                                                          // ... lands them (sp is still 0) and requests the next piece,
-    wave_sync();                                                      //     which flies during the first step's decode
+    topup();                                                          // ... land (sp is still 0); the next piece is requested and
+    wave_sync();                                                      //     flies during the first step's decode
   }
 
   if (active)
@@ -552,7 +594,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
               const uint32_t total = c + n;
               const uint32_t s8 = srcp & ~7u, sh = srcp & 7u;
               uint64_t xa = lds_ld64(ring + (rowx ^ (s8 & RMASK))), xb = lds_ld64(ring + (rowx ^ ((s8 + 8u) & RMASK))), xc = lds_ld64(ring + (rowx ^ ((s8 + 16u) & RMASK)));
-              u32x4 w = merge_low(acc, funnel24(xa, xb, xc, sh), c);     // keep the c valid bytes of the straddled chunk
+              u32x4 w = HS_MERGE_LOW(acc, funnel24(xa, xb, xc, sh), c);     // keep the c valid bytes of the straddled chunk
               lds_st128(row + (d0 ^ tsw), w);
               for (uint32_t k = 16; k < total; k += 16)
               {
@@ -577,7 +619,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
             const uint32_t d0 = q & ~15u;
             const uint32_t total = c + m;
             const u32x4 v = u32x4{ sym4, sym4, sym4, sym4 };
-            const u32x4 w = merge_low(acc, v, c);
+            const u32x4 w = HS_MERGE_LOW(acc, v, c);
             lds_st128(row + (d0 ^ tsw), w);
             for (uint32_t k = 16; k < total; k += 16)
               lds_st128(row + ((d0 + k) ^ tsw), v);
@@ -764,7 +806,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
         const uint32_t total = c + n;                                  // bytes from dst that must end up valid
         const uint32_t s8 = srcp & ~7u, sh = srcp & 7u;
         uint64_t xa = lds_ld64(ring + (rowx ^ (s8 & RMASK))), xb = lds_ld64(ring + (rowx ^ ((s8 + 8u) & RMASK))), xc = lds_ld64(ring + (rowx ^ ((s8 + 16u) & RMASK)));
-        u32x4 w = merge_low(acc, funnel24(xa, xb, xc, sh), c);         // keep the c valid bytes of the straddled chunk
+        u32x4 w = HS_MERGE_LOW(acc, funnel24(xa, xb, xc, sh), c);         // keep the c valid bytes of the straddled chunk
         lds_st128(row + (d0 ^ tsw), w);
         for (uint32_t k = 16; k < total; k += 16)
         {
@@ -794,7 +836,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
           if constexpr (16 % S == 0)
           {
             const u32x4 v = pattern_chunk16(patv, ph);                    // every chunk of the run holds the same 16 bytes
-            const u32x4 w = merge_low(acc, v, c);
+            const u32x4 w = HS_MERGE_LOW(acc, v, c);
             lds_st128(row + (d0 ^ tsw), w);
             for (uint32_t k = 16; k < total; k += 16)
               lds_st128(row + ((d0 + k) ^ tsw), v);
@@ -804,7 +846,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
           {
             uint32_t e0, e1, e2;
             pattern_dwords12(patv, ph, e0, e1, e2);
-            u32x4 w = merge_low(acc, u32x4{ e0, e1, e2, e0 }, c);
+            u32x4 w = HS_MERGE_LOW(acc, (u32x4{ e0, e1, e2, e0 }), c);
             lds_st128(row + (d0 ^ tsw), w);
             for (uint32_t k = 16; k < total; k += 16)
             {
@@ -847,11 +889,12 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 #ifdef HSRLE_STAMPS
     if (active && produced != (uint32_t)T) tIssue += 1ull << 40;          // diagnostic: partial rows
 #endif
-    publish(chunks != 0u ? (base | chunks) : 0u, CPR);                  // base is a multiple of 16 while chunks are pending (after the tail bytes it is not), chunks <= 8
-    wave_sync();
     uint32_t fi[CPR];
-#pragma unroll
-    for (int q = 0; q < CPR; q++) fi[q] = rinfo[(lane / CPR) * CPR + q];
+#ifdef HSRLE_STAMPS
+    tq0 = __builtin_readcyclecounter();
+#endif
+    HS_EXCHANGE(fi, chunks != 0u ? (base | chunks) : 0u, CPR)          // base is a multiple of 16 while chunks are pending (after the tail bytes it is not), chunks <= 8
+    HS_XSTAMP(tx3)
 #pragma unroll
     for (int h = 0; h < CPR; h += FH)                                  // FH row-groups at a time bounds the live registers
     {
@@ -869,7 +912,9 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
       for (int k = 0; k < FH; k++)
       {
         const int q = h + k;
-#ifdef HSRLE_ABLATE_STORES  // timing-only diagnostic build: only one lane in 64 stores (output is wrong)
+#if defined(HSRLE_ABLATE_STORES) && HSRLE_ABLATE_STORES == 2  // timing-only diagnostic build: no store instruction is ever executed (output is wrong)
+        if (U == 0x7FFFFFFFFFFFFFF1ull)
+#elif defined(HSRLE_ABLATE_STORES)  // timing-only diagnostic build: only one lane in 64 stores (output is wrong)
         if (lane == 0)
 #endif
         if (fAt[k] != 0xFFFFFFFFu)
@@ -877,6 +922,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
           __builtin_nontemporal_store(fv[k], (u32x4_unaligned *)(out + (uint64_t)(wgFirst + (uint32_t)q * RPI + lane / CPR) * B + fAt[k]));
       }
     }
+    HS_XSTAMP(tx4)
     base += chunks << 4;
     if (tailNow)
     {
@@ -900,6 +946,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     {
       atomicAdd(dbg + 0, tIssue); atomicAdd(dbg + 1, tDecode); atomicAdd(dbg + 2, tFlush); atomicAdd(dbg + 3, tLand);
       atomicAdd(dbg + 4, nRounds); atomicAdd(dbg + 5, iters); atomicAdd(dbg + 6, 1ull);
+      atomicAdd(dbg + 12, tx0); atomicAdd(dbg + 13, tx1); atomicAdd(dbg + 14, tx2); atomicAdd(dbg + 15, tx3); atomicAdd(dbg + 16, tx4);
     }
   }
 #endif

@@ -4,11 +4,11 @@ cd "$(dirname "$0")/.."
 run() {
   echo "== $1"
   timeout 200 python tools/gpu_probe6.py rle8_packed_multi,rle8_multi,rle8_3symlut,rle16_sym,rle64_3symlut_byte 2>&1 | grep -v amdgpu.ids | tail -3
-  for rep in 1 2 3; do timeout 300 python bench.py --no-cpu --steps 10 --warmup 3 2>&1 | grep -v amdgpu.ids | python -c "
+  for rep in $(seq 1 ${REPS:-3}); do timeout 300 python bench.py --no-cpu --steps 10 --warmup 3 2>&1 | grep -v amdgpu.ids | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        j = json.loads(l); print('dec %.2f ms %.0f GiB/s frac %.4f | enc %.0f GiB/s | ok %s' % (j['ms_per_step'], j['value'], j['roofline']['frac'], j['encode']['value'], j['bit_exact']))
+        j = json.loads(l); print('dec %.2f ms %.0f GiB/s frac %.4f w/cu %s | enc %.0f GiB/s | ok %s' % (j['ms_per_step'], j['value'], j['roofline']['frac'], j['roofline'].get('waves_per_cu'), j['encode']['value'], j['bit_exact']))
     else: print(l.rstrip()[-300:])"; done
 }
 [ -n "$SKIP_DEFAULT" ] || { HSRLE_LIB= ; unset HSRLE_LIB; run default; }
