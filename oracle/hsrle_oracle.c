@@ -563,6 +563,130 @@ static uint32_t enc_lut(const uint8_t *d, uint32_t n, int S, int aligned, int K,
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* Short family: 0 / 1 / 3 / 7 symbol LUT with one-byte packed headers.       */
+/*   parameters       rleX_Xsl_short.h:1-43                                                    */
+/*   process_symbol   rleX_Xsl_short.h:152-372  (decision, move to front, header, literals)    */
+/*   8 bit wrapper    rleX_Xsl_short.h:380-523 (+ bodies :529-667: run discovery = maximal     */
+/*                    runs of equal bytes, as in the other 8 bit multi encoders)               */
+/*   S > 1            rleX_Xsl_short_multibyte_encoder.h:18-412 (same run discovery as         */
+/*                    rleX_Xsl_multibyte_encoder.h)                                            */
+
+typedef struct { uint32_t LB, CB, RBP, RB, CINV, MAXPR, MAXPC, MAXTR, MINS, MINL, TB; } short_params_t;
+
+static void short_params(short_params_t *q, int S, int K)
+{
+  q->LB = (K == 3) ? 2 : (K == 1 ? 1 : (K == 0 ? 0 : 3));
+  q->CB = (K == 3 || K == 1) ? 3 : (K == 0 ? 4 : 2);
+  q->RBP = 8 - q->LB - q->CB;
+  q->RB = (K != 7) ? 24 - q->LB - q->CB - 9 : 24 - q->LB - q->RBP - 9;
+  q->CINV = (1u << q->CB) - 1;
+  q->MAXPR = (1u << q->RBP) - 1;
+  q->MAXPC = (1u << q->CB) - 2;
+  q->MAXTR = (1u << q->RB) - 1;
+  q->MINS = (K != 0) ? 2u : (uint32_t)S + 2;
+  q->MINL = (K != 0) ? (uint32_t)S + 11 : (uint32_t)S + 12;
+  q->TB = (K == 3) ? 4u : (K == 7 ? 2u : 8u);   /* second byte of the terminators (:474-482) */
+}
+
+static uint32_t enc_short(const uint8_t *d, uint32_t n, int S, int aligned, int K, uint8_t *out)
+{
+  sink_t s = { out, 0 };
+  put32(&s, n);
+  put32(&s, 0);
+
+  short_params_t q;
+  short_params(&q, S, K);
+  static const uint8_t init[7] = { 0x00, 0x7F, 0xFF, 0x01, 0x7E, 0x80, 0xFE };
+  uint8_t lut[7][16];
+
+  for (int k = 0; k < K; k++)
+    memset(lut[k], init[k], 16);
+
+  uint32_t lastRLE = 0;
+  int ended = 0;
+  const int al = (S == 1) ? 0 : aligned;
+  runs_t r = { d, n, S, al, 0 };
+  uint32_t p, e;
+
+  while (runs_next(&r, &p, &e))
+  {
+    const uint8_t *sym = d + p;
+    const int64_t count = (int64_t)e - p;
+    const int64_t range = (int64_t)p - lastRLE + 2;
+    int m = K;
+
+    for (int k = 0; k < K; k++)
+      if (memcmp(lut[k], sym, (size_t)S) == 0) { m = k; break; }
+
+    const int64_t sc = !al ? count - q.MINS + 2 : count / S - q.MINS / (uint32_t)S + 2;
+    const uint64_t count3 = (uint64_t)(sc - 2), range3 = (uint64_t)(range - 2);
+    const int single = range3 <= q.MAXPR && count3 <= q.MAXPC;
+    const int is19 = sc <= 511 && range <= (int64_t)q.MAXTR;
+    int64_t pen = (K > 0 && m == K) ? S : 0;
+
+    if (!single)
+    {
+      pen += 2;
+      if (!is19)
+        pen += (range <= 0xFFFFF ? (range <= (int64_t)q.MAXTR ? 0 : 2) : 4) + (sc <= 0xFFFFF ? (sc <= 511 ? 0 : 2) : 4);
+    }
+
+    if (!(count >= (int64_t)q.MINL || count >= (int64_t)q.MINS + pen))
+      continue;
+
+    if (K > 0)
+    {
+      uint8_t tmp[16];
+      memset(tmp, 0, 16);
+      memcpy(tmp, sym, (size_t)S);
+      const int from = (m == K) ? K - 1 : m;
+      for (int k = from; k > 0; k--)
+        memcpy(lut[k], lut[k - 1], 16);
+      memcpy(lut[0], tmp, 16);
+    }
+
+    const uint32_t mi = (K > 0) ? (uint32_t)m : 0;
+
+    if (single)
+      put8(&s, (mi << (q.CB + q.RBP)) | ((uint32_t)count3 << q.RBP) | (uint32_t)range3);
+    else
+    {
+      const uint32_t scx = (sc <= 511) ? (uint32_t)sc : (sc <= 0xFFFF ? 1u : 0u);
+      const uint32_t rx = (range <= (int64_t)q.MAXTR) ? (uint32_t)range : (range <= 0xFFFF ? 1u : 0u);
+      put8(&s, (mi << (q.CB + q.RBP)) | (q.CINV << q.RBP) | (((scx << (q.RB - 8)) >> 8) & 0xFF));
+      put8(&s, ((scx << (q.RB - 8)) | (rx >> 8)) & 0xFF);
+      put8(&s, rx & 0xFF);
+      if ((int64_t)scx != sc) { if (sc <= 0xFFFF) put16(&s, (uint32_t)sc); else put32(&s, (uint32_t)sc); }
+      if ((int64_t)rx != range) { if (range <= 0xFFFF) put16(&s, (uint32_t)range); else put32(&s, (uint32_t)range); }
+    }
+
+    if (K == 0 || m == K)
+      putn(&s, sym, (size_t)S);
+
+    putn(&s, d + lastRLE, p - lastRLE);
+    lastRLE = e;
+
+    if (e >= n)
+    {
+      put8(&s, q.CINV << q.RBP); put8(&s, q.TB); put8(&s, 1); put16(&s, 0); put16(&s, 0);
+      if (K == 0) put8(&s, 0);                    /* one byte, whatever the symbol width (:497-500, multibyte :370-373) */
+      ended = 1;
+    }
+  }
+
+  if (!ended)
+  {
+    const uint32_t k = n - lastRLE;
+    put8(&s, q.CINV << q.RBP); put8(&s, q.TB); put8(&s, 0); put16(&s, 0); put32(&s, k + 2);
+    if (K == 0) putzeros(&s, (size_t)S);          /* a whole zero symbol here (:517-520, multibyte :398-401) */
+    putn(&s, d + lastRLE, k);
+  }
+
+  patch32(out, 4, (uint32_t)s.at);
+  return (uint32_t)s.at;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* 8 bit Single: literal restatement                                          */
 /*   symbol pick  rle8_extreme_cpu.c:53-153 (the sse2 estimator is used on every ISA, q9)      */
 /*   encoder      rle8_extreme_cpu.h:346-700, :1103-1321                                       */
@@ -982,9 +1106,93 @@ static int dec_lut(src_t *s, dst_t *o, int S, int aligned, int K)
   return !(s->bad || o->bad);
 }
 
+/* Short family decoder: rleX_Xsl_short.h:1207-1480 (sse body; every ISA body decodes the same grammar) */
+static int dec_short(src_t *s, dst_t *o, int S, int aligned, int K)
+{
+  short_params_t q;
+  short_params(&q, S, K);
+  static const uint8_t init[7] = { 0x00, 0x7F, 0xFF, 0x01, 0x7E, 0x80, 0xFE };
+  uint8_t lut[7][16];
+  uint8_t cur[16];
+
+  memset(cur, 0, 16);                              /* K == 0: symbol starts as 0; K == 1: lut[0] = 0 */
+  memset(lut[0], 0, 16);
+  for (int k = 1; k < K; k++)
+    memset(lut[k], init[k], 16);
+
+  for (;;)
+  {
+    const uint32_t p1 = rd8(s);
+    const uint32_t idx = (K > 0) ? p1 >> (q.CB + q.RBP) : 0;
+    const uint32_t c3 = (p1 >> q.RBP) & q.CINV;
+    uint32_t cnt, range;
+
+    if (c3 == q.CINV)
+    {
+      const uint32_t p2 = rd8(s), p3 = rd8(s);
+      cnt = (p2 >> (q.RB - 8)) | ((p1 & q.MAXPR) << (8 - (q.RB - 8)));
+      range = p3 | ((p2 & ((1u << (q.RB - 8)) - 1)) << 8);
+
+      if (cnt == 0) cnt = rd32(s);
+      else if (cnt == 1) cnt = rd16(s);
+
+      if (range == 0) range = rd32(s);
+      else if (range == 1) { range = rd16(s); if (range == 0) break; }
+    }
+    else
+    {
+      cnt = c3 + 2;
+      range = (p1 & q.MAXPR) + 2;
+    }
+
+    if (K > 0)
+    {
+      if ((int)idx == K)
+      {
+        uint8_t t[16];
+        memset(t, 0, 16);
+        rdn(s, t, (size_t)S);
+        for (int k = K - 1; k > 0; k--) memcpy(lut[k], lut[k - 1], 16);
+        memcpy(lut[0], t, 16);
+      }
+      else if (idx > 0)
+      {
+        if ((int)idx > K) return 0;
+        uint8_t t[16];
+        memcpy(t, lut[idx], 16);
+        for (int k = (int)idx; k > 0; k--) memcpy(lut[k], lut[k - 1], 16);
+        memcpy(lut[0], t, 16);
+      }
+      memcpy(cur, lut[0], 16);
+    }
+    else
+    {
+      memset(cur, 0, 16);
+      rdn(s, cur, (size_t)S);
+    }
+
+    if (s->bad || range < 2)
+      return 0;
+
+    out_copy(o, s, (uint64_t)range - 2);
+
+    if (cnt == 0)
+      break;
+
+    const uint64_t runBytes = (aligned && S > 1) ? ((uint64_t)cnt + q.MINS / (uint32_t)S - 2) * (uint32_t)S : (uint64_t)cnt + q.MINS - 2;
+    out_fill(o, cur, (uint32_t)S, runBytes);
+
+    if (s->bad || o->bad)
+      return 0;
+  }
+
+  return !(s->bad || o->bad);
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* public entry points                                                                        */
 
+static int hso_short_k(int family) { return family == HSO_SHORT0 ? 0 : (family == HSO_SHORT1 ? 1 : (family == HSO_SHORT3 ? 3 : 7)); }
 static int valid_S(int S) { return S == 1 || S == 2 || S == 3 || S == 4 || S == 6 || S == 8 || S == 16; }
 
 uint32_t hso_compress(int family, int S, int aligned, const uint8_t *pIn, uint32_t inSize, uint8_t *pOut, uint32_t outSize)
@@ -1012,6 +1220,13 @@ uint32_t hso_compress(int family, int S, int aligned, const uint8_t *pIn, uint32
   case HSO_PACKED_SINGLE:
     if (S != 1) return 0;
     return enc8_single(pIn, inSize, family == HSO_PACKED_SINGLE, pOut);
+
+  case HSO_SHORT0:
+  case HSO_SHORT1:
+  case HSO_SHORT3:
+  case HSO_SHORT7:
+    if (S == 16) return 0;
+    return enc_short(pIn, inSize, S, aligned, hso_short_k(family), pOut);
   }
 
   return 0;
@@ -1024,7 +1239,8 @@ uint32_t hso_decompress(int family, int S, int aligned, const uint8_t *pIn, uint
     return 0;
 
   const int lut = family == HSO_LUT3 || family == HSO_LUT7;
-  const size_t headerSize = (S == 1 && !lut) ? 9 : 8;
+  const int shortFam = family >= HSO_SHORT0 && family <= HSO_SHORT7;
+  const size_t headerSize = (S == 1 && !lut && !shortFam) ? 9 : 8;
 
   if (inSize < headerSize)
     return 0;
@@ -1042,6 +1258,11 @@ uint32_t hso_decompress(int family, int S, int aligned, const uint8_t *pIn, uint
   {
     if (S == 16) return 0;
     ok = dec_lut(&s, &o, S, aligned, family == HSO_LUT3 ? 3 : 7);
+  }
+  else if (shortFam)
+  {
+    if (S == 16) return 0;
+    ok = dec_short(&s, &o, S, aligned, hso_short_k(family));
   }
   else
   {
@@ -1084,8 +1305,16 @@ int hso_resolve(const char *name, int *family, int *S, int *aligned, int *isDeco
     { "rle8_packed_multi_compress", HSO_PACKED, 0 }, { "rle8_packed_single_compress", HSO_PACKED_SINGLE, 0 }, { "rle8_packed_decompress", HSO_PACKED, 1 },
     { "rle8_3symlut_compress", HSO_LUT3, 0 }, { "rle8_3symlut_decompress", HSO_LUT3, 1 },
     { "rle8_7symlut_compress", HSO_LUT7, 0 }, { "rle8_7symlut_decompress", HSO_LUT7, 1 },
+    { "rle8_multi_short_compress", HSO_SHORT0, 0 }, { "rle8_multi_short_decompress", HSO_SHORT0, 1 },
+    { "rle8_1symlut_short_compress", HSO_SHORT1, 0 }, { "rle8_1symlut_short_decompress", HSO_SHORT1, 1 },
+    { "rle8_3symlut_short_compress", HSO_SHORT3, 0 }, { "rle8_3symlut_short_decompress", HSO_SHORT3, 1 },
+    { "rle8_7symlut_short_compress", HSO_SHORT7, 0 }, { "rle8_7symlut_short_decompress", HSO_SHORT7, 1 },
   };
   static const struct { const char *mid; int fam, aligned; } mids[] = {
+    { "sym_short_", HSO_SHORT0, 1 }, { "byte_short_", HSO_SHORT0, 0 },
+    { "1symlut_sym_short_", HSO_SHORT1, 1 }, { "1symlut_byte_short_", HSO_SHORT1, 0 },
+    { "3symlut_sym_short_", HSO_SHORT3, 1 }, { "3symlut_byte_short_", HSO_SHORT3, 0 },
+    { "7symlut_sym_short_", HSO_SHORT7, 1 }, { "7symlut_byte_short_", HSO_SHORT7, 0 },
     { "sym_packed_", HSO_PACKED, 1 }, { "byte_packed_", HSO_PACKED, 0 }, { "sym_", HSO_PLAIN, 1 }, { "byte_", HSO_PLAIN, 0 },
     { "3symlut_sym_", HSO_LUT3, 1 }, { "3symlut_byte_", HSO_LUT3, 0 }, { "7symlut_sym_", HSO_LUT7, 1 }, { "7symlut_byte_", HSO_LUT7, 0 },
   };
@@ -1115,7 +1344,7 @@ int hso_resolve(const char *name, int *family, int *S, int *aligned, int *isDeco
       else if (strcmp(tail, "decompress") == 0) dec = 1;
       else continue;
 
-      if (widths[w].S == 16 && (mids[m].fam == HSO_LUT3 || mids[m].fam == HSO_LUT7))
+      if (widths[w].S == 16 && (mids[m].fam == HSO_LUT3 || mids[m].fam == HSO_LUT7 || mids[m].fam >= HSO_SHORT0))
         return 0;
 
       *family = mids[m].fam; *S = widths[w].S; *aligned = mids[m].aligned; *isDecompress = dec;

@@ -28,7 +28,12 @@ enum {
   HSO_LUT3 = 2,          /* rle{W}_3symlut[_sym|_byte]                     */
   HSO_LUT7 = 3,          /* rle{W}_7symlut[_sym|_byte]                     */
   HSO_SINGLE = 4,        /* rle8_single        (8 bit only)                */
-  HSO_PACKED_SINGLE = 5  /* rle8_packed_single (8 bit only)                */
+  HSO_PACKED_SINGLE = 5, /* rle8_packed_single (8 bit only)                */
+  /* Short family (src/rle.h:202-348): one-byte packed headers, 0 / 1 / 3 / 7 symbol LUT */
+  HSO_SHORT0 = 6,        /* rle8_multi_short / rle{W}_{sym,byte}_short                */
+  HSO_SHORT1 = 7,        /* rle8_1symlut_short / rle{W}_1symlut_{sym,byte}_short      */
+  HSO_SHORT3 = 8,        /* rle8_3symlut_short / rle{W}_3symlut_{sym,byte}_short      */
+  HSO_SHORT7 = 9         /* rle8_7symlut_short / rle{W}_7symlut_{sym,byte}_short      */
 };
 
 /* reference: rle_compress_bounds, src/rle8_extreme_cpu.c:22-28 */

@@ -19,8 +19,9 @@ ORACLE_DIR = os.path.join(REPO, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "libhsrle_oracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libhsrle_ref.so")
 
-PLAIN, PACKED, LUT3, LUT7, SINGLE, PACKED_SINGLE = range(6)
-FAMILY_NAMES = {PLAIN: "plain", PACKED: "packed", LUT3: "3symlut", LUT7: "7symlut", SINGLE: "single", PACKED_SINGLE: "packed_single"}
+PLAIN, PACKED, LUT3, LUT7, SINGLE, PACKED_SINGLE, SHORT0, SHORT1, SHORT3, SHORT7 = range(10)
+FAMILY_NAMES = {PLAIN: "plain", PACKED: "packed", LUT3: "3symlut", LUT7: "7symlut", SINGLE: "single", PACKED_SINGLE: "packed_single",
+                SHORT0: "short", SHORT1: "1symlut_short", SHORT3: "3symlut_short", SHORT7: "7symlut_short"}
 
 
 class Codec:
@@ -47,12 +48,23 @@ def _codec_table():
             if S != 16:
                 t.append(Codec(f"rle{W}_3symlut_{nm}", LUT3, S, al, f"rle{W}_3symlut_{nm}_compress", f"rle{W}_3symlut_{nm}_decompress"))
                 t.append(Codec(f"rle{W}_7symlut_{nm}", LUT7, S, al, f"rle{W}_7symlut_{nm}_compress", f"rle{W}_7symlut_{nm}_decompress"))
+    # Short family (reference: src/rle.h:202-348, src/codec_funcs.h:283-388): ids 50..93 in this order
+    t.append(Codec("rle8_multi_short", SHORT0, 1, 0, "rle8_multi_short_compress", "rle8_multi_short_decompress"))
+    for fam, k in ((SHORT1, 1), (SHORT3, 3), (SHORT7, 7)):
+        t.append(Codec(f"rle8_{k}symlut_short", fam, 1, 0, f"rle8_{k}symlut_short_compress", f"rle8_{k}symlut_short_decompress"))
+    for W, S in ((16, 2), (24, 3), (32, 4), (48, 6), (64, 8)):
+        for al, nm in ((1, "sym"), (0, "byte")):
+            t.append(Codec(f"rle{W}_{nm}_short", SHORT0, S, al, f"rle{W}_{nm}_short_compress", f"rle{W}_{nm}_short_decompress"))
+            for fam, k in ((SHORT1, 1), (SHORT3, 3), (SHORT7, 7)):
+                t.append(Codec(f"rle{W}_{k}symlut_{nm}_short", fam, S, al, f"rle{W}_{k}symlut_{nm}_short_compress", f"rle{W}_{k}symlut_{nm}_short_decompress"))
     return t
 
 
 CODECS = _codec_table()
 CODEC_BY_KEY = {c.key: c for c in CODECS}
-assert len(CODECS) == 50
+EXTREME_CODECS = CODECS[:50]     # the north-star matrix
+SHORT_CODECS = CODECS[50:]
+assert len(CODECS) == 94
 
 
 def build_oracle():
