@@ -24,9 +24,16 @@ static const char *const kCodecNames[kCodecCount] = {
   "rle48_sym", "rle48_sym_packed", "rle48_3symlut_sym", "rle48_7symlut_sym", "rle48_byte", "rle48_byte_packed", "rle48_3symlut_byte", "rle48_7symlut_byte",
   "rle64_sym", "rle64_sym_packed", "rle64_3symlut_sym", "rle64_7symlut_sym", "rle64_byte", "rle64_byte_packed", "rle64_3symlut_byte", "rle64_7symlut_byte",
   "rle128_sym", "rle128_sym_packed", "rle128_byte", "rle128_byte_packed",
+  // Short family (reference: src/rle.h:202-348, src/codec_funcs.h:283-388)
+  "rle8_multi_short", "rle8_1symlut_short", "rle8_3symlut_short", "rle8_7symlut_short",
+  "rle16_sym_short", "rle16_1symlut_sym_short", "rle16_3symlut_sym_short", "rle16_7symlut_sym_short", "rle16_byte_short", "rle16_1symlut_byte_short", "rle16_3symlut_byte_short", "rle16_7symlut_byte_short",
+  "rle24_sym_short", "rle24_1symlut_sym_short", "rle24_3symlut_sym_short", "rle24_7symlut_sym_short", "rle24_byte_short", "rle24_1symlut_byte_short", "rle24_3symlut_byte_short", "rle24_7symlut_byte_short",
+  "rle32_sym_short", "rle32_1symlut_sym_short", "rle32_3symlut_sym_short", "rle32_7symlut_sym_short", "rle32_byte_short", "rle32_1symlut_byte_short", "rle32_3symlut_byte_short", "rle32_7symlut_byte_short",
+  "rle48_sym_short", "rle48_1symlut_sym_short", "rle48_3symlut_sym_short", "rle48_7symlut_sym_short", "rle48_byte_short", "rle48_1symlut_byte_short", "rle48_3symlut_byte_short", "rle48_7symlut_byte_short",
+  "rle64_sym_short", "rle64_1symlut_sym_short", "rle64_3symlut_sym_short", "rle64_7symlut_sym_short", "rle64_byte_short", "rle64_1symlut_byte_short", "rle64_3symlut_byte_short", "rle64_7symlut_byte_short",
 };
 
-static inline bool codec_is_lut(int c) { return c == 2 || c == 3 || (c >= 6 && c < 46 && (((c - 6) & 3) >= 2)); }
+static inline bool codec_is_lut(int c) { return c == 2 || c == 3 || (c >= 6 && c < 46 && (((c - 6) & 3) >= 2)) || c >= kShortBase8; }   // 8-byte stream header
 static inline uint32_t codec_header_size(int c) { return (c < 6 && !codec_is_lut(c)) ? 9u : 8u; }
 
 static DecodeLaunch g_dec[kCodecCount];
@@ -638,6 +645,20 @@ HSRLE_DEF_PAIR(rle128_sym, HSRLE_RLE128_SYM)
 HSRLE_DEF_PAIR(rle128_sym_packed, HSRLE_RLE128_SYM_PACKED)
 HSRLE_DEF_PAIR(rle128_byte, HSRLE_RLE128_BYTE)
 HSRLE_DEF_PAIR(rle128_byte_packed, HSRLE_RLE128_BYTE_PACKED)
+// Short family
+#define HSRLE_DEF_SHORT_WIDTH(W, base)                                                                                                   \
+  HSRLE_DEF_PAIR(rle##W##_sym_short, base + 0) HSRLE_DEF_PAIR(rle##W##_1symlut_sym_short, base + 1) HSRLE_DEF_PAIR(rle##W##_3symlut_sym_short, base + 2) \
+  HSRLE_DEF_PAIR(rle##W##_7symlut_sym_short, base + 3) HSRLE_DEF_PAIR(rle##W##_byte_short, base + 4) HSRLE_DEF_PAIR(rle##W##_1symlut_byte_short, base + 5) \
+  HSRLE_DEF_PAIR(rle##W##_3symlut_byte_short, base + 6) HSRLE_DEF_PAIR(rle##W##_7symlut_byte_short, base + 7)
+HSRLE_DEF_PAIR(rle8_multi_short, HSRLE_RLE8_MULTI_SHORT)
+HSRLE_DEF_PAIR(rle8_1symlut_short, HSRLE_RLE8_1SYMLUT_SHORT)
+HSRLE_DEF_PAIR(rle8_3symlut_short, HSRLE_RLE8_3SYMLUT_SHORT)
+HSRLE_DEF_PAIR(rle8_7symlut_short, HSRLE_RLE8_7SYMLUT_SHORT)
+HSRLE_DEF_SHORT_WIDTH(16, 54)
+HSRLE_DEF_SHORT_WIDTH(24, 62)
+HSRLE_DEF_SHORT_WIDTH(32, 70)
+HSRLE_DEF_SHORT_WIDTH(48, 78)
+HSRLE_DEF_SHORT_WIDTH(64, 86)
 
 // ---- container API ----
 

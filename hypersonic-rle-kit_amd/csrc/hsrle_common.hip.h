@@ -49,7 +49,8 @@ struct Traits
   static constexpr uint32_t LONG = kLut ? (uint32_t)S + 10u
                                         : (S == 1 ? (kPacked ? 11u : 9u) : (kPacked ? (kRange7 ? (uint32_t)S + 11u : (uint32_t)S + 10u) : (uint32_t)S + 11u));
   static constexpr uint32_t MAXRANGE = kLut ? ((1u << RB) - 1u) : (kRange7 ? 127u : 255u);
-  static constexpr uint32_t kHeaderSize = (S == 1 && !kLut) ? 9u : 8u;
+  static constexpr uint32_t kHeaderSize = (S == 1 && !kLut && !kShort) ? 9u : 8u;
+  static constexpr bool kMtf = kLut || (kShort && K > 0);               // keeps a move-to-front list of K symbols
   static constexpr int SW = (S + 3) / 4; // dwords per symbol
 };
 

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   bool done = true;
   bool single = false;
   uint32_t err = 0;
-  [[maybe_unused]] uint32_t lut[TR::kLut ? TR::K : 1][TR::SW];
+  [[maybe_unused]] uint32_t lut[TR::kMtf ? TR::K : 1][TR::SW];
 
   // Stream positions (sp, E, slen, lim) are VIRTUAL: position 0 is the Q-byte aligned global address at or below the
   // stream start, the stream itself begins at virtual position g0.  Top-up loads then fetch Q-byte aligned pieces, so
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   uint64_t myBase[LPR];                                             // stream starts of the LPR rows this lane helps to load
   // whether a stream has a chunk left for a lane: from the row's lim kept in a register per served row, or -- where registers are
   // what stands between 8 and 9 waves per CU (the LUT decoders of the wide symbols) -- from a 4-bit count the owner packs below E
-  constexpr bool kPackLim = TR::kLut && S > 1;
+  constexpr bool kPackLim = TR::kMtf && TR::K > 1 && S > 1;
   [[maybe_unused]] uint32_t limq[LPR];                              // lim of those rows
 
   // Per-row scalars travel between the row's owner lane and the lanes that serve the row through a 64-dword LDS array:
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
       err |= DEC_ERR_HEADER;
       done = true;
     }
-    else if constexpr (S == 1 && !TR::kLut)
+    else if constexpr (S == 1 && !TR::kLut && !TR::kShort)
     {
       const uint32_t mode = hd[8];
       if (mode == 1u) { single = true; set_sym(u32x4{ hd[9], 0, 0, 0 }); sp = g0 + 10; }
@@ -396,9 +396,9 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     }
   }
 
-  if constexpr (TR::kLut)
+  if constexpr (TR::kMtf)
   {
-    // initial move-to-front list (reference: rleX_Xsl.h:533-543)
+    // initial move-to-front list (reference: rleX_Xsl.h:533-543, rleX_Xsl_short.h:1218-1229; the 1-symbol list starts with 0)
     constexpr uint32_t init[7] = { 0x00u, 0x7Fu, 0xFFu, 0x01u, 0x7Eu, 0x80u, 0xFEu };
 #pragma unroll
     for (int k = 0; k < TR::K; k++)
@@ -483,7 +483,50 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
             [[maybe_unused]] const uint64_t lo = (uint64_t)hv.x | ((uint64_t)hv.y << 32), hi = (uint64_t)hv.z | ((uint64_t)hv.w << 32);
             uint32_t cnt, pos, nsym = sym4, range, used, endNow = 0, hbad = 0;
 
-            if constexpr (TR::kLut)
+            if constexpr (TR::kShort)
+            {
+              // Short family (rleX_Xsl_short.h:1255-1310): [idx | count3 | range] in one byte, or -- count3 all ones -- three bytes with a
+              // 9 bit count and an SRB bit range, each extended by 2 / 4 bytes when it reads 1 / 0; both fields carry value + 2
+              const uint32_t p1 = hv.x & 0xFFu, p2 = (hv.x >> 8) & 0xFFu, p3 = (hv.x >> 16) & 0xFFu;
+              [[maybe_unused]] const uint32_t idx = (TR::K > 0) ? p1 >> (TR::SCB + TR::SRBP) : 0u;
+              const uint32_t c3 = (p1 >> TR::SRBP) & TR::SCINV;
+              const bool longf = c3 == TR::SCINV;
+              uint32_t lc = (p2 >> (TR::SRB - 8u)) | ((p1 & TR::SMAXPR) << (16u - TR::SRB));
+              uint32_t lr = p3 | ((p2 & ((1u << (TR::SRB - 8u)) - 1u)) << 8);
+              pos = longf ? 3u : 1u;
+              const uint32_t cext = alignbyte(hv.y, hv.x, 3u);
+              const bool c32 = longf && lc == 0u, c16 = longf && lc == 1u;
+              lc = c32 ? cext : (c16 ? (cext & 0xFFFFu) : lc);
+              pos += c32 ? 4u : (c16 ? 2u : 0u);
+              const uint32_t rext = ex32(lo, hi, pos);                    // pos <= 7
+              const bool r32 = longf && lr == 0u, r16 = longf && lr == 1u;
+              lr = r32 ? rext : (r16 ? (rext & 0xFFFFu) : lr);
+              pos += r32 ? 4u : (r16 ? 2u : 0u);
+              endNow = (r16 && lr == 0u) ? 1u : 0u;
+              cnt = longf ? lc : c3 + 2u;
+              range = longf ? lr : (p1 & TR::SMAXPR) + 2u;
+              uint32_t sb = ex32(lo, hi, pos) & 0xFFu;                    // pos <= 11: the symbol byte of a packet that carries one
+              if constexpr (TR::K == 0)
+                pos += 1u;
+              else
+              {
+                const bool isNew = idx == (uint32_t)TR::K;
+                pos += isNew ? 1u : 0u;
+#pragma unroll
+                for (int k = 0; k < TR::K; k++)
+                  if (idx == (uint32_t)k) sb = lut[k][0];
+                const uint32_t limit = isNew ? (uint32_t)TR::K - 1u : idx;
+#pragma unroll
+                for (int k = TR::K - 1; k >= 1; k--)
+                  if ((uint32_t)k <= limit) lut[k][0] = lut[k - 1][0];
+                lut[0][0] = sb;
+              }
+              nsym = sb * 0x01010101u;
+              used = pos;
+              hbad = (!endNow && range < 2u) ? 1u : 0u;
+              range = (range >= 2u) ? range - 1u : 0u;                    // literal count + 1, like the other families
+            }
+            else if constexpr (TR::kLut)
             {
               const uint32_t w16 = hv.x & 0xFFFFu;
               const uint32_t idx = w16 >> (FAM == LUT3 ? 14 : 13);
@@ -571,7 +614,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
             const bool lastNow = endNow || cnt == 0u;
             sym4 = nsym;
             lit = (range == 0u || endNow) ? 0u : range - 1u;             // a 7 bit range byte of 0x00 carries no literals (q11)
-            run = lastNow ? 0u : cnt + shortv - (TR::kLut ? 2u : 1u);
+            run = lastNow ? 0u : (TR::kShort ? cnt + TR::SMINS - 2u : cnt + shortv - (TR::kLut ? 2u : 1u));
             if (lastNow) fl |= F_LAST;
             sp += used;
             if (hbad || sp > slen || lit > slen - sp || (lit == 0u && run == 0u && !lastNow)) { err |= DEC_ERR_STREAM; fl |= F_DONE; }
@@ -661,7 +704,80 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
           const u32x4 hv = HS_RD16(0);
           const uint64_t lo = (uint64_t)hv.x | ((uint64_t)hv.y << 32), hi = (uint64_t)hv.z | ((uint64_t)hv.w << 32);
 
-          if constexpr (TR::kLut)
+          if constexpr (TR::kShort)
+          {
+            // Short family header, see the 8 bit loop
+            const uint32_t p1 = hv.x & 0xFFu;
+            [[maybe_unused]] const uint32_t idx = (TR::K > 0) ? p1 >> (TR::SCB + TR::SRBP) : 0u;
+            const uint32_t c3 = (p1 >> TR::SRBP) & TR::SCINV;
+            if (c3 != TR::SCINV)
+            {
+              cnt = c3 + 2u;
+              range = (p1 & TR::SMAXPR) + 2u;
+              used = 1;
+            }
+            else
+            {
+              const uint32_t p2 = (hv.x >> 8) & 0xFFu, p3 = (hv.x >> 16) & 0xFFu;
+              cnt = (p2 >> (TR::SRB - 8u)) | ((p1 & TR::SMAXPR) << (16u - TR::SRB));
+              range = p3 | ((p2 & ((1u << (TR::SRB - 8u)) - 1u)) << 8);
+              used = 3;
+              if (cnt == 0u) { cnt = ex32(lo, hi, 3u); used = 7; }
+              else if (cnt == 1u) { cnt = ex32(lo, hi, 3u) & 0xFFFFu; used = 5; }
+              const uint32_t rext = ex32(lo, hi, used);
+              if (range == 0u) { range = rext; used += 4; }
+              else if (range == 1u) { range = rext & 0xFFFFu; used += 2; endNow = (range == 0u); }
+            }
+
+            if (!endNow)
+            {
+              if constexpr (TR::K == 0)
+              {
+                set_sym(mask_symbol<S>(HS_RD16(used)));                  // every packet carries its symbol
+                used += S;
+              }
+              else if (idx != 0u)
+              {
+                uint32_t tmp[TR::SW];
+                if (idx == (uint32_t)TR::K)
+                {
+                  const u32x4 nv = mask_symbol<S>(HS_RD16(used));
+                  used += S;
+#pragma unroll
+                  for (int w = 0; w < TR::SW; w++) tmp[w] = nv[w];
+                }
+                else
+                {
+#pragma unroll
+                  for (int w = 0; w < TR::SW; w++) tmp[w] = lut[0][w];
+#pragma unroll
+                  for (int k = 1; k < TR::K; k++)
+                    if (idx == (uint32_t)k)
+                    {
+#pragma unroll
+                      for (int w = 0; w < TR::SW; w++) tmp[w] = lut[k][w];
+                    }
+                }
+                const uint32_t limit = (idx == (uint32_t)TR::K) ? (uint32_t)TR::K - 1u : idx;
+#pragma unroll
+                for (int k = TR::K - 1; k >= 1; k--)
+                  if ((uint32_t)k <= limit)
+                  {
+#pragma unroll
+                    for (int w = 0; w < TR::SW; w++) lut[k][w] = lut[k - 1][w];
+                  }
+                u32x4 pv = u32x4{ 0, 0, 0, 0 };
+#pragma unroll
+                for (int w = 0; w < TR::SW; w++) { lut[0][w] = tmp[w]; pv[w] = tmp[w]; }
+                set_sym(pv);
+              }
+            }
+
+            if (!endNow && range < 2u) { err |= DEC_ERR_STREAM; fl |= F_DONE; break; }
+            lit = endNow ? 0u : range - 2u;
+            run = (cnt == 0) ? 0u : (TR::kAligned ? (cnt + TR::SMINS / (uint32_t)S - 2u) * (uint32_t)S : cnt + TR::SMINS - 2u);
+          }
+          else if constexpr (TR::kLut)
           {
             const uint32_t w16 = hv.x & 0xFFFFu;
             used = 2;

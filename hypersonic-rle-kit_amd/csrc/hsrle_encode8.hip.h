@@ -153,7 +153,7 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
   {
     h32(n);
     h32(0);
-    if constexpr (!TR::kLut) hb(0); // mode = multi
+    if constexpr (!TR::kLut && !TR::kShort) hb(0); // mode = multi
     hflush();
   }
 
@@ -225,7 +225,29 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
     int k;                                                             // 0 keep as literals, 1 short range field, 2 long range field
     [[maybe_unused]] uint32_t m = 0, c7 = 0, r7 = 0, cst = 0, rng = 0;
 
-    if constexpr (TR::kLut)
+    [[maybe_unused]] int32_t sc = 0;                                   // Short: stored count (count - SMINS + 2)
+    [[maybe_unused]] bool pack1 = false;                               // Short: the one-byte header form
+
+    if constexpr (TR::kShort)
+    {
+      // rleX_Xsl_short.h:152-197
+      rng = gap + 2u;
+      m = (uint32_t)K;
+#pragma unroll
+      for (int j = K - 1; j >= 0; j--)
+        if (((lutw >> (8 * j)) & 0xFFull) == (uint64_t)sym) m = (uint32_t)j;
+      sc = (int32_t)count - (int32_t)TR::SMINS + 2;
+      pack1 = gap <= TR::SMAXPR && (uint32_t)(sc - 2) <= TR::SMAXPC;
+      uint32_t pen = (K > 0 && m == (uint32_t)K) ? 1u : 0u;
+      if (!pack1)
+      {
+        pen += 2u;
+        if (!(sc <= (int32_t)TR::SMAXTC && rng <= TR::SMAXTR))
+          pen += ((rng <= 0xFFFFFu) ? (rng <= TR::SMAXTR ? 0u : 2u) : 4u) + ((sc <= 0xFFFFF) ? (sc <= (int32_t)TR::SMAXTC ? 0u : 2u) : 4u);
+      }
+      k = (count >= TR::SMINL || count >= TR::SMINS + pen) ? 1 : 0;
+    }
+    else if constexpr (TR::kLut)
     {
       // rleX_Xsl.h:116-132
       rng = gap + 2u;
@@ -267,7 +289,33 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
       return;
 
     // ---- header ----
-    if constexpr (TR::kLut)
+    if constexpr (TR::kShort)
+    {
+      // rleX_Xsl_short.h:199-357
+      if constexpr (K > 0)
+      {
+        const uint32_t limit = (m == (uint32_t)K) ? (uint32_t)K - 1u : m;
+        const uint64_t keepHi = lutw & ~((1ull << (8u * (limit + 1u))) - 1ull);
+        const uint64_t low = lutw & ((1ull << (8u * limit)) - 1ull);
+        lutw = keepHi | (low << 8) | (uint64_t)sym;
+      }
+      const uint32_t mi = (K > 0) ? m << (TR::SCB + TR::SRBP) : 0u;
+      if (pack1)
+        hb(mi | ((uint32_t)(sc - 2) << TR::SRBP) | gap);
+      else
+      {
+        const uint32_t scu = (uint32_t)sc;
+        const uint32_t scx = (scu <= TR::SMAXTC) ? scu : (scu <= 0xFFFFu ? 1u : 0u);
+        const uint32_t rx = (rng <= TR::SMAXTR) ? rng : (rng <= 0xFFFFu ? 1u : 0u);
+        hb(mi | (TR::SCINV << TR::SRBP) | ((scx << (TR::SRB - 8u)) >> 8));
+        hb((scx << (TR::SRB - 8u)) | (rx >> 8));
+        hb(rx);
+        if (scx != scu) { if (scu <= 0xFFFFu) h16(scu); else h32(scu); }
+        if (rx != rng) { if (rng <= 0xFFFFu) h16(rng); else h32(rng); }
+      }
+      if (K == 0 || m == (uint32_t)K) hb(sym);
+    }
+    else if constexpr (TR::kLut)
     {
       const uint32_t limit = (m == (uint32_t)K) ? (uint32_t)K - 1u : m;
       const uint64_t keepHi = lutw & ~((1ull << (8u * (limit + 1u))) - 1ull);
@@ -302,7 +350,8 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
     if (e >= n)
     {
       // end terminator (rle8_extreme_cpu.h:203-338; rleX_Xsl.h:319-338)
-      if constexpr (TR::kLut) { h16((1u << TR::RB) | 1u); h16(0); h16(0); }
+      if constexpr (TR::kShort) { hb(TR::SCINV << TR::SRBP); hb(TR::STB); hb(1); h16(0); h16(0); if (K == 0) hb(0); }   // rleX_Xsl_short.h:470-501
+      else if constexpr (TR::kLut) { h16((1u << TR::RB) | 1u); h16(0); h16(0); }
       else if constexpr (TR::kPacked) { hb(0x80); h32(0); h32(1); }
       else { hb(0); hb(0); h32(0); hb(0); h32(0); }
       hflush();
@@ -313,7 +362,8 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
   // literal terminator carrying the bytes behind the last emitted run
   auto finish_literals = [&]() {
     const uint32_t kLit = n - lastRLE;
-    if constexpr (TR::kLut) { h16(1u << TR::RB); h16(0); h32(kLit + 2u); }
+    if constexpr (TR::kShort) { hb(TR::SCINV << TR::SRBP); hb(TR::STB); hb(0); h16(0); h32(kLit + 2u); if (K == 0) hb(0); }   // :503-523
+    else if constexpr (TR::kLut) { h16(1u << TR::RB); h16(0); h32(kLit + 2u); }
     else if constexpr (TR::kPacked) { hb(0x80); h32(0); h32(((kLit + 1u) << 1) | 1u); }
     else { hb(0); hb(0); h32(0); hb(0); h32(kLit + 1u); }
     hflush();

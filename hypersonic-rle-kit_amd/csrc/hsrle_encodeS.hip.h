@@ -25,7 +25,7 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
 {
   using TR = Traits<FAM, S, AL>;
   static_assert(S == 2 || S == 3 || S == 4 || S == 6 || S == 8, "8 bit and 128 bit symbols have their own kernels");
-  static_assert(FAM == PLAIN || FAM == PACKED || FAM == LUT3 || FAM == LUT7, "multi-symbol families only");
+  static_assert(FAM == PLAIN || FAM == PACKED || FAM == LUT3 || FAM == LUT7 || (FAM >= SHORT0 && FAM <= SHORT7), "multi-symbol families only");
   constexpr int Q = 64;                      // input bytes per lane and step
   constexpr int H = 256;                     // history ring per lane (power of two)
   constexpr int LPR = Q / 16, RPL = 64 / LPR;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
   bool finished = !active;   // the whole stream is in the slot
 
   [[maybe_unused]] uint32_t lut0[K ? K : 1], lut1[K ? K : 1];          // LUT: move-to-front list, entry k = {lut0[k], lut1[k]}
-  if constexpr (TR::kLut)
+  if constexpr (TR::kMtf)
   {
     constexpr uint32_t init[7] = { 0x00u, 0x7Fu, 0xFFu, 0x01u, 0x7Eu, 0x80u, 0xFEu };
 #pragma unroll
@@ -234,7 +234,52 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
     const uint32_t count = e - p;
     const uint32_t gap = p - lastRLE;
 
-    if constexpr (TR::kLut)
+    if constexpr (TR::kShort)
+    {
+      // rleX_Xsl_short.h:152-357 (process_symbol of the Short family)
+      const uint32_t range = gap + 2u;
+      [[maybe_unused]] uint32_t m = (uint32_t)K;
+#pragma unroll
+      for (int k = K - 1; k >= 0; k--)
+        if (lut0[k] == s0 && lut1[k] == s1) m = (uint32_t)k;
+      const int32_t sc = TR::kAligned ? (int32_t)(count / SU) - (int32_t)(TR::SMINS / SU) + 2 : (int32_t)count - (int32_t)TR::SMINS + 2;
+      const bool pack1 = gap <= TR::SMAXPR && (uint32_t)(sc - 2) <= TR::SMAXPC;
+      uint32_t pen = (K > 0 && m == (uint32_t)K) ? SU : 0u;
+      if (!pack1)
+      {
+        pen += 2u;
+        if (!(sc <= (int32_t)TR::SMAXTC && range <= TR::SMAXTR))
+          pen += ((range <= 0xFFFFFu) ? (range <= TR::SMAXTR ? 0u : 2u) : 4u) + ((sc <= 0xFFFFF) ? (sc <= (int32_t)TR::SMAXTC ? 0u : 2u) : 4u);
+      }
+      if (!(count >= TR::SMINL || count >= TR::SMINS + pen))
+        return;
+
+      if constexpr (K > 0)
+      {
+        const uint32_t limit = (m == (uint32_t)K) ? (uint32_t)K - 1u : m;
+#pragma unroll
+        for (int k = K - 1; k >= 1; k--)
+          if ((uint32_t)k <= limit) { lut0[k] = lut0[k - 1]; lut1[k] = lut1[k - 1]; }
+        lut0[0] = s0; lut1[0] = s1;
+      }
+
+      const uint32_t mi = (K > 0) ? m << (TR::SCB + TR::SRBP) : 0u;
+      if (pack1)
+        hb(mi | ((uint32_t)(sc - 2) << TR::SRBP) | gap);
+      else
+      {
+        const uint32_t scu = (uint32_t)sc;
+        const uint32_t scx = (scu <= TR::SMAXTC) ? scu : (scu <= 0xFFFFu ? 1u : 0u);
+        const uint32_t rx = (range <= TR::SMAXTR) ? range : (range <= 0xFFFFu ? 1u : 0u);
+        hb(mi | (TR::SCINV << TR::SRBP) | ((scx << (TR::SRB - 8u)) >> 8));
+        hb((scx << (TR::SRB - 8u)) | (rx >> 8));
+        hb(rx);
+        if (scx != scu) { if (scu <= 0xFFFFu) h16(scu); else h32(scu); }
+        if (rx != range) { if (range <= 0xFFFFu) h16(range); else h32(range); }
+      }
+      if (K == 0 || m == (uint32_t)K) hsym(s0, s1);
+    }
+    else if constexpr (TR::kLut)
     {
       // rleX_Xsl.h:116-195 (process_symbol); SURVEY.md A.3
       constexpr uint32_t RB = TR::RB, MAXC = 127u, MAXR = (1u << RB) - 1u;
@@ -309,7 +354,8 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
     if (e >= n)
     {
       // end terminator (rleX_extreme_cpu_encode.h:373-609; rleX_Xsl_multibyte_encoder.h:329-370)
-      if constexpr (TR::kLut) { h16((1u << TR::RB) | 1u); h16(0); h16(0); }
+      if constexpr (TR::kShort) { hb(TR::SCINV << TR::SRBP); hb(TR::STB); hb(1); h16(0); h16(0); if (K == 0) hb(0); }   // one zero byte, whatever S
+      else if constexpr (TR::kLut) { h16((1u << TR::RB) | 1u); h16(0); h16(0); }
       else
       {
         if constexpr (!TR::kPacked) { hsym(0, 0); hb(0); h32(0); } else { hb(0x80); h32(0); }
@@ -323,7 +369,8 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
   // literal terminator carrying the bytes behind the last emitted run
   auto finish_literals = [&]() {
     const uint32_t kLit = n - lastRLE;
-    if constexpr (TR::kLut) { h16(1u << TR::RB); h16(0); h32(kLit + 2u); }
+    if constexpr (TR::kShort) { hb(TR::SCINV << TR::SRBP); hb(TR::STB); hb(0); h16(0); h32(kLit + 2u); if (K == 0) hsym(0, 0); }   // a whole zero symbol here
+    else if constexpr (TR::kLut) { h16(1u << TR::RB); h16(0); h32(kLit + 2u); }
     else
     {
       if constexpr (!TR::kPacked) { hsym(0, 0); hb(0); h32(0); } else { hb(0x80); h32(0); }

@@ -13,6 +13,15 @@ static hipError_t dec_packed(const DecodeArgs &a, hipStream_t st) { return launc
 static hipError_t dec_lut3(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<LUT3, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
 static hipError_t dec_lut7(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<LUT7, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
 
+static hipError_t dec_short0(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<SHORT0, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
+static hipError_t dec_short1(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<SHORT1, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
+static hipError_t dec_short3(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<SHORT3, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
+static hipError_t dec_short7(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<SHORT7, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
+static hipError_t enc_short0(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode8_blocks<SHORT0>, a, st, 0); }
+static hipError_t enc_short1(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode8_blocks<SHORT1>, a, st, 0); }
+static hipError_t enc_short3(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode8_blocks<SHORT3>, a, st, 0); }
+static hipError_t enc_short7(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode8_blocks<SHORT7>, a, st, 0); }
+
 static hipError_t enc_plain(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode8_blocks<PLAIN>, a, st, 0); }
 static hipError_t enc_packed(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode8_blocks<PACKED>, a, st, 0); }
 static hipError_t enc_lut3(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode8_blocks<LUT3>, a, st, 0); }
@@ -28,6 +37,11 @@ void register_w8(DecodeLaunch *dec, EncodeLaunch *enc)
   dec[3] = dec_lut7;   enc[3] = enc_lut7;
   dec[4] = dec_plain;  enc[4] = enc_single;
   dec[5] = dec_packed; enc[5] = enc_packed_single;
+  // Short family (rle8_multi_short, rle8_{1,3,7}symlut_short; reference: src/rle.h:202-222)
+  dec[kShortBase8 + 0] = dec_short0; enc[kShortBase8 + 0] = enc_short0;
+  dec[kShortBase8 + 1] = dec_short1; enc[kShortBase8 + 1] = enc_short1;
+  dec[kShortBase8 + 2] = dec_short3; enc[kShortBase8 + 2] = enc_short3;
+  dec[kShortBase8 + 3] = dec_short7; enc[kShortBase8 + 3] = enc_short7;
 }
 
 } // namespace hsrle

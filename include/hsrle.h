@@ -63,7 +63,17 @@ typedef enum hsrle_codec
   HSRLE_RLE128_BYTE = 48,        /* rle128_byte_*         rle.h:168-169 */
   HSRLE_RLE128_BYTE_PACKED = 49, /* rle128_byte_packed_*  rle.h:194-195 */
 
-  HSRLE_CODEC_COUNT = 50
+  /* Short family: one-byte packed headers with a 0 / 1 / 3 / 7 symbol move-to-front list.                 */
+  HSRLE_RLE8_MULTI_SHORT = 50,   /* rle8_multi_short_*     rle.h:221-222 */
+  HSRLE_RLE8_1SYMLUT_SHORT = 51, /* rle8_1symlut_short_*   rle.h:216-217 */
+  HSRLE_RLE8_3SYMLUT_SHORT = 52, /* rle8_3symlut_short_*   rle.h:202-203 */
+  HSRLE_RLE8_7SYMLUT_SHORT = 53, /* rle8_7symlut_short_*   rle.h:210-211 */
+  /* for W in 16,24,32,48,64:  base = 54 + 8 * index(W);  base + k with k =                                              */
+  /*   0 sym_short  1 1symlut_sym_short  2 3symlut_sym_short  3 7symlut_sym_short                                        */
+  /*   4 byte_short 5 1symlut_byte_short 6 3symlut_byte_short 7 7symlut_byte_short            rle.h:228-348              */
+  HSRLE_RLE16_SYM_SHORT = 54, HSRLE_RLE24_SYM_SHORT = 62, HSRLE_RLE32_SYM_SHORT = 70, HSRLE_RLE48_SYM_SHORT = 78, HSRLE_RLE64_SYM_SHORT = 86,
+
+  HSRLE_CODEC_COUNT = 94
 } hsrle_codec_t;
 
 typedef enum hsrle_status
@@ -117,6 +127,21 @@ HSRLE_DECL_PAIR(rle128_sym_packed)
 HSRLE_DECL_PAIR(rle128_byte)
 HSRLE_DECL_PAIR(rle128_byte_packed)
 
+/* Short family: rle.h:202-203, :210-211, :216-217, :221-222 (8 bit), :228-348 (16..64 bit) */
+#define HSRLE_DECL_SHORT_WIDTH(W) \
+  HSRLE_DECL_PAIR(rle##W##_sym_short) HSRLE_DECL_PAIR(rle##W##_byte_short) HSRLE_DECL_PAIR(rle##W##_1symlut_sym_short) HSRLE_DECL_PAIR(rle##W##_1symlut_byte_short) \
+  HSRLE_DECL_PAIR(rle##W##_3symlut_sym_short) HSRLE_DECL_PAIR(rle##W##_3symlut_byte_short) HSRLE_DECL_PAIR(rle##W##_7symlut_sym_short) HSRLE_DECL_PAIR(rle##W##_7symlut_byte_short)
+HSRLE_DECL_PAIR(rle8_multi_short)
+HSRLE_DECL_PAIR(rle8_1symlut_short)
+HSRLE_DECL_PAIR(rle8_3symlut_short)
+HSRLE_DECL_PAIR(rle8_7symlut_short)
+HSRLE_DECL_SHORT_WIDTH(16)
+HSRLE_DECL_SHORT_WIDTH(24)
+HSRLE_DECL_SHORT_WIDTH(32)
+HSRLE_DECL_SHORT_WIDTH(48)
+HSRLE_DECL_SHORT_WIDTH(64)
+
+#undef HSRLE_DECL_SHORT_WIDTH
 #undef HSRLE_DECL_WIDTH
 #undef HSRLE_DECL_PAIR
 

@@ -17,6 +17,9 @@ def declared_symbols():
     pairs = ["rle8_3symlut", "rle8_7symlut", "rle128_sym", "rle128_sym_packed", "rle128_byte", "rle128_byte_packed"]
     for W in (16, 24, 32, 48, 64):
         pairs += [f"rle{W}_{v}" for v in ("sym", "sym_packed", "byte", "byte_packed", "3symlut_sym", "7symlut_sym", "3symlut_byte", "7symlut_byte")]
+    pairs += ["rle8_multi_short", "rle8_1symlut_short", "rle8_3symlut_short", "rle8_7symlut_short"]
+    for W in (16, 24, 32, 48, 64):
+        pairs += [f"rle{W}_{v}_short" for v in ("sym", "byte", "1symlut_sym", "1symlut_byte", "3symlut_sym", "3symlut_byte", "7symlut_sym", "7symlut_byte")]
     for p in pairs:
         names.add(p + "_compress")
         names.add(p + "_decompress")
@@ -34,7 +37,7 @@ def lib():
 
 def test_all_declared_symbols_are_exported(lib):
     syms = declared_symbols()
-    assert len(syms) >= 2 + 100 + 15  # helpers + 50 drop-in pairs + hsrle_* API
+    assert len(syms) >= 2 + 100 + 88 + 15  # helpers + 50 extreme + 44 Short drop-in pairs + hsrle_* API
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, f"not exported: {missing}"
 
@@ -43,7 +46,8 @@ def test_reference_names_present(lib):
     """Exactly the names of the reference's rle.h for the hot path (src/rle.h:100-394)."""
     for s in ("rle_compress_bounds", "rle_decompress_additional_size", "rle8_multi_compress", "rle8_single_compress", "rle8_decompress",
               "rle8_packed_multi_compress", "rle8_packed_single_compress", "rle8_packed_decompress", "rle64_3symlut_byte_compress",
-              "rle64_3symlut_byte_decompress", "rle24_sym_packed_compress", "rle128_byte_packed_decompress"):
+              "rle64_3symlut_byte_decompress", "rle24_sym_packed_compress", "rle128_byte_packed_decompress",
+              "rle8_multi_short_compress", "rle8_1symlut_short_decompress", "rle16_sym_short_compress", "rle48_7symlut_byte_short_decompress"):
         assert hasattr(lib, s)
 
 
@@ -56,7 +60,7 @@ def test_pure_host_helpers(lib):
     assert lib.rle_decompress_additional_size() == 128
     lib.hsrle_codec_from_name.restype = ctypes.c_int
     lib.hsrle_codec_name.restype = ctypes.c_char_p
-    for i in range(50):
+    for i in range(94):
         name = lib.hsrle_codec_name(i)
         assert lib.hsrle_codec_from_name(name) == i
     assert lib.hsrle_codec_from_name(b"rle8_packed_multi") == 1 and lib.hsrle_codec_from_name(b"rle64_3symlut_byte") == 44
@@ -71,4 +75,4 @@ def test_codec_table_matches_tests_table(lib):
     from hsrle_testlib import CODECS
 
     lib.hsrle_codec_name.restype = ctypes.c_char_p
-    assert [lib.hsrle_codec_name(i).decode() for i in range(50)] == [c.key for c in CODECS]
+    assert [lib.hsrle_codec_name(i).decode() for i in range(94)] == [c.key for c in CODECS]
