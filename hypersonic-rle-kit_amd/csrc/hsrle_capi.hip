@@ -31,6 +31,12 @@ static const char *const kCodecNames[kCodecCount] = {
   "rle32_sym_short", "rle32_1symlut_sym_short", "rle32_3symlut_sym_short", "rle32_7symlut_sym_short", "rle32_byte_short", "rle32_1symlut_byte_short", "rle32_3symlut_byte_short", "rle32_7symlut_byte_short",
   "rle48_sym_short", "rle48_1symlut_sym_short", "rle48_3symlut_sym_short", "rle48_7symlut_sym_short", "rle48_byte_short", "rle48_1symlut_byte_short", "rle48_3symlut_byte_short", "rle48_7symlut_byte_short",
   "rle64_sym_short", "rle64_1symlut_sym_short", "rle64_3symlut_sym_short", "rle64_7symlut_sym_short", "rle64_byte_short", "rle64_1symlut_byte_short", "rle64_3symlut_byte_short", "rle64_7symlut_byte_short",
+  // Greedy encoders (reference: src/rle.h:398-416); the decode side is the Short decoder of the same grammar
+  "rle16_1symlut_byte_short_greedy", "rle16_3symlut_byte_short_greedy", "rle16_7symlut_byte_short_greedy",
+  "rle24_1symlut_byte_short_greedy", "rle24_3symlut_byte_short_greedy", "rle24_7symlut_byte_short_greedy",
+  "rle32_1symlut_byte_short_greedy", "rle32_3symlut_byte_short_greedy", "rle32_7symlut_byte_short_greedy",
+  "rle48_1symlut_byte_short_greedy", "rle48_3symlut_byte_short_greedy", "rle48_7symlut_byte_short_greedy",
+  "rle64_1symlut_byte_short_greedy", "rle64_3symlut_byte_short_greedy", "rle64_7symlut_byte_short_greedy",
 };
 
 static inline bool codec_is_lut(int c) { return c == 2 || c == 3 || (c >= 6 && c < 46 && (((c - 6) & 3) >= 2)) || c >= kShortBase8; }   // 8-byte stream header
@@ -659,6 +665,16 @@ HSRLE_DEF_SHORT_WIDTH(24, 62)
 HSRLE_DEF_SHORT_WIDTH(32, 70)
 HSRLE_DEF_SHORT_WIDTH(48, 78)
 HSRLE_DEF_SHORT_WIDTH(64, 86)
+// Greedy encoders: only a compress entry point each (src/rle.h:398-416); their streams go to rle{W}_{K}symlut_byte_short_decompress
+#define HSRLE_DEF_GREEDY(W, base)                                                                                                                                     \
+  uint32_t rle##W##_1symlut_byte_short_compress_greedy(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize) { return mono_compress(base + 0, pIn, inSize, pOut, outSize); } \
+  uint32_t rle##W##_3symlut_byte_short_compress_greedy(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize) { return mono_compress(base + 1, pIn, inSize, pOut, outSize); } \
+  uint32_t rle##W##_7symlut_byte_short_compress_greedy(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize) { return mono_compress(base + 2, pIn, inSize, pOut, outSize); }
+HSRLE_DEF_GREEDY(16, 94)
+HSRLE_DEF_GREEDY(24, 97)
+HSRLE_DEF_GREEDY(32, 100)
+HSRLE_DEF_GREEDY(48, 103)
+HSRLE_DEF_GREEDY(64, 106)
 
 // ---- container API ----
 

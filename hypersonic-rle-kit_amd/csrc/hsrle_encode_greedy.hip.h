@@ -1,0 +1,195 @@
+// hsrle_encode_greedy.hip.h -- the Greedy encoders of the byte-aligned 1/3/7 symbol LUT Short codecs
+// (rle{16,24,32,48,64}_{1,3,7}symlut_byte_short_compress_greedy; reference: src/rle.h:398-416).
+//
+// Replaces: src/rleX_Xsl_short.h:746-1000 (the greedy scan) + :152-372 (process_symbol of the Short family).
+//
+// Besides repeats of the symbol at hand the greedy scan tries the symbols of the move-to-front list -- and, for symbols wider
+// than 16 bit, their leading bytes -- as runs, so a 2-byte "run" of a listed symbol's first bytes can be stored in one header
+// byte.  The scan is a byte-granular state machine whose next position depends on the list (which changes with every stored
+// run), so it does not map onto the window-parallel run enumeration of k_encodeS_blocks; it runs here as what it is, one lane
+// per block with per-lane global reads and writes (the first-generation data path of hsrle_encode.hip.h).  The streams are
+// Short streams: they decode with k_decode_blocks<SHORT1/3/7, S, 0> (src/codec_funcs.h:298-388 pairs them the same way).
+// Bytes at or beyond the block end never match.
+#pragma once
+
+#include "hsrle_common.hip.h"
+#include "hsrle_encode.hip.h" // Sink, load_sym
+
+namespace hsrle {
+
+template <int FAM, int S>
+__global__ __launch_bounds__(64) void k_encode_greedy_blocks(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t nBlocks,
+                                                             uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes)
+{
+  using TR = Traits<FAM, S, 0>;
+  static_assert(TR::kShort && TR::K > 0 && S >= 2 && S <= 8, "1/3/7 symbol LUT Short codecs of the 16..64 bit symbols");
+  constexpr int K = TR::K;
+  constexpr uint32_t SU = (uint32_t)S;
+
+  const uint32_t b = xcd_tile(blockIdx.x, gridDim.x) * 64u + threadIdx.x;
+  if (b >= nBlocks)
+    return;
+
+  const uint64_t start = (uint64_t)b * B;
+  const uint32_t n = (uint32_t)((U - start) < (uint64_t)B ? (U - start) : (uint64_t)B);
+  const uint8_t *const d = in + start;
+  Sink s{ slots + (uint64_t)b * slotStride, 0u, in + U };
+  s.put32(n);
+  s.put32(0);
+
+  // move-to-front list, entry k = {lut0[k], lut1[k]} (low S bytes); rleX_Xsl_short.h:759-774
+  uint32_t lut0[K], lut1[K];
+  {
+    constexpr uint32_t init[7] = { 0x00u, 0x7Fu, 0xFFu, 0x01u, 0x7Eu, 0x80u, 0xFEu };
+#pragma unroll
+    for (int k = 0; k < K; k++)
+    {
+      const uint32_t b4 = init[k] * 0x01010101u;
+      lut0[k] = (S >= 4) ? b4 : (b4 & ((1u << (8 * (S & 3))) - 1u));
+      lut1[k] = (S == 8) ? b4 : (S == 6 ? (b4 & 0xFFFFu) : 0u);
+    }
+  }
+
+  uint32_t lastRLE = 0;
+
+  // the symbol at block position i, zero extended; bytes at or beyond n read as zero
+  auto sym_at = [&](uint32_t i, uint32_t &s0, uint32_t &s1) {
+    if (i + SU <= n)
+    {
+      const u32x4 v = load_sym<S>(d + i);
+      s0 = v.x; s1 = v.y;
+    }
+    else
+    {
+      uint64_t v = 0;
+      for (uint32_t j = 0; j < SU && i + j < n; j++) v |= (uint64_t)d[i + j] << (8u * j);
+      s0 = (uint32_t)v; s1 = (uint32_t)(v >> 32);
+    }
+  };
+  // number of equal leading bytes of two symbols (S when they are equal)
+  auto prefix = [&](uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1) -> uint32_t {
+    const uint64_t diff = (uint64_t)(a0 ^ b0) | ((uint64_t)(a1 ^ b1) << 32);
+    return diff == 0ull ? SU : (uint32_t)__builtin_ctzll(diff) >> 3;
+  };
+
+  // process_symbol (rleX_Xsl_short.h:152-372) for the run [i - count, i) of {s0, s1}
+  auto process = [&](uint32_t s0, uint32_t s1, uint32_t count, uint32_t i) -> bool {
+    const uint32_t gap = i - lastRLE - count;
+    const uint32_t range = gap + 2u;
+    uint32_t m = (uint32_t)K;
+#pragma unroll
+    for (int k = K - 1; k >= 0; k--)
+      if (lut0[k] == s0 && lut1[k] == s1) m = (uint32_t)k;
+    const int32_t sc = (int32_t)count - (int32_t)TR::SMINS + 2;
+    const bool pack1 = gap <= TR::SMAXPR && (uint32_t)(sc - 2) <= TR::SMAXPC;
+    uint32_t pen = (m == (uint32_t)K) ? SU : 0u;
+    if (!pack1)
+    {
+      pen += 2u;
+      if (!(sc <= (int32_t)TR::SMAXTC && range <= TR::SMAXTR))
+        pen += ((range <= 0xFFFFFu) ? (range <= TR::SMAXTR ? 0u : 2u) : 4u) + ((sc <= 0xFFFFF) ? (sc <= (int32_t)TR::SMAXTC ? 0u : 2u) : 4u);
+    }
+    if (!(count >= TR::SMINL || count >= TR::SMINS + pen))
+      return false;
+
+    const uint32_t limit = (m == (uint32_t)K) ? (uint32_t)K - 1u : m;
+#pragma unroll
+    for (int k = K - 1; k >= 1; k--)
+      if ((uint32_t)k <= limit) { lut0[k] = lut0[k - 1]; lut1[k] = lut1[k - 1]; }
+    lut0[0] = s0; lut1[0] = s1;
+
+    const uint32_t mi = m << (TR::SCB + TR::SRBP);
+    if (pack1)
+      s.put8(mi | ((uint32_t)(sc - 2) << TR::SRBP) | gap);
+    else
+    {
+      const uint32_t scu = (uint32_t)sc;
+      const uint32_t scx = (scu <= TR::SMAXTC) ? scu : (scu <= 0xFFFFu ? 1u : 0u);
+      const uint32_t rx = (range <= TR::SMAXTR) ? range : (range <= 0xFFFFu ? 1u : 0u);
+      s.put8((mi | (TR::SCINV << TR::SRBP) | ((scx << (TR::SRB - 8u)) >> 8)) & 0xFFu);
+      s.put8(((scx << (TR::SRB - 8u)) | (rx >> 8)) & 0xFFu);
+      s.put8(rx & 0xFFu);
+      if (scx != scu) { if (scu <= 0xFFFFu) s.put16(scu); else s.put32(scu); }
+      if (rx != range) { if (range <= 0xFFFFu) s.put16(range); else s.put32(range); }
+    }
+    if (m == (uint32_t)K) s.template put_sym<S>(u32x4{ s0, s1, 0u, 0u });
+    s.putn(d + lastRLE, gap);
+    lastRLE = i;
+    return true;
+  };
+
+  // ---- the greedy scan (rleX_Xsl_short.h:783-974) ----
+  uint32_t y0, y1;                                                     // state.symbol: starts as the complement of the first symbol
+  sym_at(0, y0, y1);
+  y0 = ~y0; y1 = ~y1;
+  if constexpr (S < 4) y0 &= (1u << (8 * S)) - 1u;
+  if constexpr (S <= 4) y1 = 0u; else if constexpr (S == 6) y1 &= 0xFFFFu;
+  uint32_t count = 0, i = 0;
+
+  while (i < n)
+  {
+    if (count != 0u && i + SU <= n)
+    {
+      uint32_t x0, x1;
+      sym_at(i, x0, x1);
+      const uint32_t j = prefix(y0, y1, x0, x1);
+      if (j == SU) { count += SU; i += SU; continue; }
+      if constexpr (S == 2) { if (j != 0u) { count += 1u; i += 1u; } }
+      else { count += j; i += j; }
+    }
+
+    for (;;)                                                           // label not_a_full_match_but_a_match (:861)
+    {
+      process(y0, y1, count, i);
+      sym_at(i, y0, y1);
+      const bool fits = i + SU <= n;
+
+      if (fits && i + 2u * SU <= n)
+      {
+        uint32_t z0, z1;
+        sym_at(i + SU, z0, z1);
+        if (z0 == y0 && z1 == y1) { count = 2u * SU; i += 2u * SU; break; }
+      }
+      if (!fits) { count = 0u; i += 1u; break; }
+
+      uint32_t pc = 0u, idx = 0u;
+      bool full = false;
+#pragma unroll
+      for (int k = 0; k < K; k++)
+        if (!full)
+        {
+          const uint32_t c = prefix(lut0[k], lut1[k], y0, y1);
+          if (c == SU) { idx = (uint32_t)k; pc = SU; full = true; }
+          else if (S != 2 && c > pc) { idx = (uint32_t)k; pc = c; }
+        }
+
+      if (S != 2 ? pc >= TR::SMINS : pc != 0u)
+      {
+        count = pc; i += pc;
+#pragma unroll
+        for (int k = 0; k < K; k++)
+          if (idx == (uint32_t)k) { y0 = lut0[k]; y1 = lut1[k]; }
+        if (S != 2 && count < SU) continue;                            // goto not_a_full_match_but_a_match
+        break;
+      }
+      count = 0u; i += 1u;
+      break;
+    }
+  }
+
+  // ---- remaining bytes (rleX_Xsl_short.h:976-1032) ----
+  if (process(y0, y1, count, i))
+  {
+    s.put8(TR::SCINV << TR::SRBP); s.put8(TR::STB); s.put8(1); s.put16(0); s.put16(0);
+  }
+  else
+  {
+    const uint32_t kLit = n - lastRLE;
+    s.put8(TR::SCINV << TR::SRBP); s.put8(TR::STB); s.put8(0); s.put16(0); s.put32(kLit + 2u);
+    s.putn(d + lastRLE, kLit);
+  }
+  s.patch32(4, s.at);
+  sizes[b] = s.at;
+}
+
+} // namespace hsrle

@@ -112,7 +112,7 @@ def lib():
     return _lib()
 
 
-CODEC_COUNT = 94   # 50 extreme codecs + 44 of the Short family (include/hsrle.h)
+CODEC_COUNT = 109  # 50 extreme codecs + 44 of the Short family + 15 Greedy encoders (include/hsrle.h)
 
 
 def codec_names():

@@ -73,7 +73,12 @@ typedef enum hsrle_codec
   /*   4 byte_short 5 1symlut_byte_short 6 3symlut_byte_short 7 7symlut_byte_short            rle.h:228-348              */
   HSRLE_RLE16_SYM_SHORT = 54, HSRLE_RLE24_SYM_SHORT = 62, HSRLE_RLE32_SYM_SHORT = 70, HSRLE_RLE48_SYM_SHORT = 78, HSRLE_RLE64_SYM_SHORT = 86,
 
-  HSRLE_CODEC_COUNT = 94
+  /* Greedy encoders (rle.h:398-416): base = 94 + 3 * index(W) + {0 1symlut, 1 3symlut, 2 7symlut}; compress =                */
+  /* rle{W}_{K}symlut_byte_short_compress_greedy, decompress = rle{W}_{K}symlut_byte_short_decompress (codec_funcs.h:298-388) */
+  HSRLE_RLE16_1SYMLUT_BYTE_SHORT_GREEDY = 94, HSRLE_RLE24_1SYMLUT_BYTE_SHORT_GREEDY = 97, HSRLE_RLE32_1SYMLUT_BYTE_SHORT_GREEDY = 100,
+  HSRLE_RLE48_1SYMLUT_BYTE_SHORT_GREEDY = 103, HSRLE_RLE64_1SYMLUT_BYTE_SHORT_GREEDY = 106,
+
+  HSRLE_CODEC_COUNT = 109
 } hsrle_codec_t;
 
 typedef enum hsrle_status
@@ -140,6 +145,18 @@ HSRLE_DECL_SHORT_WIDTH(24)
 HSRLE_DECL_SHORT_WIDTH(32)
 HSRLE_DECL_SHORT_WIDTH(48)
 HSRLE_DECL_SHORT_WIDTH(64)
+
+/* Greedy encoders of the byte-aligned LUT Short codecs: rle.h:398-416 */
+#define HSRLE_DECL_GREEDY(W) \
+  uint32_t rle##W##_1symlut_byte_short_compress_greedy(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize); \
+  uint32_t rle##W##_3symlut_byte_short_compress_greedy(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize); \
+  uint32_t rle##W##_7symlut_byte_short_compress_greedy(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize);
+HSRLE_DECL_GREEDY(16)
+HSRLE_DECL_GREEDY(24)
+HSRLE_DECL_GREEDY(32)
+HSRLE_DECL_GREEDY(48)
+HSRLE_DECL_GREEDY(64)
+#undef HSRLE_DECL_GREEDY
 
 #undef HSRLE_DECL_SHORT_WIDTH
 #undef HSRLE_DECL_WIDTH

@@ -588,102 +588,189 @@ static void short_params(short_params_t *q, int S, int K)
   q->TB = (K == 3) ? 4u : (K == 7 ? 2u : 8u);   /* second byte of the terminators (:474-482) */
 }
 
-static uint32_t enc_short(const uint8_t *d, uint32_t n, int S, int aligned, int K, uint8_t *out)
-{
-  sink_t s = { out, 0 };
-  put32(&s, n);
-  put32(&s, 0);
-
+typedef struct {
+  sink_t s;
   short_params_t q;
-  short_params(&q, S, K);
-  static const uint8_t init[7] = { 0x00, 0x7F, 0xFF, 0x01, 0x7E, 0x80, 0xFE };
+  int S, K, al;
   uint8_t lut[7][16];
+  uint32_t lastRLE;
+  const uint8_t *d;
+} short_state_t;
+
+static void short_init(short_state_t *st, const uint8_t *d, uint32_t n, int S, int aligned, int K, uint8_t *out)
+{
+  static const uint8_t init[7] = { 0x00, 0x7F, 0xFF, 0x01, 0x7E, 0x80, 0xFE };
+  st->s.o = out; st->s.at = 0;
+  put32(&st->s, n);
+  put32(&st->s, 0);
+  short_params(&st->q, S, K);
+  st->S = S; st->K = K; st->al = (S == 1) ? 0 : aligned;
+  for (int k = 0; k < K; k++)
+    memset(st->lut[k], init[k], 16);
+  st->lastRLE = 0;
+  st->d = d;
+}
+
+/* process_symbol (rleX_Xsl_short.h:152-372) for the run [i - count, i) of `sym`: decide, and if the run is stored write the packet */
+static int short_process(short_state_t *st, const uint8_t *sym, int64_t count, uint32_t i)
+{
+  const short_params_t *q = &st->q;
+  const int S = st->S, K = st->K;
+  const int64_t range = (int64_t)i - st->lastRLE - count + 2;
+  int m = K;
 
   for (int k = 0; k < K; k++)
-    memset(lut[k], init[k], 16);
+    if (memcmp(st->lut[k], sym, (size_t)S) == 0) { m = k; break; }
 
-  uint32_t lastRLE = 0;
-  int ended = 0;
-  const int al = (S == 1) ? 0 : aligned;
-  runs_t r = { d, n, S, al, 0 };
+  const int64_t sc = !st->al ? count - q->MINS + 2 : count / S - q->MINS / (uint32_t)S + 2;
+  const uint64_t count3 = (uint64_t)(sc - 2), range3 = (uint64_t)(range - 2);
+  const int single = range3 <= q->MAXPR && count3 <= q->MAXPC;
+  const int is19 = sc <= 511 && range <= (int64_t)q->MAXTR;
+  int64_t pen = (K > 0 && m == K) ? S : 0;
+
+  if (!single)
+  {
+    pen += 2;
+    if (!is19)
+      pen += (range <= 0xFFFFF ? (range <= (int64_t)q->MAXTR ? 0 : 2) : 4) + (sc <= 0xFFFFF ? (sc <= 511 ? 0 : 2) : 4);
+  }
+
+  if (!(count >= (int64_t)q->MINL || count >= (int64_t)q->MINS + pen))
+    return 0;
+
+  if (K > 0)
+  {
+    uint8_t tmp[16];
+    memset(tmp, 0, 16);
+    memcpy(tmp, sym, (size_t)S);
+    const int from = (m == K) ? K - 1 : m;
+    for (int k = from; k > 0; k--)
+      memcpy(st->lut[k], st->lut[k - 1], 16);
+    memcpy(st->lut[0], tmp, 16);
+  }
+
+  const uint32_t mi = (K > 0) ? (uint32_t)m : 0;
+  sink_t *s = &st->s;
+
+  if (single)
+    put8(s, (mi << (q->CB + q->RBP)) | ((uint32_t)count3 << q->RBP) | (uint32_t)range3);
+  else
+  {
+    const uint32_t scx = (sc <= 511) ? (uint32_t)sc : (sc <= 0xFFFF ? 1u : 0u);
+    const uint32_t rx = (range <= (int64_t)q->MAXTR) ? (uint32_t)range : (range <= 0xFFFF ? 1u : 0u);
+    put8(s, (mi << (q->CB + q->RBP)) | (q->CINV << q->RBP) | (((scx << (q->RB - 8)) >> 8) & 0xFF));
+    put8(s, ((scx << (q->RB - 8)) | (rx >> 8)) & 0xFF);
+    put8(s, rx & 0xFF);
+    if ((int64_t)scx != sc) { if (sc <= 0xFFFF) put16(s, (uint32_t)sc); else put32(s, (uint32_t)sc); }
+    if ((int64_t)rx != range) { if (range <= 0xFFFF) put16(s, (uint32_t)range); else put32(s, (uint32_t)range); }
+  }
+
+  if (K == 0 || m == K)
+    putn(s, sym, (size_t)S);
+
+  const uint32_t p = (uint32_t)((int64_t)i - count);
+  putn(s, st->d + st->lastRLE, p - st->lastRLE);
+  st->lastRLE = i;
+  return 1;
+}
+
+static uint32_t short_finish(short_state_t *st, uint32_t n, int lastStored, uint8_t *out)
+{
+  const short_params_t *q = &st->q;
+  sink_t *s = &st->s;
+
+  if (lastStored)
+  {
+    put8(s, q->CINV << q->RBP); put8(s, q->TB); put8(s, 1); put16(s, 0); put16(s, 0);
+    if (st->K == 0) put8(s, 0);                   /* one byte, whatever the symbol width (:497-500, multibyte :370-373) */
+  }
+  else
+  {
+    const uint32_t k = n - st->lastRLE;
+    put8(s, q->CINV << q->RBP); put8(s, q->TB); put8(s, 0); put16(s, 0); put32(s, k + 2);
+    if (st->K == 0) putzeros(s, (size_t)st->S);   /* a whole zero symbol here (:517-520, multibyte :398-401) */
+    putn(s, st->d + st->lastRLE, k);
+  }
+
+  patch32(out, 4, (uint32_t)s->at);
+  return (uint32_t)s->at;
+}
+
+static uint32_t enc_short(const uint8_t *d, uint32_t n, int S, int aligned, int K, uint8_t *out)
+{
+  short_state_t st;
+  short_init(&st, d, n, S, aligned, K, out);
+  runs_t r = { d, n, S, st.al, 0 };
   uint32_t p, e;
+  int ended = 0;
 
   while (runs_next(&r, &p, &e))
-  {
-    const uint8_t *sym = d + p;
-    const int64_t count = (int64_t)e - p;
-    const int64_t range = (int64_t)p - lastRLE + 2;
-    int m = K;
-
-    for (int k = 0; k < K; k++)
-      if (memcmp(lut[k], sym, (size_t)S) == 0) { m = k; break; }
-
-    const int64_t sc = !al ? count - q.MINS + 2 : count / S - q.MINS / (uint32_t)S + 2;
-    const uint64_t count3 = (uint64_t)(sc - 2), range3 = (uint64_t)(range - 2);
-    const int single = range3 <= q.MAXPR && count3 <= q.MAXPC;
-    const int is19 = sc <= 511 && range <= (int64_t)q.MAXTR;
-    int64_t pen = (K > 0 && m == K) ? S : 0;
-
-    if (!single)
-    {
-      pen += 2;
-      if (!is19)
-        pen += (range <= 0xFFFFF ? (range <= (int64_t)q.MAXTR ? 0 : 2) : 4) + (sc <= 0xFFFFF ? (sc <= 511 ? 0 : 2) : 4);
-    }
-
-    if (!(count >= (int64_t)q.MINL || count >= (int64_t)q.MINS + pen))
-      continue;
-
-    if (K > 0)
-    {
-      uint8_t tmp[16];
-      memset(tmp, 0, 16);
-      memcpy(tmp, sym, (size_t)S);
-      const int from = (m == K) ? K - 1 : m;
-      for (int k = from; k > 0; k--)
-        memcpy(lut[k], lut[k - 1], 16);
-      memcpy(lut[0], tmp, 16);
-    }
-
-    const uint32_t mi = (K > 0) ? (uint32_t)m : 0;
-
-    if (single)
-      put8(&s, (mi << (q.CB + q.RBP)) | ((uint32_t)count3 << q.RBP) | (uint32_t)range3);
-    else
-    {
-      const uint32_t scx = (sc <= 511) ? (uint32_t)sc : (sc <= 0xFFFF ? 1u : 0u);
-      const uint32_t rx = (range <= (int64_t)q.MAXTR) ? (uint32_t)range : (range <= 0xFFFF ? 1u : 0u);
-      put8(&s, (mi << (q.CB + q.RBP)) | (q.CINV << q.RBP) | (((scx << (q.RB - 8)) >> 8) & 0xFF));
-      put8(&s, ((scx << (q.RB - 8)) | (rx >> 8)) & 0xFF);
-      put8(&s, rx & 0xFF);
-      if ((int64_t)scx != sc) { if (sc <= 0xFFFF) put16(&s, (uint32_t)sc); else put32(&s, (uint32_t)sc); }
-      if ((int64_t)rx != range) { if (range <= 0xFFFF) put16(&s, (uint32_t)range); else put32(&s, (uint32_t)range); }
-    }
-
-    if (K == 0 || m == K)
-      putn(&s, sym, (size_t)S);
-
-    putn(&s, d + lastRLE, p - lastRLE);
-    lastRLE = e;
-
-    if (e >= n)
-    {
-      put8(&s, q.CINV << q.RBP); put8(&s, q.TB); put8(&s, 1); put16(&s, 0); put16(&s, 0);
-      if (K == 0) put8(&s, 0);                    /* one byte, whatever the symbol width (:497-500, multibyte :370-373) */
+    if (short_process(&st, d + p, (int64_t)e - p, e) && e >= n)
       ended = 1;
+
+  return short_finish(&st, n, ended, out);
+}
+
+/* Greedy encoders of the byte-aligned 1/3/7 symbol LUT Short codecs: rleX_Xsl_short.h:746-1000, restated step for step.    */
+/* They also try the leading bytes of the listed symbols as (partial) runs; the streams decode with the Short decoders.       */
+/* Bytes at or beyond n never match (the reference reads the symbol behind a fitting one without a bound, :884-888).           */
+static uint32_t common_prefix(const uint8_t *a, const uint8_t *b, int S) { int j = 0; while (j < S && a[j] == b[j]) j++; return (uint32_t)j; }
+
+static uint32_t enc_short_greedy(const uint8_t *d, uint32_t n, int S, int K, uint8_t *out)
+{
+  short_state_t st;
+  short_init(&st, d, n, S, 0, K, out);
+  uint8_t sym[16];
+  memset(sym, 0, 16);
+  for (int j = 0; j < S; j++) sym[j] = (uint8_t)~((uint32_t)j < n ? d[j] : 0);
+  int64_t count = 0;
+  uint64_t i = 0;
+
+  while (i < n)
+  {
+    if (count && i + (uint64_t)S <= n)
+    {
+      if (memcmp(d + i, sym, (size_t)S) == 0) { count += S; i += (uint64_t)S; continue; }
+      if (S == 2) { if (sym[0] == d[i]) { count++; i++; } }
+      else { const uint32_t j = common_prefix(sym, d + i, S); i += j; count += j; }
+    }
+
+    for (;;)   /* label not_a_full_match_but_a_match (:861) */
+    {
+      short_process(&st, sym, count, (uint32_t)i);
+
+      memset(sym, 0, 16);
+      for (int j = 0; j < S; j++) sym[j] = (i + (uint64_t)j < n) ? d[i + j] : 0;
+      const int fits = i + (uint64_t)S <= n;
+
+      if (fits && i + 2 * (uint64_t)S <= n && memcmp(d + i + S, sym, (size_t)S) == 0) { count = 2 * S; i += 2 * (uint64_t)S; break; }
+
+      if (!fits) { count = 0; i++; break; }
+
+      uint32_t pc = 0;
+      int idx = 0;
+
+      for (int j = 0; j < K; j++)
+      {
+        const uint32_t c = common_prefix(st.lut[j], sym, S);
+        if (c == (uint32_t)S) { idx = j; pc = (uint32_t)S; break; }
+        if (S != 2 && c > pc) { idx = j; pc = c; }
+      }
+
+      if (S != 2 ? pc >= st.q.MINS : pc != 0)
+      {
+        count = pc; i += pc;
+        memcpy(sym, st.lut[idx], 16);
+        if (S != 2 && count < S) continue;      /* goto not_a_full_match_but_a_match */
+        break;
+      }
+
+      count = 0; i++;
+      break;
     }
   }
 
-  if (!ended)
-  {
-    const uint32_t k = n - lastRLE;
-    put8(&s, q.CINV << q.RBP); put8(&s, q.TB); put8(&s, 0); put16(&s, 0); put32(&s, k + 2);
-    if (K == 0) putzeros(&s, (size_t)S);          /* a whole zero symbol here (:517-520, multibyte :398-401) */
-    putn(&s, d + lastRLE, k);
-  }
-
-  patch32(out, 4, (uint32_t)s.at);
-  return (uint32_t)s.at;
+  return short_finish(&st, n, short_process(&st, sym, count, (uint32_t)i), out);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -1192,7 +1279,7 @@ static int dec_short(src_t *s, dst_t *o, int S, int aligned, int K)
 /* ------------------------------------------------------------------------------------------ */
 /* public entry points                                                                        */
 
-static int hso_short_k(int family) { return family == HSO_SHORT0 ? 0 : (family == HSO_SHORT1 ? 1 : (family == HSO_SHORT3 ? 3 : 7)); }
+static int hso_short_k(int family) { return family == HSO_SHORT0 ? 0 : ((family == HSO_SHORT1 || family == HSO_GREEDY1) ? 1 : ((family == HSO_SHORT3 || family == HSO_GREEDY3) ? 3 : 7)); }
 static int valid_S(int S) { return S == 1 || S == 2 || S == 3 || S == 4 || S == 6 || S == 8 || S == 16; }
 
 uint32_t hso_compress(int family, int S, int aligned, const uint8_t *pIn, uint32_t inSize, uint8_t *pOut, uint32_t outSize)
@@ -1227,6 +1314,12 @@ uint32_t hso_compress(int family, int S, int aligned, const uint8_t *pIn, uint32
   case HSO_SHORT7:
     if (S == 16) return 0;
     return enc_short(pIn, inSize, S, aligned, hso_short_k(family), pOut);
+
+  case HSO_GREEDY1:
+  case HSO_GREEDY3:
+  case HSO_GREEDY7:
+    if (S == 1 || S == 16 || aligned) return 0;
+    return enc_short_greedy(pIn, inSize, S, hso_short_k(family), pOut);
   }
 
   return 0;
@@ -1239,7 +1332,7 @@ uint32_t hso_decompress(int family, int S, int aligned, const uint8_t *pIn, uint
     return 0;
 
   const int lut = family == HSO_LUT3 || family == HSO_LUT7;
-  const int shortFam = family >= HSO_SHORT0 && family <= HSO_SHORT7;
+  const int shortFam = family >= HSO_SHORT0 && family <= HSO_GREEDY7;   /* Greedy streams are Short streams */
   const size_t headerSize = (S == 1 && !lut && !shortFam) ? 9 : 8;
 
   if (inSize < headerSize)
@@ -1339,15 +1432,20 @@ int hso_resolve(const char *name, int *family, int *S, int *aligned, int *isDeco
         continue;
 
       const char *tail = name + wl + ml;
-      int dec;
+      int dec, fam = mids[m].fam;
       if (strcmp(tail, "compress") == 0) dec = 0;
       else if (strcmp(tail, "decompress") == 0) dec = 1;
+      else if (strcmp(tail, "compress_greedy") == 0 && !mids[m].aligned && fam >= HSO_SHORT1 && fam <= HSO_SHORT7)
+      {
+        dec = 0;
+        fam = fam == HSO_SHORT1 ? HSO_GREEDY1 : (fam == HSO_SHORT3 ? HSO_GREEDY3 : HSO_GREEDY7);   /* src/rle.h:398-416 */
+      }
       else continue;
 
       if (widths[w].S == 16 && (mids[m].fam == HSO_LUT3 || mids[m].fam == HSO_LUT7 || mids[m].fam >= HSO_SHORT0))
         return 0;
 
-      *family = mids[m].fam; *S = widths[w].S; *aligned = mids[m].aligned; *isDecompress = dec;
+      *family = fam; *S = widths[w].S; *aligned = mids[m].aligned; *isDecompress = dec;
       return 1;
     }
   }

@@ -33,7 +33,10 @@ enum {
   HSO_SHORT0 = 6,        /* rle8_multi_short / rle{W}_{sym,byte}_short                */
   HSO_SHORT1 = 7,        /* rle8_1symlut_short / rle{W}_1symlut_{sym,byte}_short      */
   HSO_SHORT3 = 8,        /* rle8_3symlut_short / rle{W}_3symlut_{sym,byte}_short      */
-  HSO_SHORT7 = 9         /* rle8_7symlut_short / rle{W}_7symlut_{sym,byte}_short      */
+  HSO_SHORT7 = 9,        /* rle8_7symlut_short / rle{W}_7symlut_{sym,byte}_short      */
+  /* Greedy encoders (src/rle.h:398-416): rle{W}_{1,3,7}symlut_byte_short_compress_greedy; their streams are Short streams and
+   * decode with rle{W}_{1,3,7}symlut_byte_short_decompress (src/codec_funcs.h:298-388); symAligned must be 0, W in 16..64 */
+  HSO_GREEDY1 = 10, HSO_GREEDY3 = 11, HSO_GREEDY7 = 12
 };
 
 /* reference: rle_compress_bounds, src/rle8_extreme_cpu.c:22-28 */

@@ -19,7 +19,7 @@ ORACLE_DIR = os.path.join(REPO, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "libhsrle_oracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libhsrle_ref.so")
 
-PLAIN, PACKED, LUT3, LUT7, SINGLE, PACKED_SINGLE, SHORT0, SHORT1, SHORT3, SHORT7 = range(10)
+PLAIN, PACKED, LUT3, LUT7, SINGLE, PACKED_SINGLE, SHORT0, SHORT1, SHORT3, SHORT7, GREEDY1, GREEDY3, GREEDY7 = range(13)
 FAMILY_NAMES = {PLAIN: "plain", PACKED: "packed", LUT3: "3symlut", LUT7: "7symlut", SINGLE: "single", PACKED_SINGLE: "packed_single",
                 SHORT0: "short", SHORT1: "1symlut_short", SHORT3: "3symlut_short", SHORT7: "7symlut_short"}
 
@@ -62,9 +62,14 @@ def _codec_table():
 
 CODECS = _codec_table()
 CODEC_BY_KEY = {c.key: c for c in CODECS}
+# Greedy encoders (reference: src/rle.h:398-416, src/codec_funcs.h:298-388): paired with the Short decoders of the same grammar
+GREEDY_CODECS = [Codec(f"rle{W}_{k}symlut_byte_short_greedy", fam, S, 0, f"rle{W}_{k}symlut_byte_short_compress_greedy", f"rle{W}_{k}symlut_byte_short_decompress")
+                 for W, S in ((16, 2), (24, 3), (32, 4), (48, 6), (64, 8)) for fam, k in ((GREEDY1, 1), (GREEDY3, 3), (GREEDY7, 7))]
 EXTREME_CODECS = CODECS[:50]     # the north-star matrix
 SHORT_CODECS = CODECS[50:]
 assert len(CODECS) == 94
+CODECS = CODECS + GREEDY_CODECS  # library codec ids 94..108 in this order
+CODEC_BY_KEY = {c.key: c for c in CODECS}
 
 
 def build_oracle():

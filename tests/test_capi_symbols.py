@@ -20,6 +20,9 @@ def declared_symbols():
     pairs += ["rle8_multi_short", "rle8_1symlut_short", "rle8_3symlut_short", "rle8_7symlut_short"]
     for W in (16, 24, 32, 48, 64):
         pairs += [f"rle{W}_{v}_short" for v in ("sym", "byte", "1symlut_sym", "1symlut_byte", "3symlut_sym", "3symlut_byte", "7symlut_sym", "7symlut_byte")]
+    for W in (16, 24, 32, 48, 64):
+        for k in (1, 3, 7):
+            names.add(f"rle{W}_{k}symlut_byte_short_compress_greedy")
     for p in pairs:
         names.add(p + "_compress")
         names.add(p + "_decompress")
@@ -37,7 +40,7 @@ def lib():
 
 def test_all_declared_symbols_are_exported(lib):
     syms = declared_symbols()
-    assert len(syms) >= 2 + 100 + 88 + 15  # helpers + 50 extreme + 44 Short drop-in pairs + hsrle_* API
+    assert len(syms) >= 2 + 100 + 88 + 15 + 15  # helpers + 50 extreme + 44 Short drop-in pairs + 15 Greedy encoders + hsrle_* API
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, f"not exported: {missing}"
 
@@ -60,7 +63,7 @@ def test_pure_host_helpers(lib):
     assert lib.rle_decompress_additional_size() == 128
     lib.hsrle_codec_from_name.restype = ctypes.c_int
     lib.hsrle_codec_name.restype = ctypes.c_char_p
-    for i in range(94):
+    for i in range(109):
         name = lib.hsrle_codec_name(i)
         assert lib.hsrle_codec_from_name(name) == i
     assert lib.hsrle_codec_from_name(b"rle8_packed_multi") == 1 and lib.hsrle_codec_from_name(b"rle64_3symlut_byte") == 44
@@ -75,4 +78,4 @@ def test_codec_table_matches_tests_table(lib):
     from hsrle_testlib import CODECS
 
     lib.hsrle_codec_name.restype = ctypes.c_char_p
-    assert [lib.hsrle_codec_name(i).decode() for i in range(94)] == [c.key for c in CODECS]
+    assert [lib.hsrle_codec_name(i).decode() for i in range(109)] == [c.key for c in CODECS]
