@@ -37,6 +37,7 @@ static const char *const kCodecNames[kCodecCount] = {
   "rle32_1symlut_byte_short_greedy", "rle32_3symlut_byte_short_greedy", "rle32_7symlut_byte_short_greedy",
   "rle48_1symlut_byte_short_greedy", "rle48_3symlut_byte_short_greedy", "rle48_7symlut_byte_short_greedy",
   "rle64_1symlut_byte_short_greedy", "rle64_3symlut_byte_short_greedy", "rle64_7symlut_byte_short_greedy",
+  "rle8_single_short",
 };
 
 static inline bool codec_is_lut(int c) { return c == 2 || c == 3 || (c >= 6 && c < 46 && (((c - 6) & 3) >= 2)) || c >= kShortBase8; }   // 8-byte stream header
@@ -675,6 +676,7 @@ HSRLE_DEF_GREEDY(24, 97)
 HSRLE_DEF_GREEDY(32, 100)
 HSRLE_DEF_GREEDY(48, 103)
 HSRLE_DEF_GREEDY(64, 106)
+HSRLE_DEF_PAIR(rle8_single_short, HSRLE_RLE8_SINGLE_SHORT)
 
 // ---- container API ----
 

@@ -14,7 +14,8 @@
 namespace hsrle {
 
 enum Family : int { PLAIN = 0, PACKED = 1, LUT3 = 2, LUT7 = 3, SINGLE = 4, PACKED_SINGLE = 5,
-                    SHORT0 = 6, SHORT1 = 7, SHORT3 = 8, SHORT7 = 9 };   // Short family: 0 / 1 / 3 / 7 symbol LUT, one-byte packed headers
+                    SHORT0 = 6, SHORT1 = 7, SHORT3 = 8, SHORT7 = 9,     // Short family: 0 / 1 / 3 / 7 symbol LUT, one-byte packed headers
+                    SHORT_SINGLE = 10 };                                // rle8_single_short: one symbol per stream, none in the packets
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -29,7 +30,8 @@ struct Traits
   static constexpr bool kSingle = (FAM == SINGLE || FAM == PACKED_SINGLE);
   // Short family (reference: src/rleX_Xsl_short.h:1-43): [lut index | count | range] in one byte, or the 3-byte
   // form with a 9 bit count and a SRB bit range; both fields carry the value + 2
-  static constexpr bool kShort = (FAM >= SHORT0 && FAM <= SHORT7);
+  static constexpr bool kShort = (FAM >= SHORT0 && FAM <= SHORT_SINGLE);
+  static constexpr bool kShortSingle = (FAM == SHORT_SINGLE);          // header parameters of the 0-symbol codec, thresholds of the LUT ones (rleX_Xsl_short.h:1-11)
   static constexpr int K = (FAM == LUT3 || FAM == SHORT3) ? 3 : ((FAM == LUT7 || FAM == SHORT7) ? 7 : (FAM == SHORT1 ? 1 : 0));
   static constexpr uint32_t SLB = (FAM == SHORT3) ? 2u : (FAM == SHORT1 ? 1u : (FAM == SHORT7 ? 3u : 0u));   // lut index bits
   static constexpr uint32_t SCB = (FAM == SHORT3 || FAM == SHORT1) ? 3u : (FAM == SHORT7 ? 2u : 4u);          // packed count bits
@@ -37,8 +39,8 @@ struct Traits
   static constexpr uint32_t SRB = (FAM == SHORT7) ? 24u - SLB - SRBP - 9u : 24u - SLB - SCB - 9u;               // long form range bits (9..11)
   static constexpr uint32_t SCINV = (1u << SCB) - 1u;                 // packed count value that selects the 3-byte form
   static constexpr uint32_t SMAXPR = (1u << SRBP) - 1u, SMAXPC = (1u << SCB) - 2u, SMAXTR = (1u << SRB) - 1u, SMAXTC = 511u;
-  static constexpr uint32_t SMINS = (K != 0) ? 2u : (uint32_t)S + 2u;                                         // shortest run that can be stored
-  static constexpr uint32_t SMINL = (K != 0) ? (uint32_t)S + 11u : (uint32_t)S + 12u;                         // runs this long are always stored
+  static constexpr uint32_t SMINS = (K != 0 || kShortSingle) ? 2u : (uint32_t)S + 2u;                                         // shortest run that can be stored
+  static constexpr uint32_t SMINL = kShortSingle ? 11u : ((K != 0) ? (uint32_t)S + 11u : (uint32_t)S + 12u);                         // runs this long are always stored
   static constexpr uint32_t STB = (FAM == SHORT3) ? 4u : (FAM == SHORT7 ? 2u : 8u);                            // second byte of the terminators
   static constexpr int RB = (FAM == LUT3) ? 7 : 6; // LUT range bits
   static constexpr bool kAligned = (S > 1) && (AL != 0);

@@ -388,6 +388,11 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
       err |= DEC_ERR_HEADER;
       done = true;
     }
+    else if constexpr (TR::kShortSingle)
+    {
+      set_sym(u32x4{ hd[8], 0, 0, 0 });                                  // the stream's one symbol sits behind the header (rleX_Xsl_short.h:1211-1216)
+      sp = g0 + 9;
+    }
     else if constexpr (S == 1 && !TR::kLut && !TR::kShort)
     {
       const uint32_t mode = hd[8];
@@ -410,7 +415,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     }
     set_sym(u32x4{ 0, 0, 0, 0 });
   }
-  else if (!single)
+  else if (!single && !TR::kShortSingle)
   {
     set_sym(u32x4{ 0, 0, 0, 0 }); // Packed decoders start with symbol 0 (rleX_extreme_cpu_decode.h:31-37, q5)
   }
@@ -506,7 +511,9 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
               cnt = longf ? lc : c3 + 2u;
               range = longf ? lr : (p1 & TR::SMAXPR) + 2u;
               uint32_t sb = ex32(lo, hi, pos) & 0xFFu;                    // pos <= 11: the symbol byte of a packet that carries one
-              if constexpr (TR::K == 0)
+              if constexpr (TR::kShortSingle)
+                sb = sym4 & 0xFFu;                                       // no symbols in the packets
+              else if constexpr (TR::K == 0)
                 pos += 1u;
               else
               {

@@ -192,4 +192,121 @@ __global__ __launch_bounds__(64) void k_encode_greedy_blocks(const uint8_t *__re
   sizes[b] = s.at;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// rle8_single_short (reference: src/rle.h:223-224; rleX_Xsl_short.h with SINGLE: wrapper :380-523, body :1058-1120), restated
+// step for step on the same per-lane data path: the symbol is picked by the estimator of the extreme Single codec
+// (single_pick_symbol), the body's skip loop passes over 16-byte windows with fewer than two occurrences of the symbol (unless
+// the last byte is one), and the position it stops at when the windows run out is never examined (the for loop's own i++).
+template <int FAM>   // SHORT_SINGLE (a template so that the header can be included by every instantiation unit)
+__global__ __launch_bounds__(64) void k_encode_single_short_blocks(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t nBlocks,
+                                                                   uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes)
+{
+  using TR = Traits<FAM, 1, 0>;
+  static_assert(FAM == SHORT_SINGLE, "rle8_single_short only");
+  const uint32_t b = xcd_tile(blockIdx.x, gridDim.x) * 64u + threadIdx.x;
+  if (b >= nBlocks)
+    return;
+
+  const uint64_t start = (uint64_t)b * B;
+  const uint32_t n = (uint32_t)((U - start) < (uint64_t)B ? (U - start) : (uint64_t)B);
+  const uint8_t *const d = in + start;
+  Sink s{ slots + (uint64_t)b * slotStride, 0u, in + U };
+
+  uint32_t prob[256], pc[256]; // per-lane histograms (private segment)
+  const uint32_t sym = single_pick_symbol(d, n, prob, pc);
+  const uint32_t bs = sym * 0x01010101u;
+  s.put32(n);
+  s.put32(0);
+  s.put8(sym);
+
+  uint32_t lastRLE = 0;
+
+  // process_symbol with SINGLE (rleX_Xsl_short.h:152-372): no list, no symbol in the packet
+  auto process = [&](int32_t count, uint32_t i) -> bool {
+    const uint32_t gap = i - lastRLE - (uint32_t)count;
+    const uint32_t range = gap + 2u;
+    const int32_t sc = count - (int32_t)TR::SMINS + 2;
+    const bool pack1 = gap <= TR::SMAXPR && (uint32_t)(sc - 2) <= TR::SMAXPC;
+    uint32_t pen = 0u;
+    if (!pack1)
+    {
+      pen = 2u;
+      if (!(sc <= (int32_t)TR::SMAXTC && range <= TR::SMAXTR))
+        pen += ((range <= 0xFFFFFu) ? (range <= TR::SMAXTR ? 0u : 2u) : 4u) + ((sc <= 0xFFFFF) ? (sc <= (int32_t)TR::SMAXTC ? 0u : 2u) : 4u);
+    }
+    if (!(count >= (int32_t)TR::SMINL || count >= (int32_t)(TR::SMINS + pen)))
+      return false;
+    if (pack1)
+      s.put8(((uint32_t)(sc - 2) << TR::SRBP) | gap);
+    else
+    {
+      const uint32_t scu = (uint32_t)sc;
+      const uint32_t scx = (scu <= TR::SMAXTC) ? scu : (scu <= 0xFFFFu ? 1u : 0u);
+      const uint32_t rx = (range <= TR::SMAXTR) ? range : (range <= 0xFFFFu ? 1u : 0u);
+      s.put8(((TR::SCINV << TR::SRBP) | ((scx << (TR::SRB - 8u)) >> 8)) & 0xFFu);
+      s.put8(((scx << (TR::SRB - 8u)) | (rx >> 8)) & 0xFFu);
+      s.put8(rx & 0xFFu);
+      if (scx != scu) { if (scu <= 0xFFFFu) s.put16(scu); else s.put32(scu); }
+      if (rx != range) { if (range <= 0xFFFFu) s.put16(range); else s.put32(range); }
+    }
+    s.putn(d + lastRLE, gap);
+    lastRLE = i;
+    return true;
+  };
+
+  int32_t count = 0;
+  int64_t i = 0;
+  const int64_t end = (int64_t)n - 16;
+
+  for (; i < end; i++)                                                  // compress_single_sse2 (:1058-1120)
+  {
+    const Cmp16 c(d + i, bs);
+    if (c.all()) { count += 16; i += 15; continue; }
+    if (c.any() || count > 1)
+    {
+      const uint32_t z = c.leading();
+      count += (int32_t)z;
+      i += z;
+      process(count, (uint32_t)i);
+    }
+    count = 0;
+    while (i < end)
+    {
+      const Cmp16 w(d + i, bs);
+      if (!w.any() || (!w.lastByte() && w.pop() < 2u))
+        i += 16;
+      else
+      {
+        i += w.first();
+        count = 1;
+        break;
+      }
+    }
+  }
+
+  for (; i < (int64_t)n; i++)                                           // scalar tail (:452-466)
+  {
+    if (d[i] == sym)
+      count++;
+    else
+    {
+      process(count, (uint32_t)i);
+      count = 0;
+    }
+  }
+
+  if (process(count, (uint32_t)i))
+  {
+    s.put8(TR::SCINV << TR::SRBP); s.put8(TR::STB); s.put8(1); s.put16(0); s.put16(0);
+  }
+  else
+  {
+    const uint32_t kLit = n - lastRLE;
+    s.put8(TR::SCINV << TR::SRBP); s.put8(TR::STB); s.put8(0); s.put16(0); s.put32(kLit + 2u);
+    s.putn(d + lastRLE, kLit);
+  }
+  s.patch32(4, s.at);
+  sizes[b] = s.at;
+}
+
 } // namespace hsrle

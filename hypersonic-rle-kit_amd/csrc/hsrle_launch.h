@@ -34,7 +34,8 @@ struct EncodeArgs
 typedef hipError_t (*DecodeLaunch)(const DecodeArgs &, hipStream_t);
 typedef hipError_t (*EncodeLaunch)(const EncodeArgs &, hipStream_t);
 
-constexpr int kCodecCount = 109;                 // 50 extreme codecs + 44 of the Short family + 15 Greedy encoders (8f-1)
+constexpr int kSingleShort = 109;                 // rle8_single_short
+constexpr int kCodecCount = 110;                 // 50 extreme codecs + 44 of the Short family + 15 Greedy encoders (8f-1)
 constexpr int kGreedyBase = 94;                   // + 3 * index(W in 16,24,32,48,64) + {0 1symlut, 1 3symlut, 2 7symlut}: rle{W}_{K}symlut_byte_short_compress_greedy
 constexpr int kShortBase8 = 50;                   // rle8_multi_short, rle8_{1,3,7}symlut_short
 constexpr int kShortBaseW = 54;                   // + 8 * index(W in 16,24,32,48,64) + {0 sym, 1 1symlut_sym, 2 3symlut_sym, 3 7symlut_sym, 4 byte, 5 1symlut_byte, 6 3symlut_byte, 7 7symlut_byte}

@@ -4,6 +4,7 @@
 #include "hsrle_decode.hip.h"
 #include "hsrle_encode.hip.h"
 #include "hsrle_encode8.hip.h"
+#include "hsrle_encode_greedy.hip.h"
 #include "hsrle_launch.h"
 
 namespace hsrle {
@@ -21,6 +22,9 @@ static hipError_t enc_short0(const EncodeArgs &a, hipStream_t st) { return launc
 static hipError_t enc_short1(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode8_blocks<SHORT1>, a, st, 0); }
 static hipError_t enc_short3(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode8_blocks<SHORT3>, a, st, 0); }
 static hipError_t enc_short7(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode8_blocks<SHORT7>, a, st, 0); }
+
+static hipError_t dec_short_single(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<SHORT_SINGLE, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
+static hipError_t enc_short_single(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_single_short_blocks<SHORT_SINGLE>, a, st); }
 
 static hipError_t enc_plain(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode8_blocks<PLAIN>, a, st, 0); }
 static hipError_t enc_packed(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode8_blocks<PACKED>, a, st, 0); }
@@ -42,6 +46,7 @@ void register_w8(DecodeLaunch *dec, EncodeLaunch *enc)
   dec[kShortBase8 + 1] = dec_short1; enc[kShortBase8 + 1] = enc_short1;
   dec[kShortBase8 + 2] = dec_short3; enc[kShortBase8 + 2] = enc_short3;
   dec[kShortBase8 + 3] = dec_short7; enc[kShortBase8 + 3] = enc_short7;
+  dec[kSingleShort] = dec_short_single; enc[kSingleShort] = enc_short_single;   // rle8_single_short (src/rle.h:223-224)
 }
 
 } // namespace hsrle

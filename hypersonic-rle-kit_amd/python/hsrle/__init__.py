@@ -112,7 +112,7 @@ def lib():
     return _lib()
 
 
-CODEC_COUNT = 109  # 50 extreme codecs + 44 of the Short family + 15 Greedy encoders (include/hsrle.h)
+CODEC_COUNT = 110  # 50 extreme codecs + 44 Short + 15 Greedy encoders + rle8_single_short (include/hsrle.h)
 
 
 def codec_names():

@@ -78,7 +78,9 @@ typedef enum hsrle_codec
   HSRLE_RLE16_1SYMLUT_BYTE_SHORT_GREEDY = 94, HSRLE_RLE24_1SYMLUT_BYTE_SHORT_GREEDY = 97, HSRLE_RLE32_1SYMLUT_BYTE_SHORT_GREEDY = 100,
   HSRLE_RLE48_1SYMLUT_BYTE_SHORT_GREEDY = 103, HSRLE_RLE64_1SYMLUT_BYTE_SHORT_GREEDY = 106,
 
-  HSRLE_CODEC_COUNT = 109
+  HSRLE_RLE8_SINGLE_SHORT = 109, /* rle8_single_short_*    rle.h:223-224 */
+
+  HSRLE_CODEC_COUNT = 110
 } hsrle_codec_t;
 
 typedef enum hsrle_status
@@ -137,6 +139,7 @@ HSRLE_DECL_PAIR(rle128_byte_packed)
   HSRLE_DECL_PAIR(rle##W##_sym_short) HSRLE_DECL_PAIR(rle##W##_byte_short) HSRLE_DECL_PAIR(rle##W##_1symlut_sym_short) HSRLE_DECL_PAIR(rle##W##_1symlut_byte_short) \
   HSRLE_DECL_PAIR(rle##W##_3symlut_sym_short) HSRLE_DECL_PAIR(rle##W##_3symlut_byte_short) HSRLE_DECL_PAIR(rle##W##_7symlut_sym_short) HSRLE_DECL_PAIR(rle##W##_7symlut_byte_short)
 HSRLE_DECL_PAIR(rle8_multi_short)
+HSRLE_DECL_PAIR(rle8_single_short)
 HSRLE_DECL_PAIR(rle8_1symlut_short)
 HSRLE_DECL_PAIR(rle8_3symlut_short)
 HSRLE_DECL_PAIR(rle8_7symlut_short)

@@ -592,6 +592,7 @@ typedef struct {
   sink_t s;
   short_params_t q;
   int S, K, al;
+  int single;            /* rle8_single_short: one symbol for the whole stream, none in the packets */
   uint8_t lut[7][16];
   uint32_t lastRLE;
   const uint8_t *d;
@@ -605,6 +606,7 @@ static void short_init(short_state_t *st, const uint8_t *d, uint32_t n, int S, i
   put32(&st->s, 0);
   short_params(&st->q, S, K);
   st->S = S; st->K = K; st->al = (S == 1) ? 0 : aligned;
+  st->single = 0;
   for (int k = 0; k < K; k++)
     memset(st->lut[k], init[k], 16);
   st->lastRLE = 0;
@@ -665,7 +667,7 @@ static int short_process(short_state_t *st, const uint8_t *sym, int64_t count, u
     if ((int64_t)rx != range) { if (range <= 0xFFFF) put16(s, (uint32_t)range); else put32(s, (uint32_t)range); }
   }
 
-  if (K == 0 || m == K)
+  if (!st->single && (K == 0 || m == K))
     putn(s, sym, (size_t)S);
 
   const uint32_t p = (uint32_t)((int64_t)i - count);
@@ -682,13 +684,13 @@ static uint32_t short_finish(short_state_t *st, uint32_t n, int lastStored, uint
   if (lastStored)
   {
     put8(s, q->CINV << q->RBP); put8(s, q->TB); put8(s, 1); put16(s, 0); put16(s, 0);
-    if (st->K == 0) put8(s, 0);                   /* one byte, whatever the symbol width (:497-500, multibyte :370-373) */
+    if (st->K == 0 && !st->single) put8(s, 0);    /* one byte, whatever the symbol width (:497-500, multibyte :370-373) */
   }
   else
   {
     const uint32_t k = n - st->lastRLE;
     put8(s, q->CINV << q->RBP); put8(s, q->TB); put8(s, 0); put16(s, 0); put32(s, k + 2);
-    if (st->K == 0) putzeros(s, (size_t)st->S);   /* a whole zero symbol here (:517-520, multibyte :398-401) */
+    if (st->K == 0 && !st->single) putzeros(s, (size_t)st->S);   /* a whole zero symbol here (:517-520, multibyte :398-401) */
     putn(s, st->d + st->lastRLE, k);
   }
 
@@ -1193,8 +1195,79 @@ static int dec_lut(src_t *s, dst_t *o, int S, int aligned, int K)
   return !(s->bad || o->bad);
 }
 
+/* rle8_single_short (rleX_Xsl_short.h with SINGLE: wrapper :380-523, body compress_single_sse2 :1058-1120), restated step   */
+/* for step: the body's skip loop passes over 16-byte windows with fewer than two occurrences of the symbol (unless the last   */
+/* byte is one), and the position it stops at when the windows run out is never examined (the for loop's own i++).            */
+static uint32_t enc_single_short(const uint8_t *d, uint32_t n, uint8_t *out)
+{
+  short_state_t st;
+  short_init(&st, d, n, 1, 0, 0, out);
+  st.single = 1;
+  st.q.MINS = 2; st.q.MINL = 3 + 4 + 4;            /* :2-7 */
+  const uint8_t symbol = single_pick_symbol(d, n);
+  put8(&st.s, symbol);
+
+  int64_t count = 0;
+  int64_t i = 0;
+  const int64_t end = (int64_t)n - 16;
+
+  for (; i < end; i++)
+  {
+    uint32_t mask = 0;
+    for (int k = 0; k < 16; k++) mask |= (uint32_t)(d[i + k] == symbol) << k;
+
+    if (mask == 0xFFFF)
+    {
+      count += 16;
+      i += 15;
+      continue;
+    }
+
+    if (mask != 0 || count > 1)
+    {
+      uint32_t z = 0;
+      while ((mask >> z) & 1) z++;
+      count += z;
+      i += z;
+      short_process(&st, &symbol, count, (uint32_t)i);
+    }
+
+    count = 0;
+
+    while (i < end)
+    {
+      uint32_t cmp = 0, pop = 0;
+      for (int k = 0; k < 16; k++) if (d[i + k] == symbol) { cmp |= 1u << k; pop++; }
+
+      if (cmp == 0 || ((cmp & 0x8000) == 0 && pop < 2))
+        i += 16;
+      else
+      {
+        uint32_t z = 0;
+        while (!((cmp >> z) & 1)) z++;
+        i += z;
+        count = 1;
+        break;
+      }
+    }
+  }
+
+  for (; i < (int64_t)n; i++)
+  {
+    if (d[i] == symbol)
+      count++;
+    else
+    {
+      short_process(&st, &symbol, count, (uint32_t)i);
+      count = 0;
+    }
+  }
+
+  return short_finish(&st, n, short_process(&st, &symbol, count, (uint32_t)i), out);
+}
+
 /* Short family decoder: rleX_Xsl_short.h:1207-1480 (sse body; every ISA body decodes the same grammar) */
-static int dec_short(src_t *s, dst_t *o, int S, int aligned, int K)
+static int dec_short(src_t *s, dst_t *o, int S, int aligned, int K, int single)
 {
   short_params_t q;
   short_params(&q, S, K);
@@ -1203,6 +1276,7 @@ static int dec_short(src_t *s, dst_t *o, int S, int aligned, int K)
   uint8_t cur[16];
 
   memset(cur, 0, 16);                              /* K == 0: symbol starts as 0; K == 1: lut[0] = 0 */
+  if (single) { q.MINS = 2; cur[0] = (uint8_t)rd8(s); }   /* rle8_single_short: the symbol sits behind the stream header (:1211-1216) */
   memset(lut[0], 0, 16);
   for (int k = 1; k < K; k++)
     memset(lut[k], init[k], 16);
@@ -1252,7 +1326,7 @@ static int dec_short(src_t *s, dst_t *o, int S, int aligned, int K)
       }
       memcpy(cur, lut[0], 16);
     }
-    else
+    else if (!single)
     {
       memset(cur, 0, 16);
       rdn(s, cur, (size_t)S);
@@ -1279,7 +1353,7 @@ static int dec_short(src_t *s, dst_t *o, int S, int aligned, int K)
 /* ------------------------------------------------------------------------------------------ */
 /* public entry points                                                                        */
 
-static int hso_short_k(int family) { return family == HSO_SHORT0 ? 0 : ((family == HSO_SHORT1 || family == HSO_GREEDY1) ? 1 : ((family == HSO_SHORT3 || family == HSO_GREEDY3) ? 3 : 7)); }
+static int hso_short_k(int family) { return (family == HSO_SHORT0 || family == HSO_SINGLE_SHORT) ? 0 : ((family == HSO_SHORT1 || family == HSO_GREEDY1) ? 1 : ((family == HSO_SHORT3 || family == HSO_GREEDY3) ? 3 : 7)); }
 static int valid_S(int S) { return S == 1 || S == 2 || S == 3 || S == 4 || S == 6 || S == 8 || S == 16; }
 
 uint32_t hso_compress(int family, int S, int aligned, const uint8_t *pIn, uint32_t inSize, uint8_t *pOut, uint32_t outSize)
@@ -1315,6 +1389,10 @@ uint32_t hso_compress(int family, int S, int aligned, const uint8_t *pIn, uint32
     if (S == 16) return 0;
     return enc_short(pIn, inSize, S, aligned, hso_short_k(family), pOut);
 
+  case HSO_SINGLE_SHORT:
+    if (S != 1) return 0;
+    return enc_single_short(pIn, inSize, pOut);
+
   case HSO_GREEDY1:
   case HSO_GREEDY3:
   case HSO_GREEDY7:
@@ -1332,7 +1410,7 @@ uint32_t hso_decompress(int family, int S, int aligned, const uint8_t *pIn, uint
     return 0;
 
   const int lut = family == HSO_LUT3 || family == HSO_LUT7;
-  const int shortFam = family >= HSO_SHORT0 && family <= HSO_GREEDY7;   /* Greedy streams are Short streams */
+  const int shortFam = family >= HSO_SHORT0 && family <= HSO_SINGLE_SHORT;   /* Greedy streams are Short streams */
   const size_t headerSize = (S == 1 && !lut && !shortFam) ? 9 : 8;
 
   if (inSize < headerSize)
@@ -1355,7 +1433,7 @@ uint32_t hso_decompress(int family, int S, int aligned, const uint8_t *pIn, uint
   else if (shortFam)
   {
     if (S == 16) return 0;
-    ok = dec_short(&s, &o, S, aligned, hso_short_k(family));
+    ok = dec_short(&s, &o, S, aligned, hso_short_k(family), family == HSO_SINGLE_SHORT);
   }
   else
   {
@@ -1398,6 +1476,7 @@ int hso_resolve(const char *name, int *family, int *S, int *aligned, int *isDeco
     { "rle8_packed_multi_compress", HSO_PACKED, 0 }, { "rle8_packed_single_compress", HSO_PACKED_SINGLE, 0 }, { "rle8_packed_decompress", HSO_PACKED, 1 },
     { "rle8_3symlut_compress", HSO_LUT3, 0 }, { "rle8_3symlut_decompress", HSO_LUT3, 1 },
     { "rle8_7symlut_compress", HSO_LUT7, 0 }, { "rle8_7symlut_decompress", HSO_LUT7, 1 },
+    { "rle8_single_short_compress", HSO_SINGLE_SHORT, 0 }, { "rle8_single_short_decompress", HSO_SINGLE_SHORT, 1 },
     { "rle8_multi_short_compress", HSO_SHORT0, 0 }, { "rle8_multi_short_decompress", HSO_SHORT0, 1 },
     { "rle8_1symlut_short_compress", HSO_SHORT1, 0 }, { "rle8_1symlut_short_decompress", HSO_SHORT1, 1 },
     { "rle8_3symlut_short_compress", HSO_SHORT3, 0 }, { "rle8_3symlut_short_decompress", HSO_SHORT3, 1 },

@@ -36,7 +36,8 @@ enum {
   HSO_SHORT7 = 9,        /* rle8_7symlut_short / rle{W}_7symlut_{sym,byte}_short      */
   /* Greedy encoders (src/rle.h:398-416): rle{W}_{1,3,7}symlut_byte_short_compress_greedy; their streams are Short streams and
    * decode with rle{W}_{1,3,7}symlut_byte_short_decompress (src/codec_funcs.h:298-388); symAligned must be 0, W in 16..64 */
-  HSO_GREEDY1 = 10, HSO_GREEDY3 = 11, HSO_GREEDY7 = 12
+  HSO_GREEDY1 = 10, HSO_GREEDY3 = 11, HSO_GREEDY7 = 12,
+  HSO_SINGLE_SHORT = 13  /* rle8_single_short (8 bit only; src/rle.h:223-224) */
 };
 
 /* reference: rle_compress_bounds, src/rle8_extreme_cpu.c:22-28 */

@@ -19,7 +19,7 @@ ORACLE_DIR = os.path.join(REPO, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "libhsrle_oracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libhsrle_ref.so")
 
-PLAIN, PACKED, LUT3, LUT7, SINGLE, PACKED_SINGLE, SHORT0, SHORT1, SHORT3, SHORT7, GREEDY1, GREEDY3, GREEDY7 = range(13)
+PLAIN, PACKED, LUT3, LUT7, SINGLE, PACKED_SINGLE, SHORT0, SHORT1, SHORT3, SHORT7, GREEDY1, GREEDY3, GREEDY7, SINGLE_SHORT = range(14)
 FAMILY_NAMES = {PLAIN: "plain", PACKED: "packed", LUT3: "3symlut", LUT7: "7symlut", SINGLE: "single", PACKED_SINGLE: "packed_single",
                 SHORT0: "short", SHORT1: "1symlut_short", SHORT3: "3symlut_short", SHORT7: "7symlut_short"}
 
@@ -69,6 +69,7 @@ EXTREME_CODECS = CODECS[:50]     # the north-star matrix
 SHORT_CODECS = CODECS[50:]
 assert len(CODECS) == 94
 CODECS = CODECS + GREEDY_CODECS  # library codec ids 94..108 in this order
+CODECS.append(Codec("rle8_single_short", SINGLE_SHORT, 1, 0, "rle8_single_short_compress", "rle8_single_short_decompress"))   # id 109
 CODEC_BY_KEY = {c.key: c for c in CODECS}
 
 

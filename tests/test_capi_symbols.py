@@ -17,7 +17,7 @@ def declared_symbols():
     pairs = ["rle8_3symlut", "rle8_7symlut", "rle128_sym", "rle128_sym_packed", "rle128_byte", "rle128_byte_packed"]
     for W in (16, 24, 32, 48, 64):
         pairs += [f"rle{W}_{v}" for v in ("sym", "sym_packed", "byte", "byte_packed", "3symlut_sym", "7symlut_sym", "3symlut_byte", "7symlut_byte")]
-    pairs += ["rle8_multi_short", "rle8_1symlut_short", "rle8_3symlut_short", "rle8_7symlut_short"]
+    pairs += ["rle8_multi_short", "rle8_single_short", "rle8_1symlut_short", "rle8_3symlut_short", "rle8_7symlut_short"]
     for W in (16, 24, 32, 48, 64):
         pairs += [f"rle{W}_{v}_short" for v in ("sym", "byte", "1symlut_sym", "1symlut_byte", "3symlut_sym", "3symlut_byte", "7symlut_sym", "7symlut_byte")]
     for W in (16, 24, 32, 48, 64):
@@ -63,7 +63,7 @@ def test_pure_host_helpers(lib):
     assert lib.rle_decompress_additional_size() == 128
     lib.hsrle_codec_from_name.restype = ctypes.c_int
     lib.hsrle_codec_name.restype = ctypes.c_char_p
-    for i in range(109):
+    for i in range(110):
         name = lib.hsrle_codec_name(i)
         assert lib.hsrle_codec_from_name(name) == i
     assert lib.hsrle_codec_from_name(b"rle8_packed_multi") == 1 and lib.hsrle_codec_from_name(b"rle64_3symlut_byte") == 44
@@ -78,4 +78,4 @@ def test_codec_table_matches_tests_table(lib):
     from hsrle_testlib import CODECS
 
     lib.hsrle_codec_name.restype = ctypes.c_char_p
-    assert [lib.hsrle_codec_name(i).decode() for i in range(109)] == [c.key for c in CODECS]
+    assert [lib.hsrle_codec_name(i).decode() for i in range(110)] == [c.key for c in CODECS]

@@ -219,7 +219,7 @@ def test_native_cli_over_the_c_abi():
         pytest.skip("hsrlekit_gpu not built (make -C hypersonic-rle-kit_amd tools)")
     r = subprocess.run([exe, "--synth", "runs", "8", "--runs", "2", "--block", "1024"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert r.stdout.count("GiB/s") >= 4 * 109 and "all codecs round-tripped" in r.stdout
+    assert r.stdout.count("GiB/s") >= 4 * 110 and "all codecs round-tripped" in r.stdout
     r = subprocess.run([exe, "--synth", "video", "1", "--runs", "1", "--codec", "rle8_packed_multi", "--host"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "drop-in" in r.stdout and "FAILED" not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
@@ -250,8 +250,7 @@ def test_reference_cli_runs_on_the_gpu_library(tmp_path):
     out = r.stdout.replace("\r", "\n")
     assert r.returncode == 0, out[-3000:] + r.stderr[-2000:]
     assert "FAILED" not in out and "8 Bit Packed" in out and "128 Bit Packed (Byte)" in out and "64 Bit 3LUT (Byte)" in out
-    # the Short rows: 88 more drop-in functions on the GPU; the Greedy rows pair the reference's CPU encoder with the
-    # GPU decoder of the same grammar (src/codec_funcs.h:298-388), `8 Bit Single Short` stays on the CPU
+    # the Short rows: 105 more drop-in functions on the GPU (44 Short pairs, rle8_single_short, 15 Greedy encoders)
     r = subprocess.run([exe, str(sample), "--extreme", "--short", "--runs", "1", "--min-time", "0", "--test"], capture_output=True, text=True, timeout=900)
     out = r.stdout.replace("\r", "\n")
     assert r.returncode == 0, out[-3000:] + r.stderr[-2000:]
