@@ -124,6 +124,40 @@ def test_malformed_block_reports_error(hs):
         hs.decompress(bad2)
 
 
+GARBAGE_KEYS = ["rle8_multi", "rle8_packed_multi", "rle8_3symlut", "rle8_7symlut", "rle16_sym", "rle24_byte_packed", "rle48_3symlut_sym", "rle64_7symlut_byte",
+                "rle128_sym_packed", "rle8_multi_short", "rle8_1symlut_short", "rle8_7symlut_short", "rle8_single_short", "rle16_sym_short",
+                "rle32_1symlut_byte_short", "rle48_3symlut_byte_short", "rle64_7symlut_sym_short"]
+
+
+@pytest.mark.parametrize("key", GARBAGE_KEYS)
+def test_garbage_streams_end_as_errors_not_hangs(hs, key):
+    """Streams are data: block streams whose packets are random bytes (stream headers and offset table intact) must end -- as an
+    error bit or as some output -- without a hang and without a byte written outside [0, uncompressedSize)."""
+    import torch
+
+    rng = random.Random(hash(key) & 0xFFFF)
+    data = mixed_runs(rng, 300000)
+    block = 1024
+    container, info = hs.compress(key, _to_dev(data), block_size=block)
+    host = bytearray(container.cpu().numpy().tobytes())
+    p0 = info.payload_start
+    table = struct.unpack_from(f"<{info.blockCount + 1}Q", host, 64)
+    for i in range(info.blockCount):
+        a, b = p0 + table[i], p0 + table[i + 1]
+        mode = rng.randrange(3)
+        for j in range(a + 10, b):                                      # keep the 8/9/10-byte stream header
+            if mode == 0 or (mode == 1 and rng.random() < 0.1) or (mode == 2 and j > (a + b) // 2):
+                host[j] = rng.randrange(256)
+    bad = torch.frombuffer(host, dtype=torch.uint8).cuda()
+    guard = 4096
+    out = torch.full((len(data) + guard,), 0xA5, dtype=torch.uint8, device="cuda")
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    hs.decompress_async(bad, info, out[: len(data)], status)
+    torch.cuda.synchronize()
+    assert bool((out[len(data):] == 0xA5).all()), "wrote beyond the output"
+    assert int(status.item()) != 0                                       # some block must have noticed (most of 293 do)
+
+
 def test_partial_block_range(hs):
     import torch
 
