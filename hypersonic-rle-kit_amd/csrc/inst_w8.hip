@@ -24,7 +24,7 @@ static hipError_t enc_short3(const EncodeArgs &a, hipStream_t st) { return launc
 static hipError_t enc_short7(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode8_blocks<SHORT7>, a, st, 0); }
 
 static hipError_t dec_short_single(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<SHORT_SINGLE, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
-static hipError_t enc_short_single(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_single_short_blocks<SHORT_SINGLE>, a, st); }
+static hipError_t enc_short_single(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_single_short_blocks<SHORT_SINGLE>, a, st, 0); }
 
 static hipError_t enc_plain(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode8_blocks<PLAIN>, a, st, 0); }
 static hipError_t enc_packed(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode8_blocks<PACKED>, a, st, 0); }
