@@ -7,6 +7,7 @@
 
 #include "hsrle_common.hip.h"
 #include "hsrle_launch.h"
+#include "hsrle_rle8m.hip.h"
 
 #include <mutex>
 #include <string.h>
@@ -564,6 +565,48 @@ static uint32_t mono_decompress(int codec, const uint8_t *pIn, uint32_t inSize, 
   return U;
 }
 
+// ---- rle8m: the reference's GPU decode path, rle8m_opencl_decompress (src/rle8_ocl.c:265-413) ----
+
+static int rle8m_decode_async(const void *dStream, uint64_t streamSize, uint32_t uncompressedSize, uint32_t sections, void *dOut, uint64_t outCapacity,
+                              uint32_t *dStatus, hipStream_t st)
+{
+  // the caller has checked device_ok() (it takes g_dev.mu, which the host-pointer path holds while it calls this)
+  if (!dStream || !dOut || streamSize < 12 || sections == 0 || uncompressedSize == 0 || outCapacity < uncompressedSize)
+    return HSRLE_ERR_ARGUMENT;
+  if (dStatus && hipMemsetAsync(dStatus, 0, 4, st) != hipSuccess)
+    return HSRLE_ERR_DEVICE;
+  hipLaunchKernelGGL(k_rle8m_decode, dim3((sections + 63u) / 64u), dim3(64), 0, st, (const uint8_t *)dStream, streamSize, (uint8_t *)dOut, dStatus);
+  return hipGetLastError() == hipSuccess ? HSRLE_OK : HSRLE_ERR_DEVICE;
+}
+
+static uint32_t rle8m_mono_decompress(const uint8_t *pIn, uint32_t inSize, uint8_t *pOut, uint32_t outSize)
+{
+  // argument + header checks of the reference (rle8_ocl.c:267-283, rle8_low_entropy_cpu.c:195-211)
+  if (pIn == nullptr || pOut == nullptr || inSize < 12 || outSize == 0)
+    return 0;
+  uint32_t expIn, expOut, sections;
+  memcpy(&expIn, pIn, 4); memcpy(&expOut, pIn + 4, 4); memcpy(&sections, pIn + 8, 4);
+  if (expOut > outSize || expIn > inSize || sections == 0 || expOut == 0 || !device_ok())
+    return 0;
+
+  std::lock_guard<std::mutex> lock(g_dev.mu);
+  if (!grow(&g_dev.monoIn, &g_dev.monoInSize, (uint64_t)expIn + 64) || !grow(&g_dev.monoOut, &g_dev.monoOutSize, (uint64_t)expOut + 64))
+    return 0;
+  if (!g_dev.monoAux && hipMalloc(&g_dev.monoAux, 256) != hipSuccess)
+    return 0;
+  uint32_t *dStatus = (uint32_t *)((uint8_t *)g_dev.monoAux + 64);
+  if (hipMemcpy(g_dev.monoIn, pIn, expIn, hipMemcpyHostToDevice) != hipSuccess)
+    return 0;
+  if (rle8m_decode_async(g_dev.monoIn, expIn, expOut, sections, g_dev.monoOut, expOut, dStatus, nullptr) != HSRLE_OK)
+    return 0;
+  uint32_t status = 1;
+  if (hipMemcpy(&status, dStatus, 4, hipMemcpyDeviceToHost) != hipSuccess || status != 0)
+    return 0;
+  if (hipMemcpy(pOut, g_dev.monoOut, expOut, hipMemcpyDeviceToHost) != hipSuccess)
+    return 0;
+  return expOut;
+}
+
 } // namespace hsrle
 
 // ====================================================================================================================
@@ -619,6 +662,35 @@ int hsrle_device_count(void)
 {
   int n = 0;
   return (hipGetDeviceCount(&n) == hipSuccess) ? n : 0;
+}
+
+// ---- rle8m: names of the reference's GPU decode path (src/rle.h:464-466) and of its CPU twin (src/rle.h:63) ----
+bool rle8m_opencl_init(const size_t inputDataSize, const size_t outputDataSize, const size_t maxSubsectionCount)
+{
+  (void)inputDataSize; (void)outputDataSize; (void)maxSubsectionCount;    // device buffers are (re)sized by the call that needs them
+  return device_ok();
+}
+void rle8m_opencl_destroy(void) {}
+uint32_t rle8m_opencl_decompress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize) { return rle8m_mono_decompress(pIn, inSize, pOut, outSize); }
+uint32_t rle8m_decompress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize) { return rle8m_mono_decompress(pIn, inSize, pOut, outSize); }
+
+int hsrle_rle8m_info_dev(const void *dStream, uint64_t streamSize, hsrle_rle8m_info_t *pInfo, void *stream)
+{
+  if (!dStream || !pInfo || streamSize < 12) return HSRLE_ERR_ARGUMENT;
+  if (!device_ok()) return HSRLE_ERR_DEVICE;
+  uint32_t h[3];
+  if (hipMemcpyAsync(h, dStream, 12, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess || hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+    return HSRLE_ERR_DEVICE;
+  if (h[0] > streamSize || h[2] == 0 || h[0] < 12ull + 4ull * (h[2] - 1) + 33ull) return HSRLE_ERR_FORMAT;
+  pInfo->compressedSize = h[0]; pInfo->uncompressedSize = h[1]; pInfo->sections = h[2];
+  return HSRLE_OK;
+}
+
+int hsrle_rle8m_decompress_dev_async(const void *dStream, const hsrle_rle8m_info_t *info, void *dOut, uint64_t outCapacity, uint32_t *dStatus, void *stream)
+{
+  if (!info) return HSRLE_ERR_ARGUMENT;
+  if (!device_ok()) return HSRLE_ERR_DEVICE;
+  return rle8m_decode_async(dStream, info->compressedSize, info->uncompressedSize, info->sections, dOut, outCapacity, dStatus, (hipStream_t)stream);
 }
 
 uint32_t rle_compress_bounds(const uint32_t inSize) { return bounds32(inSize); }

@@ -296,3 +296,37 @@ def split_container(container_bytes):
     offs = struct.unpack_from(f"<{info.blockCount + 1}Q", b, HEADER_SIZE)
     p0 = info.payload_start
     return info, [b[p0 + offs[i] : p0 + offs[i + 1]] for i in range(info.blockCount)]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# rle8m: the reference's own GPU decode path (include/hsrle.h)
+
+
+class Rle8mInfo(ctypes.Structure):
+    _fields_ = [("compressedSize", ctypes.c_uint32), ("uncompressedSize", ctypes.c_uint32), ("sections", ctypes.c_uint32)]
+
+
+def rle8m_info(stream_tensor):
+    """Header fields of a device-resident rle8m stream (synchronises)."""
+    _check_u8_cuda(stream_tensor, "stream")
+    info = Rle8mInfo()
+    L = _lib()
+    L.hsrle_rle8m_info_dev.restype = ctypes.c_int
+    L.hsrle_rle8m_info_dev.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
+    rc = L.hsrle_rle8m_info_dev(ctypes.c_void_p(stream_tensor.data_ptr()), stream_tensor.numel(), ctypes.byref(info), _stream_ptr())
+    if rc != 0:
+        raise HsrleError(rc, "hsrle_rle8m_info_dev")
+    return info
+
+
+def rle8m_decompress_async(stream_tensor, info, dst, status=None, stream=None):
+    """Enqueue the decode of a device-resident rle8m stream into `dst` (uint8 CUDA tensor); `status` optional int32 tensor."""
+    _check_u8_cuda(stream_tensor, "stream")
+    _check_u8_cuda(dst, "dst")
+    L = _lib()
+    L.hsrle_rle8m_decompress_dev_async.restype = ctypes.c_int
+    L.hsrle_rle8m_decompress_dev_async.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
+    sp = ctypes.c_void_p(status.data_ptr()) if status is not None else None
+    rc = L.hsrle_rle8m_decompress_dev_async(ctypes.c_void_p(stream_tensor.data_ptr()), ctypes.byref(info), ctypes.c_void_p(dst.data_ptr()), dst.numel(), sp, _stream_ptr(stream))
+    if rc != 0:
+        raise HsrleError(rc, "hsrle_rle8m_decompress_dev_async")

@@ -26,6 +26,7 @@
 #ifndef HSRLE_H
 #define HSRLE_H
 
+#include <stdbool.h>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -266,6 +267,21 @@ int hsrle_device_count(void);
 /* Workgroups (= wavefronts: every kernel here runs one wave per workgroup) of the codec's decode (decode != 0) or encode kernel
  * that are resident on one CU at a time, as the HIP runtime computes it from the kernel's LDS and register use; 0 on error.
  * The kernels are latency bound, so this is the first number to look at when a build got slower. */
+/* ---------------------------------------------------------------------------------------------------------- */
+/* rle8m: the reference's own GPU decode path.  `rle8m_opencl_*` are the names of      */
+/* src/rle.h:464-466 (src/rle8_ocl.c:56, :185, :265); `rle8m_decompress` is the CPU twin of the same format   */
+/* (src/rle.h:63, src/rle8_low_entropy_cpu.c:193-250).  Host pointers; one lane decodes one sub-section.      */
+/* Streams come from the reference's rle8m_compress (CPU; not replaced).                                      */
+bool rle8m_opencl_init(const size_t inputDataSize, const size_t outputDataSize, const size_t maxSubsectionCount);
+void rle8m_opencl_destroy(void);
+uint32_t rle8m_opencl_decompress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize);
+uint32_t rle8m_decompress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize);
+
+/* device-resident form: the stream header is read once (synchronises), the decode only enqueues a kernel */
+typedef struct hsrle_rle8m_info { uint32_t compressedSize, uncompressedSize, sections; } hsrle_rle8m_info_t;
+int hsrle_rle8m_info_dev(const void *dStream, uint64_t streamSize, hsrle_rle8m_info_t *pInfo, void *stream);
+int hsrle_rle8m_decompress_dev_async(const void *dStream, const hsrle_rle8m_info_t *info, void *dOut, uint64_t outCapacity, uint32_t *dStatus, void *stream);
+
 int hsrle_kernel_waves_per_cu(int codec, int decode);
 const char *hsrle_version(void);
 

@@ -1351,6 +1351,213 @@ static int dec_short(src_t *s, dst_t *o, int S, int aligned, int K, int single)
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* rle8m: the low-entropy codec in its sub-sectioned form, the format of the reference's GPU    */
+/* (OpenCL) decoder.  src/rle8_low_entropy_cpu.c:                        */
+/*   compress info  :254-338   (run statistics over the whole input, symbols by run count)     */
+/*   info bytes     :441-472 / :545-606                                                         */
+/*   section stream :474-543   (symbol, and behind a flagged symbol the code of how many more   */
+/*                              of it follow, at most 254)                                      */
+/*   container      :126-250   (u32 size, u32 inSize, u32 sections, u32 end offsets, info, ...)  */
+/*   decoder        :930-1021, src/rle8_ocl_kernel.h:8-43 (every ISA variant decodes the same   */
+/*                              grammar)                                                        */
+
+uint32_t hso_rle8m_compress_bounds(uint32_t subSections, uint32_t inSize)
+{
+  return inSize + (256 / 8) + 1 + 256 + 4 * (2 + subSections - 1 + 1);
+}
+
+typedef struct { uint8_t rle[256]; uint8_t symbolsByProb[256]; uint8_t symbolCount; } le_info_t;
+
+static void le_get_info(const uint8_t *d, uint32_t n, le_info_t *info)
+{
+  uint32_t prob[256], pcount[256];
+  uint8_t consumed[256];
+  memset(prob, 0, sizeof(prob));
+  memset(pcount, 0, sizeof(pcount));
+  memset(consumed, 0, sizeof(consumed));
+
+  uint8_t last = 0;
+  uint32_t count = 0;
+
+  if (d[0] != last)
+    pcount[last] = 0xFFFFFFFFu;
+
+  for (uint32_t i = 0; i < n; i++)
+  {
+    if (d[i] == last)
+      count++;
+    else
+    {
+      prob[last] += count;
+      pcount[last] += (count / 255) + 1;
+      count = 1;
+      last = d[i];
+    }
+  }
+
+  prob[last] += count;
+  pcount[last]++;
+
+  for (int i = 0; i < 256; i++)
+    info->rle[i] = (pcount[i] > 0) ? ((prob[i] / pcount[i]) >= 2) : 0;
+
+  uint32_t remaining = 256;
+
+  for (int i = 255; i >= 0; i--)
+    if (pcount[i] == 0)
+    {
+      consumed[i] = 1;
+      remaining--;
+      info->symbolsByProb[remaining] = (uint8_t)i;
+    }
+
+  for (uint32_t index = 0; index < remaining; index++)
+  {
+    uint32_t max = 0;
+    int maxIndex = 0;
+
+    for (int i = 0; i < 256; i++)
+      if (!consumed[i] && pcount[i] > max) { max = pcount[i]; maxIndex = i; }
+
+    info->symbolsByProb[index] = (uint8_t)maxIndex;
+    consumed[maxIndex] = 1;
+  }
+
+  info->symbolCount = (uint8_t)remaining;
+}
+
+static uint32_t le_write_info(const le_info_t *info, uint8_t *out)
+{
+  uint32_t index = 0;
+
+  for (int i = 0; i < 32; i++)
+  {
+    uint8_t v = 0;
+    for (int j = 0; j < 8; j++) v |= (uint8_t)((info->rle[j + i * 8] ? 1 : 0) << j);
+    out[index++] = v;
+  }
+
+  out[index++] = info->symbolCount;
+  const uint32_t sc = info->symbolCount ? info->symbolCount : 255;   /* sic: 256 symbols are stored as 0 and written as 255 (:460-464) */
+  memcpy(out + index, info->symbolsByProb, sc);
+  return index + sc;
+}
+
+static uint32_t le_compress_section(const uint8_t *d, uint32_t n, const le_info_t *info, uint8_t *out)
+{
+  uint32_t index = 0;
+
+  for (uint32_t i = 0; i < n; i++)
+  {
+    const uint8_t b = d[i];
+    out[index++] = b;
+
+    if (info->rle[b])
+    {
+      /* :497-511 (range 255) and :521-535 (range min(n - i - 1, 255) in the last 256 bytes) */
+      const uint32_t left = n - i - 1, target = (n >= 256) ? n - 256 : 0;
+      const uint32_t range = (i < target) ? 255 : (left < 255 ? left : 255);
+      uint32_t count = 0, j = 1;
+
+      for (; j < range; j++)
+        if (d[i + j] == b) count++; else break;
+
+      i += j - 1;
+      out[index++] = info->symbolsByProb[count & 0xFF];
+    }
+  }
+
+  return index;
+}
+
+uint32_t hso_rle8m_compress(uint32_t subSections, const uint8_t *pIn, uint32_t inSize, uint8_t *pOut, uint32_t outSize)
+{
+  if (pIn == NULL || inSize == 0 || pOut == NULL || subSections == 0 || outSize < hso_rle8m_compress_bounds(subSections, inSize))
+    return 0;
+
+  le_info_t info;
+  le_get_info(pIn, inSize, &info);
+
+  uint32_t index = 4;
+  patch32(pOut, index, inSize); index += 4;
+  patch32(pOut, index, subSections); index += 4;
+  const uint32_t table = index;
+  index += 4 * (subSections - 1);
+  index += le_write_info(&info, pOut + index);
+
+  const uint32_t ss = inSize / subSections;
+
+  for (uint32_t i = 0; i + 1 < subSections; i++)
+  {
+    if (ss == 0 || outSize - index < ss) return 0;  /* compress_with_info fails on an empty section and when the room left is below the section size (:476) */
+    index += le_compress_section(pIn + ss * i, ss, &info, pOut + index);
+    patch32(pOut, table + 4 * i, index);
+  }
+
+  if (outSize - index < inSize - ss * (subSections - 1)) return 0;
+  index += le_compress_section(pIn + ss * (subSections - 1), inSize - ss * (subSections - 1), &info, pOut + index);
+  patch32(pOut, 0, index);
+  return index;
+}
+
+uint32_t hso_rle8m_decompress(const uint8_t *pIn, uint32_t inSize, uint8_t *pOut, uint32_t outSize)
+{
+  if (pIn == NULL || pOut == NULL || inSize < 12 || outSize == 0)
+    return 0;
+
+  const uint32_t expIn = get32(pIn), expOut = get32(pIn + 4), subSections = get32(pIn + 8);
+
+  if (expOut > outSize || expIn > inSize || subSections == 0)
+    return 0;
+
+  uint64_t index = 12 + 4ull * (subSections - 1);
+  if (index + 33 > expIn) return 0;
+
+  uint8_t rle[256], symbolToCount[256], listed[256];
+  for (int i = 0; i < 256; i++) rle[i] = (pIn[index + (i >> 3)] >> (i & 7)) & 1;
+  index += 32;
+  uint32_t sc = pIn[index++];
+  if (!sc) sc = 255;
+  if (index + sc > expIn) return 0;
+  memset(listed, 0, 256);
+  for (uint32_t i = 0; i < sc; i++) { symbolToCount[pIn[index + i]] = (uint8_t)i; listed[pIn[index + i]] = 1; }
+  index += sc;
+  uint32_t next = sc;
+  for (int i = 0; i < 256; i++) if (!listed[i]) symbolToCount[i] = (uint8_t)next++;
+
+  const uint32_t ss = expOut / subSections;
+  uint64_t o = 0;
+
+  for (uint32_t k = 0; k < subSections; k++)
+  {
+    const uint64_t end = (k + 1 < subSections) ? get32(pIn + 12 + 4 * k) : expIn;
+    const uint64_t want = (k + 1 < subSections) ? ss : expOut - (uint64_t)ss * (subSections - 1);
+    const uint64_t oEnd = o + want;
+    if (end > expIn || end < index) return 0;
+
+    while (index < end)
+    {
+      const uint8_t b = pIn[index++];
+      if (o >= oEnd) return 0;
+      pOut[o++] = b;
+
+      if (rle[b])
+      {
+        if (index >= end) return 0;
+        uint32_t count = symbolToCount[pIn[index++]];
+        if (o + count > oEnd) return 0;
+        memset(pOut + o, b, count);
+        o += count;
+      }
+    }
+
+    if (o != oEnd) return 0;
+  }
+
+  return expOut;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* public entry points                                                                        */
 
 static int hso_short_k(int family) { return (family == HSO_SHORT0 || family == HSO_SINGLE_SHORT) ? 0 : ((family == HSO_SHORT1 || family == HSO_GREEDY1) ? 1 : ((family == HSO_SHORT3 || family == HSO_GREEDY3) ? 3 : 7)); }

@@ -77,6 +77,12 @@ uint32_t hso_compress_blocks(int family, int symbolBytes, int symAligned,
 uint64_t hso_decompress_blocks(int family, int symbolBytes, int symAligned, const uint8_t *payload, const uint64_t *offsets,
                                uint64_t nBlocks, uint32_t blockSize, uint8_t *pOut, uint64_t outSize);
 
+/* rle8m: the sub-sectioned low-entropy codec, the format of the reference's GPU (OpenCL) decoder (SURVEY.md 8a row a14;
+ * reference: rle8m_compress_bounds / rle8m_compress / rle8m_decompress, src/rle8_low_entropy_cpu.c:126-250) */
+uint32_t hso_rle8m_compress_bounds(uint32_t subSections, uint32_t inSize);
+uint32_t hso_rle8m_compress(uint32_t subSections, const uint8_t *pIn, uint32_t inSize, uint8_t *pOut, uint32_t outSize);
+uint32_t hso_rle8m_decompress(const uint8_t *pIn, uint32_t inSize, uint8_t *pOut, uint32_t outSize);
+
 /* oracle/hsrle_synth.c: bytes [offset, offset + size) of a deterministic synthetic workload (offset multiple of 64 KiB) */
 int hso_synth(int kind, int symbolBytes, uint64_t seed, uint64_t offset, uint8_t *out, uint64_t size);
 

@@ -8,6 +8,7 @@ Outputs (data only -- inputs and expected outputs, no reference source):
                                       streams of the 79-byte worked example of SURVEY.md A.6
   tests/golden/rle8_packed_tails.json rle8_packed_multi streams of both encoder tail flavours (SSE2 body vs AVX2 body,
                                       SURVEY.md A.5 q1) for small inputs; the canonical one is AVX2
+  tests/golden/rle8m_vectors.json     {size, sha256} of the reference's rle8m stream of every vectors.json input for 1/2/3/7/16 sections
   tests/golden/synth_manifest.json    {size, sha256} of the reference stream of every 1 MiB synthetic buffer
                                       (run-distributed per symbol width, video-shaped), cut into 64 KiB blocks, and of
                                       the monolithic 1 MiB stream
@@ -108,6 +109,17 @@ def main():
                 "blocks": [{"size": len(b), "sha256": sha(b)} for b in blocks],
             }
     json.dump(man, open(os.path.join(HERE, "synth_manifest.json"), "w"), indent=0)
+
+    # rle8m: reference streams of the small inputs for a few section counts (None where rle8m_compress gives up)
+    r8 = []
+    for name, data in inputs():
+        for sections in (1, 2, 3, 7, 16):
+            if len(data) // sections == 0:
+                continue
+            st = ref.rle8m_compress(sections, data)
+            assert st is None or ref.rle8m_decompress(st, len(data)) == data
+            r8.append({"name": name, "sections": sections, "size": 0 if st is None else len(st), "sha256": None if st is None else sha(st)})
+    json.dump(r8, open(os.path.join(HERE, "rle8m_vectors.json"), "w"), indent=0)
     print("golden vectors written:", len(vec["inputs"]), "inputs x", len(CODECS), "codecs")
 
 

@@ -129,6 +129,24 @@ class Oracle:
         assert got == nb
         return [out[i * stride : i * stride + int(sizes[i])].tobytes() for i in range(nb)]
 
+    def rle8m_compress(self, sections, data):
+        """rle8m stream of `data` with `sections` sub-sections (reference: rle8m_compress), or None where the reference fails."""
+        L = self.lib
+        L.hso_rle8m_compress_bounds.restype = ctypes.c_uint32
+        L.hso_rle8m_compress.restype = ctypes.c_uint32
+        data = bytes(data)
+        cap = L.hso_rle8m_compress_bounds(ctypes.c_uint32(sections), ctypes.c_uint32(len(data)))
+        out = ctypes.create_string_buffer(cap + 64)
+        size = L.hso_rle8m_compress(ctypes.c_uint32(sections), data, ctypes.c_uint32(len(data)), out, ctypes.c_uint32(cap))
+        return out.raw[:size] if size else None
+
+    def rle8m_decompress(self, stream, out_size):
+        L = self.lib
+        L.hso_rle8m_decompress.restype = ctypes.c_uint32
+        out = ctypes.create_string_buffer(out_size + 64)
+        got = L.hso_rle8m_decompress(bytes(stream), ctypes.c_uint32(len(stream)), out, ctypes.c_uint32(out_size))
+        return out.raw[:out_size] if got == out_size else None
+
     def compress(self, codec, data):
         data = bytes(data)
         n = len(data)
@@ -184,6 +202,23 @@ class Reference:
 
     def set_max_simd(self, level):
         self.lib.hsrle_ref_set_max_simd(level)
+
+    def rle8m_compress(self, sections, data):
+        L = self.lib
+        L.rle8m_compress_bounds.restype = ctypes.c_uint32
+        L.rle8m_compress.restype = ctypes.c_uint32
+        data = bytes(data)
+        cap = L.rle8m_compress_bounds(ctypes.c_uint32(sections), ctypes.c_uint32(len(data)))
+        out = ctypes.create_string_buffer(cap + 64)
+        size = L.rle8m_compress(ctypes.c_uint32(sections), data, ctypes.c_uint32(len(data)), out, ctypes.c_uint32(cap))
+        return out.raw[:size] if size else None
+
+    def rle8m_decompress(self, stream, out_size):
+        L = self.lib
+        L.rle8m_decompress.restype = ctypes.c_uint32
+        out = ctypes.create_string_buffer(out_size + 256)
+        got = L.rle8m_decompress(bytes(stream), ctypes.c_uint32(len(stream)), out, ctypes.c_uint32(out_size))
+        return out.raw[:out_size] if got == out_size else None
 
     def _fn(self, name):
         f = getattr(self.lib, name)

@@ -50,7 +50,8 @@ def test_reference_names_present(lib):
     for s in ("rle_compress_bounds", "rle_decompress_additional_size", "rle8_multi_compress", "rle8_single_compress", "rle8_decompress",
               "rle8_packed_multi_compress", "rle8_packed_single_compress", "rle8_packed_decompress", "rle64_3symlut_byte_compress",
               "rle64_3symlut_byte_decompress", "rle24_sym_packed_compress", "rle128_byte_packed_decompress",
-              "rle8_multi_short_compress", "rle8_1symlut_short_decompress", "rle16_sym_short_compress", "rle48_7symlut_byte_short_decompress"):
+              "rle8_multi_short_compress", "rle8_1symlut_short_decompress", "rle16_sym_short_compress", "rle48_7symlut_byte_short_decompress",
+              "rle8m_opencl_init", "rle8m_opencl_destroy", "rle8m_opencl_decompress", "rle8m_decompress"):
         assert hasattr(lib, s)
 
 

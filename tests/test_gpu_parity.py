@@ -4,6 +4,7 @@ Bit-exact bar (integer / byte work): every block stream must equal the oracle's 
 test_oracle_vs_ref.py / test_oracle_golden.py) stream for that block, and every decode must reproduce the input exactly.
 """
 import os
+import ctypes
 import random
 import struct
 
@@ -156,6 +157,46 @@ def test_garbage_streams_end_as_errors_not_hangs(hs, key):
     torch.cuda.synchronize()
     assert bool((out[len(data):] == 0xA5).all()), "wrote beyond the output"
     assert int(status.item()) != 0                                       # some block must have noticed (most of 293 do)
+
+
+def test_rle8m_decode_matches_the_oracle(hs, oracle):
+    """rle8m (the reference's own GPU decode path): streams from the oracle's rle8m_compress decode on the GPU
+    through the drop-in names of rle.h (rle8m_opencl_decompress, rle8m_decompress) and through the device API."""
+    import torch
+
+    rng = random.Random(77)
+    lib = hs.lib()
+    lib.rle8m_opencl_init.restype = ctypes.c_bool
+    assert lib.rle8m_opencl_init(ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0))
+    cases = [(mixed_runs(rng, 200000, alphabet=3), 64), (mixed_runs(rng, 70001, alphabet=256), 7), (single_symbol_mix(rng, 9000), 1),
+             (bytes([5]) * 100000 + mixed_runs(rng, 3000), 16), (mixed_runs(rng, 333), 3), (bytes(range(256)) * 40 + b"\x00" * 5000, 33),
+             (mixed_runs(rng, 1 << 20, alphabet=4), 4096)]
+    n = 0
+    for data, sections in cases:
+        st = oracle.rle8m_compress(sections, data)
+        if st is None:
+            continue
+        n += 1
+        for name in ("rle8m_opencl_decompress", "rle8m_decompress"):
+            size, got = hs.call_dropin(name, st, len(data))
+            assert size == len(data) and got == data, f"{name}: {len(data)} bytes, {sections} sections"
+        dev = _to_dev(st)
+        info = hs.rle8m_info(dev)
+        assert (info.compressedSize, info.uncompressedSize, info.sections) == (len(st), len(data), sections)
+        out = torch.full((len(data) + 256,), 0xA5, dtype=torch.uint8, device="cuda")
+        status = torch.ones(1, dtype=torch.int32, device="cuda")
+        hs.rle8m_decompress_async(dev, info, out[: len(data)], status)
+        torch.cuda.synchronize()
+        assert int(status.item()) == 0 and out[: len(data)].cpu().numpy().tobytes() == data
+        assert bool((out[len(data):] == 0xA5).all())
+        # a damaged stream ends as an error, not as a wild write
+        bad = bytearray(st)
+        for j in range(len(st) // 2, len(st), 3):
+            bad[j] = rng.randrange(256)
+        size, _ = hs.call_dropin("rle8m_decompress", bytes(bad), len(data))
+        assert size in (0, len(data))
+    assert n >= 5
+    lib.rle8m_opencl_destroy()
 
 
 def test_partial_block_range(hs):

@@ -96,3 +96,18 @@ def test_error_returns(oracle):
         assert size == len(d) and out == d
     assert oracle.call("rle8_nonexistent_compress", d, 1000)[0] == 0xFFFFFFFF
     assert oracle.bounds(100) == 293 and oracle.bounds((1 << 30) + 1) == 0
+
+
+def test_rle8m_matches_golden(oracle, vectors):
+    """rle8m streams against the vectors minted from the compiled reference."""
+    inputs = {e["name"]: base64.b64decode(e["input"]) for e in vectors["inputs"]}
+    r8 = json.load(open(os.path.join(GOLDEN, "rle8m_vectors.json")))
+    assert len(r8) > 150
+    for g in r8:
+        data = inputs[g["name"]]
+        s = oracle.rle8m_compress(g["sections"], data)
+        if g["sha256"] is None:
+            assert s is None
+        else:
+            assert s is not None and len(s) == g["size"] and sha(s) == g["sha256"], f"rle8m x{g['sections']} on {g['name']}"
+            assert oracle.rle8m_decompress(s, len(data)) == data

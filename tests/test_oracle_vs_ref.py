@@ -43,3 +43,20 @@ def test_reference_decodes_oracle_streams(oracle, reference):
 def test_bounds_helpers(oracle, reference):
     for n in (0, 1, 100, 1 << 20, 1 << 30, (1 << 30) + 1):
         assert oracle.bounds(n) == reference.lib.rle_compress_bounds(n)
+
+
+def test_rle8m_streams_identical(oracle, reference):
+    """rle8m: the oracle's restatement against rle8m_compress / rle8m_decompress of the compiled reference,
+    including the inputs on which the reference gives up (a section that outgrows the room left in the output)."""
+    rng = random.Random(5)
+    n = 0
+    for d in _inputs(21, 400):
+        for sections in (1, 2, 3, rng.choice([4, 5, 7, 8, 16, 33])):
+            if len(d) // sections == 0:
+                continue
+            r, m = reference.rle8m_compress(sections, d), oracle.rle8m_compress(sections, d)
+            assert r == m, f"rle8m x{sections}: oracle stream differs from the reference (input {len(d)} bytes)"
+            if r is not None:
+                assert oracle.rle8m_decompress(r, len(d)) == d and reference.rle8m_decompress(m, len(d)) == d
+            n += 1
+    assert n > 1000
