@@ -140,7 +140,7 @@ __global__ __launch_bounds__(64) void k_encode_greedy_blocks(const uint8_t *__re
 
     for (;;)                                                           // label not_a_full_match_but_a_match (:861)
     {
-      process(y0, y1, count, i);
+      if (count >= TR::SMINS) process(y0, y1, count, i);   // a shorter "run" (0 bytes between two literal positions) is never stored and changes no state
       sym_at(i, y0, y1);
       const bool fits = i + SU <= n;
 
