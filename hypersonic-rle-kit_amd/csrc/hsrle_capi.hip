@@ -527,6 +527,8 @@ static uint32_t mono_decompress(int codec, const uint8_t *pIn, uint32_t inSize, 
     return 0;
   if (hs == 9 && pIn[8] > 1) // unknown mode (rle8_extreme_cpu.h:759-760)
     return 0;
+  if (hs == 9 && pIn[8] == 1 && (codec == HSRLE_RLE8_MULTI || codec == HSRLE_RLE8_PACKED_MULTI))
+    codec += 4;              // rle8_decompress / rle8_packed_decompress switch on the mode byte (rle8_extreme_cpu.h:702-764): Single mode -> the general kernel
   if (U == 0 || C < hs || !device_ok())
     return 0;
 

@@ -171,7 +171,11 @@ __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
 // exactly like rle8_decompress / rle8_packed_decompress do.
 //   T = output bytes per lane and flush (LDS tile row), Q = output bytes per lane and decode/top-up step (T % Q == 0),
 //   R = per-lane stream ring size in LDS (power of two).
-template <int FAM, int S, int AL, int T, int R, int Q = T>
+//   SGL = false compiles the Single mode out of the 8 bit PLAIN / PACKED kernels (-2 % kernel time: the mode selects fold away): the
+//   launchers use it for the codec ids whose encoders only write mode 0 (rle8_multi, rle8_packed_multi); a mode-1 block in such a
+//   container is reported as DEC_ERR_MODE.  The Single codec ids and the host-pointer drop-in functions (which look at the mode
+//   byte first, like rle8_decompress does) use the general kernel.
+template <int FAM, int S, int AL, int T, int R, int Q = T, bool SGL = true>
 __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict__ payload, const uint64_t *__restrict__ offsets,
                                                       const uint8_t *__restrict__ payloadEnd, uint8_t *__restrict__ out, uint64_t U,
                                                       uint32_t B, uint32_t firstBlock, uint32_t blockCount, uint32_t *__restrict__ status)
@@ -249,7 +253,8 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   u32x4 acc = u32x4{ 0, 0, 0, 0 }; // the 16-byte chunk of the tile row that contains the write position (its low (q & 15) bytes are valid)
   bool last = false;      // the stream ends after the current packet's literals
   bool done = true;
-  bool single = false;
+  [[maybe_unused]] bool singleVar = false;
+#define single (SGL && singleVar)
   uint32_t err = 0;
   [[maybe_unused]] uint32_t lut[TR::kMtf ? TR::K : 1][TR::SW];
 
@@ -396,7 +401,11 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     else if constexpr (S == 1 && !TR::kLut && !TR::kShort)
     {
       const uint32_t mode = hd[8];
-      if (mode == 1u) { single = true; set_sym(u32x4{ hd[9], 0, 0, 0 }); sp = g0 + 10; }
+      if (mode == 1u)
+      {
+        if constexpr (SGL) { singleVar = true; set_sym(u32x4{ hd[9], 0, 0, 0 }); sp = g0 + 10; }
+        else { err |= DEC_ERR_MODE; done = true; }
+      }
       else if (mode != 0u) { err |= DEC_ERR_MODE; done = true; }
     }
   }
@@ -1079,6 +1088,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 
   if (err != 0 && status != nullptr)
     atomicOr(status, err);
+#undef single
 }
 
 } // namespace hsrle

@@ -9,8 +9,12 @@
 
 namespace hsrle {
 
-static hipError_t dec_plain(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PLAIN, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
-static hipError_t dec_packed(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PACKED, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
+// ids 0 / 1 (rle8_multi, rle8_packed_multi): their encoders only write mode 0 -> the kernel without the Single mode (k_decode_blocks SGL);
+// ids 4 / 5 (the Single codecs) and any stream whose mode byte says 1 (hsrle_capi.hip: mono_decompress) -> the general kernel
+static hipError_t dec_plain(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PLAIN, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep, false>, a, st); }
+static hipError_t dec_packed(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PACKED, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep, false>, a, st); }
+static hipError_t dec_plain_any(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PLAIN, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep, true>, a, st); }
+static hipError_t dec_packed_any(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PACKED, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep, true>, a, st); }
 static hipError_t dec_lut3(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<LUT3, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
 static hipError_t dec_lut7(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<LUT7, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
 
@@ -39,8 +43,8 @@ void register_w8(DecodeLaunch *dec, EncodeLaunch *enc)
   dec[1] = dec_packed; enc[1] = enc_packed;
   dec[2] = dec_lut3;   enc[2] = enc_lut3;
   dec[3] = dec_lut7;   enc[3] = enc_lut7;
-  dec[4] = dec_plain;  enc[4] = enc_single;
-  dec[5] = dec_packed; enc[5] = enc_packed_single;
+  dec[4] = dec_plain_any;  enc[4] = enc_single;
+  dec[5] = dec_packed_any; enc[5] = enc_packed_single;
   // Short family (rle8_multi_short, rle8_{1,3,7}symlut_short; reference: src/rle.h:202-222)
   dec[kShortBase8 + 0] = dec_short0; enc[kShortBase8 + 0] = enc_short0;
   dec[kShortBase8 + 1] = dec_short1; enc[kShortBase8 + 1] = enc_short1;

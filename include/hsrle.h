@@ -39,6 +39,8 @@ extern "C" {
 
 typedef enum hsrle_codec
 {
+  /* ids 0 / 1 name the multi-symbol ENCODERS: the blocks of such a container are mode-0 streams (what those encoders write); a     */
+  /* Single-mode block in it is reported as a format error.  The drop-in rle8_decompress / rle8_packed_decompress take either mode. */
   HSRLE_RLE8_MULTI = 0,          /* rle8_multi_compress / rle8_decompress                     rle.h:101,103 */
   HSRLE_RLE8_PACKED_MULTI = 1,   /* rle8_packed_multi_compress / rle8_packed_decompress       rle.h:173,175 */
   HSRLE_RLE8_3SYMLUT = 2,        /* rle8_3symlut_*                                            rle.h:199-200 */

@@ -199,6 +199,23 @@ def test_rle8m_decode_matches_the_oracle(hs, oracle):
     lib.rle8m_opencl_destroy()
 
 
+def test_single_mode_block_in_a_multi_container_is_a_format_error(hs):
+    """Codec ids 0 / 1 name the multi-symbol encoders; their decode kernels are compiled without the Single mode (include/hsrle.h,
+    k_decode_blocks SGL).  A container that claims id 0 but carries mode-1 streams is reported, not mis-decoded; under its own
+    id (4) the same container decodes, and the drop-in rle8_decompress takes both modes like the reference's."""
+    import torch
+
+    rng = random.Random(3)
+    data = single_symbol_mix(rng, 60000)
+    container, info = hs.compress("rle8_single", _to_dev(data), block_size=1024)
+    assert hs.decompress(container).cpu().numpy().tobytes() == data
+    fake = container.clone()
+    assert int.from_bytes(fake[12:16].cpu().numpy().tobytes(), "little") == 4   # codec field of the container header
+    fake[12] = 0
+    with pytest.raises(hs.HsrleError):
+        hs.decompress(fake)
+
+
 def test_partial_block_range(hs):
     import torch
 
