@@ -35,6 +35,18 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
 
   __shared__ __attribute__((aligned(16))) uint8_t hist[64 * H];
   __shared__ __attribute__((aligned(16))) uint32_t rinfo[64];
+  // merge masks from a 16-entry table (as in k_decode_blocks / k_encode8_blocks)
+  __shared__ __attribute__((aligned(16))) uint8_t mlut[16 * 16];
+  if (threadIdx.x < 16u)
+  {
+    const uint32_t c = threadIdx.x;
+    const uint64_t part = ~(~0ull << (8u * (c & 7u)));
+    const bool hiHalf = c >= 8u;
+    const uint32_t p0 = (uint32_t)part, p1 = (uint32_t)(part >> 32);
+    lds_st128(mlut + c * 16u, u32x4{ hiHalf ? ~0u : p0, hiHalf ? ~0u : p1, hiHalf ? p0 : 0u, hiHalf ? p1 : 0u });
+  }
+  wave_sync();
+#define HS_SMERGE(keep, fresh, c) merge_low_m(keep, fresh, lds_ld128(mlut + ((c) << 4)))
 
   const uint32_t lane = threadIdx.x;
   const uint32_t wgFirst = xcd_tile(blockIdx.x, gridDim.x) * 64u;    // XCD-aware tile order (hsrle_common.hip.h)
@@ -88,7 +100,7 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
   auto append = [&](u32x4 hv, uint32_t nb) {
     const uint32_t c = opos & 15u;
     const u32x4 lowp = (c == 0u) ? hv : funnel16(zero4, hv, 16u - c);   // hv << c bytes
-    const u32x4 w = merge_low(oacc, lowp, c);
+    const u32x4 w = HS_SMERGE(oacc, lowp, c);
     if (c + nb >= 16u)
     {
       st128(slot + (opos & ~15u), w);
@@ -149,7 +161,7 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
     const uint32_t c = opos & 15u, total = c + len;
     const uint32_t srcp = at - c;
     uint8_t *const dst = slot + (opos & ~15u);
-    u32x4 w = merge_low(oacc, viaRing ? ring_win(srcp) : glob_win(srcp), c);
+    u32x4 w = HS_SMERGE(oacc, viaRing ? ring_win(srcp) : glob_win(srcp), c);
     uint32_t k = 0;
     while (k + 16u <= total)
     {
