@@ -124,4 +124,20 @@ __device__ __forceinline__ void copy_exact(uint8_t *dst, const uint8_t *src, uin
   if (k < n) dst[k] = src[k];
 }
 
+// 16 input bytes at block position p of the block that starts at `blockAt` (p may reach below the block or beyond the input: those
+// bytes are never used and read as zero).  Kept out of line on purpose: it is the rare source of the ring encoders' literal copy.
+__device__ __forceinline__ u32x4 global_window16(const uint8_t *in, uint64_t blockAt, uint64_t U, uint32_t p)
+{
+  const int64_t g = (int64_t)blockAt + (int64_t)(int32_t)p;
+  if (g >= 0 && (uint64_t)g + 16u <= U)
+    return ld128(in + g);
+  uint32_t t[4] = { 0, 0, 0, 0 };
+  for (uint32_t k = 0; k < 16u; k++)
+  {
+    const int64_t gk = g + (int64_t)k;
+    if (gk >= 0 && (uint64_t)gk < U) t[k >> 2] |= (uint32_t)in[gk] << (8u * (k & 3u));
+  }
+  return u32x4{ t[0], t[1], t[2], t[3] };
+}
+
 } // namespace hsrle

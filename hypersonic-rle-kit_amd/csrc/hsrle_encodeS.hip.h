@@ -141,35 +141,38 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
     const uint32_t a0 = p & ~15u;
     return funnel16(lds_ld128(hist + (hbase ^ (a0 & HM))), lds_ld128(hist + (hbase ^ ((a0 + 16u) & HM))), p & 15u);
   };
-  auto glob_win = [&](uint32_t p) -> u32x4 {
-    const int64_t g = (int64_t)blockAt + (int64_t)(int32_t)p;
-    if (g >= 0 && (uint64_t)g + 16u <= U)
-      return ld128(in + g);
-    uint32_t t[4] = { 0, 0, 0, 0 };
-    for (uint32_t k = 0; k < 16u; k++)
-    {
-      const int64_t gk = g + (int64_t)k;
-      if (gk >= 0 && (uint64_t)gk < U) t[k >> 2] |= (uint32_t)in[gk] << (8u * (k & 3u));
-    }
-    return u32x4{ t[0], t[1], t[2], t[3] };
-  };
-
-  // literal bytes [at, at + len) of the block: from the ring while they are still there, else from global memory
+  // literal bytes [at, at + len) of the block: from the ring while they are still there.  Literals that have left the ring (a long
+  // stretch of runs too short to be stored) are read from global memory by a function that is kept out of line: with the two
+  // sources selected per chunk inside one loop the rare path cost the common one 10 % of the kernel.
   auto emit_literals = [&](uint32_t at, uint32_t len) {
     if (len == 0u) return;
-    const bool viaRing = at + (uint32_t)H >= avail + 16u;
     const uint32_t c = opos & 15u, total = c + len;
     const uint32_t srcp = at - c;
     uint8_t *const dst = slot + (opos & ~15u);
-    u32x4 w = HS_SMERGE(oacc, viaRing ? ring_win(srcp) : glob_win(srcp), c);
-    uint32_t k = 0;
-    while (k + 16u <= total)
+    if (__builtin_expect(at + (uint32_t)H >= avail + 16u, 1))
     {
-      st128(dst + k, w);
-      k += 16u;
-      if (k < total) w = viaRing ? ring_win(srcp + k) : glob_win(srcp + k);
+      u32x4 w = HS_SMERGE(oacc, ring_win(srcp), c);
+      uint32_t k = 0;
+      while (k + 16u <= total)
+      {
+        st128(dst + k, w);
+        k += 16u;
+        if (k < total) w = ring_win(srcp + k);
+      }
+      oacc = w;
     }
-    oacc = w;
+    else
+    {
+      u32x4 w = HS_SMERGE(oacc, global_window16(in, blockAt, U, srcp), c);
+      uint32_t k = 0;
+      while (k + 16u <= total)
+      {
+        st128(dst + k, w);
+        k += 16u;
+        if (k < total) w = global_window16(in, blockAt, U, srcp + k);
+      }
+      oacc = w;
+    }
     opos += len;
   };
 
