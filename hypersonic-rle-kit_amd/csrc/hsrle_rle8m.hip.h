@@ -134,14 +134,29 @@ __global__ __launch_bounds__(64) void k_rle8m_decode(const uint8_t *__restrict__
       if (ip >= end) { err = true; break; }
       uint32_t count = codeToCount[in_byte(ip++)];
       if (count > want - op) { err = true; break; }
-      // the bytes up to the next 16-byte boundary one by one, whole chunks as vectors, the rest one by one
-      while (count != 0u && (op & 15u) != 0u) { put(b); count--; }
-      if (count >= 16u)
+      // the run is merged into the accumulator with byte masks (the accumulator is zero above op), whole chunks are stored as vectors
+      const uint64_t bb = (uint64_t)b * 0x0101010101010101ull;
+      while (count != 0u)
       {
-        const uint64_t bb = (uint64_t)b * 0x0101010101010101ull;
-        for (; count >= 16u; count -= 16u, op += 16u) { st64(o + op, bb); st64(o + op + 8u, bb); }
+        const uint32_t c = op & 15u;
+        if (c == 0u && count >= 16u)
+        {
+          for (; count >= 16u; count -= 16u, op += 16u) { st64(o + op, bb); st64(o + op + 8u, bb); }
+          continue;
+        }
+        const uint32_t take = (16u - c < count) ? 16u - c : count, e = c + take;   // chunk bytes [c, e) become b
+        const uint64_t fromLo = (c < 8u) ? (~0ull << (8u * c)) : 0ull, fromHi = (c < 8u) ? ~0ull : (~0ull << (8u * (c - 8u)));
+        const uint64_t belowLo = (e >= 8u) ? ~0ull : ~(~0ull << (8u * e)), belowHi = (e <= 8u) ? 0ull : ((e == 16u) ? ~0ull : ~(~0ull << (8u * (e - 8u))));
+        alo |= bb & fromLo & belowLo;
+        ahi |= bb & fromHi & belowHi;
+        op += take;
+        count -= take;
+        if ((op & 15u) == 0u)
+        {
+          st64(o + op - 16u, alo); st64(o + op - 8u, ahi);
+          alo = 0; ahi = 0;
+        }
       }
-      for (; count != 0u; count--) put(b);
     }
   }
   if (!err && op != want) err = true;
