@@ -13,7 +13,8 @@
 //           appended to a 16-byte output accumulator, and every completed 16-byte chunk goes straight to the block's staging
 //           slot in HBM (the compressed side is the small side, so per-lane stores are not what limits the kernel).
 // The kernel is latency bound like the decoder (throughput scales linearly with waves per CU), so LDS is spent on nothing but
-// the ring: 16 KB per wave (XOR-swizzled rows, no pad, no mirror) = 9 waves per CU.
+// the ring: 16 KB per wave (XOR-swizzled rows, no pad, no mirror) + 1.5 KB of small tables (row scalars, merge masks, the
+// accumulator hand-back of the slow literal path) = 17.9 KB = 14 LDS granules of 1 280 bytes = 9 waves per CU.
 // Literal gaps that have left the ring (long runs, incompressible stretches) are read from global memory instead.
 #pragma once
 
