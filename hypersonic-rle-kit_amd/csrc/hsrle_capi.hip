@@ -581,6 +581,92 @@ static int rle8m_decode_async(const void *dStream, uint64_t streamSize, uint32_t
   return hipGetLastError() == hipSuccess ? HSRLE_OK : HSRLE_ERR_DEVICE;
 }
 
+// rle8m encode (device resident): workspace = [Rle8mTables][offsets u64 x (sections + 1)] + the slots / sizes / scan levels of plan_workspace
+struct Rle8mPlan
+{
+  Workspace w;
+  uint64_t offTables, offOffsets, total;
+  uint32_t slotStride;
+};
+
+static Rle8mPlan plan_rle8m(uint32_t n, uint32_t sections)
+{
+  Rle8mPlan p;
+  const uint32_t ss = n / sections, lastLen = n - ss * (sections - 1u);
+  p.slotStride = (uint32_t)align_up(2ull * (uint64_t)(lastLen > ss ? lastLen : ss) + 16ull, 16);   // a section grows to at most twice its size
+  Workspace &w = p.w;
+  w.nBlocks = sections;
+  w.t1 = (w.nBlocks + kScanTile - 1) / kScanTile;
+  w.t2 = (w.t1 + kScanTile - 1) / kScanTile;
+  w.t3 = (w.t2 + kScanTile - 1) / kScanTile;
+  uint64_t at = 0;
+  p.offTables = at; at += align_up(sizeof(Rle8mTables), 256);
+  p.offOffsets = at; at += align_up(((uint64_t)sections + 1ull) * 8ull, 256);
+  w.offSlots = at; at += align_up((uint64_t)sections * p.slotStride, 256);
+  w.offSizes = at; at += align_up((uint64_t)sections * 4ull, 256);
+  w.offL1 = at; at += align_up((w.t1 + 1) * 8ull, 256);
+  w.offL2 = at; at += align_up((w.t2 + 1) * 8ull, 256);
+  w.offL3 = at; at += align_up((w.t3 + 1) * 8ull, 256);
+  w.total = at;
+  p.total = at;
+  return p;
+}
+
+static uint32_t rle8m_bounds(uint32_t sections, uint32_t n) { return n + (256 / 8) + 1 + 256 + 4u * (2u + sections - 1u + 1u); }
+
+// the caller has checked device_ok()
+static int rle8m_encode_async(const void *dIn, uint32_t n, uint32_t sections, void *dOut, uint64_t outCapacity, void *dWs, uint64_t wsSize, uint32_t *dStatus, hipStream_t st)
+{
+  if (!dIn || !dOut || !dWs || n == 0 || sections == 0)
+    return HSRLE_ERR_ARGUMENT;
+  if (outCapacity < rle8m_bounds(sections, n))
+    return HSRLE_ERR_CAPACITY;
+  const Rle8mPlan p = plan_rle8m(n, sections);
+  if (wsSize < p.total)
+    return HSRLE_ERR_CAPACITY;
+  uint8_t *ws = (uint8_t *)dWs;
+  Rle8mTables *t = (Rle8mTables *)(ws + p.offTables);
+  uint64_t *offsets = (uint64_t *)(ws + p.offOffsets);
+  uint32_t *sizes = (uint32_t *)(ws + p.w.offSizes);
+  if (hipMemsetAsync(t, 0, sizeof(Rle8mTables), st) != hipSuccess || (dStatus && hipMemsetAsync(dStatus, 0, 4, st) != hipSuccess))
+    return HSRLE_ERR_DEVICE;
+  const uint32_t grid = (sections + 63u) / 64u;
+  hipLaunchKernelGGL(k_rle8m_stats, dim3(grid), dim3(64), 0, st, (const uint8_t *)dIn, n, sections, t);
+  hipLaunchKernelGGL(k_rle8m_info, dim3(1), dim3(256), 0, st, t, sections, (uint8_t *)dOut);
+  hipLaunchKernelGGL(k_rle8m_encode, dim3(grid), dim3(64), 0, st, (const uint8_t *)dIn, n, sections, (const Rle8mTables *)t, ws + p.w.offSlots, p.slotStride, sizes);
+  if (scan_sizes(sizes, sections, offsets, ws, p.w, st) != hipSuccess)
+    return HSRLE_ERR_DEVICE;
+  hipLaunchKernelGGL(k_rle8m_place, dim3((sections + 3u) / 4u), dim3(256), 0, st, (const uint8_t *)(ws + p.w.offSlots), p.slotStride, (const uint64_t *)offsets, (const Rle8mTables *)t,
+                     (uint8_t *)dOut, outCapacity, n, sections, dStatus);
+  return hipGetLastError() == hipSuccess ? HSRLE_OK : HSRLE_ERR_DEVICE;
+}
+
+static uint32_t rle8m_mono_compress(uint32_t sections, const uint8_t *pIn, uint32_t inSize, uint8_t *pOut, uint32_t outSize)
+{
+  // argument checks of the reference (rle8_low_entropy_cpu.c:133-134)
+  if (pIn == nullptr || inSize == 0 || pOut == nullptr || sections == 0 || outSize < rle8m_bounds(sections, inSize) || !device_ok())
+    return 0;
+  const Rle8mPlan p = plan_rle8m(inSize, sections);
+  std::lock_guard<std::mutex> lock(g_dev.mu);
+  if (!grow(&g_dev.monoIn, &g_dev.monoInSize, (uint64_t)inSize + 64) || !grow(&g_dev.monoOut, &g_dev.monoOutSize, (uint64_t)outSize + 64) || !grow(&g_dev.ws, &g_dev.wsSize, p.total))
+    return 0;
+  if (!g_dev.monoAux && hipMalloc(&g_dev.monoAux, 256) != hipSuccess)
+    return 0;
+  uint32_t *dStatus = (uint32_t *)((uint8_t *)g_dev.monoAux + 64);
+  if (hipMemcpy(g_dev.monoIn, pIn, inSize, hipMemcpyHostToDevice) != hipSuccess)
+    return 0;
+  if (rle8m_encode_async(g_dev.monoIn, inSize, sections, g_dev.monoOut, outSize, g_dev.ws, g_dev.wsSize, dStatus, nullptr) != HSRLE_OK)
+    return 0;
+  uint32_t status = 1, size = 0;
+  if (hipMemcpy(&status, dStatus, 4, hipMemcpyDeviceToHost) != hipSuccess || status != 0)
+    return 0;
+  if (hipMemcpy(&size, g_dev.monoOut, 4, hipMemcpyDeviceToHost) != hipSuccess || size == 0 || size > outSize)
+    return 0;
+  if (hipMemcpy(pOut, g_dev.monoOut, size, hipMemcpyDeviceToHost) != hipSuccess)
+    return 0;
+  return size;
+}
+
 static uint32_t rle8m_mono_decompress(const uint8_t *pIn, uint32_t inSize, uint8_t *pOut, uint32_t outSize)
 {
   // argument + header checks of the reference (rle8_ocl.c:267-283, rle8_low_entropy_cpu.c:195-211)
@@ -675,6 +761,17 @@ bool rle8m_opencl_init(const size_t inputDataSize, const size_t outputDataSize, 
 void rle8m_opencl_destroy(void) {}
 uint32_t rle8m_opencl_decompress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize) { return rle8m_mono_decompress(pIn, inSize, pOut, outSize); }
 uint32_t rle8m_decompress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize) { return rle8m_mono_decompress(pIn, inSize, pOut, outSize); }
+
+uint32_t rle8m_compress_bounds(const uint32_t subSections, const uint32_t inSize) { return rle8m_bounds(subSections, inSize); }
+uint32_t rle8m_compress(const uint32_t subSections, const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize) { return rle8m_mono_compress(subSections, pIn, inSize, pOut, outSize); }
+
+uint64_t hsrle_rle8m_compress_workspace_size(uint32_t inSize, uint32_t sections) { return (inSize == 0 || sections == 0) ? 0 : plan_rle8m(inSize, sections).total; }
+
+int hsrle_rle8m_compress_dev_async(const void *dIn, uint32_t inSize, uint32_t sections, void *dOut, uint64_t outCapacity, void *dWorkspace, uint64_t workspaceSize, uint32_t *dStatus, void *stream)
+{
+  if (!device_ok()) return HSRLE_ERR_DEVICE;
+  return rle8m_encode_async(dIn, inSize, sections, dOut, outCapacity, dWorkspace, workspaceSize, dStatus, (hipStream_t)stream);
+}
 
 int hsrle_rle8m_info_dev(const void *dStream, uint64_t streamSize, hsrle_rle8m_info_t *pInfo, void *stream)
 {

@@ -165,4 +165,248 @@ __global__ __launch_bounds__(64) void k_rle8m_decode(const uint8_t *__restrict__
   if (err && status) atomicOr(status, RLE8M_ERR_STREAM);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// rle8m encoder (the reference's rle8m_compress is a CPU function, src/rle8_low_entropy_cpu.c:131-191; this is its GPU twin, so that
+// an rle8m stream can be produced and consumed device resident).  Four kernels:
+//   k_rle8m_stats   run statistics over the WHOLE input (get_compress_info, :254-338): every maximal run adds its length to prob[sym]
+//                   and length / 255 + 1 to pcount[sym]; one lane per section counts the runs that START in its section (and follows
+//                   them across section ends), LDS histograms per workgroup, one global atomic per symbol and workgroup
+//   k_rle8m_info    which symbols carry a repeat code (prob / pcount >= 2), the symbols ordered by pcount (ties: lower symbol first;
+//                   unused symbols last, ascending), the info bytes of the stream header (:441-472)
+//   k_rle8m_encode  one lane per section (compress_with_info, :474-543) into a staging slot of twice the section size
+//   k_rle8m_place   compaction into the stream behind the header + the header itself + the capacity rule of the reference (a section
+//                   must fit into what is left of the output when its turn comes, :476) -> status bit, stream size 0
+// byte reader over global memory through a 16-byte register window.  `limit` = readable bytes behind `base` (>= 16 on the fast path:
+// the last window of the buffer is read at limit - 16 and shifted, so there is no byte loop anywhere near the hot path)
+struct ByteWindow
+{
+  const uint8_t *base;
+  uint32_t limit;
+  uint32_t wpos = 0xFFFFFF00u;
+  uint64_t lo = 0, hi = 0;
+  __device__ __forceinline__ uint32_t get(uint32_t pos)
+  {
+    if (pos - wpos >= 16u)
+    {
+      wpos = pos;
+      if (limit >= 16u)
+      {
+        const uint32_t at = (pos + 16u <= limit) ? pos : limit - 16u;
+        const uint32_t sh = 8u * (pos - at);                              // 0, or 8 .. 120 bits for the last window
+        const uint64_t a = ld64(base + at), b = ld64(base + at + 8);
+        lo = (sh == 0u) ? a : ((sh < 64u) ? ((a >> sh) | (b << (64u - sh))) : (b >> (sh - 64u)));
+        hi = (sh < 64u) ? (b >> sh) : 0ull;
+      }
+      else
+      {
+        lo = 0; hi = 0;
+        for (uint32_t j = 0; j < 16u && pos + j < limit; j++)
+        {
+          if (j < 8u) lo |= (uint64_t)base[pos + j] << (8u * j); else hi |= (uint64_t)base[pos + j] << (8u * (j - 8u));
+        }
+      }
+    }
+    const uint32_t d = pos - wpos;
+    const uint64_t v = (d & 8u) ? hi : lo;
+    return (uint32_t)(v >> (8u * (d & 7u))) & 0xFFu;
+  }
+};
+
+struct Rle8mTables                          // device scratch shared by the kernels (in the workspace)
+{
+  uint32_t prob[256], pcount[256];
+  uint8_t rle[256], order[256];
+  uint32_t listed;                          // symbols written to the header (1..255; 256 are written as 255, sic)
+  uint32_t headerSize;
+};
+
+__global__ __launch_bounds__(64) void k_rle8m_stats(const uint8_t *__restrict__ d, uint32_t n, uint32_t sections, Rle8mTables *__restrict__ t)
+{
+  __shared__ uint32_t prob[256], pcount[256];
+  const uint32_t lane = threadIdx.x;
+  for (uint32_t k = lane; k < 256u; k += 64u) { prob[k] = 0; pcount[k] = 0; }
+  __syncthreads();
+
+  const uint32_t k = blockIdx.x * 64u + lane;
+  if (k < sections)
+  {
+    const uint32_t ss = n / sections;
+    const uint64_t a = (uint64_t)k * ss, b = (k + 1u < sections) ? a + ss : (uint64_t)n;
+    // one byte per loop trip and lane (a loop per run inside a loop over the runs makes every lane wait for the longest run of its
+    // wave at every run end: 10x slower on zero-dominated data)
+    ByteWindow w{ d, n };
+    bool skipping = k > 0u;                                               // the run that came in from the section before is not mine
+    const uint32_t prev = skipping ? (uint32_t)d[a - 1] : 0u;
+    uint32_t sym = 0xFFFFFFFFu, len = 0;
+    for (uint32_t i = (uint32_t)a; i < n; i++)
+    {
+      const uint32_t c = w.get(i);
+      if (skipping)
+      {
+        if (i < (uint32_t)b && c == prev) continue;
+        skipping = false;
+      }
+      if (c == sym) { len++; continue; }                                  // the run goes on (also across section ends)
+      if (sym != 0xFFFFFFFFu)
+      {
+        atomicAdd(&prob[sym], len);
+        atomicAdd(&pcount[sym], len / 255u + 1u);
+        sym = 0xFFFFFFFFu;
+      }
+      if (i >= (uint32_t)b) break;                                        // a run that starts behind my section is not mine
+      sym = c; len = 1;
+    }
+    if (sym != 0xFFFFFFFFu)
+    {
+      atomicAdd(&prob[sym], len);
+      atomicAdd(&pcount[sym], len / 255u + 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t s2 = lane; s2 < 256u; s2 += 64u)
+  {
+    if (prob[s2]) atomicAdd(&t->prob[s2], prob[s2]);
+    if (pcount[s2]) atomicAdd(&t->pcount[s2], pcount[s2]);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_rle8m_info(Rle8mTables *__restrict__ t, uint32_t sections, uint8_t *__restrict__ out)
+{
+  __shared__ uint32_t pc[256];
+  __shared__ uint8_t order[256], flag[256];
+  const uint32_t i = threadIdx.x;
+  const uint32_t p = t->prob[i], c = t->pcount[i];
+  pc[i] = c;
+  flag[i] = (c > 0u && p / c >= 2u) ? 1 : 0;
+  __syncthreads();
+  uint32_t used = 0, rank = 0, unusedBelow = 0;
+  for (uint32_t j = 0; j < 256u; j++)
+  {
+    const uint32_t cj = pc[j];
+    used += cj != 0u;
+    if (c != 0u) rank += (cj > c) || (cj == c && j < i);
+    else unusedBelow += (cj == 0u && j < i);
+  }
+  order[(c != 0u) ? rank : used + unusedBelow] = (uint8_t)i;
+  __syncthreads();
+  t->rle[i] = flag[i];
+  t->order[i] = order[i];
+  const uint32_t listed = (used & 0xFFu) ? (used & 0xFFu) : 255u;        // symbolCount is a uint8: 256 -> 0 -> 255 symbols written (sic)
+  const uint32_t info = 12u + 4u * (sections - 1u);
+  if (i < 32u)
+  {
+    uint32_t v = 0;
+    for (uint32_t j = 0; j < 8u; j++) v |= (uint32_t)flag[i * 8u + j] << j;
+    out[info + i] = (uint8_t)v;
+  }
+  if (i == 0u)
+  {
+    out[info + 32u] = (uint8_t)used;
+    t->listed = listed;
+    t->headerSize = info + 33u + listed;
+  }
+  if (i < listed) out[info + 33u + i] = order[i];
+}
+
+__global__ __launch_bounds__(64) void k_rle8m_encode(const uint8_t *__restrict__ d, uint32_t n, uint32_t sections, const Rle8mTables *__restrict__ t,
+                                                      uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes)
+{
+  __shared__ uint32_t rleBits[8];
+  __shared__ uint8_t order[256];
+  const uint32_t lane = threadIdx.x;
+  if (lane < 8u)
+  {
+    uint32_t v = 0;
+    for (uint32_t j = 0; j < 32u; j++) v |= (uint32_t)(t->rle[lane * 32u + j] != 0) << j;
+    rleBits[lane] = v;
+  }
+  for (uint32_t k = lane; k < 256u; k += 64u) order[k] = t->order[k];
+  __syncthreads();
+
+  const uint32_t k = blockIdx.x * 64u + lane;
+  if (k >= sections)
+    return;
+  const uint32_t ss = n / sections;
+  const uint8_t *const p = d + (uint64_t)k * ss;
+  const uint32_t len = (k + 1u < sections) ? ss : n - ss * (sections - 1u);
+  uint8_t *const o = slots + (uint64_t)k * slotStride;
+  const uint32_t target = (len >= 256u) ? len - 256u : 0u;
+
+  uint64_t alo = 0, ahi = 0;
+  uint32_t op = 0;
+  auto put = [&](uint32_t b) {
+    const uint32_t sh = 8u * (op & 7u);
+    if (op & 8u) ahi |= (uint64_t)b << sh; else alo |= (uint64_t)b << sh;
+    op++;
+    if ((op & 15u) == 0u) { st64(o + op - 16u, alo); st64(o + op - 8u, ahi); alo = 0; ahi = 0; }
+  };
+
+  // one byte per loop trip and lane, as in k_rle8m_stats: either the next symbol is emitted, or the repeat scan behind a flagged one
+  // looks at one more byte
+  ByteWindow w{ p, n - k * ss };                                          // reading behind the section (inside the input) is harmless
+  uint32_t i = 0, j = 0, count = 0, range = 0, runSym = 0;
+  bool scanning = false;
+  for (;;)
+  {
+    if (!scanning)
+    {
+      if (i >= len) break;
+      const uint32_t b = w.get(i);
+      put(b);
+      if ((rleBits[b >> 5] >> (b & 31u)) & 1u)
+      {
+        const uint32_t left = len - i - 1u;
+        range = (i < target) ? 255u : (left < 255u ? left : 255u);        // :497 / :521
+        runSym = b; count = 0; j = 1; scanning = true;
+      }
+      else
+        i++;
+    }
+    else if (j < range && w.get(i + j) == runSym) { count++; j++; }
+    else
+    {
+      i += j;
+      put(order[count]);
+      scanning = false;
+    }
+  }
+  for (uint32_t j = op & ~15u; j < op; j++)
+    o[j] = (uint8_t)(((j & 8u) ? ahi : alo) >> (8u * (j & 7u)));
+  sizes[k] = op;
+}
+
+// one wave per section: copy its staged stream behind the header; wave 0 of every workgroup of 4 also writes header fields
+__global__ __launch_bounds__(256) void k_rle8m_place(const uint8_t *__restrict__ slots, uint32_t slotStride, const uint64_t *__restrict__ offsets, const Rle8mTables *__restrict__ t,
+                                                     uint8_t *__restrict__ out, uint64_t outCapacity, uint32_t n, uint32_t sections, uint32_t *__restrict__ status)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t b = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (b >= sections)
+    return;
+  const uint32_t H = t->headerSize;
+  const uint64_t off = offsets[b];
+  const uint32_t size = (uint32_t)(offsets[b + 1] - off);
+  const uint32_t ss = n / sections;
+  const uint32_t len = (b + 1u < sections) ? ss : n - ss * (sections - 1u);
+  // the reference gives up when a section is larger than what is left of the output at its turn (compress_with_info: outSize < inSize)
+  const bool fits = (uint64_t)H + off <= outCapacity && outCapacity - ((uint64_t)H + off) >= (uint64_t)len && (uint64_t)H + off + size <= 0xFFFFFFFFull && len != 0u;
+  if (!fits)
+  {
+    if (lane == 0u && status) atomicOr(status, RLE8M_ERR_STREAM);
+    return;
+  }
+  const uint8_t *src = slots + (uint64_t)b * slotStride;
+  uint8_t *dst = out + H + off;
+  for (uint32_t k = lane * 16u; k + 16u <= size; k += 64u * 16u) st128(dst + k, ld128(src + k));
+  const uint32_t body = size & ~15u;
+  if (lane < size - body) dst[body + lane] = src[body + lane];
+  if (lane == 0u)
+  {
+    if (b + 1u < sections) st32(out + 12u + 4u * b, (uint32_t)(H + off + size));   // end offset of this section
+    else st32(out, (uint32_t)(H + off + size));                                   // total size
+    if (b == 0u) { st32(out + 4, n); st32(out + 8, sections); }
+  }
+}
+
 } // namespace hsrle

@@ -330,3 +330,42 @@ def rle8m_decompress_async(stream_tensor, info, dst, status=None, stream=None):
     rc = L.hsrle_rle8m_decompress_dev_async(ctypes.c_void_p(stream_tensor.data_ptr()), ctypes.byref(info), ctypes.c_void_p(dst.data_ptr()), dst.numel(), sp, _stream_ptr(stream))
     if rc != 0:
         raise HsrleError(rc, "hsrle_rle8m_decompress_dev_async")
+
+
+def rle8m_compress_dropin(sections, data):
+    """rle8m_compress(subSections, pIn, inSize, pOut, outSize) of the library (host pointers); returns the stream or None (the reference's 0)."""
+    L = _lib()
+    L.rle8m_compress_bounds.restype = ctypes.c_uint32
+    L.rle8m_compress.restype = ctypes.c_uint32
+    data = bytes(data)
+    cap = L.rle8m_compress_bounds(ctypes.c_uint32(sections), ctypes.c_uint32(len(data)))
+    out = ctypes.create_string_buffer(cap + 64)
+    size = L.rle8m_compress(ctypes.c_uint32(sections), data, ctypes.c_uint32(len(data)), out, ctypes.c_uint32(cap))
+    return out.raw[:size] if size else None
+
+
+def rle8m_compress_async(src, sections, dst, workspace, status=None, stream=None):
+    """Enqueue the rle8m encode of the uint8 CUDA tensor `src` into `dst` (capacity >= rle8m_compress_bounds) with `sections` sub-sections."""
+    _check_u8_cuda(src, "src")
+    _check_u8_cuda(dst, "dst")
+    _check_u8_cuda(workspace, "workspace")
+    L = _lib()
+    L.hsrle_rle8m_compress_dev_async.restype = ctypes.c_int
+    L.hsrle_rle8m_compress_dev_async.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
+    sp = ctypes.c_void_p(status.data_ptr()) if status is not None else None
+    rc = L.hsrle_rle8m_compress_dev_async(ctypes.c_void_p(src.data_ptr()), src.numel(), sections, ctypes.c_void_p(dst.data_ptr()), dst.numel(),
+                                          ctypes.c_void_p(workspace.data_ptr()), workspace.numel(), sp, _stream_ptr(stream))
+    if rc != 0:
+        raise HsrleError(rc, "hsrle_rle8m_compress_dev_async")
+
+
+def rle8m_workspace_size(in_size, sections):
+    L = _lib()
+    L.hsrle_rle8m_compress_workspace_size.restype = ctypes.c_uint64
+    return int(L.hsrle_rle8m_compress_workspace_size(ctypes.c_uint32(in_size), ctypes.c_uint32(sections)))
+
+
+def rle8m_bounds(sections, in_size):
+    L = _lib()
+    L.rle8m_compress_bounds.restype = ctypes.c_uint32
+    return int(L.rle8m_compress_bounds(ctypes.c_uint32(sections), ctypes.c_uint32(in_size)))

@@ -273,11 +273,19 @@ int hsrle_device_count(void);
 /* rle8m: the reference's own GPU decode path.  `rle8m_opencl_*` are the names of      */
 /* src/rle.h:464-466 (src/rle8_ocl.c:56, :185, :265); `rle8m_decompress` is the CPU twin of the same format   */
 /* (src/rle.h:63, src/rle8_low_entropy_cpu.c:193-250).  Host pointers; one lane decodes one sub-section.      */
-/* Streams come from the reference's rle8m_compress (CPU; not replaced).                                      */
 bool rle8m_opencl_init(const size_t inputDataSize, const size_t outputDataSize, const size_t maxSubsectionCount);
 void rle8m_opencl_destroy(void);
 uint32_t rle8m_opencl_decompress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize);
 uint32_t rle8m_decompress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize);
+
+/* rle8m encode, the GPU twin of the reference's CPU function (src/rle.h:61-62, src/rle8_low_entropy_cpu.c:126-191): same stream,
+ * same failure rule (0 when a section outgrows what is left of the output at its turn).                                      */
+uint32_t rle8m_compress_bounds(const uint32_t subSections, const uint32_t inSize);
+uint32_t rle8m_compress(const uint32_t subSections, const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize);
+/* device-resident encode: only enqueues kernels; *dStatus != 0 afterwards = the reference would have returned 0 */
+uint64_t hsrle_rle8m_compress_workspace_size(uint32_t inSize, uint32_t sections);
+int hsrle_rle8m_compress_dev_async(const void *dIn, uint32_t inSize, uint32_t sections, void *dOut, uint64_t outCapacity, void *dWorkspace, uint64_t workspaceSize,
+                                   uint32_t *dStatus, void *stream);
 
 /* device-resident form: the stream header is read once (synchronises), the decode only enqueues a kernel */
 typedef struct hsrle_rle8m_info { uint32_t compressedSize, uncompressedSize, sections; } hsrle_rle8m_info_t;

@@ -51,7 +51,7 @@ def test_reference_names_present(lib):
               "rle8_packed_multi_compress", "rle8_packed_single_compress", "rle8_packed_decompress", "rle64_3symlut_byte_compress",
               "rle64_3symlut_byte_decompress", "rle24_sym_packed_compress", "rle128_byte_packed_decompress",
               "rle8_multi_short_compress", "rle8_1symlut_short_decompress", "rle16_sym_short_compress", "rle48_7symlut_byte_short_decompress",
-              "rle8m_opencl_init", "rle8m_opencl_destroy", "rle8m_opencl_decompress", "rle8m_decompress"):
+              "rle8m_opencl_init", "rle8m_opencl_destroy", "rle8m_opencl_decompress", "rle8m_decompress", "rle8m_compress", "rle8m_compress_bounds"):
         assert hasattr(lib, s)
 
 

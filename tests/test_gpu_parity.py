@@ -216,6 +216,42 @@ def test_single_mode_block_in_a_multi_container_is_a_format_error(hs):
         hs.decompress(fake)
 
 
+def test_rle8m_encode_matches_the_oracle(hs, oracle):
+    """rle8m_compress on the GPU (the reference's is a CPU function): the stream equals the oracle's byte for byte -- and the call gives
+    up (returns 0) on exactly the inputs on which the reference does (a section that outgrows the room left in the output)."""
+    import torch
+
+    rng = random.Random(78)
+    cases = [(mixed_runs(rng, 200000, alphabet=3), 64), (mixed_runs(rng, 70001, alphabet=256), 7), (single_symbol_mix(rng, 9000), 1),
+             (bytes([5]) * 100000 + mixed_runs(rng, 3000), 16), (mixed_runs(rng, 333), 3), (bytes(range(256)) * 40 + b"\x00" * 5000, 33),
+             (mixed_runs(rng, 1 << 20, alphabet=4), 4096), (bytes(rng.randrange(256) for _ in range(5000)), 2), (b"\x01\x02" * 3000, 5),
+             (b"\x00" * 70000, 9), (mixed_runs(rng, 100, alphabet=2), 100),
+             (b"ab" * 2000 + b"a" * 4000, 2)]       # 'a' carries repeat codes (one long run) and the first section is full of single a's: it outgrows the bound
+    gave_up = 0
+    for data, sections in cases:
+        want = oracle.rle8m_compress(sections, data)
+        got = hs.rle8m_compress_dropin(sections, data)
+        assert got == want, f"rle8m_compress x{sections} on {len(data)} bytes: {'GPU gave up' if got is None else 'stream differs'}"
+        if want is None:
+            gave_up += 1
+            continue
+        # device resident: encode + decode without leaving the GPU
+        src = _to_dev(data)
+        dst = torch.empty(hs.rle8m_bounds(sections, len(data)), dtype=torch.uint8, device="cuda")
+        ws = torch.empty(hs.rle8m_workspace_size(len(data), sections), dtype=torch.uint8, device="cuda")
+        status = torch.ones(1, dtype=torch.int32, device="cuda")
+        hs.rle8m_compress_async(src, sections, dst, ws, status)
+        torch.cuda.synchronize()
+        assert int(status.item()) == 0
+        info = hs.rle8m_info(dst)
+        assert dst[: info.compressedSize].cpu().numpy().tobytes() == want
+        out = torch.empty(len(data), dtype=torch.uint8, device="cuda")
+        hs.rle8m_decompress_async(dst, info, out, status)
+        torch.cuda.synchronize()
+        assert int(status.item()) == 0 and torch.equal(out, src)
+    assert gave_up >= 1
+
+
 def test_partial_block_range(hs):
     import torch
 
