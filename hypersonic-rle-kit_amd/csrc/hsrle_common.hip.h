@@ -105,9 +105,24 @@ __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b 
 // reads at or beyond srcEnd.
 __device__ __forceinline__ void copy_over(uint8_t *dst, const uint8_t *src, uint32_t n, const uint8_t *srcEnd)
 {
+  // four loads in flight before the first store: a load-store pair per trip pays one memory latency per 16 bytes
   uint32_t k = 0;
-  for (; k < n && src + k + 16 <= srcEnd; k += 16)
-    st128(dst + k, ld128(src + k));
+  while (k < n && src + k + 16 <= srcEnd)
+  {
+    u32x4 v[4];
+    bool has[4];
+#pragma unroll
+    for (uint32_t q = 0; q < 4u; q++)
+    {
+      has[q] = k + 16u * q < n && src + k + 16u * q + 16 <= srcEnd;
+      if (has[q]) v[q] = ld128(src + k + 16u * q);
+    }
+    uint32_t done = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 4u; q++)
+      if (has[q]) { st128(dst + k + 16u * q, v[q]); done += 16u; }
+    k += done;
+  }
   for (; k < n; k++)
     dst[k] = src[k];
 }
@@ -139,5 +154,75 @@ __device__ __forceinline__ u32x4 global_window16(const uint8_t *in, uint64_t blo
   }
   return u32x4{ t[0], t[1], t[2], t[3] };
 }
+
+constexpr uint32_t kLaneRingStride = 132;  // bytes per lane in the input ring: 128 + one dword, so that the lanes' rows start in different banks
+
+// Per-lane input ring in LDS (128 bytes per lane) with a wave-synchronous top-up.  The lanes of a wave drift apart in their streams,
+// so with a per-lane register window some lane waits for global memory in nearly every loop trip, and the wave with it (measured:
+// rle8m encode 17 ms per GiB).  Here ALL lanes top their rings up in the same trip (the caller decides when: every so many trips, or
+// when any lane runs low), each with up to NQ 16-byte loads that are in flight together: one memory latency per top-up.  After
+// topup<NQ>(cursor) the bytes [cursor & ~15, (cursor & ~15) + 16 NQ) are in the ring (those below the limit); NQ <= 8.
+struct LaneRing
+{
+  const uint8_t *base;
+  uint32_t limit;                           // readable bytes behind base
+  uint8_t *row;
+  uint32_t loadedEnd;                       // multiple of 16: everything below is in the ring (or behind the limit)
+  template <uint32_t NQ>
+  __device__ __forceinline__ void topup(uint32_t cursor)
+  {
+    static_assert(NQ >= 1u && NQ <= 8u, "the ring holds 8 chunks");
+    const uint32_t want = (cursor & ~15u) + 16u * NQ;
+    uint64_t ca[NQ], cb[NQ];
+#pragma unroll
+    for (uint32_t q = 0; q < NQ; q++)
+    {
+      const uint32_t pos = loadedEnd + 16u * q;
+      ca[q] = 0; cb[q] = 0;
+      if (pos < want && pos < limit)
+      {
+        if (pos + 16u <= limit) { ca[q] = ld64(base + pos); cb[q] = ld64(base + pos + 8); }
+        else if (limit >= 16u)
+        {
+          const uint32_t sh = 8u * (pos - (limit - 16u));                 // 8 .. 120: the last, partial chunk is read at limit - 16
+          const uint64_t a = ld64(base + limit - 16u), b = ld64(base + limit - 8u);
+          ca[q] = (sh < 64u) ? ((a >> sh) | (b << (64u - sh))) : (b >> (sh - 64u));
+          cb[q] = (sh < 64u) ? (b >> sh) : 0ull;
+        }
+        else
+          for (uint32_t x = 0; pos + x < limit; x++)
+          {
+            if (x < 8u) ca[q] |= (uint64_t)base[pos + x] << (8u * x); else cb[q] |= (uint64_t)base[pos + x] << (8u * (x - 8u));
+          }
+      }
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < NQ; q++)
+    {
+      const uint32_t pos = loadedEnd + 16u * q;
+      if (pos < want && pos < limit)
+      {
+        uint32_t *const r = reinterpret_cast<uint32_t *>(row + (pos & 127u));
+        r[0] = (uint32_t)ca[q]; r[1] = (uint32_t)(ca[q] >> 32); r[2] = (uint32_t)cb[q]; r[3] = (uint32_t)(cb[q] >> 32);
+      }
+    }
+    if (want > loadedEnd) loadedEnd = want;
+  }
+  __device__ __forceinline__ uint32_t get(uint32_t pos) const { return row[pos & 127u]; }
+  // the 8 bytes at pos (any alignment); reads the three dwords around them
+  __device__ __forceinline__ void get64(uint32_t pos, uint32_t &v0, uint32_t &v1) const
+  {
+    const uint32_t *const w = reinterpret_cast<const uint32_t *>(row);
+    const uint32_t k = (pos & 127u) >> 2, sh = pos & 3u;
+    const uint32_t d0 = w[k], d1 = w[(k + 1u) & 31u], d2 = w[(k + 2u) & 31u];
+    v0 = alignbyte(d1, d0, sh); v1 = alignbyte(d2, d1, sh);
+  }
+  __device__ __forceinline__ uint32_t get32(uint32_t pos) const
+  {
+    const uint32_t *const w = reinterpret_cast<const uint32_t *>(row);
+    const uint32_t k = (pos & 127u) >> 2;
+    return alignbyte(w[(k + 1u) & 31u], w[k], pos & 3u);
+  }
+};
 
 } // namespace hsrle

@@ -26,6 +26,7 @@ __global__ __launch_bounds__(64) void k_encode_greedy_blocks(const uint8_t *__re
   constexpr int K = TR::K;
   constexpr uint32_t SU = (uint32_t)S;
 
+  __shared__ __attribute__((aligned(16))) uint8_t ringMem[64 * kLaneRingStride];
   const uint32_t b = xcd_tile(blockIdx.x, gridDim.x) * 64u + threadIdx.x;
   if (b >= nBlocks)
     return;
@@ -33,6 +34,12 @@ __global__ __launch_bounds__(64) void k_encode_greedy_blocks(const uint8_t *__re
   const uint64_t start = (uint64_t)b * B;
   const uint32_t n = (uint32_t)((U - start) < (uint64_t)B ? (U - start) : (uint64_t)B);
   const uint8_t *const d = in + start;
+  // the scan reads its symbols through the LaneRing (topped up by all lanes together whenever one of them runs low); reading behind
+  // the block (inside the input) is harmless, sym_at masks what lies beyond n
+  LaneRing ring{ d, (uint32_t)((U - start) < 0xFFFFFFFFull ? (U - start) : 0xFFFFFFFFull), ringMem + threadIdx.x * kLaneRingStride, 0u };
+  auto ensure = [&](uint32_t i) {
+    if (__builtin_amdgcn_ballot_w64(i + 64u > ring.loadedEnd) != 0ull) ring.template topup<8>(i);
+  };
   Sink s{ slots + (uint64_t)b * slotStride, 0u, in + U };
   s.put32(n);
   s.put32(0);
@@ -54,17 +61,10 @@ __global__ __launch_bounds__(64) void k_encode_greedy_blocks(const uint8_t *__re
 
   // the symbol at block position i, zero extended; bytes at or beyond n read as zero
   auto sym_at = [&](uint32_t i, uint32_t &s0, uint32_t &s1) {
-    if (i + SU <= n)
-    {
-      const u32x4 v = load_sym<S>(d + i);
-      s0 = v.x; s1 = v.y;
-    }
-    else
-    {
-      uint64_t v = 0;
-      for (uint32_t j = 0; j < SU && i + j < n; j++) v |= (uint64_t)d[i + j] << (8u * j);
-      s0 = (uint32_t)v; s1 = (uint32_t)(v >> 32);
-    }
+    if constexpr (S > 4) ring.get64(i, s0, s1); else { s0 = ring.get32(i); s1 = 0u; }
+    const uint32_t have = (n - i < SU) ? n - i : SU;                     // i < n
+    const uint64_t keep = (have >= 8u) ? ~0ull : ~(~0ull << (8u * have));
+    s0 &= (uint32_t)keep; s1 &= (uint32_t)(keep >> 32);
   };
   // number of equal leading bytes of two symbols (S when they are equal)
   auto prefix = [&](uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1) -> uint32_t {
@@ -120,6 +120,7 @@ __global__ __launch_bounds__(64) void k_encode_greedy_blocks(const uint8_t *__re
 
   // ---- the greedy scan (rleX_Xsl_short.h:783-974) ----
   uint32_t y0, y1;                                                     // state.symbol: starts as the complement of the first symbol
+  ensure(0u);
   sym_at(0, y0, y1);
   y0 = ~y0; y1 = ~y1;
   if constexpr (S < 4) y0 &= (1u << (8 * S)) - 1u;
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(64) void k_encode_greedy_blocks(const uint8_t *__re
 
   while (i < n)
   {
+    ensure(i);
     if (count != 0u && i + SU <= n)
     {
       uint32_t x0, x1;
@@ -140,6 +142,7 @@ __global__ __launch_bounds__(64) void k_encode_greedy_blocks(const uint8_t *__re
 
     for (;;)                                                           // label not_a_full_match_but_a_match (:861)
     {
+      ensure(i);
       if (count >= TR::SMINS) process(y0, y1, count, i);   // a shorter "run" (0 bytes between two literal positions) is never stored and changes no state
       sym_at(i, y0, y1);
       const bool fits = i + SU <= n;

@@ -22,67 +22,13 @@ namespace hsrle {
 
 enum Rle8mError : uint32_t { RLE8M_ERR_HEADER = 1u, RLE8M_ERR_STREAM = 2u };
 
-constexpr uint32_t kRle8mRingStride = 132;  // bytes per lane in the input ring: 128 + one dword, so that the lanes' rows start in different banks
-
-// Per-lane input ring in LDS (128 bytes per lane) with a wave-synchronous top-up.  The lanes of a wave drift apart in their streams,
-// so with a per-lane register window some lane waits for global memory in nearly every loop trip, and the wave with it (measured:
-// rle8m encode 17 ms per GiB).  Here ALL lanes top their rings up in the same trip, once per kTrips trips, each with up to five 16-byte
-// loads that are in flight together: one memory latency per kTrips trips.  The caller guarantees that the read cursor moves by at
-// most 64 bytes between two top-ups (80 bytes are buffered behind the cursor's chunk).
-struct LaneRing
-{
-  const uint8_t *base;
-  uint32_t limit;                           // readable bytes behind base
-  uint8_t *row;
-  uint32_t loadedEnd;                       // multiple of 16: everything below is in the ring (or behind the limit)
-  __device__ __forceinline__ void topup(uint32_t cursor)
-  {
-    const uint32_t want = (cursor & ~15u) + 80u;
-    uint64_t ca[5], cb[5];
-#pragma unroll
-    for (uint32_t q = 0; q < 5u; q++)
-    {
-      const uint32_t pos = loadedEnd + 16u * q;
-      ca[q] = 0; cb[q] = 0;
-      if (pos < want && pos < limit)
-      {
-        if (pos + 16u <= limit) { ca[q] = ld64(base + pos); cb[q] = ld64(base + pos + 8); }
-        else if (limit >= 16u)
-        {
-          const uint32_t sh = 8u * (pos - (limit - 16u));                 // 8 .. 120: the last, partial chunk is read at limit - 16
-          const uint64_t a = ld64(base + limit - 16u), b = ld64(base + limit - 8u);
-          ca[q] = (sh < 64u) ? ((a >> sh) | (b << (64u - sh))) : (b >> (sh - 64u));
-          cb[q] = (sh < 64u) ? (b >> sh) : 0ull;
-        }
-        else
-          for (uint32_t x = 0; pos + x < limit; x++)
-          {
-            if (x < 8u) ca[q] |= (uint64_t)base[pos + x] << (8u * x); else cb[q] |= (uint64_t)base[pos + x] << (8u * (x - 8u));
-          }
-      }
-    }
-#pragma unroll
-    for (uint32_t q = 0; q < 5u; q++)
-    {
-      const uint32_t pos = loadedEnd + 16u * q;
-      if (pos < want && pos < limit)
-      {
-        uint32_t *const r = reinterpret_cast<uint32_t *>(row + (pos & 127u));
-        r[0] = (uint32_t)ca[q]; r[1] = (uint32_t)(ca[q] >> 32); r[2] = (uint32_t)cb[q]; r[3] = (uint32_t)(cb[q] >> 32);
-      }
-    }
-    if (want > loadedEnd) loadedEnd = want;
-  }
-  __device__ __forceinline__ uint32_t get(uint32_t pos) const { return row[pos & 127u]; }
-};
-
 __global__ __launch_bounds__(64) void k_rle8m_decode(const uint8_t *__restrict__ s, uint64_t streamBytes, uint8_t *__restrict__ out, uint32_t *__restrict__ status)
 {
   __shared__ uint32_t rleBits[8];          // bit b: symbol b is followed by a repeat code
   __shared__ uint8_t codeToCount[256];     // repeat code -> count (rle8_low_entropy_cpu.c:569-600)
   __shared__ uint8_t listed[256];
   __shared__ uint32_t hdr[4];              // data start, or 0 when the header is inconsistent
-  __shared__ __attribute__((aligned(16))) uint8_t ring[64 * kRle8mRingStride];
+  __shared__ __attribute__((aligned(16))) uint8_t ring[64 * kLaneRingStride];
 
   const uint32_t lane = threadIdx.x;
   const uint32_t expIn = ld32(s), expOut = ld32(s + 4), sections = ld32(s + 8);
@@ -145,7 +91,7 @@ __global__ __launch_bounds__(64) void k_rle8m_decode(const uint8_t *__restrict__
 
   // ---- input: LaneRing over the stream (at most two bytes per trip: top-up every 32 trips); output accumulator: the 16-byte chunk
   // that contains section position op ----
-  LaneRing in{ s, expIn, ring + lane * kRle8mRingStride, begin & ~15u };
+  LaneRing in{ s, expIn, ring + lane * kLaneRingStride, begin & ~15u };
   auto in_byte = [&](uint32_t pos) -> uint32_t { return in.get(pos); };
 
   uint64_t alo = 0, ahi = 0;
@@ -165,7 +111,7 @@ __global__ __launch_bounds__(64) void k_rle8m_decode(const uint8_t *__restrict__
   bool err = false;
   for (uint32_t trip = 0; ip < end; trip++)
   {
-    if ((trip & 31u) == 0u) in.topup(ip);
+    if ((trip & 31u) == 0u) in.topup<5>(ip);
     const uint32_t b = in_byte(ip++);
     if (op >= want) { err = true; break; }
     put(b);
@@ -354,7 +300,7 @@ __global__ __launch_bounds__(64) void k_rle8m_encode(const uint8_t *__restrict__
 {
   __shared__ uint32_t rleBits[8];
   __shared__ uint8_t order[256];
-  __shared__ __attribute__((aligned(16))) uint8_t ring[64 * kRle8mRingStride];
+  __shared__ __attribute__((aligned(16))) uint8_t ring[64 * kLaneRingStride];
   const uint32_t lane = threadIdx.x;
   if (lane < 8u)
   {
@@ -386,14 +332,14 @@ __global__ __launch_bounds__(64) void k_rle8m_encode(const uint8_t *__restrict__
   // one byte per loop trip and lane, as in k_rle8m_stats: either the next symbol is emitted, or the repeat scan behind a flagged one
   // looks at one more byte; input through the LaneRing (the read cursor moves by at most one byte per trip: top-up every 64 trips).
   // Reading behind the section (inside the input) is harmless.
-  LaneRing in{ p, n - k * ss, ring + lane * kRle8mRingStride, 0u };
+  LaneRing in{ p, n - k * ss, ring + lane * kLaneRingStride, 0u };
   auto in_byte = [&](uint32_t pos) -> uint32_t { return in.get(pos); };
 
   uint32_t i = 0, j = 0, count = 0, range = 0, runSym = 0;
   bool scanning = false;
   for (uint32_t trip = 0;; trip++)
   {
-    if ((trip & 63u) == 0u) in.topup(scanning ? i + j : i);
+    if ((trip & 63u) == 0u) in.topup<5>(scanning ? i + j : i);
     if (!scanning)
     {
       if (i >= len) break;
