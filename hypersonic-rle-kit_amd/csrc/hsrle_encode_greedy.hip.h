@@ -7,7 +7,7 @@
 // than 16 bit, their leading bytes -- as runs, so a 2-byte "run" of a listed symbol's first bytes can be stored in one header
 // byte.  The scan is a byte-granular state machine whose next position depends on the list (which changes with every stored
 // run), so it does not map onto the window-parallel run enumeration of k_encodeS_blocks; it runs here as what it is, one lane
-// per block with per-lane global reads and writes (the first-generation data path of hsrle_encode.hip.h).  The streams are
+// per block: symbols through the LaneRing (hsrle_common.hip.h), output through the per-lane Sink of hsrle_encode.hip.h.  The streams are
 // Short streams: they decode with k_decode_blocks<SHORT1/3/7, S, 0> (src/codec_funcs.h:298-388 pairs them the same way).
 // Bytes at or beyond the block end never match.
 #pragma once
