@@ -243,10 +243,10 @@ __global__ __launch_bounds__(64) void k_rle8m_stats(const uint8_t *__restrict__ 
       if (i >= (uint32_t)b) break;                                        // a run that starts behind my section is not mine
       sym = c; len = 1;
     }
-    if (sym != 0xFFFFFFFFu)
-    {
+    if (sym != 0xFFFFFFFFu)                                               // the run that reaches the end of the input counts once, however
+    {                                                                     // long it is (rle8_low_entropy_cpu.c: the statement behind the loop)
       atomicAdd(&prob[sym], len);
-      atomicAdd(&pcount[sym], len / 255u + 1u);
+      atomicAdd(&pcount[sym], 1u);
     }
   }
   __syncthreads();
@@ -380,8 +380,11 @@ __global__ __launch_bounds__(256) void k_rle8m_place(const uint8_t *__restrict__
   const uint32_t size = (uint32_t)(offsets[b + 1] - off);
   const uint32_t ss = n / sections;
   const uint32_t len = (b + 1u < sections) ? ss : n - ss * (sections - 1u);
-  // the reference gives up when a section is larger than what is left of the output at its turn (compress_with_info: outSize < inSize)
-  const bool fits = (uint64_t)H + off <= outCapacity && outCapacity - ((uint64_t)H + off) >= (uint64_t)len && (uint64_t)H + off + size <= 0xFFFFFFFFull && len != 0u;
+  // the reference gives up when a section is larger than what is left of the output at its turn (compress_with_info: outSize < inSize).
+  // It does not look at the section's STREAM, which can be twice as long (every byte a flagged symbol with a zero repeat code): there
+  // the reference writes behind its caller's buffer.  That is not reproduced: a stream that does not fit is a failure here.
+  const bool fits = (uint64_t)H + off <= outCapacity && outCapacity - ((uint64_t)H + off) >= (uint64_t)len && (uint64_t)H + off + size <= outCapacity &&
+                    (uint64_t)H + off + size <= 0xFFFFFFFFull && len != 0u;
   if (!fits)
   {
     if (lane == 0u && status) atomicOr(status, RLE8M_ERR_STREAM);

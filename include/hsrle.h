@@ -279,7 +279,8 @@ uint32_t rle8m_opencl_decompress(const uint8_t *pIn, const uint32_t inSize, uint
 uint32_t rle8m_decompress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize);
 
 /* rle8m encode, the GPU twin of the reference's CPU function (src/rle.h:61-62, src/rle8_low_entropy_cpu.c:126-191): same stream,
- * same failure rule (0 when a section outgrows what is left of the output at its turn).                                      */
+ * same failure rule (0 when a section outgrows what is left of the output at its turn) -- plus one the reference lacks: 0 as well
+ * when a section's STREAM (up to twice the section) does not fit, where the reference writes behind pOut + outSize.           */
 uint32_t rle8m_compress_bounds(const uint32_t subSections, const uint32_t inSize);
 uint32_t rle8m_compress(const uint32_t subSections, const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize);
 /* device-resident encode: only enqueues kernels; *dStatus != 0 afterwards = the reference would have returned 0 */

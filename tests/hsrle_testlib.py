@@ -136,9 +136,12 @@ class Oracle:
         L.hso_rle8m_compress.restype = ctypes.c_uint32
         data = bytes(data)
         cap = L.hso_rle8m_compress_bounds(ctypes.c_uint32(sections), ctypes.c_uint32(len(data)))
-        out = ctypes.create_string_buffer(cap + 64)
+        # the reference checks the room left against a section's INPUT size; its stream can be twice as long, and then the reference
+        # writes behind `cap` (restated faithfully).  Room for that, and such a result counts as a failure (self.rle8m_overflowed).
+        out = ctypes.create_string_buffer(cap + 2 * len(data) + 64)
         size = L.hso_rle8m_compress(ctypes.c_uint32(sections), data, ctypes.c_uint32(len(data)), out, ctypes.c_uint32(cap))
-        return out.raw[:size] if size else None
+        self.rle8m_overflowed = size > cap
+        return out.raw[:size] if 0 < size <= cap else None
 
     def rle8m_decompress(self, stream, out_size):
         L = self.lib
@@ -209,9 +212,10 @@ class Reference:
         L.rle8m_compress.restype = ctypes.c_uint32
         data = bytes(data)
         cap = L.rle8m_compress_bounds(ctypes.c_uint32(sections), ctypes.c_uint32(len(data)))
-        out = ctypes.create_string_buffer(cap + 64)
+        out = ctypes.create_string_buffer(cap + 2 * len(data) + 64)   # see Oracle.rle8m_compress
         size = L.rle8m_compress(ctypes.c_uint32(sections), data, ctypes.c_uint32(len(data)), out, ctypes.c_uint32(cap))
-        return out.raw[:size] if size else None
+        self.rle8m_overflowed = size > cap
+        return out.raw[:size] if 0 < size <= cap else None
 
     def rle8m_decompress(self, stream, out_size):
         L = self.lib

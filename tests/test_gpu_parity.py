@@ -252,6 +252,32 @@ def test_rle8m_encode_matches_the_oracle(hs, oracle):
     assert gave_up >= 1
 
 
+def test_rle8m_fuzz_small_and_ragged_inputs(hs, oracle):
+    """rle8m on the fuzz grammar at small sizes: inputs shorter than one 16-byte window, sections of a few bytes, a last section
+    that takes the remainder, input lengths that are no multiple of 16 (the tails of the kernels' input rings and accumulators)."""
+    rng = random.Random(4711)
+    n = gave_up = 0
+    for it in range(260):
+        length = rng.choice([1, 2, 3, 7, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 100, 127, 129, 255, 257, 500, 1000, 1023, 2049, 3000])
+        k = it % 3
+        data = mixed_runs(rng, length, alphabet=rng.choice([2, 3, 8, 256])) if k == 0 else single_symbol_mix(rng, length) if k == 1 else fuzz_sections(rng, max_sections=3)[:length]
+        if not data:
+            continue
+        sections = rng.choice([1, 1, 2, 3, 5, 8, 13, 64, len(data)])
+        if len(data) // sections == 0:
+            sections = 1
+        want = oracle.rle8m_compress(sections, data)      # None also where the reference writes behind its output (a section stream
+        got = hs.rle8m_compress_dropin(sections, data)    # of up to twice the section size): the GPU reports a failure there, in bounds
+        assert got == want, f"rle8m_compress x{sections} on {len(data)} bytes ({data[:40].hex()}...)"
+        if want is None:
+            gave_up += 1
+            continue
+        size, back = hs.call_dropin("rle8m_decompress", want, len(data))
+        assert size == len(data) and back == data, f"rle8m_decompress x{sections} on {len(data)} bytes"
+        n += 1
+    assert n >= 150
+
+
 def test_partial_block_range(hs):
     import torch
 
