@@ -1,5 +1,5 @@
 # differential stress test on the GPU: python tools/gpu_stress.py [seconds] [seed]
-# random inputs of many shapes x all 50 codecs x several block sizes: every block stream must equal the oracle's, the decode must
+# random inputs of many shapes x all 110 codecs (+ rle8m) x several block sizes: every block stream must equal the oracle's, the decode must
 # equal the input, the status word must be 0.  Prints the first mismatches and a summary; exit code 1 on any failure.
 import sys, os, time, random
 sys.path.insert(0,'tests'); sys.path.insert(0,'hypersonic-rle-kit_amd/python')
@@ -44,6 +44,19 @@ while time.time()-t0<budget:
             hsrle.decompress_async(cont,info,out,st); torch.cuda.synchronize()
             if int(st[0].item())!=0 or not torch.equal(out,src):
                 bad+=1; print('DECODE MISMATCH',c.key,'block size',bs,'input len',len(data),'status',int(st[0].item()),'seed',seed,flush=True)
+    # rle8m: stream == oracle's (None where the reference gives up or overruns its output), decode == input
+    for sections in rng.sample([1,2,3,7,16,64,255,1024,max(1,len(data)//rng.choice([5,64,333,4096]))],3):
+        if len(data)//sections==0 or len(data)>(1<<22): continue
+        want=ora.rle8m_compress(sections,data); got=hsrle.rle8m_compress_dropin(sections,data)
+        cases+=1; blocks+=sections
+        if got!=want:
+            bad+=1; print('RLE8M ENCODE MISMATCH sections',sections,'input len',len(data),'gpu',None if got is None else len(got),'oracle',None if want is None else len(want),'seed',seed,flush=True)
+        if want is not None:
+            dev=torch.from_numpy(np.frombuffer(want,dtype=np.uint8).copy()).cuda(); inf=hsrle.rle8m_info(dev)
+            out=torch.zeros(len(data),dtype=torch.uint8,device='cuda'); st=torch.ones(1,dtype=torch.int32,device='cuda')
+            hsrle.rle8m_decompress_async(dev,inf,out,st); torch.cuda.synchronize()
+            if int(st.item())!=0 or not torch.equal(out,src):
+                bad+=1; print('RLE8M DECODE MISMATCH sections',sections,'input len',len(data),'status',int(st.item()),'seed',seed,flush=True)
     if bad>20: break
 print('stress: %d codec x block-size cases, %d block streams compared, %d failures, %.0f s'%(cases,blocks,bad,time.time()-t0))
 sys.exit(1 if bad else 0)
