@@ -569,6 +569,8 @@ static uint32_t mono_decompress(int codec, const uint8_t *pIn, uint32_t inSize, 
 
 // ---- rle8m: the reference's GPU decode path, rle8m_opencl_decompress (src/rle8_ocl.c:265-413) ----
 
+constexpr uint32_t kRle8mWaveBelow = 131072u;   // measured on 1 GiB: 65 536 sections 570 (wave) against 321 GiB/s (lane), 262 144 sections 344-498 against 612-680
+
 static int rle8m_decode_async(const void *dStream, uint64_t streamSize, uint32_t uncompressedSize, uint32_t sections, void *dOut, uint64_t outCapacity,
                               uint32_t *dStatus, hipStream_t st)
 {
@@ -577,7 +579,13 @@ static int rle8m_decode_async(const void *dStream, uint64_t streamSize, uint32_t
     return HSRLE_ERR_ARGUMENT;
   if (dStatus && hipMemsetAsync(dStatus, 0, 4, st) != hipSuccess)
     return HSRLE_ERR_DEVICE;
-  hipLaunchKernelGGL(k_rle8m_decode, dim3((sections + 63u) / 64u), dim3(64), 0, st, (const uint8_t *)dStream, streamSize, (uint8_t *)dOut, dStatus);
+  // few, large sections: one wave per section (one lane per section needs ~1e5 sections to fill the GPU)
+  static const int forced = getenv("HSRLE_RLE8M_DECODE") ? atoi(getenv("HSRLE_RLE8M_DECODE")) : 0;   // 1 = lane, 2 = wave kernel (A/B runs)
+  const bool wave = forced ? forced == 2 : sections < kRle8mWaveBelow;
+  if (wave)
+    hipLaunchKernelGGL(k_rle8m_decode_wave, dim3(sections), dim3(64), 0, st, (const uint8_t *)dStream, streamSize, (uint8_t *)dOut, dStatus);
+  else
+    hipLaunchKernelGGL(k_rle8m_decode, dim3((sections + 63u) / 64u), dim3(64), 0, st, (const uint8_t *)dStream, streamSize, (uint8_t *)dOut, dStatus);
   return hipGetLastError() == hipSuccess ? HSRLE_OK : HSRLE_ERR_DEVICE;
 }
 

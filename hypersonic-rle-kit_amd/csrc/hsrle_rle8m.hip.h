@@ -22,16 +22,11 @@ namespace hsrle {
 
 enum Rle8mError : uint32_t { RLE8M_ERR_HEADER = 1u, RLE8M_ERR_STREAM = 2u };
 
-__global__ __launch_bounds__(64) void k_rle8m_decode(const uint8_t *__restrict__ s, uint64_t streamBytes, uint8_t *__restrict__ out, uint32_t *__restrict__ status)
+// header of an rle8m stream -> the two lookup tables in LDS; returns the offset of the first section stream, 0 when the header is
+// inconsistent.  Every workgroup rebuilds the tables (a few hundred instructions against ~1e6 for its sections).
+__device__ __forceinline__ uint32_t rle8m_tables(const uint8_t *__restrict__ s, uint64_t streamBytes, uint32_t lane, uint32_t *rleBits, uint8_t *codeToCount, uint8_t *listed, uint32_t *hdr)
 {
-  __shared__ uint32_t rleBits[8];          // bit b: symbol b is followed by a repeat code
-  __shared__ uint8_t codeToCount[256];     // repeat code -> count (rle8_low_entropy_cpu.c:569-600)
-  __shared__ uint8_t listed[256];
-  __shared__ uint32_t hdr[4];              // data start, or 0 when the header is inconsistent
-  __shared__ __attribute__((aligned(16))) uint8_t ring[64 * kLaneRingStride];
-
-  const uint32_t lane = threadIdx.x;
-  const uint32_t expIn = ld32(s), expOut = ld32(s + 4), sections = ld32(s + 8);
+  const uint32_t expIn = ld32(s), sections = ld32(s + 8);
   const uint64_t info = 12ull + 4ull * (uint64_t)(sections - 1u);
 
   // ---- header: every workgroup rebuilds the two tables (a few hundred instructions against ~1e6 for its 64 sections) ----
@@ -67,7 +62,20 @@ __global__ __launch_bounds__(64) void k_rle8m_decode(const uint8_t *__restrict__
     hdr[0] = 0u;
   __syncthreads();
 
-  const uint32_t dataStart = hdr[0];
+  return hdr[0];
+}
+
+__global__ __launch_bounds__(64) void k_rle8m_decode(const uint8_t *__restrict__ s, uint64_t streamBytes, uint8_t *__restrict__ out, uint32_t *__restrict__ status)
+{
+  __shared__ uint32_t rleBits[8];          // bit b: symbol b is followed by a repeat code
+  __shared__ uint8_t codeToCount[256];     // repeat code -> count (rle8_low_entropy_cpu.c:569-600)
+  __shared__ uint8_t listed[256];
+  __shared__ uint32_t hdr[4];              // data start, or 0 when the header is inconsistent
+  __shared__ __attribute__((aligned(16))) uint8_t ring[64 * kLaneRingStride];
+
+  const uint32_t lane = threadIdx.x;
+  const uint32_t expIn = ld32(s), expOut = ld32(s + 4), sections = ld32(s + 8);
+  const uint32_t dataStart = rle8m_tables(s, streamBytes, lane, rleBits, codeToCount, listed, hdr);
   const uint32_t k = blockIdx.x * 64u + lane;
   if (dataStart == 0u)
   {
@@ -149,6 +157,112 @@ __global__ __launch_bounds__(64) void k_rle8m_decode(const uint8_t *__restrict__
   for (uint32_t j = op & ~15u; j < op && !err; j++)                    // the last partial chunk
     o[j] = (uint8_t)(((j & 8u) ? ahi : alo) >> (8u * (j & 7u)));
   if (err && status) atomicOr(status, RLE8M_ERR_STREAM);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// rle8m decode, one WAVE per section: for streams with few, large sections (one lane per section leaves the GPU to a lane's dependent
+// instruction chain: 16 384 sections of 64 KiB decode at 97 GiB/s).  64 stream bytes per step, one per lane:
+//   * which bytes are symbols and which are repeat codes follows from the flagged bytes alone: a byte is a code iff the run of
+//     flagged-valued bytes right before it has odd length (the run starts with a symbol; symbol, code, symbol, ... while the values stay
+//     flagged).  The run length below a lane comes from the ballot of the flagged lanes, its parity across windows is one carried bit;
+//   * a flagged symbol in lane 63 has its code in the next window: it emits its own byte now, lane 0 of the next window the repeats;
+//   * output offsets = exclusive wave scan of the packet lengths (1 + count); every lane writes its own packet.
+__global__ __launch_bounds__(64) void k_rle8m_decode_wave(const uint8_t *__restrict__ s, uint64_t streamBytes, uint8_t *__restrict__ out, uint32_t *__restrict__ status)
+{
+  __shared__ uint32_t rleBits[8];
+  __shared__ uint8_t codeToCount[256];
+  __shared__ uint8_t listed[256];
+  __shared__ uint32_t hdr[4];
+
+  const uint32_t lane = threadIdx.x;
+  const uint32_t expIn = ld32(s), expOut = ld32(s + 4), sections = ld32(s + 8);
+  const uint32_t dataStart = rle8m_tables(s, streamBytes, lane, rleBits, codeToCount, listed, hdr);
+  const uint32_t k = blockIdx.x;
+  if (dataStart == 0u)
+  {
+    if (k == 0u && lane == 0u && status) atomicOr(status, RLE8M_ERR_HEADER);
+    return;
+  }
+  if (k >= sections)
+    return;
+
+  const uint32_t ss = expOut / sections;
+  const uint32_t begin = (k == 0u) ? dataStart : ld32(s + 12u + 4u * (k - 1u));
+  const uint32_t end = (k + 1u < sections) ? ld32(s + 12u + 4u * k) : expIn;
+  const uint32_t want = (k + 1u < sections) ? ss : expOut - ss * (sections - 1u);
+  uint8_t *const o = out + (uint64_t)k * ss;
+  if (begin < dataStart || end < begin || end > expIn)
+  {
+    if (lane == 0u && status) atomicOr(status, RLE8M_ERR_HEADER);
+    return;
+  }
+
+  uint32_t op = 0, carry = 0, pendSym = 0;
+  bool err = false;
+  uint32_t bNext = (begin + lane < end) ? (uint32_t)s[begin + lane] : 0u;
+  for (uint32_t ip = begin; ip < end; ip += 64u)
+  {
+    const uint32_t pos = ip + lane;
+    const bool valid = pos < end;
+    const uint32_t b = bNext;
+    bNext = (pos + 64u < end) ? (uint32_t)s[pos + 64u] : 0u;              // the next window is on its way while this one is decoded
+    const bool fl = valid && ((rleBits[b >> 5] >> (b & 31u)) & 1u);
+    const uint64_t F = __builtin_amdgcn_ballot_w64(fl);
+    // length of the run of flagged lanes right below this lane
+    uint32_t below = 0;
+    if (lane != 0u)
+    {
+      const uint64_t x = ~F << (64u - lane);                              // bit 63 = lane - 1
+      below = (x == 0ull) ? lane : (uint32_t)__builtin_clzll(x);
+      if (below > lane) below = lane;
+    }
+    const bool isCode = valid && (((below + ((below == lane) ? carry : 0u)) & 1u) != 0u);
+    const bool isSym = valid && !isCode;
+    const uint32_t nb = (uint32_t)__shfl_down((int)b, 1);
+    uint32_t runLen = 0, v = b;
+    bool bad = false;
+    if (isSym)
+    {
+      runLen = 1u;
+      if (fl)
+      {
+        if (pos + 1u >= end) bad = true;                                  // a flagged symbol without its code
+        else if (lane != 63u) runLen += codeToCount[nb];
+      }
+    }
+    else if (isCode && lane == 0u)                                        // (only lane 0 can be a code whose symbol sits in the window before)
+    {
+      runLen = codeToCount[b];
+      v = pendSym;
+    }
+    // exclusive scan of the packet lengths
+    uint32_t incl = runLen;
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1)
+    {
+      const uint32_t t = (uint32_t)__shfl_up((int)incl, d);
+      if (lane >= d) incl += t;
+    }
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull || total > want - op) { err = true; break; }
+    // every lane writes its packet: bytes up to the next 16-byte line of the output, whole lines, the rest
+    {
+      uint8_t *q = o + op + (incl - runLen);
+      uint32_t left = runLen;
+      const uint32_t vv = v * 0x01010101u;
+      const u32x4 line{ vv, vv, vv, vv };
+      while (left != 0u && (((uintptr_t)q & 15u) != 0u || left < 16u)) { *q++ = (uint8_t)v; left--; }
+      for (; left >= 16u; left -= 16u, q += 16) st128(q, line);
+      for (; left != 0u; left--) *q++ = (uint8_t)v;
+    }
+    op += total;
+    const uint32_t top = (F == ~0ull) ? 64u : (uint32_t)__builtin_clzll(~F);   // flagged lanes at the top of the window
+    carry = (top + ((top == 64u) ? carry : 0u)) & 1u;
+    pendSym = (uint32_t)__shfl((int)b, 63);
+  }
+  if (!err && (op != want || carry != 0u)) err = true;
+  if (err && lane == 0u && status) atomicOr(status, RLE8M_ERR_STREAM);
 }
 
 

@@ -170,7 +170,8 @@ def test_rle8m_decode_matches_the_oracle(hs, oracle):
     assert lib.rle8m_opencl_init(ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0))
     cases = [(mixed_runs(rng, 200000, alphabet=3), 64), (mixed_runs(rng, 70001, alphabet=256), 7), (single_symbol_mix(rng, 9000), 1),
              (bytes([5]) * 100000 + mixed_runs(rng, 3000), 16), (mixed_runs(rng, 333), 3), (bytes(range(256)) * 40 + b"\x00" * 5000, 33),
-             (mixed_runs(rng, 1 << 20, alphabet=4), 4096)]
+             (mixed_runs(rng, 1 << 20, alphabet=4), 4096),
+             (mixed_runs(rng, 1 << 20, alphabet=5), 200000), (single_symbol_mix(rng, 600000), 150000)]   # >= 131072 sections: one lane per section; below: one wave
     n = 0
     for data, sections in cases:
         st = oracle.rle8m_compress(sections, data)
