@@ -639,9 +639,15 @@ static int rle8m_encode_async(const void *dIn, uint32_t n, uint32_t sections, vo
   if (hipMemsetAsync(t, 0, sizeof(Rle8mTables), st) != hipSuccess || (dStatus && hipMemsetAsync(dStatus, 0, 4, st) != hipSuccess))
     return HSRLE_ERR_DEVICE;
   const uint32_t grid = (sections + 63u) / 64u;
-  hipLaunchKernelGGL(k_rle8m_stats, dim3(grid), dim3(64), 0, st, (const uint8_t *)dIn, n, sections, t);
+  // the statistics are over the whole input: one lane per 4 KiB piece, whatever the section count
+  const uint32_t pieces = (n / 4096u > sections) ? n / 4096u : sections;
+  hipLaunchKernelGGL(k_rle8m_stats, dim3((pieces + 63u) / 64u), dim3(64), 0, st, (const uint8_t *)dIn, n, pieces, t);
   hipLaunchKernelGGL(k_rle8m_info, dim3(1), dim3(256), 0, st, t, sections, (uint8_t *)dOut);
-  hipLaunchKernelGGL(k_rle8m_encode, dim3(grid), dim3(64), 0, st, (const uint8_t *)dIn, n, sections, (const Rle8mTables *)t, ws + p.w.offSlots, p.slotStride, sizes);
+  static const int forced = getenv("HSRLE_RLE8M_ENCODE") ? atoi(getenv("HSRLE_RLE8M_ENCODE")) : 0;   // 1 = lane, 2 = wave kernel (A/B runs)
+  if (forced ? forced == 2 : sections < kRle8mWaveBelow)
+    hipLaunchKernelGGL(k_rle8m_encode_wave, dim3(sections), dim3(64), 0, st, (const uint8_t *)dIn, n, sections, (const Rle8mTables *)t, ws + p.w.offSlots, p.slotStride, sizes);
+  else
+    hipLaunchKernelGGL(k_rle8m_encode, dim3(grid), dim3(64), 0, st, (const uint8_t *)dIn, n, sections, (const Rle8mTables *)t, ws + p.w.offSlots, p.slotStride, sizes);
   if (scan_sizes(sizes, sections, offsets, ws, p.w, st) != hipSuccess)
     return HSRLE_ERR_DEVICE;
   hipLaunchKernelGGL(k_rle8m_place, dim3((sections + 3u) / 4u), dim3(256), 0, st, (const uint8_t *)(ws + p.w.offSlots), p.slotStride, (const uint64_t *)offsets, (const Rle8mTables *)t,

@@ -321,6 +321,7 @@ struct Rle8mTables                          // device scratch shared by the kern
   uint32_t headerSize;
 };
 
+// (`sections` here is any partition of the input into pieces: the statistics are over the whole input)
 __global__ __launch_bounds__(64) void k_rle8m_stats(const uint8_t *__restrict__ d, uint32_t n, uint32_t sections, Rle8mTables *__restrict__ t)
 {
   __shared__ uint32_t prob[256], pcount[256];
@@ -479,6 +480,75 @@ __global__ __launch_bounds__(64) void k_rle8m_encode(const uint8_t *__restrict__
   for (uint32_t j = op & ~15u; j < op; j++)
     o[j] = (uint8_t)(((j & 8u) ? ahi : alo) >> (8u * (j & 7u)));
   sizes[k] = op;
+}
+
+// k_rle8m_encode with one WAVE per section (few, large sections).  The token grammar is position-parallel: a symbol without a repeat
+// code is its own token; within a maximal run of a flagged symbol -- cut at the section start and before the section's last byte, which
+// the reference's scan never reaches (range = left, j < range) -- tokens start every 255 bytes (count <= 254).  Every lane looks at one
+// byte, decides whether a token ENDS there (no token starts inside another, so emitting at the end keeps the order) and the count is the
+// distance to the run start modulo 255; run starts come from the ballot of the run breaks, offsets from a wave scan.
+__global__ __launch_bounds__(64) void k_rle8m_encode_wave(const uint8_t *__restrict__ d, uint32_t n, uint32_t sections, const Rle8mTables *__restrict__ t,
+                                                           uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes)
+{
+  __shared__ uint32_t rleBits[8];
+  __shared__ uint8_t order[256];
+  const uint32_t lane = threadIdx.x;
+  if (lane < 8u)
+  {
+    uint32_t v = 0;
+    for (uint32_t j = 0; j < 32u; j++) v |= (uint32_t)(t->rle[lane * 32u + j] != 0) << j;
+    rleBits[lane] = v;
+  }
+  for (uint32_t k = lane; k < 256u; k += 64u) order[k] = t->order[k];
+  __syncthreads();
+
+  const uint32_t k = blockIdx.x;
+  if (k >= sections)
+    return;
+  const uint32_t ss = n / sections;
+  const uint8_t *const p = d + (uint64_t)k * ss;
+  const uint32_t len = (k + 1u < sections) ? ss : n - ss * (sections - 1u);
+  uint8_t *const o = slots + (uint64_t)k * slotStride;
+
+  uint32_t op = 0, carryPrev = 0, carryRunStart = 0;
+  uint32_t bNext = (lane < len) ? (uint32_t)p[lane] : 0u;
+  for (uint32_t ip = 0; ip < len; ip += 64u)
+  {
+    const uint32_t pos = ip + lane;
+    const bool valid = pos < len;
+    const uint32_t b = bNext;
+    bNext = (pos + 64u < len) ? (uint32_t)p[pos + 64u] : 0u;
+    const uint32_t up = (uint32_t)__shfl_up((int)b, 1), down = (uint32_t)__shfl_down((int)b, 1), first = (uint32_t)__shfl((int)bNext, 0);
+    const uint32_t prevb = (lane == 0u) ? carryPrev : up;
+    const uint32_t nextb = (lane == 63u) ? first : down;
+    const bool brk = valid && (pos == 0u || b != prevb || pos == len - 1u);
+    const uint64_t B = __builtin_amdgcn_ballot_w64(brk);
+    const uint64_t mine = B & (~0ull >> (63u - lane));                   // breaks at or below this lane
+    const uint32_t runStart = mine ? ip + (63u - (uint32_t)__builtin_clzll(mine)) : carryRunStart;
+    const uint32_t rel = pos - runStart;
+    const bool fl = valid && ((rleBits[b >> 5] >> (b & 31u)) & 1u);
+    const bool nextBreaks = pos + 1u >= len - 1u || nextb != b;           // (the last byte of the section is a break)
+    const bool isEnd = valid && (!fl || pos == len - 1u || nextBreaks || (rel + 1u) % 255u == 0u);
+    const uint32_t outLen = isEnd ? (fl ? 2u : 1u) : 0u;
+    uint32_t incl = outLen;
+#pragma unroll
+    for (uint32_t dd = 1; dd < 64u; dd <<= 1)
+    {
+      const uint32_t x = (uint32_t)__shfl_up((int)incl, dd);
+      if (lane >= dd) incl += x;
+    }
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+    if (isEnd)
+    {
+      uint8_t *q = o + op + (incl - outLen);
+      q[0] = (uint8_t)b;
+      if (fl) q[1] = order[rel % 255u];
+    }
+    op += total;
+    carryPrev = (uint32_t)__shfl((int)b, 63);
+    carryRunStart = (uint32_t)__shfl((int)runStart, 63);
+  }
+  if (lane == 0u) sizes[k] = op;
 }
 
 // one wave per section: copy its staged stream behind the header; wave 0 of every workgroup of 4 also writes header fields
