@@ -1,4 +1,4 @@
-// hsrle_rle8m.hip.h -- decoder for rle8m streams: the low-entropy codec in its sub-sectioned form, the format of the reference's
+// hsrle_rle8m.hip.h -- decoder and encoder for rle8m streams: the low-entropy codec in its sub-sectioned form, the format of the reference's
 // own GPU path.
 //
 // Replaces: src/rle8_ocl.c:265-413 (rle8m_opencl_decompress: upload, one work-item per section, blocking read-back),
@@ -10,10 +10,11 @@
 // a byte sequence in which every flagged symbol is followed by the code of how many more of it follow (0..254; code = the count's
 // position in the symbol order); section k decodes to uncompressedSize / sections bytes (the last one to the remainder).
 //
-// One lane decodes one section (the reference's OpenCL kernel does the same with one work-item per section and byte accesses to
-// global memory); here the input is read through a 16-byte register window and the output is assembled in a 16-byte register
-// accumulator, so global memory only sees 16-byte accesses, and the two lookup tables live in LDS.  First-generation data path
-// (per-lane global access): the sections of neighbouring lanes are section-size apart.
+// Two forms of each direction.  Many small sections (>= 131072): one LANE per section, like the reference's OpenCL kernel (one
+// work-item per section, byte accesses to global memory) -- but the input comes through a per-lane LDS ring that all lanes of a wave
+// top up in the same loop trip (LaneRing, hsrle_common.hip.h) and the output is assembled in a 16-byte register accumulator, so global
+// memory only sees 16-byte accesses; the lookup tables live in LDS.  Fewer, larger sections: one WAVE per section, 64 stream bytes
+// per step (k_rle8m_decode_wave, k_rle8m_encode_wave): both grammars are position-parallel, see the kernels.
 #pragma once
 
 #include "hsrle_common.hip.h"
