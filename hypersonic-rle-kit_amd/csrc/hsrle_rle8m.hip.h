@@ -253,9 +253,18 @@ __global__ __launch_bounds__(64) void k_rle8m_decode_wave(const uint8_t *__restr
       uint32_t left = runLen;
       const uint32_t vv = v * 0x01010101u;
       const u32x4 line{ vv, vv, vv, vv };
-      while (left != 0u && (((uintptr_t)q & 15u) != 0u || left < 16u)) { *q++ = (uint8_t)v; left--; }
+      // at most four stores up to the next 16-byte line, whole lines, at most four stores for the rest (a byte loop here was most
+      // of the kernel's instructions)
+      const uint64_t v8 = (uint64_t)vv * 0x0000000100000001ull;
+      if (((uintptr_t)q & 1u) && left >= 1u) { *q = (uint8_t)v; q += 1; left -= 1u; }
+      if (((uintptr_t)q & 2u) && left >= 2u) { st16(q, vv & 0xFFFFu); q += 2; left -= 2u; }
+      if (((uintptr_t)q & 4u) && left >= 4u) { st32(q, vv); q += 4; left -= 4u; }
+      if (((uintptr_t)q & 8u) && left >= 8u) { st64(q, v8); q += 8; left -= 8u; }
       for (; left >= 16u; left -= 16u, q += 16) st128(q, line);
-      for (; left != 0u; left--) *q++ = (uint8_t)v;
+      if (left & 8u) { st64(q, v8); q += 8; }
+      if (left & 4u) { st32(q, vv); q += 4; }
+      if (left & 2u) { st16(q, vv & 0xFFFFu); q += 2; }
+      if (left & 1u) *q = (uint8_t)v;
     }
     op += total;
     const uint32_t top = (F == ~0ull) ? 64u : (uint32_t)__builtin_clzll(~F);   // flagged lanes at the top of the window
