@@ -245,7 +245,7 @@ __global__ __launch_bounds__(64) void k_rle8m_decode_wave(const uint8_t *__restr
       const uint32_t t = (uint32_t)__shfl_up((int)incl, d);
       if (lane >= d) incl += t;
     }
-    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     if (__builtin_amdgcn_ballot_w64(bad) != 0ull || total > want - op) { err = true; break; }
     // every lane writes its packet: bytes up to the next 16-byte line of the output, whole lines, the rest
     {
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(64) void k_rle8m_decode_wave(const uint8_t *__restr
     op += total;
     const uint32_t top = (F == ~0ull) ? 64u : (uint32_t)__builtin_clzll(~F);   // flagged lanes at the top of the window
     carry = (top + ((top == 64u) ? carry : 0u)) & 1u;
-    pendSym = (uint32_t)__shfl((int)b, 63);
+    pendSym = (uint32_t)__builtin_amdgcn_readlane((int)b, 63);
   }
   if (!err && (op != want || carry != 0u)) err = true;
   if (err && lane == 0u && status) atomicOr(status, RLE8M_ERR_STREAM);
@@ -539,24 +539,19 @@ __global__ __launch_bounds__(64) void k_rle8m_encode_wave(const uint8_t *__restr
     const bool fl = valid && ((rleBits[b >> 5] >> (b & 31u)) & 1u);
     const bool nextBreaks = pos + 1u >= len - 1u || nextb != b;           // (the last byte of the section is a break)
     const bool isEnd = valid && (!fl || pos == len - 1u || nextBreaks || (rel + 1u) % 255u == 0u);
-    const uint32_t outLen = isEnd ? (fl ? 2u : 1u) : 0u;
-    uint32_t incl = outLen;
-#pragma unroll
-    for (uint32_t dd = 1; dd < 64u; dd <<= 1)
-    {
-      const uint32_t x = (uint32_t)__shfl_up((int)incl, dd);
-      if (lane >= dd) incl += x;
-    }
-    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+    // a token is one byte, or two with a repeat code: the offsets are population counts of the lanes below (no scan needed)
+    const uint64_t E = __builtin_amdgcn_ballot_w64(isEnd), E2 = __builtin_amdgcn_ballot_w64(isEnd && fl);
+    const uint32_t off = __builtin_amdgcn_mbcnt_hi((uint32_t)(E >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)E, 0u)) +
+                         __builtin_amdgcn_mbcnt_hi((uint32_t)(E2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)E2, 0u));
     if (isEnd)
     {
-      uint8_t *q = o + op + (incl - outLen);
+      uint8_t *q = o + op + off;
       q[0] = (uint8_t)b;
       if (fl) q[1] = order[rel % 255u];
     }
-    op += total;
-    carryPrev = (uint32_t)__shfl((int)b, 63);
-    carryRunStart = (uint32_t)__shfl((int)runStart, 63);
+    op += (uint32_t)__builtin_popcountll(E) + (uint32_t)__builtin_popcountll(E2);
+    carryPrev = (uint32_t)__builtin_amdgcn_readlane((int)b, 63);
+    carryRunStart = (uint32_t)__builtin_amdgcn_readlane((int)runStart, 63);
   }
   if (lane == 0u) sizes[k] = op;
 }
