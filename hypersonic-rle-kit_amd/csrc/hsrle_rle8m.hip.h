@@ -210,6 +210,14 @@ __global__ __launch_bounds__(64) void k_rle8m_decode_wave(const uint8_t *__restr
     bNext = (pos + 64u < end) ? (uint32_t)s[pos + 64u] : 0u;              // the next window is on its way while this one is decoded
     const bool fl = valid && ((rleBits[b >> 5] >> (b & 31u)) & 1u);
     const uint64_t F = __builtin_amdgcn_ballot_w64(fl);
+    if (F == 0ull && carry == 0u)                                         // no repeat code in this window: its bytes are the output
+    {
+      const uint32_t nv = (end - ip < 64u) ? end - ip : 64u;
+      if (nv > want - op) { err = true; break; }
+      if (valid) o[op + lane] = (uint8_t)b;
+      op += nv;
+      continue;
+    }
     // length of the run of flagged lanes right below this lane
     uint32_t below = 0;
     if (lane != 0u)
@@ -528,6 +536,7 @@ __global__ __launch_bounds__(64) void k_rle8m_encode_wave(const uint8_t *__restr
     const bool valid = pos < len;
     const uint32_t b = bNext;
     bNext = (pos + 64u < len) ? (uint32_t)p[pos + 64u] : 0u;
+    const bool fl = valid && ((rleBits[b >> 5] >> (b & 31u)) & 1u);
     const uint32_t up = (uint32_t)__shfl_up((int)b, 1), down = (uint32_t)__shfl_down((int)b, 1), first = (uint32_t)__shfl((int)bNext, 0);
     const uint32_t prevb = (lane == 0u) ? carryPrev : up;
     const uint32_t nextb = (lane == 63u) ? first : down;
@@ -536,7 +545,6 @@ __global__ __launch_bounds__(64) void k_rle8m_encode_wave(const uint8_t *__restr
     const uint64_t mine = B & (~0ull >> (63u - lane));                   // breaks at or below this lane
     const uint32_t runStart = mine ? ip + (63u - (uint32_t)__builtin_clzll(mine)) : carryRunStart;
     const uint32_t rel = pos - runStart;
-    const bool fl = valid && ((rleBits[b >> 5] >> (b & 31u)) & 1u);
     const bool nextBreaks = pos + 1u >= len - 1u || nextb != b;           // (the last byte of the section is a break)
     const bool isEnd = valid && (!fl || pos == len - 1u || nextBreaks || (rel + 1u) % 255u == 0u);
     // a token is one byte, or two with a repeat code: the offsets are population counts of the lanes below (no scan needed)
