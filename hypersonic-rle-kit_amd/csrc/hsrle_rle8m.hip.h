@@ -10,7 +10,7 @@
 // a byte sequence in which every flagged symbol is followed by the code of how many more of it follow (0..254; code = the count's
 // position in the symbol order); section k decodes to uncompressedSize / sections bytes (the last one to the remainder).
 //
-// Two forms of each direction.  Many small sections (>= 131072): one LANE per section, like the reference's OpenCL kernel (one
+// Two forms of each direction (the choice is made in hsrle_capi.hip).  Many small sections: one LANE per section, like the reference's OpenCL kernel (one
 // work-item per section, byte accesses to global memory) -- but the input comes through a per-lane LDS ring that all lanes of a wave
 // top up in the same loop trip (LaneRing, hsrle_common.hip.h) and the output is assembled in a 16-byte register accumulator, so global
 // memory only sees 16-byte accesses; the lookup tables live in LDS.  Fewer, larger sections: one WAVE per section, 64 stream bytes
@@ -51,12 +51,16 @@ __device__ __forceinline__ uint32_t rle8m_tables(const uint8_t *__restrict__ s, 
       listed[sym] = 1;
     }
     __syncthreads();
-    if (lane == 0u)
     {
-      uint32_t next = listedCount;                                       // the symbols that are not listed take the remaining counts in ascending order
-      for (uint32_t k = 0; k < 256u; k++)
-        if (!listed[k]) codeToCount[k] = (uint8_t)next++;
-      hdr[0] = (uint32_t)(info + 33u + listedCount);
+      uint32_t next = listedCount;                                       // the symbols that are not listed take the remaining counts in ascending order:
+      for (uint32_t c = 0; c < 256u; c += 64u)                           // 64 symbols per step, ranks from the ballot of the unlisted ones
+      {
+        const bool unl = !listed[c + lane];
+        const uint64_t m = __builtin_amdgcn_ballot_w64(unl);
+        if (unl) codeToCount[c + lane] = (uint8_t)(next + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)));
+        next += (uint32_t)__builtin_popcountll(m);
+      }
+      if (lane == 0u) hdr[0] = (uint32_t)(info + 33u + listedCount);
     }
   }
   else if (lane == 0u)
