@@ -339,6 +339,7 @@ struct Rle8mTables                          // device scratch shared by the kern
 {
   uint32_t prob[256], pcount[256];
   uint8_t rle[256], order[256];
+  uint32_t rleBits[8];                      // rle[] as a bitmap (bit b of word b / 32), what the encode kernels read
   uint32_t listed;                          // symbols written to the header (1..255; 256 are written as 255, sic)
   uint32_t headerSize;
 };
@@ -423,6 +424,12 @@ __global__ __launch_bounds__(256) void k_rle8m_info(Rle8mTables *__restrict__ t,
     for (uint32_t j = 0; j < 8u; j++) v |= (uint32_t)flag[i * 8u + j] << j;
     out[info + i] = (uint8_t)v;
   }
+  if (i < 8u)
+  {
+    uint32_t v = 0;
+    for (uint32_t j = 0; j < 32u; j++) v |= (uint32_t)flag[i * 32u + j] << j;
+    t->rleBits[i] = v;
+  }
   if (i == 0u)
   {
     out[info + 32u] = (uint8_t)used;
@@ -436,16 +443,11 @@ __global__ __launch_bounds__(64) void k_rle8m_encode(const uint8_t *__restrict__
                                                       uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes)
 {
   __shared__ uint32_t rleBits[8];
-  __shared__ uint8_t order[256];
+  __shared__ __attribute__((aligned(4))) uint8_t order[256];
   __shared__ __attribute__((aligned(16))) uint8_t ring[64 * kLaneRingStride];
   const uint32_t lane = threadIdx.x;
-  if (lane < 8u)
-  {
-    uint32_t v = 0;
-    for (uint32_t j = 0; j < 32u; j++) v |= (uint32_t)(t->rle[lane * 32u + j] != 0) << j;
-    rleBits[lane] = v;
-  }
-  for (uint32_t k = lane; k < 256u; k += 64u) order[k] = t->order[k];
+  if (lane < 8u) rleBits[lane] = t->rleBits[lane];
+  reinterpret_cast<uint32_t *>(order)[lane] = reinterpret_cast<const uint32_t *>(t->order)[lane];   // 64 lanes x 4 bytes
   __syncthreads();
 
   const uint32_t k = blockIdx.x * 64u + lane;
@@ -513,15 +515,10 @@ __global__ __launch_bounds__(64) void k_rle8m_encode_wave(const uint8_t *__restr
                                                            uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes)
 {
   __shared__ uint32_t rleBits[8];
-  __shared__ uint8_t order[256];
+  __shared__ __attribute__((aligned(4))) uint8_t order[256];
   const uint32_t lane = threadIdx.x;
-  if (lane < 8u)
-  {
-    uint32_t v = 0;
-    for (uint32_t j = 0; j < 32u; j++) v |= (uint32_t)(t->rle[lane * 32u + j] != 0) << j;
-    rleBits[lane] = v;
-  }
-  for (uint32_t k = lane; k < 256u; k += 64u) order[k] = t->order[k];
+  if (lane < 8u) rleBits[lane] = t->rleBits[lane];
+  reinterpret_cast<uint32_t *>(order)[lane] = reinterpret_cast<const uint32_t *>(t->order)[lane];   // 64 lanes x 4 bytes
   __syncthreads();
 
   const uint32_t k = blockIdx.x;
