@@ -272,7 +272,8 @@ int hsrle_device_count(void);
 /* ---------------------------------------------------------------------------------------------------------- */
 /* rle8m: the reference's own GPU decode path.  `rle8m_opencl_*` are the names of      */
 /* src/rle.h:464-466 (src/rle8_ocl.c:56, :185, :265); `rle8m_decompress` is the CPU twin of the same format   */
-/* (src/rle.h:63, src/rle8_low_entropy_cpu.c:193-250).  Host pointers; one lane decodes one sub-section.      */
+/* (src/rle.h:63, src/rle8_low_entropy_cpu.c:193-250).  Host pointers; one wave (few or large sub-sections)  */
+/* or one lane (many small ones) decodes one sub-section.                                                     */
 bool rle8m_opencl_init(const size_t inputDataSize, const size_t outputDataSize, const size_t maxSubsectionCount);
 void rle8m_opencl_destroy(void);
 uint32_t rle8m_opencl_decompress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize);
