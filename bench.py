@@ -112,6 +112,42 @@ def cpu_baseline(container_prefix, n_blocks, block_size, codec_key, expect):
     return res
 
 
+def spawn_ranks(n, result_fd):
+    """Start n ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, the contract of torch.distributed.run)
+    from a parent that never touches the GPU; rank 0's stdout (the one JSON line) is relayed to the parent's stdout."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    # a rank that dies leaves the others waiting in a collective: poll, and end exactly the processes started here when one fails
+    import threading
+
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            failed = True
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.2)
+    codes = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    if out0 and out0[0] and not failed:
+        os.write(result_fd, out0[0])
+    return 1 if failed else max(abs(c) for c in codes)
+
+
 def main():
     # stdout carries exactly ONE line: the JSON result of rank 0.  Libraries print to fd 1 too (RCCL prints its version banner
     # there when a communicator is created), so everything else is sent to stderr for the lifetime of the process.
@@ -130,11 +166,24 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
 
-    import torch
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process becomes the launcher.  It has not touched the GPU (no torch import,
+        # no HIP call) and never will: it starts N children of this same script, one rank per GPU, relays rank 0's JSON line and exits
+        # with the worst child's code.  (Children are ordinary child processes: nothing that has initialised the GPU is ever exec'd.)
+        sys.exit(spawn_ranks(args.gpus, result_fd))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or without a launcher)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("HSRLE_BENCH_DRYRUN") == "1":   # launcher plumbing check (tests/test_bench_launcher.py): no GPU is touched
+        if rank == 0:
+            os.write(result_fd, (json.dumps({"dryrun": True, "n_gpus": world, "master": os.environ.get("MASTER_ADDR")}) + "\n").encode())
+        return
+
+    import torch
+
     assert torch.cuda.is_available(), "bench.py needs a GPU (the library has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -143,6 +192,12 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if "MASTER_ADDR" not in os.environ:   # HSRLE_FORCE_DIST=1 on one GPU without a launcher: a world of one
+            import socket
+
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s.getsockname()[1]), RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
 
     import hsrle

@@ -1,0 +1,70 @@
+"""hsrle.dist over RCCL (backend "nccl") on the hardware that is there: a world of ONE rank on a 1-GPU box.
+It runs in a child process so that the process group never meets pytest's own process.  Covered: RCCL init, the all_gather of the
+per-rank (blocks, payload) pairs, gather == the local container, scatter(gather(x)) == x, decode of the scattered container, and the
+point-to-point piece path (a transfer above 1 GiB is cut into <= 1 GiB messages: hsrle/dist.py `_pieces`) as a self send/recv."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import json, os, socket, sys, time
+sys.path.insert(0, os.path.join(%(repo)r, "hypersonic-rle-kit_amd", "python"))
+import torch, torch.distributed as dist
+s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=dev)
+import hsrle
+from hsrle import dist as hd
+res = {}
+size = (1 << 30) + (1 << 28) + 4096 * 3 + 77          # payload of the incompressible buffer > 1 GiB: two pieces
+for name, kind in (("runs", hsrle.SYNTH_RUNS), ("noise", None)):
+    if kind is None:
+        g = torch.Generator(device=dev); g.manual_seed(7)
+        src = torch.randint(0, 256, (size,), dtype=torch.uint8, device=dev, generator=g)
+    else:
+        src = hsrle.synth(kind, 1, 101, size, device=dev)
+    container, info = hsrle.compress("rle8_packed_multi", src, block_size=4096)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    full = hd.gather_container(container, size, root=0)
+    torch.cuda.synchronize(); res["gather_ms_" + name] = (time.perf_counter() - t0) * 1e3
+    assert torch.equal(full, container[: full.numel()]), "gather of one rank differs from its own container"
+    back = hd.scatter_container(full, root=0)
+    assert torch.equal(back, full), "scatter(gather(x)) != x"
+    out = hsrle.decompress(back)
+    assert torch.equal(out, src)
+    res["payload_" + name] = int(info.payloadSize)
+    # the point-to-point path on one device: a self send/recv of the whole payload, cut into <= 1 GiB pieces like gather/scatter do
+    p0 = info.payload_start
+    pay = container[p0 : p0 + info.payloadSize]
+    dst = torch.zeros_like(pay)
+    ops = hd._pieces(dist.isend, pay, 0, None) + hd._pieces(dist.irecv, dst, 0, None)
+    res["pieces_" + name] = len(ops) // 2
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    hd._p2p(ops)
+    torch.cuda.synchronize(); res["self_p2p_ms_" + name] = (time.perf_counter() - t0) * 1e3
+    assert torch.equal(dst, pay), "self send/recv changed the payload"
+    del src, container, full, back, out, dst
+dist.destroy_process_group()
+print("RESULT " + json.dumps(res))
+"""
+
+
+@pytest.mark.gpu
+def test_rccl_world_of_one_gather_scatter_and_pieces():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", CHILD % {"repo": REPO}], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    res = json.loads(line[7:])
+    assert res["pieces_noise"] == 2 and res["payload_noise"] > (1 << 30)   # the > 1 GiB transfer really was cut
+    out = os.path.join(REPO, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "rccl_world1.json"), "w") as f:
+            json.dump(res, f, indent=1)
