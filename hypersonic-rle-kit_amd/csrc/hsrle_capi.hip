@@ -7,7 +7,10 @@
 
 #include "hsrle_common.hip.h"
 #include "hsrle_launch.h"
+#include "hsrle_index.hip.h"
 #include "hsrle_rle8m.hip.h"
+
+#include <stdlib.h>
 
 #include <mutex>
 #include <string.h>
@@ -46,18 +49,19 @@ static inline uint32_t codec_header_size(int c) { return (c < 6 && !codec_is_lut
 
 static DecodeLaunch g_dec[kCodecCount];
 static EncodeLaunch g_enc[kCodecCount];
+static IndexLaunch g_idx[kCodecCount];
 static std::once_flag g_tableOnce;
 
 static void init_tables()
 {
   std::call_once(g_tableOnce, [] {
-    register_w8(g_dec, g_enc);
-    register_w16(g_dec, g_enc);
-    register_w24(g_dec, g_enc);
-    register_w32(g_dec, g_enc);
-    register_w48(g_dec, g_enc);
-    register_w64(g_dec, g_enc);
-    register_w128(g_dec, g_enc);
+    register_w8(g_dec, g_enc, g_idx);
+    register_w16(g_dec, g_enc, g_idx);
+    register_w24(g_dec, g_enc, g_idx);
+    register_w32(g_dec, g_enc, g_idx);
+    register_w48(g_dec, g_enc, g_idx);
+    register_w64(g_dec, g_enc, g_idx);
+    register_w128(g_dec, g_enc, g_idx);
   });
 }
 
@@ -289,8 +293,8 @@ struct DeviceState
   int deviceChecked = 0; // 0 = not yet, 1 = ok, -1 = no device
   void *ws = nullptr;    // cached compression workspace
   uint64_t wsSize = 0;
-  void *monoIn = nullptr, *monoOut = nullptr, *monoAux = nullptr; // staging of the drop-in (host pointer) path
-  uint64_t monoInSize = 0, monoOutSize = 0;
+  void *monoIn = nullptr, *monoOut = nullptr, *monoAux = nullptr, *monoWs = nullptr; // staging of the drop-in (host pointer) path
+  uint64_t monoInSize = 0, monoOutSize = 0, monoWsSize = 0;
 };
 
 static DeviceState g_dev;
@@ -470,7 +474,177 @@ static int decompress_blocks_async(const void *dContainer, const hsrle_container
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// drop-in (host pointer, monolithic stream) path: one block spanning the whole input.
+// monolithic stream decode: index passes (hsrle_index.hip.h) + the block kernel started from entry records
+
+// symbol-state slots of the codec's decoder (IndexState<FAM>::KE): 0 plain / Single / 0-symbol Short, 1 Packed / 1-symbol list, 3, 7
+static int codec_state_slots(int c)
+{
+  static const int byVariant[8] = { 0, 1, 3, 7, 0, 1, 3, 7 };
+  if (c < 6) { static const int k8[6] = { 0, 1, 3, 7, 0, 1 }; return k8[c]; }
+  if (c < 46) return byVariant[(c - 6) & 7];
+  if (c < 50) return (c & 1) ? 1 : 0;                      // 46 sym, 47 sym_packed, 48 byte, 49 byte_packed
+  if (c < kShortBaseW) return byVariant[c - kShortBase8];
+  if (c < kGreedyBase) return byVariant[(c - kShortBaseW) & 7];
+  if (c < kSingleShort) { static const int kg[3] = { 1, 3, 7 }; return kg[(c - kGreedyBase) % 3]; }
+  return 0;
+}
+
+struct MonoPlan
+{
+  uint32_t G, M, B, R, KE;
+  uint64_t nb;
+  uint64_t offG, offE, offOlen, offT, offEntry, offOutStart, offStateIn, offFix, offList, offCtrl, offRec, total;
+};
+
+static uint32_t pow2_floor(uint64_t v) { uint32_t r = 1; while ((uint64_t)r * 2u <= v) r *= 2u; return r; }
+static uint32_t env_u32(const char *name, uint32_t dflt) { const char *e = getenv(name); return (e && *e) ? (uint32_t)strtoul(e, nullptr, 10) : dflt; }
+
+static uint32_t g_monoTune[3] = { env_u32("HSRLE_MONO_BLOCK", 0), env_u32("HSRLE_MONO_REGION", 0), env_u32("HSRLE_MONO_LOOKBACK", 0) };
+
+static MonoPlan plan_mono(int codec, uint32_t U, uint32_t C, uint32_t p0)
+{
+  MonoPlan m;
+  // output bytes per decode lane: enough lanes to fill the GPU (>= 2^18 where the stream allows it), at most the container's 4 KiB
+  uint32_t B = pow2_floor((uint64_t)U >> 18);
+  B = B < 256u ? 256u : (B > 4096u ? 4096u : B);
+  // stream bytes per index lane, and the look-back of its entry guess
+  uint32_t G = pow2_floor((uint64_t)C >> 15);
+  G = G < 2048u ? 2048u : (G > 8192u ? 8192u : G);
+  const uint32_t tB = g_monoTune[0], tG = g_monoTune[1], tM = g_monoTune[2];   // tuning / test knobs (hsrle_mono_tuning, HSRLE_MONO_* in the environment)
+  if (tB >= 128u && tB <= (1u << 20) && (tB % 128u) == 0u) B = tB;
+  if (tG >= 32u && tG <= (1u << 24)) G = tG;
+  m.B = B; m.G = G;
+  m.M = tM ? tM : 1024u;
+  m.R = (uint32_t)(((uint64_t)(C - p0) + G - 1u) / G);
+  if (m.R == 0u) m.R = 1u;
+  m.KE = (uint32_t)codec_state_slots(codec);
+  m.nb = ((uint64_t)U + B - 1u) / B;
+  const uint64_t ks = m.KE ? m.KE : 1u;
+  uint64_t at = 0;
+  m.offG = at; at += align_up(4ull * m.R, 256);
+  m.offE = at; at += align_up(4ull * m.R, 256);
+  m.offOlen = at; at += align_up(8ull * m.R, 256);
+  m.offT = at; at += align_up(4ull * m.R * ks, 256);
+  m.offEntry = at; at += align_up(4ull * m.R, 256);
+  m.offOutStart = at; at += align_up(8ull * m.R, 256);
+  m.offStateIn = at; at += align_up(4ull * m.R * ks, 256);
+  m.offFix = at; at += align_up(4ull * m.R, 256);
+  m.offList = at; at += align_up(4ull * m.R, 256);
+  m.offCtrl = at; at += 256;
+  m.offRec = at; at += align_up(4ull * kEntryRecDwords * m.nb, 256);
+  m.total = at;
+  return m;
+}
+
+static hipError_t launch_resolve(const MonoPlan &m, uint8_t *ws, uint32_t p0, uint64_t U, hipStream_t st)
+{
+#define HSRLE_RESOLVE(KE)                                                                                                                                        \
+  hipLaunchKernelGGL(k_index_resolve<KE>, dim3(1), dim3(kResolveThreads), 0, st, (const uint32_t *)(ws + m.offG), (const uint32_t *)(ws + m.offE),               \
+                     (const uint64_t *)(ws + m.offOlen), (const uint32_t *)(ws + m.offT), m.R, p0, m.G, U, (uint32_t *)(ws + m.offEntry),                         \
+                     (uint64_t *)(ws + m.offOutStart), (uint32_t *)(ws + m.offStateIn), (uint32_t *)(ws + m.offFix), (uint32_t *)(ws + m.offList),                \
+                     (uint32_t *)(ws + m.offCtrl))
+  switch (m.KE)
+  {
+  case 0: HSRLE_RESOLVE(0); break;
+  case 1: HSRLE_RESOLVE(1); break;
+  case 3: HSRLE_RESOLVE(3); break;
+  default: HSRLE_RESOLVE(7); break;
+  }
+#undef HSRLE_RESOLVE
+  return hipGetLastError();
+}
+
+// what the first bytes of a stream say (reference: rle8_extreme_cpu.h:704-712, :759-760, rleX_extreme_cpu.h:84-91, rleX_Xsl.h:1850-1858)
+struct MonoHeader
+{
+  uint32_t U, C, p0, single, singleSym;
+  int codec;   // the id whose kernels decode it (Single mode streams of ids 0 / 1 -> ids 4 / 5)
+};
+
+static bool mono_header(int codec, const uint8_t *h16, uint32_t inSize, uint32_t outSize, MonoHeader *mh)
+{
+  if (codec < 0 || codec >= kCodecCount)
+    return false;
+  const uint32_t hs = codec_header_size(codec);
+  if (inSize < hs)
+    return false;
+  memcpy(&mh->U, h16, 4);
+  memcpy(&mh->C, h16 + 4, 4);
+  if (mh->U > outSize || mh->C > inSize)
+    return false;
+  if (hs == 9 && h16[8] > 1) // unknown mode (rle8_extreme_cpu.h:759-760)
+    return false;
+  mh->single = 0; mh->singleSym = 0; mh->p0 = hs; mh->codec = codec;
+  if (hs == 9 && h16[8] == 1)
+  {
+    // rle8_decompress / rle8_packed_decompress switch on the mode byte (rle8_extreme_cpu.h:702-764): Single mode -> the general kernel
+    if (codec == HSRLE_RLE8_MULTI || codec == HSRLE_RLE8_PACKED_MULTI) mh->codec = codec + 4;
+    mh->single = 1; mh->singleSym = h16[9]; mh->p0 = 10;
+  }
+  else if (codec == kSingleShort) { mh->singleSym = h16[8]; mh->p0 = 9; }   // rleX_Xsl_short.h:1211-1216
+  if (mh->U == 0 || mh->C < mh->p0 + 2u || mh->C > 0x7FFFFF00u)
+    return false;
+  return true;
+}
+
+// dStream: 128-byte aligned, readable up to C + 64.  stats (optional): [0] regions, [1] repair rounds, [2] regions walked again.
+// Synchronises the stream (the repair loop reads the resolve pass's verdict).  Returns HSRLE_OK / HSRLE_ERR_FORMAT / HSRLE_ERR_DEVICE.
+static int mono_decode_dev(const MonoHeader &mh, const uint8_t *dStream, uint8_t *dOut, uint8_t *ws, const MonoPlan &m, uint32_t *stats, hipStream_t st)
+{
+  init_tables();
+  if (!g_dec[mh.codec] || !g_idx[mh.codec])
+    return HSRLE_ERR_UNSUPPORTED;
+  uint32_t *ctrl = (uint32_t *)(ws + m.offCtrl);
+  if (hipMemsetAsync(ctrl, 0, 256, st) != hipSuccess || hipMemsetAsync(ws + m.offRec, 0, 4ull * kEntryRecDwords * m.nb, st) != hipSuccess)
+    return HSRLE_ERR_DEVICE;
+
+  IndexArgs ia{};
+  ia.stream = dStream; ia.C = mh.C; ia.p0 = mh.p0; ia.G = m.G; ia.M = m.M; ia.R = m.R; ia.single = mh.single; ia.singleSym = mh.singleSym;
+  ia.list = nullptr; ia.listCount = 0; ia.fix = (const uint32_t *)(ws + m.offFix);
+  ia.g = (uint32_t *)(ws + m.offG); ia.e = (uint32_t *)(ws + m.offE); ia.olen = (uint64_t *)(ws + m.offOlen); ia.t = (uint32_t *)(ws + m.offT);
+  ia.entry = (const uint32_t *)(ws + m.offEntry); ia.outStart = (const uint64_t *)(ws + m.offOutStart); ia.stateIn = (const uint32_t *)(ws + m.offStateIn);
+  ia.U = mh.U; ia.B = m.B; ia.rec = (uint32_t *)(ws + m.offRec);
+
+  if (g_idx[mh.codec](ia, 0, st) != hipSuccess)
+    return HSRLE_ERR_DEVICE;
+  uint32_t rounds = 0, rewalked = 0;
+  uint32_t verdict[4] = { 0, 0, 0, 0 };
+  for (;;)
+  {
+    if (launch_resolve(m, ws, mh.p0, mh.U, st) != hipSuccess)
+      return HSRLE_ERR_DEVICE;
+    if (hipMemcpyAsync(verdict, ctrl, sizeof(verdict), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+      return HSRLE_ERR_DEVICE;
+    if (verdict[0] == 0u)
+      break;
+    if (rounds++ > m.R)                                    // every round proves at least one more region: cannot happen
+      return HSRLE_ERR_DEVICE;
+    rewalked += verdict[0];
+    ia.list = (const uint32_t *)(ws + m.offList); ia.listCount = verdict[0];
+    if (g_idx[mh.codec](ia, 0, st) != hipSuccess)
+      return HSRLE_ERR_DEVICE;
+  }
+  if (stats) { stats[0] = m.R; stats[1] = rounds; stats[2] = rewalked; }
+  if (verdict[1] != 0u)
+    return HSRLE_ERR_FORMAT;
+
+  ia.list = nullptr; ia.listCount = 0;
+  if (g_idx[mh.codec](ia, 1, st) != hipSuccess)
+    return HSRLE_ERR_DEVICE;
+  uint32_t *dStatus = ctrl + 8;
+  DecodeArgs da{ dStream, nullptr, dStream + mh.C + HSRLE_CONTAINER_TAIL_PAD, dOut, mh.U, m.B, 0u, (uint32_t)m.nb, dStatus };
+  da.entries = (const uint32_t *)(ws + m.offRec);
+  da.streamLen = mh.C;
+  if (g_dec[mh.codec](da, st) != hipSuccess)
+    return HSRLE_ERR_DEVICE;
+  uint32_t status = 1;
+  if (hipMemcpyAsync(&status, dStatus, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+    return HSRLE_ERR_DEVICE;
+  return status == 0u ? HSRLE_OK : HSRLE_ERR_FORMAT;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// drop-in (host pointer, monolithic stream) path.  Decode: index + block kernel (above).  Encode: one block spanning the whole input.
 
 static uint32_t mono_compress(int codec, const uint8_t *pIn, uint32_t inSize, uint8_t *pOut, uint32_t outSize)
 {
@@ -513,58 +687,26 @@ static uint32_t mono_decompress(int codec, const uint8_t *pIn, uint32_t inSize, 
   // argument + header checks of the reference (rle8_extreme_cpu.h:704-712, rleX_extreme_cpu.h:84-91, rleX_Xsl.h:1850-1858)
   if (pIn == nullptr || pOut == nullptr || inSize == 0 || outSize == 0)
     return 0;
-  if (codec < 0 || codec >= kCodecCount)
+  if (codec < 0 || codec >= kCodecCount || inSize < codec_header_size(codec))
     return 0;
-  const uint32_t hs = codec_header_size(codec);
-  if (inSize < hs)
-    return 0;
-
-  uint32_t U, C;
-  memcpy(&U, pIn, 4);
-  memcpy(&C, pIn + 4, 4);
-
-  if (U > outSize || C > inSize)
-    return 0;
-  if (hs == 9 && pIn[8] > 1) // unknown mode (rle8_extreme_cpu.h:759-760)
-    return 0;
-  if (hs == 9 && pIn[8] == 1 && (codec == HSRLE_RLE8_MULTI || codec == HSRLE_RLE8_PACKED_MULTI))
-    codec += 4;              // rle8_decompress / rle8_packed_decompress switch on the mode byte (rle8_extreme_cpu.h:702-764): Single mode -> the general kernel
-  if (U == 0 || C < hs || !device_ok())
+  uint8_t h16[16] = { 0 };
+  memcpy(h16, pIn, inSize < 16u ? inSize : 16u);
+  MonoHeader mh;
+  if (!mono_header(codec, h16, inSize, outSize, &mh) || !device_ok())
     return 0;
 
-  init_tables();
-  if (!g_dec[codec])
-    return 0;
-
+  const MonoPlan m = plan_mono(mh.codec, mh.U, mh.C, mh.p0);
   std::lock_guard<std::mutex> lock(g_dev.mu);
-  if (!grow(&g_dev.monoIn, &g_dev.monoInSize, (uint64_t)C + 64) || !grow(&g_dev.monoOut, &g_dev.monoOutSize, (uint64_t)U + 64))
+  if (!grow(&g_dev.monoIn, &g_dev.monoInSize, (uint64_t)mh.C + 256) || !grow(&g_dev.monoOut, &g_dev.monoOutSize, (uint64_t)mh.U + 64) ||
+      !grow(&g_dev.monoWs, &g_dev.monoWsSize, m.total))
     return 0;
-  if (!g_dev.monoAux && hipMalloc(&g_dev.monoAux, 256) != hipSuccess)
+  if (hipMemcpy(g_dev.monoIn, pIn, mh.C, hipMemcpyHostToDevice) != hipSuccess || hipMemset((uint8_t *)g_dev.monoIn + mh.C, 0, 128) != hipSuccess)
     return 0;
-
-  uint8_t *aux = (uint8_t *)g_dev.monoAux;
-  const uint64_t table[2] = { 0, C };
-  uint32_t zero = 0;
-  if (hipMemcpy(g_dev.monoIn, pIn, C, hipMemcpyHostToDevice) != hipSuccess || hipMemset((uint8_t *)g_dev.monoIn + C, 0, 64) != hipSuccess ||
-      hipMemcpy(aux, table, sizeof(table), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(aux + 64, &zero, 4, hipMemcpyHostToDevice) != hipSuccess)
+  if (mono_decode_dev(mh, (const uint8_t *)g_dev.monoIn, (uint8_t *)g_dev.monoOut, (uint8_t *)g_dev.monoWs, m, nullptr, nullptr) != HSRLE_OK)
     return 0;
-
-  // one block of (rounded-up) size: the kernel clips everything to U
-  const uint32_t B = (U > HSRLE_MAX_BLOCK_SIZE - 128u) ? HSRLE_MAX_BLOCK_SIZE : (uint32_t)align_up(U, 128);
-  if (U > B)
-    return 0; // a single stream above 1 GiB cannot come from the reference encoder (rle_compress_bounds)
-
-  DecodeArgs da{ (const uint8_t *)g_dev.monoIn, (const uint64_t *)aux, (const uint8_t *)g_dev.monoIn + C + HSRLE_CONTAINER_TAIL_PAD, (uint8_t *)g_dev.monoOut, U, B, 0u, 1u,
-                 (uint32_t *)(aux + 64) };
-  if (g_dec[codec](da, nullptr) != hipSuccess)
+  if (hipMemcpy(pOut, g_dev.monoOut, mh.U, hipMemcpyDeviceToHost) != hipSuccess)
     return 0;
-
-  uint32_t status = 1;
-  if (hipMemcpy(&status, aux + 64, 4, hipMemcpyDeviceToHost) != hipSuccess || status != 0)
-    return 0;
-  if (hipMemcpy(pOut, g_dev.monoOut, U, hipMemcpyDeviceToHost) != hipSuccess)
-    return 0;
-  return U;
+  return mh.U;
 }
 
 // ---- rle8m: the reference's GPU decode path, rle8m_opencl_decompress (src/rle8_ocl.c:265-413) ----
@@ -997,6 +1139,36 @@ int hsrle_decompress_host(const void *pContainer, uint64_t containerSize, void *
   }
   if (dIn) (void)hipFree(dIn);
   if (dOut) (void)hipFree(dOut);
+  return rc;
+}
+
+void hsrle_mono_tuning(uint32_t blockSize, uint32_t regionSize, uint32_t lookBack)
+{
+  g_monoTune[0] = blockSize; g_monoTune[1] = regionSize; g_monoTune[2] = lookBack;
+}
+
+uint64_t hsrle_decompress_mono_workspace_size(int codec, uint32_t uncompressedSize, uint32_t compressedSize)
+{
+  if (codec < 0 || codec >= kCodecCount || uncompressedSize == 0 || compressedSize < 10u) return 0;
+  return plan_mono(codec, uncompressedSize, compressedSize, codec_header_size(codec)).total;
+}
+
+int hsrle_decompress_mono_dev(int codec, const void *dStream, uint32_t streamSize, void *dOut, uint64_t outCapacity, void *dWorkspace, uint64_t workspaceSize,
+                              uint32_t *pUncompressedSize, uint32_t *pStats, void *stream)
+{
+  if (!dStream || !dOut || !dWorkspace || codec < 0 || codec >= kCodecCount || streamSize < codec_header_size(codec) || ((uintptr_t)dStream & 127u) != 0u)
+    return HSRLE_ERR_ARGUMENT;
+  if (!device_ok()) return HSRLE_ERR_DEVICE;
+  uint8_t h16[16] = { 0 };
+  if (hipMemcpyAsync(h16, dStream, streamSize < 16u ? streamSize : 16u, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess || hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+    return HSRLE_ERR_DEVICE;
+  MonoHeader mh;
+  if (!mono_header(codec, h16, streamSize, outCapacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)outCapacity, &mh))
+    return HSRLE_ERR_FORMAT;
+  const MonoPlan m = plan_mono(mh.codec, mh.U, mh.C, mh.p0);
+  if (workspaceSize < m.total) return HSRLE_ERR_CAPACITY;
+  const int rc = mono_decode_dev(mh, (const uint8_t *)dStream, (uint8_t *)dOut, (uint8_t *)dWorkspace, m, pStats, (hipStream_t)stream);
+  if (rc == HSRLE_OK && pUncompressedSize) *pUncompressedSize = mh.U;
   return rc;
 }
 

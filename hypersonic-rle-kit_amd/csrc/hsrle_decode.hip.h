@@ -178,8 +178,12 @@ __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
 template <int FAM, int S, int AL, int T, int R, int Q = T, bool SGL = true>
 __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict__ payload, const uint64_t *__restrict__ offsets,
                                                       const uint8_t *__restrict__ payloadEnd, uint8_t *__restrict__ out, uint64_t U,
-                                                      uint32_t B, uint32_t firstBlock, uint32_t blockCount, uint32_t *__restrict__ status)
+                                                      uint32_t B, uint32_t firstBlock, uint32_t blockCount, uint32_t *__restrict__ status,
+                                                      const uint32_t *__restrict__ entries, uint32_t streamLen)
 {
+  // entries != nullptr: `payload` is ONE monolithic reference stream of streamLen bytes and lane b starts from entry record b (the
+  // decoder state at output position b * B, hsrle_index.hip.h) instead of from the header of block stream b; everything behind the
+  // prologue is the same -- a lane still produces the B output bytes [b * B, (b + 1) * B)
   using TR = Traits<FAM, S, AL>;
   constexpr int TS = T;                      // tile row stride: no pad -- the 16-byte chunks of a row are XOR-swizzled by the row index instead (TSW)
   constexpr int RS = R;                      // ring row stride: no pad, no mirror -- chunks are XOR-swizzled by the row index (rowx), every 8-byte piece is addressed on its own
@@ -267,7 +271,9 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     uint64_t base0 = 0;
     if (active)
     {
-      uint64_t off0 = offsets[b], off1 = offsets[b + 1];
+      uint64_t off0, off1;
+      if (entries != nullptr) { off0 = entries[(uint64_t)b * kEntryRecDwords]; off1 = streamLen; }
+      else { off0 = offsets[b]; off1 = offsets[b + 1]; }
       // the offset table is data too: an entry outside the payload (or a negative / oversized stream length) must end as an error
       // bit, never as a wild read -- the lane then sees an empty stream at offset 0, which fails the header check
       const uint64_t payloadBytes = (uint64_t)(payloadEnd - payload);
@@ -383,7 +389,17 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     wave_sync();                                                      //     flies during the first step's decode
   }
 
-  if (active)
+  const uint32_t *const rec = (entries != nullptr && active) ? entries + (uint64_t)b * kEntryRecDwords : nullptr;
+  if (rec != nullptr)
+  {
+    const uint32_t rf = rec[3];
+    sp = g0; lit = rec[1]; run = rec[2];
+    phase = rf & 0xFFu;
+    last = (rf & REC_LAST) != 0u;
+    if constexpr (SGL) singleVar = (rf & REC_SINGLE) != 0u;
+    if (lit > slen - sp) { err |= DEC_ERR_STREAM; done = true; }
+  }
+  else if (active)
   {
     sp = g0 + TR::kHeaderSize;
     const uint8_t *hd = ring + (rowx ^ g0);                            // g0 is a multiple of 16 and < R: one whole chunk
@@ -427,6 +443,18 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   else if (!single && !TR::kShortSingle)
   {
     set_sym(u32x4{ 0, 0, 0, 0 }); // Packed decoders start with symbol 0 (rleX_extreme_cpu_decode.h:31-37, q5)
+  }
+  if (rec != nullptr)
+  {
+    set_sym(u32x4{ rec[4], rec[5], rec[6], rec[7] });
+    if constexpr (TR::kMtf)
+    {
+#pragma unroll
+      for (int k = 0; k < TR::K; k++)
+#pragma unroll
+        for (int w = 0; w < TR::SW; w++)
+          lut[k][w] = rec[8 + k * TR::SW + w];
+    }
   }
 
   uint32_t base = 0;      // block offset of the first byte of the tile row (multiple of 16); the row holds [base, o)

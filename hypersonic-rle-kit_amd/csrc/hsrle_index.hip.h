@@ -1,0 +1,567 @@
+// hsrle_index.hip.h -- entry-point index of ONE monolithic reference stream, so that the block decoder can work on it with one lane
+// per 256 .. 4096 output bytes instead of one lane per stream ("index pass + expand pass").
+//
+// A reference stream has no random access: the position of packet N+1 is known only after packet N's header (its literal count)
+// has been read (reference: src/rleX_extreme_cpu_decode.h:129-162, src/rle8_extreme_cpu.h:1849-1899, src/rleX_Xsl.h:580-760).  What
+// the format does offer is that the packet chain SYNCHRONISES: a walk that starts at a wrong byte either dies within a few hops (a
+// junk range field with the 4-byte flag points far outside the stream) or falls onto a true packet boundary and is the true chain
+// from there on.  The index is built from that, and then PROVEN, never assumed:
+//
+//   k_index_walk     the stream is cut into regions of G bytes; one lane per region.  The lane guesses where the first packet of
+//                    its region starts (it walks from up to M bytes in front of the region, restarting one byte further on whenever
+//                    the walk dies), then walks its region from that guess: exit position (first packet start behind the region),
+//                    output bytes of the packets that start in the region, and the region's effect on the decoder's symbol state
+//                    (Packed: the last symbol; LUT / Short: the move-to-front list) as a K-entry transformer whose entries are
+//                    "slot j of the incoming list" or "the symbol stored at stream offset x".
+//   k_index_resolve  one workgroup chains the regions from the stream's first packet: region r is right iff the chain arrives
+//                    exactly at its guess.  A region the chain jumps over (a literal stretch longer than a region) is skipped; a
+//                    region whose guess is wrong is put on the repair list with the true entry and walked again (k_index_walk with
+//                    the list), until no region is left on the list.  So a wrong guess costs time, never correctness.  The same
+//                    pass scans the output sizes (output offset of every region) and composes the state transformers (symbol state
+//                    at every region entry), and checks that the chain ends in the stream's last packet with exactly U output bytes.
+//   k_index_records  one lane per region again, now with known entry, output offset and symbol state: for every output position
+//                    b * B that falls into one of its packets it writes the decoder state at that position (stream position,
+//                    literal / run bytes left, pattern phase, current symbol, move-to-front list): an ENTRY RECORD.
+//   k_decode_blocks  (hsrle_decode.hip.h) takes its per-lane start state from the records instead of a block stream header.
+#pragma once
+
+#include "hsrle_common.hip.h"
+#include "hsrle_decode.hip.h"   // ex32
+#include "hsrle_launch.h"
+
+namespace hsrle {
+
+constexpr uint32_t IDX_DEAD = 0xFFFFFFFFu;   // exit: the walk met a malformed packet
+constexpr uint32_t IDX_END = 0xFFFFFFFEu;    // exit: the walk met the stream's last packet
+constexpr uint32_t IDX_SKIP = 0xFFFFFFFDu;   // entry: no packet of the chain starts in this region
+constexpr uint32_t IDX_OLD = 0x80000000u;    // transformer entry: slot (v & 15) of the incoming list; otherwise the stream offset of the symbol (< 2^31)
+constexpr uint32_t IDX_INIT = 0xC0000000u;   // resolved state entry: entry (v & 15) of the list a decoder starts with
+
+constexpr int kResolveThreads = 512;
+
+enum IndexStatus : uint32_t
+{
+  IDXS_STREAM = 1u,    // the true chain meets a malformed packet / never reaches the last packet
+  IDXS_SIZE = 2u       // the chain does not produce exactly the header's uncompressed size
+};
+
+// symbol-state slots a decoder of this family carries from packet to packet
+template <int FAM>
+struct IndexState
+{
+  static constexpr int KE = (FAM == PACKED) ? 1 : Traits<FAM, 1, 0>::K;
+};
+
+struct Pkt
+{
+  uint32_t used;     // header bytes
+  uint32_t lit;      // literal bytes that follow the header (they come BEFORE the run in the output)
+  uint32_t run;      // run bytes
+  uint32_t op;       // state slots: < KE move slot op to the front, == KE push the symbol at symAt
+  uint32_t symAt;    // stream offset of the symbol this packet carries
+  bool hasSym, last, bad;
+};
+
+// One packet header at stream offset p (the stream is readable up to C + 32).  The field rules are those of the decoder
+// (hsrle_decode.hip.h): the two must agree on every stream, which tests/test_gpu_mono.py checks by decoding through
+// the index what the block kernel decodes on its own.
+template <int FAM, int S, int AL>
+__device__ __forceinline__ Pkt parse_packet(const uint8_t *__restrict__ s, uint32_t p, uint32_t C, bool single)
+{
+  using TR = Traits<FAM, S, AL>;
+  constexpr int KE = IndexState<FAM>::KE;
+  Pkt k;
+  k.used = 1; k.lit = 0; k.run = 0; k.op = 0; k.symAt = p; k.hasSym = false; k.last = false; k.bad = false;
+  if (p + 2u > C) { k.bad = true; return k; }
+
+  const uint64_t lo = ld64(s + p), hi = ld64(s + p + 8);
+  auto u32at = [&](uint32_t pos) -> uint32_t { return pos <= 12u ? ex32(lo, hi, pos) : ld32(s + p + pos); };
+
+  uint32_t cnt, range, pos;
+  bool endNow = false, hbad = false;
+
+  if constexpr (TR::kShort)
+  {
+    const uint32_t p1 = (uint32_t)lo & 0xFFu, p2 = ((uint32_t)lo >> 8) & 0xFFu, p3 = ((uint32_t)lo >> 16) & 0xFFu;
+    const uint32_t idx = (TR::K > 0) ? p1 >> (TR::SCB + TR::SRBP) : 0u;
+    const uint32_t c3 = (p1 >> TR::SRBP) & TR::SCINV;
+    if (c3 != TR::SCINV)
+    {
+      cnt = c3 + 2u;
+      range = (p1 & TR::SMAXPR) + 2u;
+      pos = 1;
+    }
+    else
+    {
+      cnt = (p2 >> (TR::SRB - 8u)) | ((p1 & TR::SMAXPR) << (16u - TR::SRB));
+      range = p3 | ((p2 & ((1u << (TR::SRB - 8u)) - 1u)) << 8);
+      pos = 3;
+      if (cnt == 0u) { cnt = u32at(3u); pos = 7; }
+      else if (cnt == 1u) { cnt = u32at(3u) & 0xFFFFu; pos = 5; }
+      const uint32_t rext = u32at(pos);
+      if (range == 0u) { range = rext; pos += 4; }
+      else if (range == 1u) { range = rext & 0xFFFFu; pos += 2; endNow = (range == 0u); }
+    }
+    if constexpr (TR::kShortSingle) { }
+    else if constexpr (TR::K == 0) { k.hasSym = true; k.symAt = p + pos; pos += S; }
+    else
+    {
+      k.op = idx;
+      if (idx == (uint32_t)TR::K) { k.hasSym = true; k.symAt = p + pos; pos += S; }
+    }
+    hbad = !endNow && range < 2u;
+    k.last = endNow || cnt == 0u;
+    k.lit = (endNow || range < 2u) ? 0u : range - 2u;
+    k.run = k.last ? 0u : (TR::kAligned ? (cnt + TR::SMINS / (uint32_t)S - 2u) * (uint32_t)S : cnt + TR::SMINS - 2u);
+  }
+  else if constexpr (TR::kLut)
+  {
+    const uint32_t w16 = (uint32_t)lo & 0xFFFFu;
+    const uint32_t idx = w16 >> (FAM == LUT3 ? 14 : 13);
+    cnt = (w16 >> TR::RB) & 0x7Fu;
+    range = w16 & ((1u << TR::RB) - 1u);
+    pos = 2;
+    k.op = idx;
+    if (idx == (uint32_t)TR::K) { k.hasSym = true; k.symAt = p + 2u; pos += S; }
+    if (cnt == 0u) { cnt = u32at(pos); pos += 4; }
+    else if (cnt == 1u) { cnt = u32at(pos) & 0xFFFFu; pos += 2; }
+    if (range == 0u) { range = u32at(pos); pos += 4; }
+    else if (range == 1u) { range = u32at(pos) & 0xFFFFu; pos += 2; endNow = (range == 0u); }
+    hbad = !endNow && range < 2u;
+    k.last = endNow || cnt == 0u;
+    k.lit = (endNow || range < 2u) ? 0u : range - 2u;
+    k.run = k.last ? 0u : (TR::kAligned ? (cnt + 3u / (uint32_t)S - 2u) * (uint32_t)S : cnt + 1u);
+  }
+  else
+  {
+    const bool sgl = (S == 1) && single;
+    if constexpr (!TR::kPacked)
+    {
+      pos = sgl ? 0u : (uint32_t)S;
+      k.hasSym = !sgl;
+      cnt = u32at(pos) & 0xFFu; pos += 1;
+      if (cnt == 0u) { cnt = u32at(pos); pos += 4; }
+    }
+    else
+    {
+      const uint32_t b0 = (uint32_t)lo & 0xFFu;
+      cnt = sgl ? b0 : (b0 & 0x7Fu);
+      pos = 1;
+      if (cnt == 0u) { cnt = u32at(1u); pos = 5; }
+      if (!sgl && !(b0 & 0x80u)) { k.hasSym = true; k.symAt = p + pos; k.op = 1; pos += S; }
+    }
+    const uint32_t w = u32at(pos);
+    const uint32_t r0 = w & 0xFFu;
+    if (TR::kRange7 && !sgl)
+    {
+      if (r0 & 1u) { range = w >> 1; pos += 4; endNow = (range == 0u); }
+      else { range = r0 >> 1; pos += 1; }
+    }
+    else
+    {
+      range = r0; pos += 1;
+      if (r0 == 0u) { range = u32at(pos); pos += 4; endNow = (range == 0u); }
+    }
+    const uint32_t shortv = sgl ? (TR::kPacked ? 2u : 4u) : TR::SHORT;
+    k.last = endNow || cnt == 0u;
+    k.lit = (range == 0u || endNow) ? 0u : range - 1u;            // a 7 bit range byte of 0x00 carries no literals (A.5 q11)
+    k.run = k.last ? 0u : (TR::kAligned ? (cnt + TR::SHORT / (uint32_t)S - 1u) * (uint32_t)S : cnt + shortv - 1u);
+  }
+  (void)KE;
+  k.used = pos;
+  const uint32_t sp = p + pos;
+  k.bad = hbad || sp > C || k.lit > C - sp || (k.lit == 0u && k.run == 0u && !k.last);
+  return k;
+}
+
+// move-to-front bookkeeping on K u32 entries: op < K moves slot op to the front, op == K pushes v
+template <int K>
+__device__ __forceinline__ void state_apply(uint32_t (&t)[K > 0 ? K : 1], uint32_t op, uint32_t v)
+{
+  if constexpr (K > 0)
+  {
+    uint32_t front = v;
+#pragma unroll
+    for (int j = 0; j < K; j++)
+      if (op == (uint32_t)j) front = t[j];
+    const uint32_t limit = (op >= (uint32_t)K) ? (uint32_t)K - 1u : op;
+#pragma unroll
+    for (int j = K - 1; j >= 1; j--)
+      if ((uint32_t)j <= limit) t[j] = t[j - 1];
+    t[0] = front;
+  }
+}
+
+// ---- pass 1 (and the repair passes): one lane per region ----
+template <int FAM, int S, int AL>
+__global__ __launch_bounds__(64) void k_index_walk(const uint8_t *__restrict__ s, uint32_t C, uint32_t p0, uint32_t G, uint32_t M, uint32_t R, uint32_t single,
+                                                   const uint32_t *__restrict__ list, uint32_t listCount, const uint32_t *__restrict__ fix,
+                                                   uint32_t *__restrict__ gOut, uint32_t *__restrict__ eOut, uint64_t *__restrict__ olenOut, uint32_t *__restrict__ tOut)
+{
+  constexpr int KE = IndexState<FAM>::KE;
+  const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+  uint32_t r;
+  if (list != nullptr) { if (i >= listCount) return; r = list[i]; }
+  else { if (i >= R) return; r = i; }
+
+  const uint32_t start = p0 + r * G, endr = start + G;
+  const bool sgl = single != 0u;
+  uint32_t q;
+  if (list != nullptr) q = fix[r];
+  else if (r == 0u) q = p0;
+  else
+  {
+    // guess: the first walk from <= M bytes in front of the region that survives until the region starts.  A walk that begins at
+    // the stream's first packet IS the chain; any other one is taken for dead when it claims a literal stretch of M bytes or more
+    // (a true one of that size makes the chain jump, and then k_index_resolve hands this region its entry anyway).
+    const bool fromStart = start - p0 <= M;
+    const uint32_t a = fromStart ? p0 : start - M;
+    q = start;
+    uint32_t hopsLeft = 4u * M + 64u;
+    for (uint32_t t = a; t < start && hopsLeft != 0u; t++)
+    {
+      uint32_t x = t;
+      bool dead = false;
+      while (x < start)
+      {
+        if (hopsLeft-- == 0u) { dead = true; break; }
+        const Pkt k = parse_packet<FAM, S, AL>(s, x, C, sgl);
+        if (k.bad || k.last || (k.lit >= M && !(fromStart && t == a))) { dead = true; break; }
+        x += k.used + k.lit;
+      }
+      if (!dead) { q = x; break; }
+      if (fromStart && t == a) break;              // the true chain itself ends / breaks in front of this region: nothing to guess
+    }
+  }
+
+  uint64_t ol = 0;
+  uint32_t tr[KE > 0 ? KE : 1];
+#pragma unroll
+  for (int j = 0; j < (KE > 0 ? KE : 1); j++) tr[j] = IDX_OLD | (uint32_t)j;
+  uint32_t x = q, ex;
+  for (;;)
+  {
+    if (x >= endr) { ex = x; break; }
+    const Pkt k = parse_packet<FAM, S, AL>(s, x, C, sgl);
+    if (k.bad) { ex = IDX_DEAD; break; }
+    ol += (uint64_t)k.lit + (uint64_t)k.run;
+    state_apply<KE>(tr, k.op, k.symAt);
+    if (k.last) { ex = IDX_END; break; }
+    x += k.used + k.lit;
+  }
+  gOut[r] = q;
+  eOut[r] = ex;
+  olenOut[r] = ol;
+  if constexpr (KE > 0)
+  {
+#pragma unroll
+    for (int j = 0; j < KE; j++) tOut[(uint64_t)r * KE + j] = tr[j];
+  }
+}
+
+// ---- pass 2: chain the regions, scan sizes and states.  ONE workgroup. ----
+// ctrl: [0] regions on the repair list, [1] IndexStatus bits (final only when [0] == 0), [2..3] output bytes of the chain
+template <int KE>
+__device__ __forceinline__ void state_compose(uint32_t (&out)[KE > 0 ? KE : 1], const uint32_t (&first)[KE > 0 ? KE : 1], const uint32_t (&then)[KE > 0 ? KE : 1])
+{
+#pragma unroll
+  for (int j = 0; j < KE; j++)
+  {
+    const uint32_t v = then[j];
+    uint32_t w = v;
+    if ((v >> 30) == 2u)
+    {
+#pragma unroll
+      for (int m = 0; m < KE; m++)
+        if ((v & 15u) == (uint32_t)m) w = first[m];
+    }
+    out[j] = w;
+  }
+}
+
+template <int KE>
+__global__ __launch_bounds__(kResolveThreads) void k_index_resolve(const uint32_t *__restrict__ g, const uint32_t *__restrict__ e, const uint64_t *__restrict__ olen,
+                                                                   const uint32_t *__restrict__ tIn, uint32_t R, uint32_t p0, uint32_t G, uint64_t U,
+                                                                   uint32_t *__restrict__ entry, uint64_t *__restrict__ outStart, uint32_t *__restrict__ stateIn,
+                                                                   uint32_t *__restrict__ fix, uint32_t *__restrict__ list, uint32_t *__restrict__ ctrl)
+{
+  constexpr int NT = kResolveThreads;
+  constexpr int KS = KE > 0 ? KE : 1;
+  constexpr uint8_t F_NONE = 0, F_OK = 1, F_SKIP = 2, F_DIRTY = 3;
+  __shared__ uint32_t sg[NT], se[NT];
+  __shared__ uint8_t sflag[NT];
+  __shared__ uint64_t swave[NT / 64];
+  __shared__ uint32_t sT1[2 * NT * KS];
+#define HS_ST(buf, t, j) sT1[((uint32_t)(buf) * NT + (uint32_t)(t)) * KS + (uint32_t)(j)]
+  __shared__ uint32_t sCur, sEnded, sTrusted, sDirty, sStatus;
+  __shared__ uint32_t sCarryState[KS];
+  __shared__ uint64_t sCarryOut;
+
+  const uint32_t tid = threadIdx.x;
+  if (tid == 0)
+  {
+    sCur = p0; sEnded = 0; sTrusted = 1; sDirty = 0; sStatus = 0; sCarryOut = 0;
+#pragma unroll
+    for (int j = 0; j < KS; j++) sCarryState[j] = IDX_INIT | (uint32_t)j;
+  }
+  __syncthreads();
+
+  for (uint32_t base = 0; base < R; base += NT)
+  {
+    const uint32_t r = base + tid;
+    const bool valid = r < R;
+    const uint32_t gg = valid ? g[r] : 0u, ee = valid ? e[r] : 0u;
+    sg[tid] = gg; se[tid] = ee;
+    __syncthreads();
+    const uint32_t prev = (tid == 0) ? sCur : se[tid - 1];
+    const uint32_t endr = p0 + (r + 1u) * G;
+    const bool ok = !valid || (sEnded == 0u && prev == gg && gg < endr && ee < IDX_SKIP);
+    const int allok = __syncthreads_and(ok ? 1 : 0);
+    const uint32_t n = (R - base < (uint32_t)NT) ? R - base : (uint32_t)NT;
+
+    if (allok)
+    {
+      sflag[tid] = valid ? F_OK : F_NONE;
+      if (tid == 0) sCur = se[n - 1u];
+    }
+    else if (tid == 0)
+    {
+      // the rare path, one thread over the batch: jumps over regions, the end of the chain, wrong guesses
+      uint32_t cur = sCur, ended = sEnded, trusted = sTrusted;
+      // (always from global memory: a choice between the LDS copy and the global array becomes a flat access that this compiler cannot encode)
+      auto next_guess = [&](uint32_t k, uint32_t rr) -> uint32_t { (void)k; return g[rr + 1u]; };
+      for (uint32_t k = 0; k < n; k++)
+      {
+        const uint32_t rr = base + k;
+        const uint32_t endk = p0 + (rr + 1u) * G;
+        if (ended || cur >= endk) { sflag[k] = F_SKIP; continue; }
+        if (cur == sg[k])
+        {
+          sflag[k] = F_OK;
+          const uint32_t x = se[k];
+          if (x < IDX_SKIP) cur = x;
+          else if (trusted) { if (x == IDX_DEAD) sStatus |= IDXS_STREAM; ended = 1; }
+          else if (rr + 1u < R) cur = next_guess(k, rr);                          // behind a wrong guess nothing is final: go on from the next guess
+        }
+        else
+        {
+          // wrong guess: this region is walked again from `cur`.  Until then nothing behind it is proven; the chain is continued
+          // from the next region's own guess so that further wrong guesses are found (and repaired) in the same round.
+          sflag[k] = F_DIRTY;
+          fix[rr] = cur;
+          list[sDirty++] = rr;
+          trusted = 0;
+          if (rr + 1u < R) cur = next_guess(k, rr);
+        }
+      }
+      for (uint32_t k = n; k < (uint32_t)NT; k++) sflag[k] = F_NONE;
+      sCur = cur; sEnded = ended; sTrusted = trusted;
+    }
+    __syncthreads();
+
+    const uint8_t fl = sflag[tid];
+    // exclusive scan of the output sizes
+    const uint64_t v = (fl == F_OK) ? olen[r] : 0ull;
+    uint64_t xsum = v;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+      const uint64_t y = __shfl_up(xsum, d, 64);
+      if ((int)lane >= d) xsum += y;
+    }
+    if (lane == 63u) swave[wave] = xsum;
+    // inclusive scan of the state transformers (Hillis-Steele through LDS)
+    if constexpr (KE > 0)
+    {
+#pragma unroll
+      for (int j = 0; j < KE; j++) HS_ST(0, tid, j) = (fl == F_OK) ? tIn[(uint64_t)r * KE + j] : (IDX_OLD | (uint32_t)j);
+    }
+    __syncthreads();
+    uint64_t wbase = 0, wall = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; w++)
+    {
+      const uint64_t t = swave[w];
+      if ((uint32_t)w < wave) wbase += t;
+      wall += t;
+    }
+    int cb = 0;
+    if constexpr (KE > 0)
+    {
+      for (int d = 1; d < NT; d <<= 1)
+      {
+        uint32_t tmp[KS], mine[KS], before[KS];
+#pragma unroll
+        for (int j = 0; j < KE; j++) { mine[j] = HS_ST(cb, tid, j); before[j] = HS_ST(cb, (int)tid >= d ? tid - d : tid, j); }
+        state_compose<KE>(tmp, before, mine);
+        if ((int)tid < d)
+        {
+#pragma unroll
+          for (int j = 0; j < KE; j++) tmp[j] = mine[j];
+        }
+#pragma unroll
+        for (int j = 0; j < KE; j++) HS_ST(cb ^ 1, tid, j) = tmp[j];
+        __syncthreads();
+        cb ^= 1;
+      }
+    }
+    if (valid)
+    {
+      entry[r] = (fl == F_OK) ? gg : IDX_SKIP;
+      outStart[r] = sCarryOut + wbase + xsum - v;
+      if constexpr (KE > 0)
+      {
+        uint32_t st[KS], carry[KS], excl[KS];
+#pragma unroll
+        for (int j = 0; j < KE; j++) { carry[j] = sCarryState[j]; excl[j] = (tid == 0) ? (IDX_OLD | (uint32_t)j) : HS_ST(cb, tid - 1, j); }
+        state_compose<KE>(st, carry, excl);
+#pragma unroll
+        for (int j = 0; j < KE; j++) stateIn[(uint64_t)r * KE + j] = st[j];
+      }
+    }
+    __syncthreads();
+    if (tid == 0)
+    {
+      sCarryOut += wall;
+      if constexpr (KE > 0)
+      {
+        uint32_t st[KS], carry[KS], all[KS];
+#pragma unroll
+        for (int j = 0; j < KE; j++) { carry[j] = sCarryState[j]; all[j] = HS_ST(cb, NT - 1, j); }
+        state_compose<KE>(st, carry, all);
+#pragma unroll
+        for (int j = 0; j < KE; j++) sCarryState[j] = st[j];
+      }
+    }
+    __syncthreads();
+  }
+
+  if (tid == 0)
+  {
+    uint32_t status = sStatus;
+    if (sDirty == 0u)
+    {
+      if (sEnded == 0u) status |= IDXS_STREAM;                          // the chain never reached the stream's last packet
+      if (sCarryOut != U) status |= IDXS_SIZE;
+    }
+    ctrl[0] = sDirty;
+    ctrl[1] = status;
+    ctrl[2] = (uint32_t)sCarryOut;
+    ctrl[3] = (uint32_t)(sCarryOut >> 32);
+  }
+}
+
+// symbol of a resolved state entry as the decoder keeps it: masked to S bytes in up to four dwords
+template <int S>
+__device__ __forceinline__ u32x4 index_symbol(const uint8_t *__restrict__ s, uint32_t v, bool packedInit)
+{
+  if ((v >> 30) == 3u)
+  {
+    constexpr uint32_t init[7] = { 0x00u, 0x7Fu, 0xFFu, 0x01u, 0x7Eu, 0x80u, 0xFEu };      // rleX_Xsl.h:533-543 (Packed decoders start with symbol 0)
+    const uint32_t b = packedInit ? 0u : init[(v & 15u) % 7u] * 0x01010101u;
+    u32x4 m = u32x4{ b, b, b, b };
+    if constexpr (S == 1) m = u32x4{ b & 0xFFu, 0, 0, 0 };
+    else if constexpr (S == 2) m = u32x4{ b & 0xFFFFu, 0, 0, 0 };
+    else if constexpr (S == 3) m = u32x4{ b & 0xFFFFFFu, 0, 0, 0 };
+    else if constexpr (S == 4) m = u32x4{ b, 0, 0, 0 };
+    else if constexpr (S == 6) m = u32x4{ b, b & 0xFFFFu, 0, 0 };
+    else if constexpr (S == 8) m = u32x4{ b, b, 0, 0 };
+    return m;
+  }
+  const u32x4 x = ld128(s + v);
+  if constexpr (S == 1) return u32x4{ x.x & 0xFFu, 0, 0, 0 };
+  else if constexpr (S == 2) return u32x4{ x.x & 0xFFFFu, 0, 0, 0 };
+  else if constexpr (S == 3) return u32x4{ x.x & 0xFFFFFFu, 0, 0, 0 };
+  else if constexpr (S == 4) return u32x4{ x.x, 0, 0, 0 };
+  else if constexpr (S == 6) return u32x4{ x.x, x.y & 0xFFFFu, 0, 0 };
+  else if constexpr (S == 8) return u32x4{ x.x, x.y, 0, 0 };
+  else return x;
+}
+
+// ---- pass 3: the decoder state at every output position b * B ----
+template <int FAM, int S, int AL>
+__global__ __launch_bounds__(64) void k_index_records(const uint8_t *__restrict__ s, uint32_t C, uint32_t p0, uint32_t G, uint32_t R, uint32_t single, uint32_t singleSym,
+                                                      const uint32_t *__restrict__ entry, const uint64_t *__restrict__ outStart, const uint32_t *__restrict__ stateIn,
+                                                      uint64_t U, uint32_t B, uint32_t *__restrict__ rec)
+{
+  using TR = Traits<FAM, S, AL>;
+  constexpr int KE = IndexState<FAM>::KE;
+  constexpr int KS = KE > 0 ? KE : 1;
+  constexpr int SW = TR::SW;
+  const uint32_t r = blockIdx.x * 64u + threadIdx.x;
+  if (r >= R) return;
+  uint32_t x = entry[r];
+  if (x == IDX_SKIP) return;
+  const uint32_t endr = p0 + (r + 1u) * G;
+  const bool sgl = single != 0u;
+  uint64_t o = outStart[r];
+
+  // the state as offsets / init tags (what the transformers carry); symbols are fetched when a record is written
+  uint32_t st[KS];
+#pragma unroll
+  for (int j = 0; j < KS; j++) st[j] = (KE > 0) ? stateIn[(uint64_t)r * KS + j] : 0u;
+  uint32_t curSym = IDX_INIT;      // offset / tag of the current packet's symbol (families without a list)
+
+  while (x < endr)
+  {
+    const Pkt k = parse_packet<FAM, S, AL>(s, x, C, sgl);
+    if (k.bad) break;                                                    // cannot happen: k_index_walk walked this chain
+    state_apply<KE>(st, k.op, k.symAt);
+    if (k.hasSym) curSym = k.symAt;
+    const uint64_t outEnd = o + (uint64_t)k.lit + (uint64_t)k.run;
+    const uint32_t body = x + k.used;
+    for (uint64_t b = (o + B - 1u) / B; b * B < outEnd && b * B < U; b++)
+    {
+      const uint64_t X = b * B;
+      const uint64_t into = X - o;
+      uint32_t *const w = rec + b * (uint64_t)kEntryRecDwords;
+      uint32_t rsp, rlit, rrun, phase = 0;
+      if (into < (uint64_t)k.lit) { rsp = body + (uint32_t)into; rlit = k.lit - (uint32_t)into; rrun = k.run; }
+      else
+      {
+        const uint64_t t = into - k.lit;
+        rsp = body + k.lit; rlit = 0; rrun = k.run - (uint32_t)t;
+        phase = (uint32_t)(t % (uint64_t)S);
+      }
+      u32x4 sym;
+      if constexpr (KE > 0) sym = index_symbol<S>(s, st[0], FAM == PACKED);
+      else if (sgl || TR::kShortSingle) sym = u32x4{ singleSym & 0xFFu, 0, 0, 0 };
+      else sym = index_symbol<S>(s, curSym, true);
+      w[0] = rsp; w[1] = rlit; w[2] = rrun; w[3] = phase | (k.last ? REC_LAST : 0u) | (sgl ? REC_SINGLE : 0u);
+      w[4] = sym.x; w[5] = sym.y; w[6] = sym.z; w[7] = sym.w;
+      if constexpr (TR::kMtf)
+      {
+#pragma unroll
+        for (int j = 0; j < KE; j++)
+        {
+          const u32x4 v = index_symbol<S>(s, st[j], false);
+          w[8 + j * SW] = v.x;
+          if constexpr (SW > 1) w[8 + j * SW + 1] = v.y;
+        }
+      }
+    }
+    o = outEnd;
+    if (k.last) break;
+    x = body + k.lit;
+  }
+}
+
+// host side: walk (records == 0) or record pass (records != 0) of one codec grammar
+template <int FAM, int S, int AL>
+inline hipError_t launch_index(const IndexArgs &a, int records, hipStream_t st)
+{
+  if (records)
+    hipLaunchKernelGGL((k_index_records<FAM, S, AL>), dim3((a.R + 63u) / 64u), dim3(64), 0, st, a.stream, a.C, a.p0, a.G, a.R, a.single, a.singleSym, a.entry, a.outStart, a.stateIn,
+                       a.U, a.B, a.rec);
+  else
+  {
+    const uint32_t n = a.list ? a.listCount : a.R;
+    if (n == 0u) return hipSuccess;
+    hipLaunchKernelGGL((k_index_walk<FAM, S, AL>), dim3((n + 63u) / 64u), dim3(64), 0, st, a.stream, a.C, a.p0, a.G, a.M, a.R, a.single, a.list, a.listCount, a.fix, a.g, a.e,
+                       a.olen, a.t);
+  }
+  return hipGetLastError();
+}
+
+} // namespace hsrle

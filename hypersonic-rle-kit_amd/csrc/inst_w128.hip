@@ -1,6 +1,7 @@
 // 128 bit symbols: rle128_{sym,byte}[_packed]  (reference: src/rle.h:124-125, :146-147, :168-169, :194-195)
 #include "hsrle_decode.hip.h"
 #include "hsrle_encode.hip.h"
+#include "hsrle_index.hip.h"
 #include "hsrle_launch.h"
 
 namespace hsrle {
@@ -15,8 +16,14 @@ static hipError_t enc_sym_packed(const EncodeArgs &a, hipStream_t st) { return l
 static hipError_t enc_byte(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<PLAIN, 16, 0>, a, st); }
 static hipError_t enc_byte_packed(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<PACKED, 16, 0>, a, st); }
 
-void register_w128(DecodeLaunch *dec, EncodeLaunch *enc)
+static hipError_t idx_sym(const IndexArgs &a, int records, hipStream_t st) { return launch_index<PLAIN, 16, 1>(a, records, st); }
+static hipError_t idx_sym_packed(const IndexArgs &a, int records, hipStream_t st) { return launch_index<PACKED, 16, 1>(a, records, st); }
+static hipError_t idx_byte(const IndexArgs &a, int records, hipStream_t st) { return launch_index<PLAIN, 16, 0>(a, records, st); }
+static hipError_t idx_byte_packed(const IndexArgs &a, int records, hipStream_t st) { return launch_index<PACKED, 16, 0>(a, records, st); }
+
+void register_w128(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx)
 {
+  idx[46] = idx_sym; idx[47] = idx_sym_packed; idx[48] = idx_byte; idx[49] = idx_byte_packed;
   dec[46] = dec_sym;         enc[46] = enc_sym;
   dec[47] = dec_sym_packed;  enc[47] = enc_sym_packed;
   dec[48] = dec_byte;        enc[48] = enc_byte;

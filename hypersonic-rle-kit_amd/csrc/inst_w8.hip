@@ -5,6 +5,7 @@
 #include "hsrle_encode.hip.h"
 #include "hsrle_encode8.hip.h"
 #include "hsrle_encode_greedy.hip.h"
+#include "hsrle_index.hip.h"
 #include "hsrle_launch.h"
 
 namespace hsrle {
@@ -37,8 +38,21 @@ static hipError_t enc_lut7(const EncodeArgs &a, hipStream_t st) { return launch_
 static hipError_t enc_single(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<SINGLE, 1, 0>, a, st, 0); }            // no residency cap: +40 % on run data, +20 % on noise, -8 % on video-shaped
 static hipError_t enc_packed_single(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<PACKED_SINGLE, 1, 0>, a, st, 0); }
 
-void register_w8(DecodeLaunch *dec, EncodeLaunch *enc)
+static hipError_t idx_plain(const IndexArgs &a, int records, hipStream_t st) { return launch_index<PLAIN, 1, 0>(a, records, st); }
+static hipError_t idx_packed(const IndexArgs &a, int records, hipStream_t st) { return launch_index<PACKED, 1, 0>(a, records, st); }
+static hipError_t idx_lut3(const IndexArgs &a, int records, hipStream_t st) { return launch_index<LUT3, 1, 0>(a, records, st); }
+static hipError_t idx_lut7(const IndexArgs &a, int records, hipStream_t st) { return launch_index<LUT7, 1, 0>(a, records, st); }
+static hipError_t idx_short0(const IndexArgs &a, int records, hipStream_t st) { return launch_index<SHORT0, 1, 0>(a, records, st); }
+static hipError_t idx_short1(const IndexArgs &a, int records, hipStream_t st) { return launch_index<SHORT1, 1, 0>(a, records, st); }
+static hipError_t idx_short3(const IndexArgs &a, int records, hipStream_t st) { return launch_index<SHORT3, 1, 0>(a, records, st); }
+static hipError_t idx_short7(const IndexArgs &a, int records, hipStream_t st) { return launch_index<SHORT7, 1, 0>(a, records, st); }
+static hipError_t idx_short_single(const IndexArgs &a, int records, hipStream_t st) { return launch_index<SHORT_SINGLE, 1, 0>(a, records, st); }
+
+void register_w8(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx)
 {
+  idx[0] = idx_plain; idx[1] = idx_packed; idx[2] = idx_lut3; idx[3] = idx_lut7; idx[4] = idx_plain; idx[5] = idx_packed;
+  idx[kShortBase8 + 0] = idx_short0; idx[kShortBase8 + 1] = idx_short1; idx[kShortBase8 + 2] = idx_short3; idx[kShortBase8 + 3] = idx_short7;
+  idx[kSingleShort] = idx_short_single;
   dec[0] = dec_plain;  enc[0] = enc_plain;
   dec[1] = dec_packed; enc[1] = enc_packed;
   dec[2] = dec_lut3;   enc[2] = enc_lut3;

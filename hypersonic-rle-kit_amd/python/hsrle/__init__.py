@@ -102,6 +102,12 @@ def _lib():
     L.hsrle_compress_host.argtypes = [ci, vp, u64, vp, u64, u32, ctypes.POINTER(u64)]
     L.hsrle_decompress_host.restype = ci
     L.hsrle_decompress_host.argtypes = [vp, u64, vp, u64, ctypes.POINTER(u64)]
+    L.hsrle_decompress_mono_workspace_size.restype = u64
+    L.hsrle_decompress_mono_workspace_size.argtypes = [ci, u32, u32]
+    L.hsrle_decompress_mono_dev.restype = ci
+    L.hsrle_decompress_mono_dev.argtypes = [ci, vp, u32, vp, u64, vp, u64, ctypes.POINTER(u32), ctypes.POINTER(u32), vp]
+    L.hsrle_mono_tuning.restype = None
+    L.hsrle_mono_tuning.argtypes = [u32, u32, u32]
     L.hsrle_synth_dev_async.restype = ci
     L.hsrle_synth_dev_async.argtypes = [ci, ci, u64, vp, u64, vp]
     _LIB = L
@@ -172,6 +178,34 @@ def mono_decompress(codec, stream, out_size=None):
     out = ctypes.create_string_buffer(max(out_size, 1))
     size = _lib().hsrle_decompress_mono(codec_id(codec), stream, len(stream), out, out_size)
     return out.raw[:size] if size else None
+
+
+def mono_tuning(block=0, region=0, lookback=0):
+    """Knobs of the monolithic decode (hsrle_mono_tuning): any values give the same output; 0 = the library's choice."""
+    _lib().hsrle_mono_tuning(block, region, lookback)
+
+
+def mono_decompress_dev(codec, stream_tensor, dst=None, workspace=None, return_stats=False):
+    """Decode ONE monolithic reference stream that lives in device memory (uint8 CUDA tensor with >= 64 bytes of slack behind the
+    stream's last byte, 128-byte aligned) into device memory.  Returns the output tensor (and (regions, rounds, rewalked))."""
+    import torch
+
+    _check_u8_cuda(stream_tensor, "stream")
+    head = stream_tensor[:8].cpu().numpy().tobytes()
+    usize, csize = int.from_bytes(head[:4], "little"), int.from_bytes(head[4:8], "little")
+    if dst is None:
+        dst = torch.empty(max(usize, 1), dtype=torch.uint8, device=stream_tensor.device)
+    cid = codec_id(codec)
+    need = _lib().hsrle_decompress_mono_workspace_size(cid, usize, csize)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=stream_tensor.device)
+    n = ctypes.c_uint32(0)
+    stats = (ctypes.c_uint32 * 3)()
+    rc = _lib().hsrle_decompress_mono_dev(cid, ctypes.c_void_p(stream_tensor.data_ptr()), csize, ctypes.c_void_p(dst.data_ptr()), dst.numel(),
+                                          ctypes.c_void_p(workspace.data_ptr()), workspace.numel(), ctypes.byref(n), stats, _stream_ptr())
+    if rc != OK:
+        raise HsrleError(rc, "hsrle_decompress_mono_dev")
+    return (dst[: n.value], tuple(stats)) if return_stats else dst[: n.value]
 
 
 def call_dropin(name, data, out_cap):

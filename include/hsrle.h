@@ -173,6 +173,22 @@ HSRLE_DECL_GREEDY(64)
 uint32_t hsrle_compress_mono(int codec, const uint8_t *pIn, uint32_t inSize, uint8_t *pOut, uint32_t outSize);
 uint32_t hsrle_decompress_mono(int codec, const uint8_t *pIn, uint32_t inSize, uint8_t *pOut, uint32_t outSize);
 
+/*
+ * Device-resident form of <codec>_decompress: ONE monolithic reference stream (what the reference's encoders and `hsrlekit` write:
+ * src/main.c:835, :970; decoded there by src/rle8_extreme_cpu.h:702-764, src/rleX_extreme_cpu_decode.h:27-164, src/rleX_Xsl.h:1848-1881)
+ * in device memory, decoded into device memory.  A stream has no random access, so the library first builds an entry-point index
+ * (speculative packet walks per stream region, then a pass that PROVES the chain and repairs wrong guesses: csrc/hsrle_index.hip.h)
+ * and then runs the block kernel from those entry points.  dStream must be 128-byte aligned and readable up to streamSize + 64.
+ * dWorkspace >= hsrle_decompress_mono_workspace_size().  Synchronises `stream`.  pStats (optional, host, 3 values): stream regions,
+ * repair rounds, regions walked again.  Returns HSRLE_OK, HSRLE_ERR_FORMAT (malformed stream / sizes do not match the header), ...
+ */
+uint64_t hsrle_decompress_mono_workspace_size(int codec, uint32_t uncompressedSize, uint32_t compressedSize);
+int hsrle_decompress_mono_dev(int codec, const void *dStream, uint32_t streamSize, void *dOut, uint64_t outCapacity, void *dWorkspace, uint64_t workspaceSize,
+                              uint32_t *pUncompressedSize, uint32_t *pStats, void *stream);
+/* tuning / test knob of the monolithic decode: output bytes per decode lane (multiple of 128), stream bytes per index lane, look-back
+ * bytes of the entry guess; 0 = the library's choice.  Any values give the same output: the index is proven, not assumed. */
+void hsrle_mono_tuning(uint32_t blockSize, uint32_t regionSize, uint32_t lookBack);
+
 /* ---------------------------------------------------------------------------------------------------------- */
 /* 2. device-resident block container API                                                                      */
 

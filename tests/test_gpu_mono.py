@@ -1,0 +1,172 @@
+"""Monolithic reference streams on the GPU: the rle.h-named decoders and hsrle_decompress_mono_dev build an
+entry-point index of the ONE stream (csrc/hsrle_index.hip.h: speculative walks per stream region, a proving pass, repairs) and run
+the block kernel from the entry records.  Bar: the decode equals the input the oracle's (= the reference's) encoder was given, for
+every codec, whatever the index parameters are -- tiny regions and look-backs force wrong guesses, jumps over regions and repairs."""
+import hashlib
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from hsrle_testlib import CODECS, CODEC_BY_KEY, FUZZ_LENGTHS, SYNTH_RUNS, SYNTH_VIDEO, fuzz_sections, mixed_runs, single_symbol_mix
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def hs():
+    import torch
+
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    import hsrle
+
+    hsrle.lib()
+    yield hsrle
+    hsrle.mono_tuning(0, 0, 0)
+
+
+def _dev_stream(stream):
+    """Stream bytes in device memory as hsrle_decompress_mono_dev wants them: 128-byte aligned, 64 readable bytes behind the end."""
+    import torch
+
+    t = torch.zeros(len(stream) + 64, dtype=torch.uint8, device="cuda")
+    t[: len(stream)] = torch.frombuffer(bytearray(stream), dtype=torch.uint8).cuda()
+    return t
+
+
+def _mixed_input(seed, size):
+    rng = random.Random(seed)
+    parts, n = [], 0
+    while n < size:
+        k = rng.randrange(5)
+        if k == 0:
+            d = fuzz_sections(rng)
+        elif k == 1:
+            d = mixed_runs(rng, rng.choice([40, 200, 1000, 3000]))
+        elif k == 2:
+            d = single_symbol_mix(rng, rng.choice([64, 333, 3000]))
+        elif k == 3:
+            d = bytes(rng.randrange(256) for _ in range(rng.choice([1, 7, 130, 300, 700])))      # literal stretches: the chain jumps over regions
+        else:
+            d = fuzz_sections(rng, lengths=FUZZ_LENGTHS, max_sections=3)
+        parts.append(d)
+        n += len(d)
+    return b"".join(parts)[:size]
+
+
+TUNINGS = [(0, 0, 0), (128, 64, 40), (256, 300, 16), (128, 32, 1024), (1024, 4096, 64)]
+
+
+@pytest.mark.parametrize("codec", CODECS[:94] + [CODECS[109]], ids=lambda c: c.key)
+def test_every_codec_through_the_index(hs, oracle, codec):
+    data = _mixed_input(4242 + CODECS.index(codec), 40000)
+    stream = oracle.compress(codec, data)
+    assert stream is not None
+    for tune in TUNINGS:
+        hs.mono_tuning(*tune)
+        size, dec = hs.call_dropin(codec.dname, stream, len(data))
+        assert size == len(data) and dec == data, f"{codec.key} tuning {tune}"
+    hs.mono_tuning(0, 0, 0)
+
+
+@pytest.mark.parametrize("key", ["rle8_single", "rle8_packed_single", "rle8_single_short"])
+def test_single_symbol_streams(hs, oracle, key):
+    codec = CODEC_BY_KEY[key]
+    rng = random.Random(9)
+    for tune in TUNINGS:
+        hs.mono_tuning(*tune)
+        for n in (1, 17, 300, 5000, 70000):
+            data = single_symbol_mix(rng, n)
+            stream = oracle.compress(codec, data)
+            size, dec = hs.call_dropin(codec.dname, stream, len(data))
+            assert size == len(data) and dec == data, f"{key} n={n} tuning {tune}"
+    hs.mono_tuning(0, 0, 0)
+
+
+@pytest.mark.parametrize("key", ["rle8_packed_multi", "rle8_multi", "rle8_7symlut", "rle24_byte_packed", "rle64_3symlut_byte", "rle128_sym", "rle32_1symlut_byte_short"])
+def test_shapes_that_stress_the_chain(hs, oracle, key):
+    """One literal spanning thousands of regions, one run spanning all blocks, runs longer than 2^16 / 2^24, alternating both."""
+    codec = CODEC_BY_KEY[key]
+    rng = random.Random(5)
+    noise = bytes(rng.randrange(256) for _ in range(300000))
+    cases = [noise, bytes(3000000), noise[:100] + bytes(70000) + noise[:33] + b"\x07" * 17000000 + noise[:5000],
+             b"".join(noise[i * 50 : i * 50 + 50] + bytes([i & 255]) * (3 + i % 40) for i in range(4000))]
+    for tune in ((0, 0, 0), (128, 64, 40), (4096, 8192, 1024)):
+        hs.mono_tuning(*tune)
+        for data in cases:
+            stream = oracle.compress(codec, data)
+            size, dec = hs.call_dropin(codec.dname, stream, len(data))
+            assert size == len(data) and dec == data, f"{key} len {len(data)} tuning {tune}"
+    hs.mono_tuning(0, 0, 0)
+
+
+def test_malformed_streams_fail_cleanly(hs, oracle):
+    """Streams are data: garbage behind an intact header, truncation, wrong sizes -> 0, never a hang or a write outside the output."""
+    import torch
+
+    rng = random.Random(3)
+    for key in ("rle8_packed_multi", "rle8_3symlut", "rle16_sym", "rle48_7symlut_byte", "rle8_multi_short", "rle64_3symlut_sym_short"):
+        codec = CODEC_BY_KEY[key]
+        data = mixed_runs(rng, 200000)
+        stream = bytearray(oracle.compress(codec, data))
+        for tune in ((0, 0, 0), (128, 64, 40)):
+            hs.mono_tuning(*tune)
+            bad = bytearray(stream)
+            for j in range(len(bad) // 2, len(bad)):
+                bad[j] = rng.randrange(256)
+            size, _ = hs.call_dropin(codec.dname, bytes(bad), len(data))
+            assert size in (0, len(data))                                   # garbage may by chance still be a stream of the right size
+            lie = bytearray(stream)
+            lie[0:4] = (len(data) - 1).to_bytes(4, "little")               # header claims one byte less than the packets produce
+            assert hs.call_dropin(codec.dname, bytes(lie), len(data))[0] == 0
+            cut = bytearray(stream[: len(stream) * 2 // 3])
+            cut[4:8] = len(cut).to_bytes(4, "little")                        # truncated stream with a consistent header
+            assert hs.call_dropin(codec.dname, bytes(cut), len(data))[0] == 0
+            # device form: the bytes behind the output stay untouched
+            t = _dev_stream(bytes(bad))
+            out = torch.full((len(data) + 4096,), 0xA5, dtype=torch.uint8, device="cuda")
+            try:
+                hs.mono_decompress_dev(key, t, dst=out[: len(data)])
+            except hs.HsrleError:
+                pass
+            assert bool((out[len(data):] == 0xA5).all())
+    hs.mono_tuning(0, 0, 0)
+
+
+@pytest.mark.parametrize("key,kind,size", [("rle8_packed_multi", SYNTH_RUNS, 64 << 20), ("rle8_packed_multi", SYNTH_VIDEO, 64 << 20), ("rle64_3symlut_byte", SYNTH_VIDEO, 88473600),
+                                           ("rle8_3symlut", SYNTH_RUNS, 32 << 20), ("rle16_sym_packed", SYNTH_RUNS, 32 << 20), ("rle32_7symlut_byte_short", SYNTH_VIDEO, 32 << 20)])
+def test_device_resident_mono_decode_of_synthetic_workloads(hs, oracle, key, kind, size):
+    """BASELINE-shaped buffers as ONE stream each (the oracle's = the reference's encoder writes it), decoded in device memory."""
+    import torch
+
+    codec = CODEC_BY_KEY[key]
+    data = oracle.synth(kind, codec.S, 2, size)
+    stream = oracle.compress(codec, data.tobytes())
+    t = _dev_stream(stream)
+    out, stats = hs.mono_decompress_dev(key, t, return_stats=True)
+    assert out.numel() == size and torch.equal(out.cpu(), torch.from_numpy(data)), f"{key}: decode differs"
+    regions, rounds, rewalked = stats
+    assert rewalked <= max(8, regions // 10), f"{key}: {rewalked} of {regions} regions guessed wrong"
+
+
+def test_monolithic_manifest_against_the_reference(hs, oracle):
+    """tests/golden/mono_manifest.json (minted by make_golden.py from the COMPILED REFERENCE): sha256 of the monolithic stream of the
+    deterministic synthetic buffers.  The oracle's stream must hash the same (so the bytes the GPU decodes are the reference's), and the
+    GPU's decode of it must be the generator's bytes."""
+    import torch
+
+    path = os.path.join(GOLDEN, "mono_manifest.json")
+    if not os.path.exists(path):
+        pytest.skip("mono manifest not minted")
+    for case in json.load(open(path))["cases"]:
+        if case["size"] > (96 << 20):
+            continue                                                       # the 1 GiB cases: test_full_size_mono_stream
+        codec = CODEC_BY_KEY[case["codec"]]
+        data = oracle.synth(case["kind"], codec.S, case["seed"], case["size"])
+        stream = oracle.compress(codec, data.tobytes())
+        assert hashlib.sha256(stream).hexdigest() == case["stream_sha256"], case
+        out = hs.mono_decompress_dev(codec.key, _dev_stream(stream))
+        assert hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest() == case["input_sha256"]
