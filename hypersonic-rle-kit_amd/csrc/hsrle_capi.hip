@@ -514,7 +514,13 @@ static MonoPlan plan_mono(int codec, uint32_t U, uint32_t C, uint32_t p0)
   if (tB >= 128u && tB <= (1u << 20) && (tB % 128u) == 0u) B = tB;
   if (tG >= 32u && tG <= (1u << 24)) G = tG;
   m.B = B; m.G = G;
-  m.M = tM ? tM : 1024u;
+  // Look-back of the entry guess.  Formats with the 7-bit-or-4-byte range field (8 bit Packed, byte-aligned Packed) kill a walk that
+  // starts at a wrong byte within a few hops (every other junk range byte claims a 4-byte literal count that points outside the
+  // stream), so 1 KiB in front of a region is plenty.  The other formats' junk walks live on and only find the chain by falling onto
+  // one of its packet starts (1 hop in ~40 on random literals): they start with 4 KiB, and mono_decode_dev widens the look-back when
+  // too many guesses turn out wrong.
+  const bool range7 = (codec == 1 || (codec >= 6 && codec < 50 && (codec == 49 || (codec < 46 && ((codec - 6) & 7) == 5))));
+  m.M = tM ? tM : (range7 ? 1024u : 4096u);
   m.R = (uint32_t)(((uint64_t)(C - p0) + G - 1u) / G);
   if (m.R == 0u) m.R = 1u;
   m.KE = (uint32_t)codec_state_slots(codec);
@@ -620,11 +626,19 @@ static int mono_decode_dev(const MonoHeader &mh, const uint8_t *dStream, uint8_t
     if (rounds++ > m.R)                                    // every round proves at least one more region: cannot happen
       return HSRLE_ERR_DEVICE;
     rewalked += verdict[0];
-    ia.list = (const uint32_t *)(ws + m.offList); ia.listCount = verdict[0];
+    if (rounds == 1u && verdict[0] > 8u && verdict[0] > m.R / 32u && ia.M < 65536u && g_monoTune[2] == 0u)
+    {
+      // the guesses of this stream do not find the chain within the look-back (wrong guesses come in streaks, and a streak is repaired
+      // one region per round): guess again, everywhere, from four times as far back
+      ia.M *= 4u;
+      ia.list = nullptr; ia.listCount = 0;
+      rounds = 0;
+    }
+    else { ia.list = (const uint32_t *)(ws + m.offList); ia.listCount = verdict[0]; }
     if (g_idx[mh.codec](ia, 0, st) != hipSuccess)
       return HSRLE_ERR_DEVICE;
   }
-  if (stats) { stats[0] = m.R; stats[1] = rounds; stats[2] = rewalked; }
+  if (stats) { stats[0] = m.R; stats[1] = rounds; stats[2] = rewalked; stats[3] = ia.M; }
   if (verdict[1] != 0u)
     return HSRLE_ERR_FORMAT;
 

@@ -103,7 +103,11 @@ __device__ __forceinline__ Pkt parse_packet(const uint8_t *__restrict__ s, uint3
       else if (range == 1u) { range = rext & 0xFFFFu; pos += 2; endNow = (range == 0u); }
     }
     if constexpr (TR::kShortSingle) { }
-    else if constexpr (TR::K == 0) { k.hasSym = true; k.symAt = p + pos; pos += S; }
+    else if constexpr (TR::K == 0)
+    {
+      // every packet carries its symbol; the END terminator carries ONE zero byte whatever the symbol width (rleX_Xsl_short.h:497-520)
+      k.hasSym = true; k.symAt = p + pos; pos += endNow ? 1u : (uint32_t)S;
+    }
     else
     {
       k.op = idx;
@@ -525,8 +529,8 @@ __global__ __launch_bounds__(64) void k_index_records(const uint8_t *__restrict_
         phase = (uint32_t)(t % (uint64_t)S);
       }
       u32x4 sym;
-      if constexpr (KE > 0) sym = index_symbol<S>(s, st[0], FAM == PACKED);
-      else if (sgl || TR::kShortSingle) sym = u32x4{ singleSym & 0xFFu, 0, 0, 0 };
+      if (sgl || TR::kShortSingle) sym = u32x4{ singleSym & 0xFFu, 0, 0, 0 };
+      else if constexpr (KE > 0) sym = index_symbol<S>(s, st[0], FAM == PACKED);
       else sym = index_symbol<S>(s, curSym, true);
       w[0] = rsp; w[1] = rlit; w[2] = rrun; w[3] = phase | (k.last ? REC_LAST : 0u) | (sgl ? REC_SINGLE : 0u);
       w[4] = sym.x; w[5] = sym.y; w[6] = sym.z; w[7] = sym.w;

@@ -187,7 +187,7 @@ def mono_tuning(block=0, region=0, lookback=0):
 
 def mono_decompress_dev(codec, stream_tensor, dst=None, workspace=None, return_stats=False):
     """Decode ONE monolithic reference stream that lives in device memory (uint8 CUDA tensor with >= 64 bytes of slack behind the
-    stream's last byte, 128-byte aligned) into device memory.  Returns the output tensor (and (regions, rounds, rewalked))."""
+    stream's last byte, 128-byte aligned) into device memory.  Returns the output tensor (and (regions, rounds, rewalked, lookback))."""
     import torch
 
     _check_u8_cuda(stream_tensor, "stream")
@@ -200,7 +200,7 @@ def mono_decompress_dev(codec, stream_tensor, dst=None, workspace=None, return_s
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=stream_tensor.device)
     n = ctypes.c_uint32(0)
-    stats = (ctypes.c_uint32 * 3)()
+    stats = (ctypes.c_uint32 * 4)()
     rc = _lib().hsrle_decompress_mono_dev(cid, ctypes.c_void_p(stream_tensor.data_ptr()), csize, ctypes.c_void_p(dst.data_ptr()), dst.numel(),
                                           ctypes.c_void_p(workspace.data_ptr()), workspace.numel(), ctypes.byref(n), stats, _stream_ptr())
     if rc != OK:
