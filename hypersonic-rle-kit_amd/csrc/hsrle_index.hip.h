@@ -210,48 +210,44 @@ __global__ __launch_bounds__(64) void k_index_walk(const uint8_t *__restrict__ s
 
   const uint32_t start = p0 + r * G, endr = start + G;
   const bool sgl = single != 0u;
-  uint32_t q;
-  if (list != nullptr) q = fix[r];
-  else if (r == 0u) q = p0;
-  else
-  {
-    // guess: the first walk from <= M bytes in front of the region that survives until the region starts.  A walk that begins at
-    // the stream's first packet IS the chain; any other one is taken for dead when it claims a literal stretch of M bytes or more
-    // (a true one of that size makes the chain jump, and then k_index_resolve hands this region its entry anyway).
-    const bool fromStart = start - p0 <= M;
-    const uint32_t a = fromStart ? p0 : start - M;
-    q = start;
-    uint32_t hopsLeft = 4u * M + 64u;
-    for (uint32_t t = a; t < start && hopsLeft != 0u; t++)
-    {
-      uint32_t x = t;
-      bool dead = false;
-      while (x < start)
-      {
-        if (hopsLeft-- == 0u) { dead = true; break; }
-        const Pkt k = parse_packet<FAM, S, AL>(s, x, C, sgl);
-        if (k.bad || k.last || (k.lit >= M && !(fromStart && t == a))) { dead = true; break; }
-        x += k.used + k.lit;
-      }
-      if (!dead) { q = x; break; }
-      if (fromStart && t == a) break;              // the true chain itself ends / breaks in front of this region: nothing to guess
-    }
-  }
 
+  // ONE loop, one packet per trip, whatever a lane is doing (guessing or walking its region): nested loops would make the whole wave
+  // wait for the lane with the most restarts in every restart round.
+  //   guess: the first walk from <= M bytes in front of the region that survives until the region starts.  A walk that begins at the
+  //   stream's first packet IS the chain; any other one is taken for dead when it claims a literal stretch of M bytes or more (a
+  //   true one of that size makes the chain jump, and then k_index_resolve hands this region its entry anyway); a dead walk is
+  //   started again one byte further on.
+  const bool fromStart = start - p0 <= M;
+  bool guessing = (list == nullptr) && r != 0u;
+  uint32_t t = fromStart ? p0 : start - M;       // where the current guess walk started
+  uint32_t hopsLeft = 4u * M + 64u;
+  uint32_t x = guessing ? t : ((list != nullptr) ? fix[r] : p0);
+  uint32_t q = x, ex = 0;
   uint64_t ol = 0;
   uint32_t tr[KE > 0 ? KE : 1];
 #pragma unroll
   for (int j = 0; j < (KE > 0 ? KE : 1); j++) tr[j] = IDX_OLD | (uint32_t)j;
-  uint32_t x = q, ex;
+
   for (;;)
   {
-    if (x >= endr) { ex = x; break; }
-    const Pkt k = parse_packet<FAM, S, AL>(s, x, C, sgl);
-    if (k.bad) { ex = IDX_DEAD; break; }
-    ol += (uint64_t)k.lit + (uint64_t)k.run;
-    state_apply<KE>(tr, k.op, k.symAt);
-    if (k.last) { ex = IDX_END; break; }
-    x += k.used + k.lit;
+    if (guessing && x >= start) { guessing = false; q = x; }
+    if (!guessing && x >= endr) { ex = x; break; }
+    const Pkt k = parse_packet<FAM, S, AL>(s, x, C, sgl);      // the one parse site of the loop: guessing and walking lanes share it
+    if (guessing)
+    {
+      const bool truth = fromStart && t == p0;
+      if (hopsLeft-- == 0u || (truth && (k.bad || k.last))) { guessing = false; q = start; x = start; }      // nothing (left) to guess: any entry will do
+      else if (k.bad || k.last || (k.lit >= M && !truth)) { t++; x = t; if (t >= start) { guessing = false; q = start; } }
+      else x += k.used + k.lit;
+    }
+    else
+    {
+      if (k.bad) { ex = IDX_DEAD; break; }
+      ol += (uint64_t)k.lit + (uint64_t)k.run;
+      state_apply<KE>(tr, k.op, k.symAt);
+      if (k.last) { ex = IDX_END; break; }
+      x += k.used + k.lit;
+    }
   }
   gOut[r] = q;
   eOut[r] = ex;
@@ -293,7 +289,7 @@ __global__ __launch_bounds__(kResolveThreads) void k_index_resolve(const uint32_
   constexpr int KS = KE > 0 ? KE : 1;
   constexpr uint8_t F_NONE = 0, F_OK = 1, F_SKIP = 2, F_DIRTY = 3;
   __shared__ uint32_t sg[NT], se[NT];
-  __shared__ uint8_t sflag[NT];
+  __shared__ uint8_t sflag[NT], sok[NT];
   __shared__ uint64_t swave[NT / 64];
   __shared__ uint32_t sT1[2 * NT * KS];
 #define HS_ST(buf, t, j) sT1[((uint32_t)(buf) * NT + (uint32_t)(t)) * KS + (uint32_t)(j)]
@@ -317,25 +313,45 @@ __global__ __launch_bounds__(kResolveThreads) void k_index_resolve(const uint32_
     const uint32_t gg = valid ? g[r] : 0u, ee = valid ? e[r] : 0u;
     sg[tid] = gg; se[tid] = ee;
     __syncthreads();
-    const uint32_t prev = (tid == 0) ? sCur : se[tid - 1];
+    const uint32_t cur0 = sCur, ended0 = sEnded;                        // (read in front of the barrier below: thread 0 writes them behind it)
+    const uint32_t prev = (tid == 0) ? cur0 : se[tid - 1];
     const uint32_t endr = p0 + (r + 1u) * G;
-    const bool ok = !valid || (sEnded == 0u && prev == gg && gg < endr && ee < IDX_SKIP);
+    const bool ok = !valid || (ended0 == 0u && prev == gg && gg < endr && ee < IDX_SKIP);
     const int allok = __syncthreads_and(ok ? 1 : 0);
     const uint32_t n = (R - base < (uint32_t)NT) ? R - base : (uint32_t)NT;
+    sok[tid] = ok ? 1 : 0;
+    const bool allSkipped = ended0 != 0u || cur0 >= p0 + (base + n) * G;   // the chain is over, or jumps over the whole batch
 
     if (allok)
     {
       sflag[tid] = valid ? F_OK : F_NONE;
       if (tid == 0) sCur = se[n - 1u];
     }
-    else if (tid == 0)
+    else if (allSkipped)
+      sflag[tid] = valid ? F_SKIP : F_NONE;
+    else
+      sflag[tid] = valid ? F_OK : F_NONE;                                 // what thread 0 does not touch below is a proven link
+    __syncthreads();
+    if (!allok && !allSkipped && tid == 0)
     {
-      // the rare path, one thread over the batch: jumps over regions, the end of the chain, wrong guesses
+      // the rare path, one thread over the batch: jumps over regions, the end of the chain, wrong guesses.  While the walk is IN SYNC
+      // (it stands where the previous region's walk left) the parallel check above already holds the answer: stretches of regions
+      // that passed it are skipped over.
       uint32_t cur = sCur, ended = sEnded, trusted = sTrusted;
+      bool insync = true;
       // (always from global memory: a choice between the LDS copy and the global array becomes a flat access that this compiler cannot encode)
       auto next_guess = [&](uint32_t k, uint32_t rr) -> uint32_t { (void)k; return g[rr + 1u]; };
       for (uint32_t k = 0; k < n; k++)
       {
+        if (insync && !ended && sok[k])
+        {
+          uint32_t j = k + 1u;
+          while (j < n && sok[j]) j++;
+          cur = se[j - 1u];                                                // regions k .. j-1 keep F_OK
+          k = j - 1u;
+          continue;
+        }
+        insync = false;
         const uint32_t rr = base + k;
         const uint32_t endk = p0 + (rr + 1u) * G;
         if (ended || cur >= endk) { sflag[k] = F_SKIP; continue; }
@@ -343,7 +359,7 @@ __global__ __launch_bounds__(kResolveThreads) void k_index_resolve(const uint32_
         {
           sflag[k] = F_OK;
           const uint32_t x = se[k];
-          if (x < IDX_SKIP) cur = x;
+          if (x < IDX_SKIP) { cur = x; insync = true; }
           else if (trusted) { if (x == IDX_DEAD) sStatus |= IDXS_STREAM; ended = 1; }
           else if (rr + 1u < R) cur = next_guess(k, rr);                          // behind a wrong guess nothing is final: go on from the next guess
         }
