@@ -50,18 +50,19 @@ static inline uint32_t codec_header_size(int c) { return (c < 6 && !codec_is_lut
 static DecodeLaunch g_dec[kCodecCount];
 static EncodeLaunch g_enc[kCodecCount];
 static IndexLaunch g_idx[kCodecCount];
+static SubBlockLaunch g_sub[kCodecCount];
 static std::once_flag g_tableOnce;
 
 static void init_tables()
 {
   std::call_once(g_tableOnce, [] {
-    register_w8(g_dec, g_enc, g_idx);
-    register_w16(g_dec, g_enc, g_idx);
-    register_w24(g_dec, g_enc, g_idx);
-    register_w32(g_dec, g_enc, g_idx);
-    register_w48(g_dec, g_enc, g_idx);
-    register_w64(g_dec, g_enc, g_idx);
-    register_w128(g_dec, g_enc, g_idx);
+    register_w8(g_dec, g_enc, g_idx, g_sub);
+    register_w16(g_dec, g_enc, g_idx, g_sub);
+    register_w24(g_dec, g_enc, g_idx, g_sub);
+    register_w32(g_dec, g_enc, g_idx, g_sub);
+    register_w48(g_dec, g_enc, g_idx, g_sub);
+    register_w64(g_dec, g_enc, g_idx, g_sub);
+    register_w128(g_dec, g_enc, g_idx, g_sub);
   });
 }
 
@@ -69,6 +70,8 @@ static inline uint32_t bounds32(uint32_t n) { return (n > (1u << 30)) ? 0u : n +
 static inline uint32_t slot_stride(uint32_t B) { return (bounds32(B) + 15u) & ~15u; }
 static inline uint64_t block_count(uint64_t U, uint32_t B) { return (U + B - 1) / B; }
 static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+static uint32_t pow2_floor(uint64_t v) { uint32_t r = 1; while ((uint64_t)r * 2u <= v && r < 0x80000000u) r *= 2u; return r; }
 
 static bool valid_block_size(uint32_t B) { return B >= HSRLE_MIN_BLOCK_SIZE && B <= HSRLE_MAX_BLOCK_SIZE && (B % 128u) == 0; }
 
@@ -474,6 +477,70 @@ static int decompress_blocks_async(const void *dContainer, const hsrle_container
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// split decode of a container: every block is cut into sub-blocks of SB output bytes.  One lane per block walks the block's packets
+// (k_container_records) and leaves the decoder state at every SB bytes; the block kernel then runs one lane per SUB-block.  For
+// containers with too few blocks to fill the GPU with one lane per block (an 88 MB frame in 4 KiB blocks has 21 600): the block size,
+// and with it the compression ratio, stays what it is.
+
+static uint32_t split_sub_block(const hsrle_container_info_t *info, uint32_t want)
+{
+  const uint32_t B = info->blockSize;
+  if (want == 0u)
+  {
+    want = pow2_floor(info->uncompressedSize >> 18);                 // >= 2^18 lanes where the buffer allows it
+    want = want < 256u ? 256u : want;
+  }
+  if (want >= B || (want % 128u) != 0u || (B % want) != 0u)
+    return B;                                                           // no split
+  return want;
+}
+
+static int decompress_split_async(const void *dContainer, const hsrle_container_info_t *info, uint32_t first, uint32_t count, void *dOut, uint64_t cap, uint32_t *dStatus,
+                                  void *dWs, uint64_t wsSize, uint32_t subBlock, hipStream_t st)
+{
+  if (dContainer == nullptr || info == nullptr || dOut == nullptr)
+    return HSRLE_ERR_ARGUMENT;
+  if (info->codec >= (uint32_t)kCodecCount || !valid_block_size(info->blockSize) || info->blockCount != block_count(info->uncompressedSize, info->blockSize))
+    return HSRLE_ERR_FORMAT;
+  const uint32_t SB = split_sub_block(info, subBlock);
+  if (SB == info->blockSize)
+    return decompress_blocks_async(dContainer, info, first, count, dOut, cap, dStatus, st);
+  if ((uint64_t)first + count > info->blockCount)
+    return HSRLE_ERR_ARGUMENT;
+  if (cap < info->uncompressedSize)
+    return HSRLE_ERR_CAPACITY;
+  if (!device_ok())
+    return HSRLE_ERR_DEVICE;
+  if (count == 0)
+    return HSRLE_OK;
+  init_tables();
+  if (!g_dec[info->codec] || !g_sub[info->codec])
+    return HSRLE_ERR_UNSUPPORTED;
+
+  const uint32_t per = info->blockSize / SB;
+  const uint64_t subFirst = (uint64_t)first * per;
+  const uint64_t subAll = (info->uncompressedSize + SB - 1u) / SB;
+  uint64_t subEnd = ((uint64_t)first + count) * per;
+  if (subEnd > subAll) subEnd = subAll;
+  if (subEnd - subFirst > 0xFFFFFFF0ull || subEnd > 0xFFFFFFF0ull)
+    return HSRLE_ERR_ARGUMENT;
+  if (dWs == nullptr || wsSize < (subEnd - subFirst) * 4ull * kEntryRecDwords)
+    return HSRLE_ERR_CAPACITY;
+
+  const uint8_t *container = (const uint8_t *)dContainer;
+  const uint8_t *payload = container + HSRLE_CONTAINER_HEADER_SIZE + 8ull * ((uint64_t)info->blockCount + 1ull);
+  DecodeArgs da{ payload, (const uint64_t *)(container + HSRLE_CONTAINER_HEADER_SIZE), payload + info->payloadSize + HSRLE_CONTAINER_TAIL_PAD,
+                 (uint8_t *)dOut, info->uncompressedSize, info->blockSize, first, count, dStatus };
+  // records are indexed by the global sub-block number: hand the kernel the address record 0 would have
+  uint32_t *rec0 = (uint32_t *)((uintptr_t)dWs - (uintptr_t)(subFirst * 4ull * kEntryRecDwords));
+  if (g_sub[info->codec](da, SB, rec0, st) != hipSuccess)
+    return HSRLE_ERR_DEVICE;
+  da.B = SB; da.firstBlock = (uint32_t)subFirst; da.blockCount = (uint32_t)(subEnd - subFirst);
+  da.entries = (const uint32_t *)dWs; da.entryBase = (uint32_t)subFirst;
+  return g_dec[info->codec](da, st) == hipSuccess ? HSRLE_OK : HSRLE_ERR_DEVICE;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // monolithic stream decode: index passes (hsrle_index.hip.h) + the block kernel started from entry records
 
 // symbol-state slots of the codec's decoder (IndexState<FAM>::KE): 0 plain / Single / 0-symbol Short, 1 Packed / 1-symbol list, 3, 7
@@ -496,7 +563,6 @@ struct MonoPlan
   uint64_t offG, offE, offOlen, offT, offEntry, offOutStart, offStateIn, offFix, offList, offCtrl, offRec, total;
 };
 
-static uint32_t pow2_floor(uint64_t v) { uint32_t r = 1; while ((uint64_t)r * 2u <= v) r *= 2u; return r; }
 static uint32_t env_u32(const char *name, uint32_t dflt) { const char *e = getenv(name); return (e && *e) ? (uint32_t)strtoul(e, nullptr, 10) : dflt; }
 
 static uint32_t g_monoTune[3] = { env_u32("HSRLE_MONO_BLOCK", 0), env_u32("HSRLE_MONO_REGION", 0), env_u32("HSRLE_MONO_LOOKBACK", 0) };
@@ -648,7 +714,7 @@ static int mono_decode_dev(const MonoHeader &mh, const uint8_t *dStream, uint8_t
   uint32_t *dStatus = ctrl + 8;
   DecodeArgs da{ dStream, nullptr, dStream + mh.C + HSRLE_CONTAINER_TAIL_PAD, dOut, mh.U, m.B, 0u, (uint32_t)m.nb, dStatus };
   da.entries = (const uint32_t *)(ws + m.offRec);
-  da.streamLen = mh.C;
+  da.entryBase = 0;
   if (g_dec[mh.codec](da, st) != hipSuccess)
     return HSRLE_ERR_DEVICE;
   uint32_t status = 1;
@@ -1083,6 +1149,26 @@ int hsrle_decompress_dev_async(const void *dContainer, const hsrle_container_inf
 {
   if (!info) return HSRLE_ERR_ARGUMENT;
   return decompress_blocks_async(dContainer, info, 0, info->blockCount, dOut, outCapacity, dStatus, (hipStream_t)stream);
+}
+
+uint32_t hsrle_split_sub_block_size(const hsrle_container_info_t *info, uint32_t subBlockSize)
+{
+  if (!info || !valid_block_size(info->blockSize)) return 0;
+  return split_sub_block(info, subBlockSize);
+}
+
+uint64_t hsrle_decompress_split_workspace_size(const hsrle_container_info_t *info, uint32_t blockCount, uint32_t subBlockSize)
+{
+  if (!info || !valid_block_size(info->blockSize)) return 0;
+  const uint32_t SB = split_sub_block(info, subBlockSize);
+  if (SB == info->blockSize) return 0;
+  return (uint64_t)blockCount * (info->blockSize / SB) * 4ull * kEntryRecDwords;
+}
+
+int hsrle_decompress_split_dev_async(const void *dContainer, const hsrle_container_info_t *info, uint32_t firstBlock, uint32_t blockCount, void *dOut, uint64_t outCapacity,
+                                     uint32_t *dStatus, void *dWorkspace, uint64_t workspaceSize, uint32_t subBlockSize, void *stream)
+{
+  return decompress_split_async(dContainer, info, firstBlock, blockCount, dOut, outCapacity, dStatus, dWorkspace, workspaceSize, subBlockSize, (hipStream_t)stream);
 }
 
 int hsrle_decompress_dev(const void *dContainer, uint64_t containerSize, void *dOut, uint64_t outCapacity, uint64_t *pUncompressedSize, void *stream)

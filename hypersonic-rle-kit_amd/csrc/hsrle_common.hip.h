@@ -20,9 +20,9 @@ enum Family : int { PLAIN = 0, PACKED = 1, LUT3 = 2, LUT7 = 3, SINGLE = 4, PACKE
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-// Entry record of the monolithic-stream path (hsrle_index.hip.h writes them, k_decode_blocks starts from them): the decoder state at
-// output position b * B of ONE reference stream.  dwords: [0] stream position, [1] literal bytes left, [2] run bytes left,
-// [3] pattern phase | flags, [4..7] current symbol, [8..] move-to-front list (K entries of SW dwords)
+// Entry record (hsrle_index.hip.h writes them, k_decode_blocks starts from them): the decoder state at output position b * B of a
+// reference stream.  dwords: [0..1] stream position relative to `payload`, [2] literal bytes left, [3] run bytes left, [4] pattern
+// phase | flags, [5] bytes from that position to the stream's end, [6..9] current symbol, [10..] move-to-front list (K x SW dwords)
 constexpr uint32_t kEntryRecDwords = 24;
 constexpr uint32_t REC_LAST = 0x100u, REC_SINGLE = 0x200u;
 

@@ -179,11 +179,12 @@ template <int FAM, int S, int AL, int T, int R, int Q = T, bool SGL = true>
 __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict__ payload, const uint64_t *__restrict__ offsets,
                                                       const uint8_t *__restrict__ payloadEnd, uint8_t *__restrict__ out, uint64_t U,
                                                       uint32_t B, uint32_t firstBlock, uint32_t blockCount, uint32_t *__restrict__ status,
-                                                      const uint32_t *__restrict__ entries, uint32_t streamLen)
+                                                      const uint32_t *__restrict__ entries, uint32_t entryBase)
 {
-  // entries != nullptr: `payload` is ONE monolithic reference stream of streamLen bytes and lane b starts from entry record b (the
-  // decoder state at output position b * B, hsrle_index.hip.h) instead of from the header of block stream b; everything behind the
-  // prologue is the same -- a lane still produces the B output bytes [b * B, (b + 1) * B)
+  // entries != nullptr: lane b starts from entry record (b - entryBase) -- the decoder state at output position b * B of a stream that
+  // lies somewhere in `payload` (ONE monolithic reference stream, or sub-block b of a container block; hsrle_index.hip.h writes the
+  // records) -- instead of from the header of block stream b; everything behind the prologue is the same: a lane still produces the
+  // B output bytes [b * B, (b + 1) * B)
   using TR = Traits<FAM, S, AL>;
   constexpr int TS = T;                      // tile row stride: no pad -- the 16-byte chunks of a row are XOR-swizzled by the row index instead (TSW)
   constexpr int RS = R;                      // ring row stride: no pad, no mirror -- chunks are XOR-swizzled by the row index (rowx), every 8-byte piece is addressed on its own
@@ -272,7 +273,12 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     if (active)
     {
       uint64_t off0, off1;
-      if (entries != nullptr) { off0 = entries[(uint64_t)b * kEntryRecDwords]; off1 = streamLen; }
+      if (entries != nullptr)
+      {
+        const uint32_t *const er = entries + (uint64_t)(b - entryBase) * kEntryRecDwords;
+        off0 = (uint64_t)er[0] | ((uint64_t)er[1] << 32);
+        off1 = off0 + er[5];
+      }
       else { off0 = offsets[b]; off1 = offsets[b + 1]; }
       // the offset table is data too: an entry outside the payload (or a negative / oversized stream length) must end as an error
       // bit, never as a wild read -- the lane then sees an empty stream at offset 0, which fails the header check
@@ -389,11 +395,11 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     wave_sync();                                                      //     flies during the first step's decode
   }
 
-  const uint32_t *const rec = (entries != nullptr && active) ? entries + (uint64_t)b * kEntryRecDwords : nullptr;
+  const uint32_t *const rec = (entries != nullptr && active) ? entries + (uint64_t)(b - entryBase) * kEntryRecDwords : nullptr;
   if (rec != nullptr)
   {
-    const uint32_t rf = rec[3];
-    sp = g0; lit = rec[1]; run = rec[2];
+    const uint32_t rf = rec[4];
+    sp = g0; lit = rec[2]; run = rec[3];
     phase = rf & 0xFFu;
     last = (rf & REC_LAST) != 0u;
     if constexpr (SGL) singleVar = (rf & REC_SINGLE) != 0u;
@@ -446,14 +452,14 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   }
   if (rec != nullptr)
   {
-    set_sym(u32x4{ rec[4], rec[5], rec[6], rec[7] });
+    set_sym(u32x4{ rec[6], rec[7], rec[8], rec[9] });
     if constexpr (TR::kMtf)
     {
 #pragma unroll
       for (int k = 0; k < TR::K; k++)
 #pragma unroll
         for (int w = 0; w < TR::SW; w++)
-          lut[k][w] = rec[8 + k * TR::SW + w];
+          lut[k][w] = rec[10 + k * TR::SW + w];
     }
   }
 

@@ -499,42 +499,32 @@ __device__ __forceinline__ u32x4 index_symbol(const uint8_t *__restrict__ s, uin
   else return x;
 }
 
-// ---- pass 3: the decoder state at every output position b * B ----
+// Walk the packets of the stream `s` (C bytes; its first byte sits at byte `sBase` of what the decoder will call `payload`) from
+// packet start x while x < endr, with o = output position of that packet's first byte and st = symbol state in front of it, and write
+// an entry record for every output position b * B (< limit) that falls into one of the packets.
+//   record dwords: [0..1] stream position (relative to `payload`), [2] literal bytes left, [3] run bytes left, [4] phase | flags,
+//   [5] bytes from that position to the stream's end, [6..9] current symbol, [10..] move-to-front list
+// Returns 0 (stopped at endr), 1 (the stream's last packet was walked) or 2 (malformed packet); o = output position behind the walk.
 template <int FAM, int S, int AL>
-__global__ __launch_bounds__(64) void k_index_records(const uint8_t *__restrict__ s, uint32_t C, uint32_t p0, uint32_t G, uint32_t R, uint32_t single, uint32_t singleSym,
-                                                      const uint32_t *__restrict__ entry, const uint64_t *__restrict__ outStart, const uint32_t *__restrict__ stateIn,
-                                                      uint64_t U, uint32_t B, uint32_t *__restrict__ rec)
+__device__ __forceinline__ uint32_t walk_emit_records(const uint8_t *__restrict__ s, uint64_t sBase, uint32_t C, uint32_t x, uint32_t endr, uint64_t &o,
+                                                      uint32_t (&st)[IndexState<FAM>::KE > 0 ? IndexState<FAM>::KE : 1], bool sgl, uint32_t singleSym,
+                                                      uint64_t limit, uint32_t B, uint32_t *__restrict__ rec)
 {
   using TR = Traits<FAM, S, AL>;
   constexpr int KE = IndexState<FAM>::KE;
-  constexpr int KS = KE > 0 ? KE : 1;
   constexpr int SW = TR::SW;
-  const uint32_t r = blockIdx.x * 64u + threadIdx.x;
-  if (r >= R) return;
-  uint32_t x = entry[r];
-  if (x == IDX_SKIP) return;
-  const uint32_t endr = p0 + (r + 1u) * G;
-  const bool sgl = single != 0u;
-  uint64_t o = outStart[r];
-
-  // the state as offsets / init tags (what the transformers carry); symbols are fetched when a record is written
-  uint32_t st[KS];
-#pragma unroll
-  for (int j = 0; j < KS; j++) st[j] = (KE > 0) ? stateIn[(uint64_t)r * KS + j] : 0u;
   uint32_t curSym = IDX_INIT;      // offset / tag of the current packet's symbol (families without a list)
-
   while (x < endr)
   {
     const Pkt k = parse_packet<FAM, S, AL>(s, x, C, sgl);
-    if (k.bad) break;                                                    // cannot happen: k_index_walk walked this chain
+    if (k.bad) return 2u;
     state_apply<KE>(st, k.op, k.symAt);
     if (k.hasSym) curSym = k.symAt;
     const uint64_t outEnd = o + (uint64_t)k.lit + (uint64_t)k.run;
     const uint32_t body = x + k.used;
-    for (uint64_t b = (o + B - 1u) / B; b * B < outEnd && b * B < U; b++)
+    for (uint64_t b = (o + B - 1u) / B; b * B < outEnd && b * B < limit; b++)
     {
-      const uint64_t X = b * B;
-      const uint64_t into = X - o;
+      const uint64_t into = b * B - o;
       uint32_t *const w = rec + b * (uint64_t)kEntryRecDwords;
       uint32_t rsp, rlit, rrun, phase = 0;
       if (into < (uint64_t)k.lit) { rsp = body + (uint32_t)into; rlit = k.lit - (uint32_t)into; rrun = k.run; }
@@ -548,23 +538,93 @@ __global__ __launch_bounds__(64) void k_index_records(const uint8_t *__restrict_
       if (sgl || TR::kShortSingle) sym = u32x4{ singleSym & 0xFFu, 0, 0, 0 };
       else if constexpr (KE > 0) sym = index_symbol<S>(s, st[0], FAM == PACKED);
       else sym = index_symbol<S>(s, curSym, true);
-      w[0] = rsp; w[1] = rlit; w[2] = rrun; w[3] = phase | (k.last ? REC_LAST : 0u) | (sgl ? REC_SINGLE : 0u);
-      w[4] = sym.x; w[5] = sym.y; w[6] = sym.z; w[7] = sym.w;
+      const uint64_t at = sBase + rsp;
+      w[0] = (uint32_t)at; w[1] = (uint32_t)(at >> 32); w[2] = rlit; w[3] = rrun;
+      w[4] = phase | (k.last ? REC_LAST : 0u) | (sgl ? REC_SINGLE : 0u);
+      w[5] = C - rsp;
+      w[6] = sym.x; w[7] = sym.y; w[8] = sym.z; w[9] = sym.w;
       if constexpr (TR::kMtf)
       {
 #pragma unroll
         for (int j = 0; j < KE; j++)
         {
           const u32x4 v = index_symbol<S>(s, st[j], false);
-          w[8 + j * SW] = v.x;
-          if constexpr (SW > 1) w[8 + j * SW + 1] = v.y;
+          w[10 + j * SW] = v.x;
+          if constexpr (SW > 1) w[10 + j * SW + 1] = v.y;
         }
       }
     }
     o = outEnd;
-    if (k.last) break;
+    if (k.last) return 1u;
     x = body + k.lit;
   }
+  return 0u;
+}
+
+// ---- pass 3: the decoder state at every output position b * B ----
+template <int FAM, int S, int AL>
+__global__ __launch_bounds__(64) void k_index_records(const uint8_t *__restrict__ s, uint32_t C, uint32_t p0, uint32_t G, uint32_t R, uint32_t single, uint32_t singleSym,
+                                                      const uint32_t *__restrict__ entry, const uint64_t *__restrict__ outStart, const uint32_t *__restrict__ stateIn,
+                                                      uint64_t U, uint32_t B, uint32_t *__restrict__ rec)
+{
+  constexpr int KE = IndexState<FAM>::KE;
+  constexpr int KS = KE > 0 ? KE : 1;
+  const uint32_t r = blockIdx.x * 64u + threadIdx.x;
+  if (r >= R) return;
+  const uint32_t x = entry[r];
+  if (x == IDX_SKIP) return;
+  uint64_t o = outStart[r];
+  // the state as offsets / init tags (what the transformers carry); symbols are fetched when a record is written
+  uint32_t st[KS];
+#pragma unroll
+  for (int j = 0; j < KS; j++) st[j] = (KE > 0) ? stateIn[(uint64_t)r * KS + j] : 0u;
+  (void)walk_emit_records<FAM, S, AL>(s, 0ull, C, x, p0 + (r + 1u) * G, o, st, single != 0u, singleSym, U, B, rec);   // (cannot meet a malformed packet: k_index_walk walked this chain)
+}
+
+// ---- the same for a block container: one lane per block walks the block's stream from its first packet (known: no guessing, no
+//      resolve pass) and writes the decoder state at every SB output bytes, so that k_decode_blocks can put B / SB lanes on a block.
+//      What the block kernel checks in its prologue (table entry, stream header, mode byte) is checked here.
+template <int FAM, int S, int AL>
+__global__ __launch_bounds__(64) void k_container_records(const uint8_t *__restrict__ payload, const uint64_t *__restrict__ offsets, const uint8_t *__restrict__ payloadEnd,
+                                                          uint64_t U, uint32_t B, uint32_t firstBlock, uint32_t blockCount, uint32_t SB, uint32_t allowSingle,
+                                                          uint32_t *__restrict__ rec, uint32_t *__restrict__ status)
+{
+  using TR = Traits<FAM, S, AL>;
+  constexpr int KE = IndexState<FAM>::KE;
+  constexpr int KS = KE > 0 ? KE : 1;
+  const uint32_t i = xcd_tile(blockIdx.x, gridDim.x) * 64u + threadIdx.x;
+  if (i >= blockCount) return;
+  const uint32_t b = firstBlock + i;
+  uint32_t err = 0;
+  const uint64_t off0 = offsets[b], off1 = offsets[b + 1];
+  const uint64_t payloadBytes = (uint64_t)(payloadEnd - payload);
+  const uint64_t start = (uint64_t)b * B;
+  const uint32_t blen = (uint32_t)((U - start) < (uint64_t)B ? (U - start) : (uint64_t)B);
+  if (off0 > off1 || off1 > payloadBytes || off1 - off0 > 0xFFFFFF00ull) err = DEC_ERR_HEADER;
+  else
+  {
+    const uint8_t *const s = payload + off0;
+    const uint32_t C = (uint32_t)(off1 - off0);
+    uint32_t p0 = TR::kHeaderSize, sgl = 0, sym = 0;
+    if (C < TR::kHeaderSize + 2u || ld32(s) != blen || ld32(s + 4) != C) err = DEC_ERR_HEADER;
+    else if constexpr (TR::kShortSingle) { sym = s[8]; p0 = 9; }
+    else if constexpr (S == 1 && !TR::kLut && !TR::kShort)
+    {
+      const uint32_t mode = s[8];
+      if (mode == 1u) { if (allowSingle) { sgl = 1; sym = s[9]; p0 = 10; } else err = DEC_ERR_MODE; }
+      else if (mode != 0u) err = DEC_ERR_MODE;
+    }
+    if (err == 0u)
+    {
+      uint32_t st[KS];
+#pragma unroll
+      for (int j = 0; j < KS; j++) st[j] = IDX_INIT | (uint32_t)j;
+      uint64_t o = start;
+      const uint32_t how = walk_emit_records<FAM, S, AL>(s, off0, C, p0, 0xFFFFFFF0u, o, st, sgl != 0u, sym, start + blen, SB, rec);
+      if (how != 1u || o != start + blen) err = DEC_ERR_STREAM;
+    }
+  }
+  if (err != 0u && status != nullptr) atomicOr(status, err);
 }
 
 // host side: walk (records == 0) or record pass (records != 0) of one codec grammar
@@ -581,6 +641,14 @@ inline hipError_t launch_index(const IndexArgs &a, int records, hipStream_t st)
     hipLaunchKernelGGL((k_index_walk<FAM, S, AL>), dim3((n + 63u) / 64u), dim3(64), 0, st, a.stream, a.C, a.p0, a.G, a.M, a.R, a.single, a.list, a.listCount, a.fix, a.g, a.e,
                        a.olen, a.t);
   }
+  return hipGetLastError();
+}
+
+template <int FAM, int S, int AL>
+inline hipError_t launch_container_records(const DecodeArgs &a, uint32_t SB, uint32_t allowSingle, uint32_t *rec, hipStream_t st)
+{
+  hipLaunchKernelGGL((k_container_records<FAM, S, AL>), dim3((a.blockCount + 63u) / 64u), dim3(64), 0, st, a.payload, a.offsets, a.payloadEnd, a.U, a.B, a.firstBlock, a.blockCount, SB,
+                     allowSingle, rec, a.status);
   return hipGetLastError();
 }
 

@@ -18,8 +18,8 @@ struct DecodeArgs
   uint32_t B, firstBlock, blockCount;
   uint32_t *status;
   int *residentWorkgroups = nullptr; // query mode: no launch; receives the number of workgroups (= waves) of this kernel that fit on one CU
-  const uint32_t *entries = nullptr; // monolithic stream: `payload` is the stream, lane b starts from entry record b (hsrle_index.hip.h)
-  uint32_t streamLen = 0;
+  const uint32_t *entries = nullptr; // lane b starts from entry record b - entryBase (hsrle_index.hip.h) instead of from a block stream header
+  uint32_t entryBase = 0;
 };
 
 // index passes over one monolithic stream (hsrle_index.hip.h)
@@ -33,6 +33,8 @@ struct IndexArgs
   const uint32_t *entry; const uint64_t *outStart; const uint32_t *stateIn; uint64_t U; uint32_t B; uint32_t *rec;   // record pass
 };
 typedef hipError_t (*IndexLaunch)(const IndexArgs &, int records, hipStream_t);
+// container blocks cut into sub-blocks of SB output bytes: entry records for [firstBlock, firstBlock + blockCount) of `a` into rec
+typedef hipError_t (*SubBlockLaunch)(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t);
 
 struct EncodeArgs
 {
@@ -67,13 +69,13 @@ constexpr int kDecodeStep = HSRLE_DECODE_STEP; // output bytes per lane and deco
 constexpr int kDecodeTile = HSRLE_DECODE_TILE; // bytes produced per lane and round (k_decode_blocks T)
 constexpr int kDecodeRing = HSRLE_DECODE_RING; // per-lane stream ring in LDS (k_decode_blocks R)
 
-void register_w8(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx);
-void register_w16(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx);
-void register_w24(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx);
-void register_w32(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx);
-void register_w48(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx);
-void register_w64(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx);
-void register_w128(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx);
+void register_w8(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub);
+void register_w16(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub);
+void register_w24(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub);
+void register_w32(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub);
+void register_w48(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub);
+void register_w64(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub);
+void register_w128(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub);
 
 template <typename KERNEL>
 inline hipError_t launch_decode(KERNEL k, const DecodeArgs &a, hipStream_t st)
@@ -81,7 +83,7 @@ inline hipError_t launch_decode(KERNEL k, const DecodeArgs &a, hipStream_t st)
   if (a.residentWorkgroups != nullptr)
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(a.residentWorkgroups, k, 64, 0);
   const uint32_t grid = (a.blockCount + 63u) / 64u;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(64), 0, st, a.payload, a.offsets, a.payloadEnd, a.out, a.U, a.B, a.firstBlock, a.blockCount, a.status, a.entries, a.streamLen);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(64), 0, st, a.payload, a.offsets, a.payloadEnd, a.out, a.U, a.B, a.firstBlock, a.blockCount, a.status, a.entries, a.entryBase);
   return hipGetLastError();
 }
 

@@ -21,8 +21,14 @@ static hipError_t idx_sym_packed(const IndexArgs &a, int records, hipStream_t st
 static hipError_t idx_byte(const IndexArgs &a, int records, hipStream_t st) { return launch_index<PLAIN, 16, 0>(a, records, st); }
 static hipError_t idx_byte_packed(const IndexArgs &a, int records, hipStream_t st) { return launch_index<PACKED, 16, 0>(a, records, st); }
 
-void register_w128(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx)
+static hipError_t sub_sym(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<PLAIN, 16, 1>(a, SB, 0u, rec, st); }
+static hipError_t sub_sym_packed(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<PACKED, 16, 1>(a, SB, 0u, rec, st); }
+static hipError_t sub_byte(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<PLAIN, 16, 0>(a, SB, 0u, rec, st); }
+static hipError_t sub_byte_packed(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<PACKED, 16, 0>(a, SB, 0u, rec, st); }
+
+void register_w128(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub)
 {
+  sub[46] = sub_sym; sub[47] = sub_sym_packed; sub[48] = sub_byte; sub[49] = sub_byte_packed;
   idx[46] = idx_sym; idx[47] = idx_sym_packed; idx[48] = idx_byte; idx[49] = idx_byte_packed;
   dec[46] = dec_sym;         enc[46] = enc_sym;
   dec[47] = dec_sym_packed;  enc[47] = enc_sym_packed;

@@ -48,8 +48,23 @@ static hipError_t idx_short3(const IndexArgs &a, int records, hipStream_t st) { 
 static hipError_t idx_short7(const IndexArgs &a, int records, hipStream_t st) { return launch_index<SHORT7, 1, 0>(a, records, st); }
 static hipError_t idx_short_single(const IndexArgs &a, int records, hipStream_t st) { return launch_index<SHORT_SINGLE, 1, 0>(a, records, st); }
 
-void register_w8(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx)
+static hipError_t sub_plain(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<PLAIN, 1, 0>(a, SB, 0u, rec, st); }
+static hipError_t sub_packed(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<PACKED, 1, 0>(a, SB, 0u, rec, st); }
+static hipError_t sub_plain_any(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<PLAIN, 1, 0>(a, SB, 1u, rec, st); }
+static hipError_t sub_packed_any(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<PACKED, 1, 0>(a, SB, 1u, rec, st); }
+static hipError_t sub_lut3(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<LUT3, 1, 0>(a, SB, 0u, rec, st); }
+static hipError_t sub_lut7(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<LUT7, 1, 0>(a, SB, 0u, rec, st); }
+static hipError_t sub_short0(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<SHORT0, 1, 0>(a, SB, 0u, rec, st); }
+static hipError_t sub_short1(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<SHORT1, 1, 0>(a, SB, 0u, rec, st); }
+static hipError_t sub_short3(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<SHORT3, 1, 0>(a, SB, 0u, rec, st); }
+static hipError_t sub_short7(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<SHORT7, 1, 0>(a, SB, 0u, rec, st); }
+static hipError_t sub_short_single(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<SHORT_SINGLE, 1, 0>(a, SB, 0u, rec, st); }
+
+void register_w8(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub)
 {
+  sub[0] = sub_plain; sub[1] = sub_packed; sub[2] = sub_lut3; sub[3] = sub_lut7; sub[4] = sub_plain_any; sub[5] = sub_packed_any;
+  sub[kShortBase8 + 0] = sub_short0; sub[kShortBase8 + 1] = sub_short1; sub[kShortBase8 + 2] = sub_short3; sub[kShortBase8 + 3] = sub_short7;
+  sub[kSingleShort] = sub_short_single;
   idx[0] = idx_plain; idx[1] = idx_packed; idx[2] = idx_lut3; idx[3] = idx_lut7; idx[4] = idx_plain; idx[5] = idx_packed;
   idx[kShortBase8 + 0] = idx_short0; idx[kShortBase8 + 1] = idx_short1; idx[kShortBase8 + 2] = idx_short3; idx[kShortBase8 + 3] = idx_short7;
   idx[kSingleShort] = idx_short_single;

@@ -108,6 +108,12 @@ def _lib():
     L.hsrle_decompress_mono_dev.argtypes = [ci, vp, u32, vp, u64, vp, u64, ctypes.POINTER(u32), ctypes.POINTER(u32), vp]
     L.hsrle_mono_tuning.restype = None
     L.hsrle_mono_tuning.argtypes = [u32, u32, u32]
+    L.hsrle_split_sub_block_size.restype = u32
+    L.hsrle_split_sub_block_size.argtypes = [ctypes.POINTER(ContainerInfo), u32]
+    L.hsrle_decompress_split_workspace_size.restype = u64
+    L.hsrle_decompress_split_workspace_size.argtypes = [ctypes.POINTER(ContainerInfo), u32, u32]
+    L.hsrle_decompress_split_dev_async.restype = ci
+    L.hsrle_decompress_split_dev_async.argtypes = [vp, ctypes.POINTER(ContainerInfo), u32, u32, vp, u64, vp, vp, u64, u32, vp]
     L.hsrle_synth_dev_async.restype = ci
     L.hsrle_synth_dev_async.argtypes = [ci, ci, u64, vp, u64, vp]
     _LIB = L
@@ -293,6 +299,24 @@ def decompress_async(container, info, dst, status=None, first_block=0, block_cou
                                                   ctypes.c_void_p(dst.data_ptr()), dst.numel(), sp, _stream_ptr(stream))
     if rc != OK:
         raise HsrleError(rc, "hsrle_decompress_blocks_dev_async")
+
+
+def split_workspace_size(info, block_count=None, sub_block=0):
+    return int(_lib().hsrle_decompress_split_workspace_size(ctypes.byref(info), info.blockCount if block_count is None else block_count, sub_block))
+
+
+def decompress_split_async(container, info, dst, workspace, status=None, sub_block=0, first_block=0, block_count=None, stream=None):
+    """Split decode (hsrle_decompress_split_dev_async): one decode lane per `sub_block` output bytes instead of per block."""
+    _check_u8_cuda(container, "container")
+    _check_u8_cuda(dst, "dst")
+    if block_count is None:
+        block_count = info.blockCount - first_block
+    sp = ctypes.c_void_p(status.data_ptr()) if status is not None else None
+    wp, wn = (ctypes.c_void_p(workspace.data_ptr()), workspace.numel()) if workspace is not None else (None, 0)
+    rc = _lib().hsrle_decompress_split_dev_async(ctypes.c_void_p(container.data_ptr()), ctypes.byref(info), first_block, block_count, ctypes.c_void_p(dst.data_ptr()), dst.numel(),
+                                                 sp, wp, wn, sub_block, _stream_ptr(stream))
+    if rc != OK:
+        raise HsrleError(rc, "hsrle_decompress_split_dev_async")
 
 
 def decompress(container, dst=None):

@@ -267,6 +267,20 @@ int hsrle_decompress_dev(const void *dContainer, uint64_t containerSize, void *d
 int hsrle_decompress_blocks_dev_async(const void *dContainer, const hsrle_container_info_t *info, uint32_t firstBlock, uint32_t blockCount,
                                       void *dOut, uint64_t outCapacity, uint32_t *dStatus, void *stream);
 
+/*
+ * Split decode: for containers with too few blocks to fill the GPU with one lane per block (one lane walks one block's packet chain:
+ * ~10^5 blocks are needed; BASELINE config 3, an 88 MB frame in 4 KiB blocks, has 21 600).  One lane per block first walks the block's
+ * packets and leaves the decoder state at every subBlockSize output bytes (csrc/hsrle_index.hip.h), then the block kernel runs one lane
+ * per SUB-block.  The container, its block size and its compression ratio are what they are: nothing is re-encoded.
+ *   subBlockSize: multiple of 128 that divides blockSize; 0 = the library's choice (hsrle_split_sub_block_size tells which; when it
+ *   returns blockSize no split happens and no workspace is needed).  dWorkspace >= hsrle_decompress_split_workspace_size(info,
+ *   blockCount, subBlockSize) bytes.  Only enqueues kernels: graph-capturable.  dStatus as in hsrle_decompress_dev_async.
+ */
+uint32_t hsrle_split_sub_block_size(const hsrle_container_info_t *info, uint32_t subBlockSize);
+uint64_t hsrle_decompress_split_workspace_size(const hsrle_container_info_t *info, uint32_t blockCount, uint32_t subBlockSize);
+int hsrle_decompress_split_dev_async(const void *dContainer, const hsrle_container_info_t *info, uint32_t firstBlock, uint32_t blockCount, void *dOut, uint64_t outCapacity,
+                                     uint32_t *dStatus, void *dWorkspace, uint64_t workspaceSize, uint32_t subBlockSize, void *stream);
+
 /* ---------------------------------------------------------------------------------------------------------- */
 /* 3. host convenience wrappers (allocate device buffers, copy, run 2, copy back)                              */
 

@@ -1,0 +1,108 @@
+"""Split decode of block containers (hsrle_decompress_split_dev_async): one lane per block walks the block's packets and leaves the
+decoder state every SB output bytes, then one lane per SUB-block decodes.  Bar: the same bytes as the plain block decode (= the input),
+for every codec and every legal sub-block size; malformed blocks are reported, nothing outside the output is written."""
+import random
+import struct
+
+import pytest
+
+from hsrle_testlib import CODECS, CODEC_BY_KEY, SYNTH_VIDEO, mixed_runs, single_symbol_mix, fuzz_sections, FUZZ_LENGTHS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hs():
+    import torch
+
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    import hsrle
+
+    hsrle.lib()
+    return hsrle
+
+
+def _data(seed, size):
+    rng = random.Random(seed)
+    parts, n = [], 0
+    while n < size:
+        k = rng.randrange(4)
+        d = (fuzz_sections(rng) if k == 0 else mixed_runs(rng, rng.choice([100, 1000, 3000])) if k == 1 else single_symbol_mix(rng, rng.choice([64, 333, 3000]))
+             if k == 2 else bytes(rng.randrange(256) for _ in range(rng.choice([3, 130, 700, 5000]))))
+        parts.append(d)
+        n += len(d)
+    return b"".join(parts)[:size]
+
+
+def _split(hs, container, info, n, sub, first=0, count=None, guard=0):
+    import torch
+
+    count = info.blockCount - first if count is None else count
+    ws = torch.empty(max(hs.split_workspace_size(info, count, sub), 16), dtype=torch.uint8, device="cuda")
+    out = torch.full((n + guard,), 0xA5, dtype=torch.uint8, device="cuda")
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    hs.decompress_split_async(container, info, out[:n], ws, status, sub_block=sub, first_block=first, block_count=count)
+    torch.cuda.synchronize()
+    return out, int(status.item())
+
+
+@pytest.mark.parametrize("codec", CODECS, ids=lambda c: c.key)
+def test_split_decode_equals_the_input(hs, codec):
+    import torch
+
+    data = _data(99 + CODECS.index(codec), 150000 + 77)
+    src = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    for block, subs in ((1024, (128, 256, 512)), (4096, (512, 0)), (1536, (128, 768))):
+        container, info = hs.compress(codec.key, src, block_size=block)
+        for sub in subs:
+            out, status = _split(hs, container, info, len(data), sub, guard=512)
+            assert status == 0 and out[: len(data)].cpu().numpy().tobytes() == data, f"{codec.key} block {block} sub {sub}"
+            assert bool((out[len(data):] == 0xA5).all())
+
+
+def test_split_decode_of_a_block_range(hs):
+    import torch
+
+    data = _data(5, 300000)
+    src = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    container, info = hs.compress("rle8_packed_multi", src, block_size=2048)
+    first, count = 17, 50
+    out, status = _split(hs, container, info, len(data), 256, first=first, count=count)
+    host = out.cpu().numpy().tobytes()
+    assert status == 0 and host[first * 2048 : (first + count) * 2048] == data[first * 2048 : (first + count) * 2048]
+    assert set(host[: first * 2048]) == {0xA5} and set(host[(first + count) * 2048 :]) == {0xA5}
+
+
+def test_split_decode_reports_malformed_blocks(hs):
+    import torch
+
+    rng = random.Random(8)
+    data = mixed_runs(rng, 200000)
+    for key in ("rle8_packed_multi", "rle8_3symlut", "rle32_byte", "rle64_7symlut_byte_short"):
+        container, info = hs.compress(key, torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda(), block_size=1024)
+        host = bytearray(container.cpu().numpy().tobytes())
+        p0 = info.payload_start
+        table = struct.unpack_from(f"<{info.blockCount + 1}Q", host, 64)
+        for i in range(0, info.blockCount, 3):
+            a, b = p0 + table[i], p0 + table[i + 1]
+            for j in range(a + 10, b):
+                host[j] = rng.randrange(256)
+        bad = torch.frombuffer(host, dtype=torch.uint8).cuda()
+        out, status = _split(hs, bad, info, len(data), 256, guard=4096)
+        assert status != 0 and bool((out[len(data):] == 0xA5).all())
+        host2 = bytearray(container.cpu().numpy().tobytes())
+        host2[64 + 8 * 3 : 64 + 8 * 4] = struct.pack("<Q", 1 << 40)          # table entry outside the payload
+        out, status = _split(hs, torch.frombuffer(host2, dtype=torch.uint8).cuda(), info, len(data), 256, guard=4096)
+        assert status != 0 and bool((out[len(data):] == 0xA5).all())
+
+
+def test_config3_frame_split_decode(hs, oracle):
+    """BASELINE config 3 at its own size and block size: 88 473 600 bytes video-shaped, rle64_3symlut_byte, 4 KiB blocks."""
+    import torch
+
+    size = 88473600
+    src = hs.synth(SYNTH_VIDEO, 8, 3, size, device="cuda")
+    container, info = hs.compress("rle64_3symlut_byte", src, block_size=4096)
+    for sub in (0, 1024, 256):
+        out, status = _split(hs, container, info, size, sub)
+        assert status == 0 and torch.equal(out[:size], src), f"sub {sub}"
