@@ -217,6 +217,34 @@ __global__ void k_finish_container(uint8_t *__restrict__ container, uint32_t cod
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// 64 bit hash of every block stream of a container (include/hsrle.h: hsrle_hash_blocks_dev_async): what the big-config manifests pin
+// (tests/golden/big/, minted from the compiled reference) -- every block of an 8 GiB container is compared, not a sample.
+
+__device__ __forceinline__ uint64_t rotl64(uint64_t v, int sh) { return (v << sh) | (v >> (64 - sh)); }
+
+__global__ __launch_bounds__(256) void k_hash_blocks(const uint8_t *__restrict__ payload, const uint64_t *__restrict__ offsets, uint64_t payloadBytes, uint32_t firstBlock,
+                                                     uint32_t blockCount, uint64_t *__restrict__ out)
+{
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= blockCount) return;
+  const uint64_t off0 = offsets[firstBlock + i], off1 = offsets[firstBlock + i + 1u];
+  if (off0 > off1 || off1 > payloadBytes) { out[i] = 0; return; }
+  const uint8_t *p = payload + off0;
+  const uint64_t len = off1 - off0;
+  uint64_t h = 0x9E3779B97F4A7C15ull ^ (len * 0xD6E8FEB86659FD93ull);
+  uint64_t k = 0;
+  for (; k + 8 <= len; k += 8)
+    h = rotl64(h ^ ld64(p + k), 27) * 0x9E3779B97F4A7C15ull + 0x165667B19E3779F9ull;
+  if (k < len)
+  {
+    uint64_t w = 0;
+    for (uint32_t j = 0; k + j < len; j++) w |= (uint64_t)p[k + j] << (8u * j);
+    h = rotl64(h ^ w, 27) * 0x9E3779B97F4A7C15ull + 0x165667B19E3779F9ull;
+  }
+  out[i] = h ^ (h >> 31);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // synthetic workloads.  One lane generates one 64 KiB chunk; chunks are independent so the same
 // bytes can be produced on the CPU (oracle/hsrle_synth.c, tests/hsrle_testlib.py:synth_chunk_py) for any slice.
 
@@ -1270,6 +1298,18 @@ int hsrle_decompress_mono_dev(int codec, const void *dStream, uint32_t streamSiz
   const int rc = mono_decode_dev(mh, (const uint8_t *)dStream, (uint8_t *)dOut, (uint8_t *)dWorkspace, m, pStats, (hipStream_t)stream);
   if (rc == HSRLE_OK && pUncompressedSize) *pUncompressedSize = mh.U;
   return rc;
+}
+
+int hsrle_hash_blocks_dev_async(const void *dContainer, const hsrle_container_info_t *info, uint32_t firstBlock, uint32_t blockCount, uint64_t *dHashes, void *stream)
+{
+  if (!dContainer || !info || !dHashes || (uint64_t)firstBlock + blockCount > info->blockCount) return HSRLE_ERR_ARGUMENT;
+  if (!device_ok()) return HSRLE_ERR_DEVICE;
+  if (blockCount == 0) return HSRLE_OK;
+  const uint8_t *container = (const uint8_t *)dContainer;
+  const uint8_t *payload = container + HSRLE_CONTAINER_HEADER_SIZE + 8ull * ((uint64_t)info->blockCount + 1ull);
+  hipLaunchKernelGGL(k_hash_blocks, dim3((blockCount + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, payload, (const uint64_t *)(container + HSRLE_CONTAINER_HEADER_SIZE),
+                     info->payloadSize, firstBlock, blockCount, dHashes);
+  return hipGetLastError() == hipSuccess ? HSRLE_OK : HSRLE_ERR_DEVICE;
 }
 
 int hsrle_synth_dev_async(int kind, int symbolBytes, uint64_t seed, void *dOut, uint64_t size, void *stream)

@@ -114,6 +114,8 @@ def _lib():
     L.hsrle_decompress_split_workspace_size.argtypes = [ctypes.POINTER(ContainerInfo), u32, u32]
     L.hsrle_decompress_split_dev_async.restype = ci
     L.hsrle_decompress_split_dev_async.argtypes = [vp, ctypes.POINTER(ContainerInfo), u32, u32, vp, u64, vp, vp, u64, u32, vp]
+    L.hsrle_hash_blocks_dev_async.restype = ci
+    L.hsrle_hash_blocks_dev_async.argtypes = [vp, ctypes.POINTER(ContainerInfo), u32, u32, vp, vp]
     L.hsrle_synth_dev_async.restype = ci
     L.hsrle_synth_dev_async.argtypes = [ci, ci, u64, vp, u64, vp]
     _LIB = L
@@ -299,6 +301,20 @@ def decompress_async(container, info, dst, status=None, first_block=0, block_cou
                                                   ctypes.c_void_p(dst.data_ptr()), dst.numel(), sp, _stream_ptr(stream))
     if rc != OK:
         raise HsrleError(rc, "hsrle_decompress_blocks_dev_async")
+
+
+def hash_blocks(container, info, first_block=0, block_count=None):
+    """64 bit hash of every block stream (hsrle_hash_blocks_dev_async) as an int64 CUDA tensor (bit pattern of the uint64 values)."""
+    import torch
+
+    _check_u8_cuda(container, "container")
+    if block_count is None:
+        block_count = info.blockCount - first_block
+    out = torch.empty(block_count, dtype=torch.int64, device=container.device)
+    rc = _lib().hsrle_hash_blocks_dev_async(ctypes.c_void_p(container.data_ptr()), ctypes.byref(info), first_block, block_count, ctypes.c_void_p(out.data_ptr()), _stream_ptr())
+    if rc != OK:
+        raise HsrleError(rc, "hsrle_hash_blocks_dev_async")
+    return out
 
 
 def split_workspace_size(info, block_count=None, sub_block=0):

@@ -281,6 +281,16 @@ uint64_t hsrle_decompress_split_workspace_size(const hsrle_container_info_t *inf
 int hsrle_decompress_split_dev_async(const void *dContainer, const hsrle_container_info_t *info, uint32_t firstBlock, uint32_t blockCount, void *dOut, uint64_t outCapacity,
                                      uint32_t *dStatus, void *dWorkspace, uint64_t workspaceSize, uint32_t subBlockSize, void *stream);
 
+/*
+ * 64 bit hash of every block stream of blocks [firstBlock, firstBlock + blockCount) of a device-resident container into dHashes
+ * (device, blockCount values): an integrity check that covers EVERY block (the big-config manifests under tests/golden/big/ hold the
+ * reference encoder's values).  For the bytes p[0, len) of a stream:
+ *   h = 0x9E3779B97F4A7C15 ^ (len * 0xD6E8FEB86659FD93);
+ *   for every 8-byte little-endian word w (the last one zero padded): h = rotl64(h ^ w, 27) * 0x9E3779B97F4A7C15 + 0x165667B19E3779F9;
+ *   h ^= h >> 31
+ */
+int hsrle_hash_blocks_dev_async(const void *dContainer, const hsrle_container_info_t *info, uint32_t firstBlock, uint32_t blockCount, uint64_t *dHashes, void *stream);
+
 /* ---------------------------------------------------------------------------------------------------------- */
 /* 3. host convenience wrappers (allocate device buffers, copy, run 2, copy back)                              */
 

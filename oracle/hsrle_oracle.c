@@ -1789,3 +1789,34 @@ uint64_t hso_decompress_blocks(int family, int S, int aligned, const uint8_t *pa
 
   return produced;
 }
+
+/* ---- big-config manifests: hash of every block stream of the ORACLE's encoder (oracle/hsrle_hash.h), to be compared with the roll-ups
+ *      the compiled reference minted (tests/golden/big/, tests/test_oracle_golden.py) ---- */
+#include "hsrle_hash.h"
+#include <stdlib.h>
+
+uint64_t hso_hash64(const uint8_t *p, uint64_t len) { return hsrle_hash64(p, len); }
+
+uint64_t hso_hash_blocks(int family, int S, int aligned, const uint8_t *pIn, uint64_t inSize, uint32_t blockSize, uint64_t *pHashes, uint32_t *pSizes)
+{
+  const uint32_t stride = hso_compress_bounds(blockSize) + 64;
+  uint8_t *tmp = (uint8_t *)malloc(stride);
+  if (!tmp || blockSize == 0) { free(tmp); return 0; }
+  const uint64_t nBlocks = (inSize + blockSize - 1) / blockSize;
+  for (uint64_t b = 0; b < nBlocks; b++)
+  {
+    const uint64_t off = b * blockSize;
+    const uint32_t len = (uint32_t)((inSize - off) < blockSize ? (inSize - off) : blockSize);
+    const uint32_t c = hso_compress(family, S, aligned, pIn + off, len, tmp, stride);
+    if (c == 0) { free(tmp); return 0; }
+    pHashes[b] = hsrle_hash64(tmp, c);
+    if (pSizes) pSizes[b] = c;
+  }
+  free(tmp);
+  return nBlocks;
+}
+
+void hso_rollups(const uint64_t *hashes, uint64_t n, uint64_t group, uint64_t *out)
+{
+  for (uint64_t g = 0; g * group < n; g++) out[g] = hsrle_rollup(hashes + g * group, (n - g * group) < group ? (n - g * group) : group);
+}

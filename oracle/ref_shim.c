@@ -126,3 +126,96 @@ uint64_t hsrle_ref_decode_blocks_mt(hsrle_ref_codec_fn fn, const uint8_t *payloa
   }
   return total;
 }
+
+/* ---- big-config manifests (tests/golden/make_big_manifest.py): encode every block of a buffer with one of the reference's compress
+ *      functions over nThreads POSIX threads, the block streams back to back per thread range (compacted by the caller through the
+ *      sizes), and hash every stream (oracle/hsrle_hash.h).  guard != 0: every block is encoded from a private copy that is followed by
+ *      the guard pad of SURVEY.md 8c (pad bytes differ from the bytes 1,2,3,4,6,8,16 positions in front of them), because the reference
+ *      encoders of the symbols wider than 8 bit read up to 2 S - 1 bytes past inSize and this repository's semantics is "bytes beyond
+ *      the end never match". ---- */
+#include "hsrle_hash.h"
+#include <stdlib.h>
+
+typedef struct
+{
+  hsrle_ref_codec_fn fn;
+  const uint8_t *in;
+  uint64_t inSize, first, count;
+  uint32_t blockSize, stride;
+  int guard;
+  uint8_t *slots;
+  uint32_t *sizes;
+  uint64_t *hashes;
+  int failed;
+} hsrle_ref_enc_job;
+
+static void *hsrle_ref_enc_worker(void *p)
+{
+  hsrle_ref_enc_job *j = (hsrle_ref_enc_job *)p;
+  uint8_t *tmp = j->guard ? (uint8_t *)malloc((size_t)j->blockSize + 128) : 0;
+  for (uint64_t b = j->first; b < j->first + j->count; b++)
+  {
+    const uint64_t off = b * j->blockSize;
+    const uint32_t len = (uint32_t)((j->inSize - off) < j->blockSize ? (j->inSize - off) : j->blockSize);
+    const uint8_t *src = j->in + off;
+    if (tmp)
+    {
+      memcpy(tmp, src, len);
+      for (uint32_t k = len; k < len + 64; k++)
+      {
+        static const int d[7] = { 1, 2, 3, 4, 6, 8, 16 };
+        uint8_t v = 0;
+        for (;;)
+        {
+          int clash = 0;
+          for (int q = 0; q < 7; q++) if (k >= (uint32_t)d[q] && tmp[k - d[q]] == v) clash = 1;
+          if (!clash) break;
+          v++;
+        }
+        tmp[k] = v;
+      }
+      src = tmp;
+    }
+    uint8_t *dst = j->slots + (b - j->first) * (uint64_t)j->stride;
+    const uint32_t c = j->fn(src, len, dst, j->stride);
+    if (c == 0) { j->failed = 1; break; }
+    j->sizes[b] = c;
+    j->hashes[b] = hsrle_hash64(dst, c);
+  }
+  free(tmp);
+  return 0;
+}
+
+/* slots: nBlocks * stride bytes; thread t's blocks start at slot index firstBlock_t (i.e. block b's stream is at slots + b * stride) */
+uint64_t hsrle_ref_encode_hash_blocks_mt(hsrle_ref_codec_fn fn, const uint8_t *pIn, uint64_t inSize, uint32_t blockSize, int guard, uint8_t *pSlots, uint32_t stride,
+                                         uint32_t *pSizes, uint64_t *pHashes, int nThreads)
+{
+  const uint64_t nBlocks = (inSize + blockSize - 1) / blockSize;
+  if (nThreads < 1) nThreads = 1;
+  if (nThreads > 256) nThreads = 256;
+  pthread_t th[256];
+  hsrle_ref_enc_job jobs[256];
+  for (int t = 0; t < nThreads; t++)
+  {
+    const uint64_t b0 = nBlocks * (uint64_t)t / (uint64_t)nThreads, b1 = nBlocks * (uint64_t)(t + 1) / (uint64_t)nThreads;
+    jobs[t] = (hsrle_ref_enc_job){ fn, pIn, inSize, b0, b1 - b0, blockSize, stride, guard, pSlots + b0 * (uint64_t)stride, pSizes, pHashes, 0 };
+    if (pthread_create(&th[t], 0, hsrle_ref_enc_worker, &jobs[t]) != 0) { hsrle_ref_enc_worker(&jobs[t]); th[t] = 0; }
+  }
+  int failed = 0;
+  for (int t = 0; t < nThreads; t++) { if (th[t]) pthread_join(th[t], 0); failed |= jobs[t].failed; }
+  return failed ? 0 : nBlocks;
+}
+
+/* payload = the block streams back to back; returns its size */
+uint64_t hsrle_ref_compact(const uint8_t *pSlots, uint32_t stride, const uint32_t *pSizes, uint64_t nBlocks, uint8_t *pOut)
+{
+  uint64_t at = 0;
+  for (uint64_t b = 0; b < nBlocks; b++) { memcpy(pOut + at, pSlots + b * (uint64_t)stride, pSizes[b]); at += pSizes[b]; }
+  return at;
+}
+
+uint64_t hsrle_ref_hash64(const uint8_t *p, uint64_t len) { return hsrle_hash64(p, len); }
+void hsrle_ref_rollups(const uint64_t *hashes, uint64_t n, uint64_t group, uint64_t *out)
+{
+  for (uint64_t g = 0; g * group < n; g++) out[g] = hsrle_rollup(hashes + g * group, (n - g * group) < group ? (n - g * group) : group);
+}

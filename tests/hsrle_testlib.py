@@ -380,3 +380,45 @@ def build_container(codec_index, uncompressed_size, block_size, streams):
     total = 64 + 8 * (nb + 1) + len(payload) + 32
     head = b"HSRLEKIT" + struct.pack("<IIQIIQQ", 1, codec_index, uncompressed_size, block_size, nb, len(payload), total) + bytes(16)
     return head + struct.pack(f"<{nb + 1}Q", *offs) + payload + bytes(32)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# big-config manifests (tests/golden/big/, minted from the compiled reference by tests/golden/make_big_manifest.py)
+
+BIG_DIR = os.path.join(REPO, "tests", "golden", "big")
+
+
+def big_manifest():
+    import json
+
+    path = os.path.join(BIG_DIR, "manifest.json")
+    return json.load(open(path)) if os.path.exists(path) else None
+
+
+def big_case(codec_key, kind, seed, size, block):
+    """(name, entry, roll-ups as uint64 array) of the manifest case with these generator parameters, or None."""
+    man = big_manifest()
+    if not man:
+        return None
+    for name, e in man["cases"].items():
+        if (e["codec"], e["kind"], e["seed"], e["size"], e["block"]) == (codec_key, kind, seed, size, block):
+            return name, e, np.fromfile(os.path.join(BIG_DIR, name + ".rollup.u64"), dtype="<u8")
+    return None
+
+
+def rollups(hashes, group=256):
+    """Roll-up per `group` block hashes (oracle/hsrle_hash.h): r = 0; r = (rotl64(r, 7) ^ b) * 0x9E3779B97F4A7C15 -- vectorised over the groups."""
+    h = np.ascontiguousarray(hashes).view(np.uint64)
+    n = h.size
+    groups = (n + group - 1) // group
+    padded = np.zeros(groups * group, dtype=np.uint64)
+    padded[:n] = h
+    padded = padded.reshape(groups, group)
+    counts = np.minimum(group, n - np.arange(groups) * group)
+    r = np.zeros(groups, dtype=np.uint64)
+    mul = np.uint64(0x9E3779B97F4A7C15)
+    with np.errstate(over="ignore"):
+        for k in range(group):
+            nxt = (((r << np.uint64(7)) | (r >> np.uint64(57))) ^ padded[:, k]) * mul
+            r = np.where(k < counts, nxt, r)
+    return r
