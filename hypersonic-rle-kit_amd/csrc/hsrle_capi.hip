@@ -318,28 +318,58 @@ __global__ __launch_bounds__(64) void k_synth(int kind, int S, uint64_t seed, ui
 // ------------------------------------------------------------------------------------------------------------------
 // device state
 
+// Per DEVICE (hipGetDevice() of the calling thread): the staging buffers of the host-pointer drop-in functions.  A drop-in call holds
+// the device's mutex from its first copy to its last, so concurrent drop-in calls on one device run one after the other (the reference's
+// own callers are single threaded: src/main.c, src/rle_fuzz.c); calls on different devices do not meet.  The device-pointer API keeps NO
+// library-owned state between calls: what it needs beyond the caller's buffers is allocated stream-ordered (hipMallocAsync on the
+// caller's stream) for the duration of the call.
+constexpr int kMaxDevices = 64;
 struct DeviceState
 {
   std::mutex mu;
-  int deviceChecked = 0; // 0 = not yet, 1 = ok, -1 = no device
-  void *ws = nullptr;    // cached compression workspace
+  void *ws = nullptr;    // rle8m drop-in: compression workspace
   uint64_t wsSize = 0;
   void *monoIn = nullptr, *monoOut = nullptr, *monoAux = nullptr, *monoWs = nullptr; // staging of the drop-in (host pointer) path
   uint64_t monoInSize = 0, monoOutSize = 0, monoWsSize = 0;
 };
 
-static DeviceState g_dev;
+static DeviceState g_devs[kMaxDevices];
+static std::once_flag g_deviceOnce;
+static int g_deviceCount = 0;
 
 static bool device_ok()
 {
-  std::lock_guard<std::mutex> lock(g_dev.mu);
-  if (g_dev.deviceChecked == 0)
-  {
+  std::call_once(g_deviceOnce, [] {
     int n = 0;
-    g_dev.deviceChecked = (hipGetDeviceCount(&n) == hipSuccess && n > 0) ? 1 : -1;
-  }
-  return g_dev.deviceChecked == 1;
+    g_deviceCount = (hipGetDeviceCount(&n) == hipSuccess && n > 0) ? n : 0;
+    // stream-ordered allocations are kept by the pool instead of going back to the driver at every synchronisation (the workspace of
+    // an 8 GiB compression is 9 GB: allocating it anew for every call would cost more than the call)
+    for (int d = 0; d < g_deviceCount; d++)
+    {
+      hipMemPool_t pool;
+      uint64_t keep = ~0ull;
+      if (hipDeviceGetDefaultMemPool(&pool, d) == hipSuccess) (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
+  });
+  return g_deviceCount > 0;
 }
+
+static DeviceState &this_device()
+{
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = 0;
+  return g_devs[d];
+}
+
+// scratch for the duration of one call on `st`: stream-ordered, so concurrent calls on other streams (or threads) never share it
+static void *scratch_alloc(uint64_t bytes, hipStream_t st)
+{
+  void *p = nullptr;
+  if (hipMallocAsync(&p, bytes, st) == hipSuccess) return p;
+  (void)hipGetLastError();
+  return nullptr;
+}
+static void scratch_free(void *p, hipStream_t st) { if (p) (void)hipFreeAsync(p, st); }
 
 static bool grow(void **p, uint64_t *have, uint64_t need)
 {
@@ -428,12 +458,13 @@ static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, ui
 
   const Workspace w = plan_workspace(U, B);
 
+  void *own = nullptr;
   if (dWs == nullptr)
   {
-    std::lock_guard<std::mutex> lock(g_dev.mu);
-    if (!grow(&g_dev.ws, &g_dev.wsSize, w.total))
+    own = scratch_alloc(w.total, st);                    // freed (stream-ordered) behind the last kernel below
+    if (!own)
       return HSRLE_ERR_DEVICE;
-    dWs = g_dev.ws;
+    dWs = own;
   }
   else if (wsSize < w.total)
     return HSRLE_ERR_CAPACITY;
@@ -445,14 +476,17 @@ static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, ui
   uint8_t *payload = container + HSRLE_CONTAINER_HEADER_SIZE + 8ull * ((uint64_t)nBlocks + 1ull);
 
   EncodeArgs ea{ (const uint8_t *)dIn, U, B, nBlocks, ws + w.offSlots, slot_stride(B), (uint32_t *)(ws + w.offSizes) };
-  if (g_enc[codec](ea, st) != hipSuccess)
-    return HSRLE_ERR_DEVICE;
-  if (scan_sizes(ea.sizes, nBlocks, offsets, ws, w, st) != hipSuccess)
-    return HSRLE_ERR_DEVICE;
-
-  hipLaunchKernelGGL(k_compact, dim3((nBlocks + 3u) / 4u), dim3(256), 0, st, ea.slots, ea.slotStride, (const uint64_t *)offsets, payload, nBlocks);
-  hipLaunchKernelGGL(k_finish_container, dim3(1), dim3(64), 0, st, container, (uint32_t)codec, U, B, nBlocks);
-  return hipGetLastError() == hipSuccess ? HSRLE_OK : HSRLE_ERR_DEVICE;
+  int rc = HSRLE_OK;
+  if (g_enc[codec](ea, st) != hipSuccess || scan_sizes(ea.sizes, nBlocks, offsets, ws, w, st) != hipSuccess)
+    rc = HSRLE_ERR_DEVICE;
+  else
+  {
+    hipLaunchKernelGGL(k_compact, dim3((nBlocks + 3u) / 4u), dim3(256), 0, st, ea.slots, ea.slotStride, (const uint64_t *)offsets, payload, nBlocks);
+    hipLaunchKernelGGL(k_finish_container, dim3(1), dim3(64), 0, st, container, (uint32_t)codec, U, B, nBlocks);
+    if (hipGetLastError() != hipSuccess) rc = HSRLE_ERR_DEVICE;
+  }
+  scratch_free(own, st);
+  return rc;
 }
 
 static int check_info(const ContainerHeader &h, uint64_t containerSize, hsrle_container_info_t *info)
@@ -768,24 +802,25 @@ static uint32_t mono_compress(int codec, const uint8_t *pIn, uint32_t inSize, ui
   if (!g_enc[codec])
     return 0;
 
-  std::lock_guard<std::mutex> lock(g_dev.mu);
+  DeviceState &D = this_device();
+  std::lock_guard<std::mutex> lock(D.mu);
   const uint32_t stride = (bounds32(inSize) + 15u) & ~15u;
-  if (!grow(&g_dev.monoIn, &g_dev.monoInSize, (uint64_t)inSize + 64) || !grow(&g_dev.monoOut, &g_dev.monoOutSize, (uint64_t)stride + 64))
+  if (!grow(&D.monoIn, &D.monoInSize, (uint64_t)inSize + 64) || !grow(&D.monoOut, &D.monoOutSize, (uint64_t)stride + 64))
     return 0;
-  if (!g_dev.monoAux && hipMalloc(&g_dev.monoAux, 256) != hipSuccess)
-    return 0;
-
-  if (hipMemcpy(g_dev.monoIn, pIn, inSize, hipMemcpyHostToDevice) != hipSuccess)
+  if (!D.monoAux && hipMalloc(&D.monoAux, 256) != hipSuccess)
     return 0;
 
-  EncodeArgs ea{ (const uint8_t *)g_dev.monoIn, inSize, inSize, 1u, (uint8_t *)g_dev.monoOut, stride, (uint32_t *)g_dev.monoAux };
+  if (hipMemcpy(D.monoIn, pIn, inSize, hipMemcpyHostToDevice) != hipSuccess)
+    return 0;
+
+  EncodeArgs ea{ (const uint8_t *)D.monoIn, inSize, inSize, 1u, (uint8_t *)D.monoOut, stride, (uint32_t *)D.monoAux };
   if (g_enc[codec](ea, nullptr) != hipSuccess)
     return 0;
 
   uint32_t size = 0;
-  if (hipMemcpy(&size, g_dev.monoAux, 4, hipMemcpyDeviceToHost) != hipSuccess || size == 0 || size > outSize)
+  if (hipMemcpy(&size, D.monoAux, 4, hipMemcpyDeviceToHost) != hipSuccess || size == 0 || size > outSize)
     return 0;
-  if (hipMemcpy(pOut, g_dev.monoOut, size, hipMemcpyDeviceToHost) != hipSuccess)
+  if (hipMemcpy(pOut, D.monoOut, size, hipMemcpyDeviceToHost) != hipSuccess)
     return 0;
   return size;
 }
@@ -804,15 +839,16 @@ static uint32_t mono_decompress(int codec, const uint8_t *pIn, uint32_t inSize, 
     return 0;
 
   const MonoPlan m = plan_mono(mh.codec, mh.U, mh.C, mh.p0);
-  std::lock_guard<std::mutex> lock(g_dev.mu);
-  if (!grow(&g_dev.monoIn, &g_dev.monoInSize, (uint64_t)mh.C + 256) || !grow(&g_dev.monoOut, &g_dev.monoOutSize, (uint64_t)mh.U + 64) ||
-      !grow(&g_dev.monoWs, &g_dev.monoWsSize, m.total))
+  DeviceState &D = this_device();
+  std::lock_guard<std::mutex> lock(D.mu);
+  if (!grow(&D.monoIn, &D.monoInSize, (uint64_t)mh.C + 256) || !grow(&D.monoOut, &D.monoOutSize, (uint64_t)mh.U + 64) ||
+      !grow(&D.monoWs, &D.monoWsSize, m.total))
     return 0;
-  if (hipMemcpy(g_dev.monoIn, pIn, mh.C, hipMemcpyHostToDevice) != hipSuccess || hipMemset((uint8_t *)g_dev.monoIn + mh.C, 0, 128) != hipSuccess)
+  if (hipMemcpy(D.monoIn, pIn, mh.C, hipMemcpyHostToDevice) != hipSuccess || hipMemset((uint8_t *)D.monoIn + mh.C, 0, 128) != hipSuccess)
     return 0;
-  if (mono_decode_dev(mh, (const uint8_t *)g_dev.monoIn, (uint8_t *)g_dev.monoOut, (uint8_t *)g_dev.monoWs, m, nullptr, nullptr) != HSRLE_OK)
+  if (mono_decode_dev(mh, (const uint8_t *)D.monoIn, (uint8_t *)D.monoOut, (uint8_t *)D.monoWs, m, nullptr, nullptr) != HSRLE_OK)
     return 0;
-  if (hipMemcpy(pOut, g_dev.monoOut, mh.U, hipMemcpyDeviceToHost) != hipSuccess)
+  if (hipMemcpy(pOut, D.monoOut, mh.U, hipMemcpyDeviceToHost) != hipSuccess)
     return 0;
   return mh.U;
 }
@@ -824,7 +860,7 @@ constexpr uint32_t kRle8mWaveBelow = 131072u;   // measured on 1 GiB: 65 536 sec
 static int rle8m_decode_async(const void *dStream, uint64_t streamSize, uint32_t uncompressedSize, uint32_t sections, void *dOut, uint64_t outCapacity,
                               uint32_t *dStatus, hipStream_t st)
 {
-  // the caller has checked device_ok() (it takes g_dev.mu, which the host-pointer path holds while it calls this)
+  // the caller has checked device_ok()
   if (!dStream || !dOut || streamSize < 12 || sections == 0 || uncompressedSize == 0 || outCapacity < uncompressedSize)
     return HSRLE_ERR_ARGUMENT;
   if (dStatus && hipMemsetAsync(dStatus, 0, 4, st) != hipSuccess)
@@ -913,22 +949,23 @@ static uint32_t rle8m_mono_compress(uint32_t sections, const uint8_t *pIn, uint3
   if (pIn == nullptr || inSize == 0 || pOut == nullptr || sections == 0 || outSize < rle8m_bounds(sections, inSize) || !device_ok())
     return 0;
   const Rle8mPlan p = plan_rle8m(inSize, sections);
-  std::lock_guard<std::mutex> lock(g_dev.mu);
-  if (!grow(&g_dev.monoIn, &g_dev.monoInSize, (uint64_t)inSize + 64) || !grow(&g_dev.monoOut, &g_dev.monoOutSize, (uint64_t)outSize + 64) || !grow(&g_dev.ws, &g_dev.wsSize, p.total))
+  DeviceState &D = this_device();
+  std::lock_guard<std::mutex> lock(D.mu);
+  if (!grow(&D.monoIn, &D.monoInSize, (uint64_t)inSize + 64) || !grow(&D.monoOut, &D.monoOutSize, (uint64_t)outSize + 64) || !grow(&D.ws, &D.wsSize, p.total))
     return 0;
-  if (!g_dev.monoAux && hipMalloc(&g_dev.monoAux, 256) != hipSuccess)
+  if (!D.monoAux && hipMalloc(&D.monoAux, 256) != hipSuccess)
     return 0;
-  uint32_t *dStatus = (uint32_t *)((uint8_t *)g_dev.monoAux + 64);
-  if (hipMemcpy(g_dev.monoIn, pIn, inSize, hipMemcpyHostToDevice) != hipSuccess)
+  uint32_t *dStatus = (uint32_t *)((uint8_t *)D.monoAux + 64);
+  if (hipMemcpy(D.monoIn, pIn, inSize, hipMemcpyHostToDevice) != hipSuccess)
     return 0;
-  if (rle8m_encode_async(g_dev.monoIn, inSize, sections, g_dev.monoOut, outSize, g_dev.ws, g_dev.wsSize, dStatus, nullptr) != HSRLE_OK)
+  if (rle8m_encode_async(D.monoIn, inSize, sections, D.monoOut, outSize, D.ws, D.wsSize, dStatus, nullptr) != HSRLE_OK)
     return 0;
   uint32_t status = 1, size = 0;
   if (hipMemcpy(&status, dStatus, 4, hipMemcpyDeviceToHost) != hipSuccess || status != 0)
     return 0;
-  if (hipMemcpy(&size, g_dev.monoOut, 4, hipMemcpyDeviceToHost) != hipSuccess || size == 0 || size > outSize)
+  if (hipMemcpy(&size, D.monoOut, 4, hipMemcpyDeviceToHost) != hipSuccess || size == 0 || size > outSize)
     return 0;
-  if (hipMemcpy(pOut, g_dev.monoOut, size, hipMemcpyDeviceToHost) != hipSuccess)
+  if (hipMemcpy(pOut, D.monoOut, size, hipMemcpyDeviceToHost) != hipSuccess)
     return 0;
   return size;
 }
@@ -943,20 +980,21 @@ static uint32_t rle8m_mono_decompress(const uint8_t *pIn, uint32_t inSize, uint8
   if (expOut > outSize || expIn > inSize || sections == 0 || expOut == 0 || !device_ok())
     return 0;
 
-  std::lock_guard<std::mutex> lock(g_dev.mu);
-  if (!grow(&g_dev.monoIn, &g_dev.monoInSize, (uint64_t)expIn + 64) || !grow(&g_dev.monoOut, &g_dev.monoOutSize, (uint64_t)expOut + 64))
+  DeviceState &D = this_device();
+  std::lock_guard<std::mutex> lock(D.mu);
+  if (!grow(&D.monoIn, &D.monoInSize, (uint64_t)expIn + 64) || !grow(&D.monoOut, &D.monoOutSize, (uint64_t)expOut + 64))
     return 0;
-  if (!g_dev.monoAux && hipMalloc(&g_dev.monoAux, 256) != hipSuccess)
+  if (!D.monoAux && hipMalloc(&D.monoAux, 256) != hipSuccess)
     return 0;
-  uint32_t *dStatus = (uint32_t *)((uint8_t *)g_dev.monoAux + 64);
-  if (hipMemcpy(g_dev.monoIn, pIn, expIn, hipMemcpyHostToDevice) != hipSuccess)
+  uint32_t *dStatus = (uint32_t *)((uint8_t *)D.monoAux + 64);
+  if (hipMemcpy(D.monoIn, pIn, expIn, hipMemcpyHostToDevice) != hipSuccess)
     return 0;
-  if (rle8m_decode_async(g_dev.monoIn, expIn, expOut, sections, g_dev.monoOut, expOut, dStatus, nullptr) != HSRLE_OK)
+  if (rle8m_decode_async(D.monoIn, expIn, expOut, sections, D.monoOut, expOut, dStatus, nullptr) != HSRLE_OK)
     return 0;
   uint32_t status = 1;
   if (hipMemcpy(&status, dStatus, 4, hipMemcpyDeviceToHost) != hipSuccess || status != 0)
     return 0;
-  if (hipMemcpy(pOut, g_dev.monoOut, expOut, hipMemcpyDeviceToHost) != hipSuccess)
+  if (hipMemcpy(pOut, D.monoOut, expOut, hipMemcpyDeviceToHost) != hipSuccess)
     return 0;
   return expOut;
 }
@@ -1205,8 +1243,8 @@ int hsrle_decompress_dev(const void *dContainer, uint64_t containerSize, void *d
   int rc = hsrle_container_info_dev(dContainer, containerSize, &info, stream);
   if (rc != HSRLE_OK) return rc;
 
-  uint32_t *dStatus = nullptr;
-  if (hipMalloc((void **)&dStatus, 4) != hipSuccess) return HSRLE_ERR_DEVICE;
+  uint32_t *dStatus = (uint32_t *)scratch_alloc(4, (hipStream_t)stream);
+  if (!dStatus) return HSRLE_ERR_DEVICE;
   uint32_t status = 0;
   bool ok = hipMemsetAsync(dStatus, 0, 4, (hipStream_t)stream) == hipSuccess;
   if (ok)
@@ -1214,7 +1252,7 @@ int hsrle_decompress_dev(const void *dContainer, uint64_t containerSize, void *d
     rc = decompress_blocks_async(dContainer, &info, 0, info.blockCount, dOut, outCapacity, dStatus, (hipStream_t)stream);
     ok = hipMemcpyAsync(&status, dStatus, 4, hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess && hipStreamSynchronize((hipStream_t)stream) == hipSuccess;
   }
-  (void)hipFree(dStatus);
+  scratch_free(dStatus, (hipStream_t)stream);
   if (rc != HSRLE_OK) return rc;
   if (!ok) return HSRLE_ERR_DEVICE;
   if (status != 0) return HSRLE_ERR_FORMAT;

@@ -185,6 +185,9 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   // lies somewhere in `payload` (ONE monolithic reference stream, or sub-block b of a container block; hsrle_index.hip.h writes the
   // records) -- instead of from the header of block stream b; everything behind the prologue is the same: a lane still produces the
   // B output bytes [b * B, (b + 1) * B)
+#ifdef HSRLE_NO_ENTRIES  // A/B builds only: the kernel without the entry-record prologue
+  entries = nullptr;
+#endif
   using TR = Traits<FAM, S, AL>;
   constexpr int TS = T;                      // tile row stride: no pad -- the 16-byte chunks of a row are XOR-swizzled by the row index instead (TSW)
   constexpr int RS = R;                      // ring row stride: no pad, no mirror -- chunks are XOR-swizzled by the row index (rowx), every 8-byte piece is addressed on its own

@@ -94,6 +94,8 @@ def gather_container(local_container, total_uncompressed_size, root=0, group=Non
     infos = [t.cpu().tolist() for t in infos]
     codec = max(i[0] for i in infos)
     block_size = max(i[1] for i in infos)
+    if any(i[2] > 0 and (i[0] != codec or i[1] != block_size) for i in infos):
+        raise ValueError("gather_container: the ranks do not agree on codec / block size")
     counts = [i[2] for i in infos]
     psizes = [i[3] for i in infos]
     nblocks, payload = sum(counts), sum(psizes)
@@ -196,3 +198,88 @@ def scatter_container(container, root=0, device=None, group=None):
         t = local[HEADER_SIZE : HEADER_SIZE + 8 * (count + 1)].view(torch.int64)
         t -= p0
     return local
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the same two operations through the library's C ABI (include/hsrle.h section 4: hsrle_gather_container_rccl /
+# hsrle_scatter_container_rccl over a communicator the library creates with ncclCommInitRank).  torch.distributed only carries the
+# 128-byte unique id to the ranks.  Opt-in (HSRLE_DIST_C=1 in bench.py): the torch path above is the one the CPU tests (gloo) cover.
+
+_C_COMMS = {}
+
+
+def c_comm(group=None):
+    """ncclComm_t (as int) of the library for `group`, created on first use on the current CUDA device."""
+    import ctypes
+
+    import hsrle
+
+    key = id(group)
+    if key in _C_COMMS:
+        return _C_COMMS[key]
+    L = hsrle.lib()
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    ident = (ctypes.c_uint8 * 128)()
+    if rank == 0:
+        rc = L.hsrle_rccl_unique_id(ident)
+        if rc != 0:
+            raise hsrle.HsrleError(rc, "hsrle_rccl_unique_id")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    t = torch.tensor(list(ident), dtype=torch.uint8, device=dev if dist.get_backend(group) == "nccl" else "cpu")
+    dist.broadcast(t, 0, group=group)
+    ident = (ctypes.c_uint8 * 128)(*t.cpu().tolist())
+    comm = ctypes.c_void_p()
+    rc = L.hsrle_rccl_comm_create(ident, world, rank, ctypes.byref(comm))
+    if rc != 0:
+        raise hsrle.HsrleError(rc, "hsrle_rccl_comm_create")
+    _C_COMMS[key] = comm
+    return comm
+
+
+def gather_container_c(local_container, total_uncompressed_size, root=0, group=None):
+    """gather_container through hsrle_gather_container_rccl.  Returns the assembled container on root, None elsewhere."""
+    import ctypes
+
+    import hsrle
+
+    L = hsrle.lib()
+    L.hsrle_gather_container_rccl.restype = ctypes.c_int
+    L.hsrle_gather_container_rccl.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64,
+                                              ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p]
+    comm = c_comm(group)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    n = local_container.numel() if local_container is not None else 0
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([n], dtype=torch.int64, device=dev), group=group)
+    cap = sum(int(x.item()) for x in sizes)                               # the parts' headers / tail pads make this an upper bound
+    out = torch.empty(cap, dtype=torch.uint8, device=dev) if rank == root else None
+    total = ctypes.c_uint64(0)
+    rc = L.hsrle_gather_container_rccl(comm, root, ctypes.c_void_p(local_container.data_ptr()) if n else None, n, total_uncompressed_size,
+                                       ctypes.c_void_p(out.data_ptr()) if out is not None else None, cap, ctypes.byref(total),
+                                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        raise hsrle.HsrleError(rc, "hsrle_gather_container_rccl")
+    return out[: total.value] if out is not None else None
+
+
+def scatter_container_c(container, shard_capacity, root=0, group=None):
+    """scatter_container through hsrle_scatter_container_rccl; shard_capacity >= hsrle.container_bound(shard bytes, block size)."""
+    import ctypes
+
+    import hsrle
+
+    L = hsrle.lib()
+    L.hsrle_scatter_container_rccl.restype = ctypes.c_int
+    L.hsrle_scatter_container_rccl.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64),
+                                               ctypes.c_void_p]
+    comm = c_comm(group)
+    rank = dist.get_rank(group)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    local = torch.empty(shard_capacity, dtype=torch.uint8, device=dev)
+    size = ctypes.c_uint64(0)
+    rc = L.hsrle_scatter_container_rccl(comm, root, ctypes.c_void_p(container.data_ptr()) if rank == root else None, container.numel() if rank == root else 0,
+                                        ctypes.c_void_p(local.data_ptr()), shard_capacity, ctypes.byref(size), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        raise hsrle.HsrleError(rc, "hsrle_scatter_container_rccl")
+    return local[: size.value] if size.value else None

@@ -19,9 +19,16 @@
  *
  *  3. Host convenience wrappers around 2 (`hsrle_compress_host`, `hsrle_decompress_host`).
  *
- * All functions are thread safe; device state is created lazily on first use (like the reference's
- * rle8m_opencl_decompress does, reference: src/rle8_ocl.c:324).  The library never falls back to a CPU codec:
- * if no HIP device is usable every entry point fails (drop-in functions return 0, hsrle_* return an error code).
+ *  4. Multi-GPU: one container from the containers of W ranks and back, over RCCL (section 4 below).
+ *
+ * Threads and streams.  The device-pointer functions (2, 4, hsrle_decompress_mono_dev) keep NO library-owned state between calls: they
+ * work on the caller's buffers, and what they need beyond those (the compression workspace when dWorkspace is NULL, status words) is
+ * allocated stream-ordered on the caller's stream for the duration of the call.  Any number of threads may call them at the same time,
+ * on the same or on different streams and devices (the device is the calling thread's current HIP device).  The host-pointer drop-in
+ * functions (1, 3) stage through per-device buffers and hold that device's lock for the whole call: they are safe to call from several
+ * threads, and calls on one device run one after the other (the reference's own callers are single threaded: src/main.c, src/rle_fuzz.c).
+ * Device state is created lazily on first use (like the reference's rle8m_opencl_decompress does, src/rle8_ocl.c:324).  The library never
+ * falls back to a CPU codec: if no HIP device is usable every entry point fails (drop-in functions return 0, hsrle_* an error code).
  */
 #ifndef HSRLE_H
 #define HSRLE_H
@@ -296,6 +303,32 @@ int hsrle_hash_blocks_dev_async(const void *dContainer, const hsrle_container_in
 
 int hsrle_compress_host(int codec, const void *pIn, uint64_t inSize, void *pOut, uint64_t outCapacity, uint32_t blockSize, uint64_t *pContainerSize);
 int hsrle_decompress_host(const void *pContainer, uint64_t containerSize, void *pOut, uint64_t outCapacity, uint64_t *pUncompressedSize);
+
+/* ---------------------------------------------------------------------------------------------------------- */
+/* 4. multi-GPU: the path shards by independent blocks -- rank r of W encodes / decodes the contiguous block range
+ *    [r * n / W, (r + 1) * n / W) with sections 2 of this header and needs no collective for that.  The ONE exchange step is
+ *    assembling one container from the per-rank containers (and cutting one into per-rank containers); these functions do it over
+ *    RCCL (xGMI inside a node): an all-gather of the per-rank sizes, then grouped point-to-point transfers of [offset table | payload]
+ *    straight into their final places, offsets re-based by a small kernel.  One process per GPU; the communicator belongs to the caller.
+ *    RCCL is loaded on first use (librccl.so.1); HSRLE_ERR_UNSUPPORTED if it is not there.  The reference has nothing comparable (it
+ *    is single device); its closest precedent is the sub-section container of rle8m (src/rle8_low_entropy_cpu.c:131-191).             */
+
+#define HSRLE_RCCL_ID_BYTES 128
+/* rank 0: a fresh id (ncclGetUniqueId) to be handed to every rank by whatever the host program uses (MPI, torch.distributed, a file) */
+int hsrle_rccl_unique_id(void *id128);
+/* every rank, on its current HIP device: ncclCommInitRank.  *pComm is an ncclComm_t; a communicator the program already has works too */
+int hsrle_rccl_comm_create(const void *id128, int worldSize, int rank, void **pComm);
+int hsrle_rccl_comm_destroy(void *comm);
+/*
+ * Collective over `comm`.  dLocal / localSize: this rank's container (device memory; NULL / 0 if the rank owns no block).  On the root,
+ * dOut (device, capacity >= the sum of the parts, at most hsrle_container_bound(totalUncompressedSize, blockSize)) receives the one
+ * container; *pTotalSize its size (every rank learns it).  All non-empty ranks must agree on codec and block size (HSRLE_ERR_FORMAT).
+ * Enqueues on `stream` after two small synchronising reads (header, sizes).
+ */
+int hsrle_gather_container_rccl(void *comm, int root, const void *dLocal, uint64_t localSize, uint64_t totalUncompressedSize, void *dOut, uint64_t outCapacity,
+                                uint64_t *pTotalSize, void *stream);
+/* The inverse: the root's container is cut into one container per rank (contiguous block ranges, blocks renumbered from 0). */
+int hsrle_scatter_container_rccl(void *comm, int root, const void *dContainer, uint64_t containerSize, void *dLocal, uint64_t localCapacity, uint64_t *pLocalSize, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------------- */
 /* synthetic workloads of BASELINE.json generated directly in device memory (bench / tests)     */

@@ -50,7 +50,15 @@ for name, kind in (("runs", hsrle.SYNTH_RUNS), ("noise", None)):
     hd._p2p(ops)
     torch.cuda.synchronize(); res["self_p2p_ms_" + name] = (time.perf_counter() - t0) * 1e3
     assert torch.equal(dst, pay), "self send/recv changed the payload"
-    del src, container, full, back, out, dst
+    # the same through the library's C ABI (hsrle_gather_container_rccl / hsrle_scatter_container_rccl over its own communicator)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    fullc = hd.gather_container_c(container, size, root=0)
+    torch.cuda.synchronize(); res["c_gather_ms_" + name] = (time.perf_counter() - t0) * 1e3
+    assert torch.equal(fullc, full), "C-ABI gather differs from the torch gather"
+    backc = hd.scatter_container_c(fullc, fullc.numel(), root=0)
+    torch.cuda.synchronize()
+    assert torch.equal(backc, full), "C-ABI scatter(gather(x)) != x"
+    del src, container, full, back, out, dst, fullc, backc
 dist.destroy_process_group()
 print("RESULT " + json.dumps(res))
 """
