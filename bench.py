@@ -33,16 +33,19 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s pe
 
 
 def measured_traffic(codec, size, block):
-    """HBM bytes per decode launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json: FETCH_SIZE and
-    WRITE_SIZE, one counter per pass, KiB units as rocprofv3 reports them; uncorrected -- see DESIGN.md §5).  None when the
-    workload is not the one that was profiled."""
+    """HBM bytes per decode launch from the committed rocprofv3 PMC passes of this workload (profiles/r02_traffic.json; None for any other
+    workload).  FETCH_SIZE tallies every L2 -> fabric read request at 64 bytes whether it asks for 64 or 128 (calibrated with
+    tools/ubench/fetch_calib.hip on a buffer of known size, profiles/r02_fetch_calibration.txt), so the read side is known between two
+    bounds: every chunk at least once (the container) and 128 bytes per counted request.  Returns (upper bound, detail)."""
     try:
-        t = json.load(open(os.path.join(REPO, "profiles", "r01_traffic.json")))
+        t = json.load(open(os.path.join(REPO, "profiles", "r02_traffic.json")))
         if t["codec"] == codec and t["size"] == size and t["block"] == block:
-            return int(t["fetch_bytes"] + t["write_bytes"])
+            return int(t["traffic_upper_bound_bytes"]), {"fetch_size_raw": t["fetch_size_raw_bytes"], "fabric_read_requests": t["fabric_read_requests"],
+                                                          "fetch_bounds": [t["fetch_lower_bound_bytes"], t["fetch_upper_bound_bytes"]], "write_size": t["write_bytes"],
+                                                          "traffic_bounds": [t["traffic_lower_bound_bytes"], t["traffic_upper_bound_bytes"]], "source": "profiles/r02_traffic.json"}
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def cpu_baseline(container_prefix, n_blocks, block_size, codec_key, expect):
@@ -110,6 +113,15 @@ def cpu_baseline(container_prefix, n_blocks, block_size, codec_key, expect):
             if tb is not None and same:
                 res["all_cores"] = {"value": round(usize / 2**30 / tb, 2), "unit": "GiB/s", "cores": nthreads, "note": "best of %d runs, one block range per POSIX thread" % runs}
     return res
+
+
+def kernel_name(codec_key):
+    """The decode kernel instantiation behind a codec id (hsrle_decode.hip.h: k_decode_blocks<FAM, S, AL, T, R, Q, SGL>)."""
+    from hsrle_testlib import CODEC_BY_KEY, FAMILY_NAMES
+
+    c = CODEC_BY_KEY[codec_key]
+    fam = FAMILY_NAMES.get(c.family, str(c.family)).upper()
+    return f"k_decode_blocks<{fam},{c.S},{'sym' if c.aligned else 'byte'}>"
 
 
 def spawn_ranks(n, result_fd):
@@ -304,6 +316,7 @@ def main():
         del full
 
     if rank == 0:
+        traffic, traffic_detail = measured_traffic(args.codec, size, args.block)
         total_units = size * world
         alg_bytes = size + info.totalSize
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
@@ -326,8 +339,9 @@ def main():
             "parity": parity,
             "encode": {"value": round(size / 2**30 / (enc_ms * 1e-3), 2), "unit": "GiB/s", "ms": round(enc_ms, 4), "note": "same buffer, encode kernel + size scan + compaction"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": measured_traffic(args.codec, size, args.block), "kernel": "k_decode_blocks<PACKED,1>", "waves_per_cu": hsrle.kernel_waves_per_cu(args.codec, True), "kernel_ms": round(kernel_ms, 4),
-                         "algorithmic_bytes": int(alg_bytes), "note": "algorithmic bytes = container (compressed) + uncompressed output per launch; PMC traffic in profiles/"},
+                         "traffic": traffic, "traffic_detail": traffic_detail, "kernel": kernel_name(args.codec), "waves_per_cu": hsrle.kernel_waves_per_cu(args.codec, True), "kernel_ms": round(kernel_ms, 4),
+                         "algorithmic_bytes": int(alg_bytes),
+                         "note": "algorithmic bytes = container (compressed) + uncompressed output per launch; traffic = upper bound of the PMC passes in profiles/ (128 B per counted fabric read request + WRITE_SIZE), lower bound in traffic_detail"},
         }
         if gather_ms is not None:
             line["gather_ms"] = round(gather_ms, 3)

@@ -338,6 +338,24 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   // Every chunk of the container is requested exactly once -- no re-requests, no dummy loads of predicated-off lanes: the L1's
   // outstanding-request slots are what bounds this kernel under full occupancy (TCP_PENDING_STALL 60 %), and the
   // previous policy (request Q bytes behind E every step, drop what does not fit) spent 1.8x the compressed bytes on them.
+#ifdef HSRLE_REQ_STATS  // diagnostic build (tools/fetch_calib.sh): how the top-up's load instructions cover the 128-byte lines
+  unsigned long long nFullLine = 0, nHalfLine = 0, nBothHalves = 0, nOneHalf = 0;
+  // one row's LPR serving lanes sit side by side: a line is asked for as a whole iff all of them load in the same instruction
+  auto count_requests = [&](bool loads) {
+    const unsigned long long m = __ballot(loads);
+    for (uint32_t grp = 0; grp < 64u / LPR; grp++)
+    {
+      const uint32_t bits = (uint32_t)(m >> (grp * LPR)) & ((1u << LPR) - 1u);
+      if (bits == (1u << LPR) - 1u && LPR == 8) nFullLine++;
+      else
+      {
+        if (bits & 0x0Fu) nHalfLine++;
+        if (bits & 0xF0u) nHalfLine++;
+        if ((bits & 0x0Fu) && (bits & 0xF0u)) nBothHalves++; else if (bits) nOneHalf++;
+      }
+    }
+  };
+#endif
   static_assert(RPL % 8 == 0, "the ring swizzle of row q * RPL + g must not depend on q");
   const uint32_t serveBase = ((lane / LPR) * (uint32_t)RS) ^ rsw_of(lane / LPR);   // ring row (swizzled) of the first row this lane serves
   auto topup = [&]() {
@@ -360,6 +378,10 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     HS_XSTAMP(tx1)
 #pragma unroll
     for (int q = 0; q < LPR; q++)
+    {
+#ifdef HSRLE_REQ_STATS
+      count_requests(landed[q] && (kPackLim ? (((pfPos[q] + (uint32_t)Q - (ri[q] & ~15u)) >> 4) < (ri[q] & 15u)) : (limq[q] - pfPos[q] > (uint32_t)Q)));
+#endif
       if (landed[q])
       {
         // the chunk Q bytes further on exists iff it starts below lim
@@ -371,6 +393,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
         else
           pfPos[q] = 0xFFFFFFFFu;                                         // this lane's part of the stream is complete
       }
+    }
     HS_XSTAMP(tx2)
   };
   // prologue: fill the ring, then read the stream header from it
@@ -389,6 +412,9 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     const uint32_t rowLim = (uint32_t)__shfl((int)lim, r, 64);
     if constexpr (!kPackLim) limq[q] = rowLim;
     pfPos[q] = (lane % LPR) * 16u;                                    // the first Q bytes of every stream ...
+#ifdef HSRLE_REQ_STATS
+    count_requests(pfPos[q] < rowLim);
+#endif
     if (pfPos[q] < rowLim) pf[q] = ld128(payload + myBase[q] + pfPos[q]);
     else pfPos[q] = 0xFFFFFFFFu;
   }
@@ -1117,6 +1143,14 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
       atomicAdd(dbg + 4, nRounds); atomicAdd(dbg + 5, iters); atomicAdd(dbg + 6, 1ull);
       atomicAdd(dbg + 12, tx0); atomicAdd(dbg + 13, tx1); atomicAdd(dbg + 14, tx2); atomicAdd(dbg + 15, tx3); atomicAdd(dbg + 16, tx4);
     }
+  }
+#endif
+
+#ifdef HSRLE_REQ_STATS
+  if (status != nullptr && lane == 0)
+  {
+    unsigned long long *dbg = (unsigned long long *)(status + 16);
+    atomicAdd(dbg + 0, nFullLine); atomicAdd(dbg + 1, nHalfLine); atomicAdd(dbg + 2, nBothHalves); atomicAdd(dbg + 3, nOneHalf);
   }
 #endif
 
