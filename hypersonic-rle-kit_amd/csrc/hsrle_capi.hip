@@ -71,6 +71,7 @@ static inline uint32_t slot_stride(uint32_t B) { return (bounds32(B) + 15u) & ~1
 static inline uint64_t block_count(uint64_t U, uint32_t B) { return (U + B - 1) / B; }
 static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
+static uint32_t env_u32(const char *name, uint32_t dflt) { const char *e = getenv(name); return (e && *e) ? (uint32_t)strtoul(e, nullptr, 10) : dflt; }
 static uint32_t pow2_floor(uint64_t v) { uint32_t r = 1; while ((uint64_t)r * 2u <= v && r < 0x80000000u) r *= 2u; return r; }
 
 static bool valid_block_size(uint32_t B) { return B >= HSRLE_MIN_BLOCK_SIZE && B <= HSRLE_MAX_BLOCK_SIZE && (B % 128u) == 0; }
@@ -128,8 +129,10 @@ __global__ __launch_bounds__(kScanThreads) void k_tile_sums(const TIN *__restric
 
 // out[i] = tileBase[wg] + exclusive prefix of in within the tile; out[n] = grand total when writeTotal.
 // `in` and `out` may alias (in-place scan of a sums level): every thread reads its items before it writes them.
+// `carry` (may be null): a device value added to every result -- the chunked compression scans chunk after chunk, each starting at the
+// total of the chunks in front of it (which is the out[n] the previous chunk's scan wrote: carry may alias out[0]).
 template <typename TIN>
-__global__ __launch_bounds__(kScanThreads) void k_tile_scan(const TIN *in, uint64_t n, const uint64_t *tileBase, uint64_t *out, int writeTotal)
+__global__ __launch_bounds__(kScanThreads) void k_tile_scan(const TIN *in, uint64_t n, const uint64_t *tileBase, uint64_t *out, int writeTotal, const uint64_t *carry = nullptr)
 {
   const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
   uint64_t v[kScanItems];
@@ -141,7 +144,8 @@ __global__ __launch_bounds__(kScanThreads) void k_tile_scan(const TIN *in, uint6
     acc += v[k];
   }
   uint64_t total;
-  uint64_t run = wg_exclusive_scan_u64(acc, &total) + (tileBase ? tileBase[blockIdx.x] : 0);
+  const uint64_t carried = carry ? *carry : 0;
+  uint64_t run = wg_exclusive_scan_u64(acc, &total) + (tileBase ? tileBase[blockIdx.x] : 0) + carried;
 #pragma unroll
   for (int k = 0; k < kScanItems; k++)
   {
@@ -329,6 +333,7 @@ struct DeviceState
   std::mutex mu;
   void *ws = nullptr;    // rle8m drop-in: compression workspace
   uint64_t wsSize = 0;
+  hipStream_t aux = nullptr;   // second stream of the chunked compression
   void *monoIn = nullptr, *monoOut = nullptr, *monoAux = nullptr, *monoWs = nullptr; // staging of the drop-in (host pointer) path
   uint64_t monoInSize = 0, monoOutSize = 0, monoWsSize = 0;
 };
@@ -385,9 +390,24 @@ static bool grow(void **p, uint64_t *have, uint64_t need)
 }
 
 // workspace layout: [slots][sizes u32][level-1 sums u64][level-2 sums u64][level-3 sums u64]
+//
+// Optionally (encode_chunk_blocks) inputs are compressed CHUNK by chunk: the compaction of chunk k (bandwidth bound, no LDS) runs on a
+// second stream while the encode kernel (latency bound, LDS limited to 9 waves per CU) works on chunk k + 1, and the staging slots are
+// two chunks' worth instead of the whole input's (8 GiB: 2.3 GB instead of 9 GB).  The scan of a chunk's stream sizes starts at the
+// running total the previous chunk left in the offset table.
+static uint32_t encode_chunk_blocks()
+{
+  // OFF by default: measured on the 8 GiB headline buffer the overlap does not pay -- 1 130 GiB/s in one piece against 846 / 964 / 1 015 /
+  // 1 063 GiB/s with chunks of 131 072 / 262 144 / 524 288 / 1 048 576 blocks (the compaction's traffic slows the encode kernel by more
+  // than its own 1.8 ms, and every chunk boundary drains the GPU).  HSRLE_ENCODE_CHUNK_BLOCKS=n turns it on for callers that would rather
+  // have the smaller workspace (two chunks of staging slots instead of the whole input's).
+  static const uint32_t v = [] { const uint32_t e = env_u32("HSRLE_ENCODE_CHUNK_BLOCKS", 0); return e ? e : 0xFFFFFFF0u; }();
+  return v;
+}
+
 struct Workspace
 {
-  uint64_t nBlocks, t1, t2, t3;
+  uint64_t nBlocks, chunk, nChunks, t1, t2, t3;
   uint64_t offSlots, offSizes, offL1, offL2, offL3, total;
 };
 
@@ -395,11 +415,15 @@ static Workspace plan_workspace(uint64_t U, uint32_t B)
 {
   Workspace w;
   w.nBlocks = block_count(U, B);
-  w.t1 = (w.nBlocks + kScanTile - 1) / kScanTile;
+  w.chunk = encode_chunk_blocks();
+  if (w.nBlocks < w.chunk + w.chunk / 2u) w.chunk = w.nBlocks;            // no short last chunk: up to 1.5 chunks go in one piece
+  w.nChunks = (w.nBlocks + w.chunk - 1) / w.chunk;
+  const uint64_t slotBlocks = w.nChunks > 1 ? 2u * w.chunk : w.nBlocks;
+  w.t1 = (w.chunk + kScanTile - 1) / kScanTile;
   w.t2 = (w.t1 + kScanTile - 1) / kScanTile;
   w.t3 = (w.t2 + kScanTile - 1) / kScanTile;
   uint64_t at = 0;
-  w.offSlots = at; at += align_up(w.nBlocks * (uint64_t)slot_stride(B), 256);
+  w.offSlots = at; at += align_up(slotBlocks * (uint64_t)slot_stride(B), 256);
   w.offSizes = at; at += align_up(w.nBlocks * 4ull, 256);
   w.offL1 = at; at += align_up((w.t1 + 1) * 8ull, 256);
   w.offL2 = at; at += align_up((w.t2 + 1) * 8ull, 256);
@@ -408,34 +432,45 @@ static Workspace plan_workspace(uint64_t U, uint32_t B)
   return w;
 }
 
-// exclusive scan of `n` values (u32 at level 0) into out[0..n] (out[n] = total) using the pre-planned sum levels
-static hipError_t scan_sizes(const uint32_t *sizes, uint64_t n, uint64_t *out, uint8_t *ws, const Workspace &w, hipStream_t st)
+// exclusive scan of `n` values (u32 at level 0) into out[0..n] (out[n] = total) using the pre-planned sum levels; `carry` as in k_tile_scan
+static hipError_t scan_sizes(const uint32_t *sizes, uint64_t n, uint64_t *out, uint8_t *ws, const Workspace &w, hipStream_t st, const uint64_t *carry = nullptr)
 {
   uint64_t *l1 = (uint64_t *)(ws + w.offL1), *l2 = (uint64_t *)(ws + w.offL2), *l3 = (uint64_t *)(ws + w.offL3);
+  const uint64_t t1 = (n + kScanTile - 1) / kScanTile, t2 = (t1 + kScanTile - 1) / kScanTile, t3 = (t2 + kScanTile - 1) / kScanTile;
 
-  if (w.t1 > 1)
+  if (t1 > 1)
   {
-    hipLaunchKernelGGL(k_tile_sums<uint32_t>, dim3((uint32_t)w.t1), dim3(kScanThreads), 0, st, sizes, n, l1);
-    if (w.t2 > 1)
+    hipLaunchKernelGGL(k_tile_sums<uint32_t>, dim3((uint32_t)t1), dim3(kScanThreads), 0, st, sizes, n, l1);
+    if (t2 > 1)
     {
-      hipLaunchKernelGGL(k_tile_sums<uint64_t>, dim3((uint32_t)w.t2), dim3(kScanThreads), 0, st, l1, w.t1, l2);
-      if (w.t3 > 1)
+      hipLaunchKernelGGL(k_tile_sums<uint64_t>, dim3((uint32_t)t2), dim3(kScanThreads), 0, st, l1, t1, l2);
+      if (t3 > 1)
         return hipErrorInvalidValue; // > 2048^3 blocks: not representable anyway
-      hipLaunchKernelGGL(k_tile_scan<uint64_t>, dim3(1), dim3(kScanThreads), 0, st, l2, w.t2, (const uint64_t *)nullptr, l3, 0);
-      hipLaunchKernelGGL(k_tile_scan<uint64_t>, dim3((uint32_t)w.t2), dim3(kScanThreads), 0, st, l1, w.t1, l3, l1, 0);
+      hipLaunchKernelGGL(k_tile_scan<uint64_t>, dim3(1), dim3(kScanThreads), 0, st, l2, t2, (const uint64_t *)nullptr, l3, 0, (const uint64_t *)nullptr);
+      hipLaunchKernelGGL(k_tile_scan<uint64_t>, dim3((uint32_t)t2), dim3(kScanThreads), 0, st, l1, t1, l3, l1, 0, (const uint64_t *)nullptr);
     }
     else
     {
-      hipLaunchKernelGGL(k_tile_scan<uint64_t>, dim3(1), dim3(kScanThreads), 0, st, l1, w.t1, (const uint64_t *)nullptr, l1, 0);
+      hipLaunchKernelGGL(k_tile_scan<uint64_t>, dim3(1), dim3(kScanThreads), 0, st, l1, t1, (const uint64_t *)nullptr, l1, 0, (const uint64_t *)nullptr);
     }
-    hipLaunchKernelGGL(k_tile_scan<uint32_t>, dim3((uint32_t)w.t1), dim3(kScanThreads), 0, st, sizes, n, l1, out, 1);
+    hipLaunchKernelGGL(k_tile_scan<uint32_t>, dim3((uint32_t)t1), dim3(kScanThreads), 0, st, sizes, n, l1, out, 1, carry);
   }
   else
   {
-    hipLaunchKernelGGL(k_tile_scan<uint32_t>, dim3(1), dim3(kScanThreads), 0, st, sizes, n, (const uint64_t *)nullptr, out, 1);
+    hipLaunchKernelGGL(k_tile_scan<uint32_t>, dim3(1), dim3(kScanThreads), 0, st, sizes, n, (const uint64_t *)nullptr, out, 1, carry);
   }
 
   return hipGetLastError();
+}
+
+// the device's second stream (compaction behind the encode kernel); created once, shared by concurrent calls (their compactions then
+// simply queue up behind each other)
+static hipStream_t aux_stream()
+{
+  DeviceState &D = this_device();
+  std::lock_guard<std::mutex> lock(D.mu);
+  if (!D.aux && hipStreamCreateWithFlags(&D.aux, hipStreamNonBlocking) != hipSuccess) D.aux = nullptr;
+  return D.aux;
 }
 
 static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, uint64_t cap, uint32_t B, void *dWs, uint64_t wsSize, hipStream_t st)
@@ -474,14 +509,50 @@ static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, ui
   const uint32_t nBlocks = (uint32_t)w.nBlocks;
   uint64_t *offsets = (uint64_t *)(container + HSRLE_CONTAINER_HEADER_SIZE);
   uint8_t *payload = container + HSRLE_CONTAINER_HEADER_SIZE + 8ull * ((uint64_t)nBlocks + 1ull);
-
-  EncodeArgs ea{ (const uint8_t *)dIn, U, B, nBlocks, ws + w.offSlots, slot_stride(B), (uint32_t *)(ws + w.offSizes) };
+  const uint32_t stride = slot_stride(B);
+  uint32_t *sizes = (uint32_t *)(ws + w.offSizes);
   int rc = HSRLE_OK;
-  if (g_enc[codec](ea, st) != hipSuccess || scan_sizes(ea.sizes, nBlocks, offsets, ws, w, st) != hipSuccess)
+
+  hipStream_t aux = w.nChunks > 1 ? aux_stream() : nullptr;
+  if (w.nChunks > 1 && aux == nullptr)
     rc = HSRLE_ERR_DEVICE;
+  else if (w.nChunks <= 1)
+  {
+    EncodeArgs ea{ (const uint8_t *)dIn, U, B, nBlocks, ws + w.offSlots, stride, sizes };
+    if (g_enc[codec](ea, st) != hipSuccess || scan_sizes(sizes, nBlocks, offsets, ws, w, st) != hipSuccess)
+      rc = HSRLE_ERR_DEVICE;
+    else
+      hipLaunchKernelGGL(k_compact, dim3((nBlocks + 3u) / 4u), dim3(256), 0, st, ea.slots, stride, (const uint64_t *)offsets, payload, nBlocks);
+  }
   else
   {
-    hipLaunchKernelGGL(k_compact, dim3((nBlocks + 3u) / 4u), dim3(256), 0, st, ea.slots, ea.slotStride, (const uint64_t *)offsets, payload, nBlocks);
+    // chunk k: encode + size scan on the caller's stream, compaction on the second stream; the slot buffer of chunk k is free again when
+    // the compaction of chunk k - 2 is done
+    hipEvent_t scanned = nullptr, compacted[2] = { nullptr, nullptr };
+    bool ok = hipEventCreateWithFlags(&scanned, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&compacted[0], hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&compacted[1], hipEventDisableTiming) == hipSuccess;
+    for (uint64_t k = 0; k < w.nChunks && ok; k++)
+    {
+      const uint64_t first = k * w.chunk;
+      const uint32_t count = (uint32_t)((w.nBlocks - first) < w.chunk ? (w.nBlocks - first) : w.chunk);
+      uint8_t *slots = ws + w.offSlots + (k & 1u) * w.chunk * (uint64_t)stride;
+      if (k >= 2) ok = hipStreamWaitEvent(st, compacted[k & 1u], 0) == hipSuccess;
+      EncodeArgs ea{ (const uint8_t *)dIn + first * B, U - first * B, B, count, slots, stride, sizes + first };
+      ok = ok && g_enc[codec](ea, st) == hipSuccess && scan_sizes(sizes + first, count, offsets + first, ws, w, st, k ? offsets + first : nullptr) == hipSuccess &&
+           hipEventRecord(scanned, st) == hipSuccess && hipStreamWaitEvent(aux, scanned, 0) == hipSuccess;
+      if (!ok) break;
+      hipLaunchKernelGGL(k_compact, dim3((count + 3u) / 4u), dim3(256), 0, aux, (const uint8_t *)slots, stride, (const uint64_t *)(offsets + first), payload, count);
+      ok = hipEventRecord(compacted[k & 1u], aux) == hipSuccess;
+    }
+    // the caller's stream continues when every compaction is done
+    ok = ok && hipStreamWaitEvent(st, compacted[0], 0) == hipSuccess && hipStreamWaitEvent(st, compacted[1], 0) == hipSuccess;
+    if (scanned) (void)hipEventDestroy(scanned);
+    if (compacted[0]) (void)hipEventDestroy(compacted[0]);
+    if (compacted[1]) (void)hipEventDestroy(compacted[1]);
+    if (!ok) rc = HSRLE_ERR_DEVICE;
+  }
+  if (rc == HSRLE_OK)
+  {
     hipLaunchKernelGGL(k_finish_container, dim3(1), dim3(64), 0, st, container, (uint32_t)codec, U, B, nBlocks);
     if (hipGetLastError() != hipSuccess) rc = HSRLE_ERR_DEVICE;
   }
@@ -625,7 +696,6 @@ struct MonoPlan
   uint64_t offG, offE, offOlen, offT, offEntry, offOutStart, offStateIn, offFix, offList, offCtrl, offRec, total;
 };
 
-static uint32_t env_u32(const char *name, uint32_t dflt) { const char *e = getenv(name); return (e && *e) ? (uint32_t)strtoul(e, nullptr, 10) : dflt; }
 
 static uint32_t g_monoTune[3] = { env_u32("HSRLE_MONO_BLOCK", 0), env_u32("HSRLE_MONO_REGION", 0), env_u32("HSRLE_MONO_LOOKBACK", 0) };
 
@@ -891,7 +961,7 @@ static Rle8mPlan plan_rle8m(uint32_t n, uint32_t sections)
   const uint32_t ss = n / sections, lastLen = n - ss * (sections - 1u);
   p.slotStride = (uint32_t)align_up(2ull * (uint64_t)(lastLen > ss ? lastLen : ss) + 16ull, 16);   // a section grows to at most twice its size
   Workspace &w = p.w;
-  w.nBlocks = sections;
+  w.nBlocks = sections; w.chunk = sections; w.nChunks = 1;
   w.t1 = (w.nBlocks + kScanTile - 1) / kScanTile;
   w.t2 = (w.t1 + kScanTile - 1) / kScanTile;
   w.t3 = (w.t2 + kScanTile - 1) / kScanTile;
