@@ -8,6 +8,7 @@
 #include "hsrle_common.hip.h"
 #include "hsrle_launch.h"
 #include "hsrle_index.hip.h"
+#include "hsrle_mono_encode.hip.h"
 #include "hsrle_rle8m.hip.h"
 
 #include <stdlib.h>
@@ -51,12 +52,13 @@ static DecodeLaunch g_dec[kCodecCount];
 static EncodeLaunch g_enc[kCodecCount];
 static IndexLaunch g_idx[kCodecCount];
 static SubBlockLaunch g_sub[kCodecCount];
+static MonoEncodeLaunch g_menc[kCodecCount];
 static std::once_flag g_tableOnce;
 
 static void init_tables()
 {
   std::call_once(g_tableOnce, [] {
-    register_w8(g_dec, g_enc, g_idx, g_sub);
+    register_w8(g_dec, g_enc, g_idx, g_sub, g_menc);
     register_w16(g_dec, g_enc, g_idx, g_sub);
     register_w24(g_dec, g_enc, g_idx, g_sub);
     register_w32(g_dec, g_enc, g_idx, g_sub);
@@ -856,6 +858,96 @@ static int mono_decode_dev(const MonoHeader &mh, const uint8_t *dStream, uint8_t
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// monolithic stream encode by many lanes (hsrle_mono_encode.hip.h): cut behind long runs, block kernels in MONO mode, compaction
+
+// the run length every state of the codec's encoder stores (SURVEY.md A.2 LONG / the Short family's SMINL); 0 = the codec is not cut
+static uint32_t mono_cut_long(int codec)
+{
+  if (codec == HSRLE_RLE8_MULTI) return 6u;              // rle8_extreme_cpu.h:974: count >= 6 whatever the range
+  if (codec == HSRLE_RLE8_PACKED_MULTI) return 11u;      // :978 (body) and :122 (tail)
+  if (codec == HSRLE_RLE8_MULTI_SHORT) return 13u;       // rleX_Xsl_short.h: RLEX_EXTREME_MIN_LONG of the 0-symbol codec (S + 12)
+  return 0u;
+}
+
+struct MonoEncPlan
+{
+  uint32_t G, pieces;
+  uint64_t offCutPos, offCutSym, offFlags, offIdx, offStarts, offSyms, offSlotOff, offSizes, offOffsets, offL1, offL2, offL3, offCtrl, offSlots, total;
+};
+
+static MonoEncPlan plan_mono_encode(uint32_t U)
+{
+  MonoEncPlan m;
+  uint32_t G = 4096u;
+  if (g_monoTune[1] >= 32u && g_monoTune[1] <= (1u << 24)) G = g_monoTune[1];
+  m.G = G;
+  m.pieces = (uint32_t)(((uint64_t)U + G - 1u) / G);
+  const uint64_t n = m.pieces;
+  const uint64_t t1 = (n + 2 + kScanTile - 1) / kScanTile, t2 = (t1 + kScanTile - 1) / kScanTile, t3 = (t2 + kScanTile - 1) / kScanTile;
+  uint64_t at = 0;
+  m.offCutPos = at; at += align_up(8ull * n, 256);
+  m.offCutSym = at; at += align_up(n, 256);
+  m.offFlags = at; at += align_up(4ull * n, 256);
+  m.offIdx = at; at += align_up(8ull * (n + 1), 256);
+  m.offStarts = at; at += align_up(8ull * (n + 2), 256);
+  m.offSyms = at; at += align_up(n + 1, 256);
+  m.offSlotOff = at; at += align_up(8ull * (n + 1), 256);
+  m.offSizes = at; at += align_up(4ull * (n + 1), 256);
+  m.offOffsets = at; at += align_up(8ull * (n + 2), 256);
+  m.offL1 = at; at += align_up(8ull * (t1 + 1), 256);
+  m.offL2 = at; at += align_up(8ull * (t2 + 1), 256);
+  m.offL3 = at; at += align_up(8ull * (t3 + 1), 256);
+  m.offCtrl = at; at += 256;
+  m.offSlots = at; at += align_up((uint64_t)U + ((uint64_t)U >> 7) + 256ull * (n + 2) + 4096ull, 256);
+  m.total = at;
+  return m;
+}
+
+// dOut: capacity >= rle_compress_bounds(U).  Synchronises the stream twice (chunk count, stream size).
+static int mono_encode_dev(int codec, const uint8_t *dIn, uint32_t U, uint8_t *dOut, uint8_t *ws, const MonoEncPlan &m, uint32_t *pSize, uint32_t *pChunks, hipStream_t st)
+{
+  init_tables();
+  const uint32_t longc = mono_cut_long(codec);
+  if (!g_menc[codec] || longc == 0u)
+    return HSRLE_ERR_UNSUPPORTED;
+  const uint32_t hs = codec_header_size(codec);
+  uint64_t *cutPos = (uint64_t *)(ws + m.offCutPos), *idx = (uint64_t *)(ws + m.offIdx), *starts = (uint64_t *)(ws + m.offStarts), *slotOff = (uint64_t *)(ws + m.offSlotOff);
+  uint64_t *offsets = (uint64_t *)(ws + m.offOffsets);
+  uint8_t *cutSym = ws + m.offCutSym, *syms = ws + m.offSyms;
+  uint32_t *flags = (uint32_t *)(ws + m.offFlags), *sizes = (uint32_t *)(ws + m.offSizes), *ctrl = (uint32_t *)(ws + m.offCtrl);
+  Workspace w{};
+  w.offL1 = m.offL1; w.offL2 = m.offL2; w.offL3 = m.offL3;
+
+  hipLaunchKernelGGL(k_mono_cuts8, dim3((m.pieces + 63u) / 64u), dim3(64), 0, st, dIn, (uint64_t)U, m.G, m.pieces, longc, cutPos, cutSym, flags);
+  if (scan_sizes(flags, m.pieces, idx, ws, w, st) != hipSuccess)
+    return HSRLE_ERR_DEVICE;
+  hipLaunchKernelGGL(k_mono_scatter, dim3((m.pieces + 255u) / 256u), dim3(256), 0, st, (const uint64_t *)cutPos, (const uint8_t *)cutSym, (const uint32_t *)flags, (const uint64_t *)idx,
+                     m.pieces, (uint64_t)U, starts, syms, slotOff, ctrl);
+  hipLaunchKernelGGL(k_mono_longest, dim3(1), dim3(256), 0, st, (const uint64_t *)starts, ctrl);
+  uint32_t head[2] = { 0, 0 };
+  if (hipMemcpyAsync(head, ctrl, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+    return HSRLE_ERR_DEVICE;
+  const uint32_t chunks = head[0], longest = head[1];
+  if (chunks == 0u || chunks > m.pieces + 1u)
+    return HSRLE_ERR_DEVICE;
+  if (pChunks) *pChunks = chunks;
+
+  EncodeArgs ea{ dIn, (uint64_t)U, 0u, chunks, ws + m.offSlots, 0u, sizes };
+  MonoEncodeArgs ma{ starts, syms, slotOff, 2u * (longest / 64u) + 64u };
+  if (g_menc[codec](ea, ma, st) != hipSuccess || scan_sizes(sizes, chunks, offsets, ws, w, st) != hipSuccess)
+    return HSRLE_ERR_DEVICE;
+  hipLaunchKernelGGL(k_compact_var, dim3((chunks + 3u) / 4u), dim3(256), 0, st, (const uint8_t *)(ws + m.offSlots), (const uint64_t *)slotOff, (const uint64_t *)offsets, dOut + hs, chunks);
+  hipLaunchKernelGGL(k_mono_finish, dim3(1), dim3(64), 0, st, dOut, U, hs, (const uint64_t *)offsets, (const uint32_t *)ctrl, ctrl);
+  uint32_t tail[2] = { 0, 0 };
+  if (hipGetLastError() != hipSuccess || hipMemcpyAsync(tail, ctrl + 2, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+    return HSRLE_ERR_DEVICE;
+  if (tail[1] != 0u || tail[0] == 0u)
+    return HSRLE_ERR_DEVICE;
+  *pSize = tail[0];
+  return HSRLE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // drop-in (host pointer, monolithic stream) path.  Decode: index + block kernel (above).  Encode: one block spanning the whole input.
 
 static uint32_t mono_compress(int codec, const uint8_t *pIn, uint32_t inSize, uint8_t *pOut, uint32_t outSize)
@@ -877,6 +969,25 @@ static uint32_t mono_compress(int codec, const uint8_t *pIn, uint32_t inSize, ui
   const uint32_t stride = (bounds32(inSize) + 15u) & ~15u;
   if (!grow(&D.monoIn, &D.monoInSize, (uint64_t)inSize + 64) || !grow(&D.monoOut, &D.monoOutSize, (uint64_t)stride + 64))
     return 0;
+
+  // many lanes where the codec allows it (cuts behind long runs, hsrle_mono_encode.hip.h); else -- and for inputs of one piece -- one lane
+  if (mono_cut_long(codec) != 0u && g_menc[codec])
+  {
+    const MonoEncPlan m = plan_mono_encode(inSize);
+    if (m.pieces >= 2u)
+    {
+      if (!grow(&D.monoWs, &D.monoWsSize, m.total))
+        return 0;
+      if (hipMemcpy(D.monoIn, pIn, inSize, hipMemcpyHostToDevice) != hipSuccess)
+        return 0;
+      uint32_t size = 0;
+      if (mono_encode_dev(codec, (const uint8_t *)D.monoIn, inSize, (uint8_t *)D.monoOut, (uint8_t *)D.monoWs, m, &size, nullptr, nullptr) != HSRLE_OK || size == 0 || size > outSize)
+        return 0;
+      if (hipMemcpy(pOut, D.monoOut, size, hipMemcpyDeviceToHost) != hipSuccess)
+        return 0;
+      return size;
+    }
+  }
   if (!D.monoAux && hipMalloc(&D.monoAux, 256) != hipSuccess)
     return 0;
 
@@ -1381,6 +1492,24 @@ int hsrle_decompress_host(const void *pContainer, uint64_t containerSize, void *
 void hsrle_mono_tuning(uint32_t blockSize, uint32_t regionSize, uint32_t lookBack)
 {
   g_monoTune[0] = blockSize; g_monoTune[1] = regionSize; g_monoTune[2] = lookBack;
+}
+
+uint64_t hsrle_compress_mono_workspace_size(int codec, uint32_t inSize)
+{
+  if (codec < 0 || codec >= kCodecCount || inSize == 0 || inSize > (1u << 30) || mono_cut_long(codec) == 0u) return 0;
+  return plan_mono_encode(inSize).total;
+}
+
+int hsrle_compress_mono_dev(int codec, const void *dIn, uint32_t inSize, void *dOut, uint64_t outCapacity, void *dWorkspace, uint64_t workspaceSize, uint32_t *pStreamSize,
+                            uint32_t *pChunks, void *stream)
+{
+  if (!dIn || !dOut || !dWorkspace || !pStreamSize || codec < 0 || codec >= kCodecCount || inSize == 0) return HSRLE_ERR_ARGUMENT;
+  if (inSize > (1u << 30) || mono_cut_long(codec) == 0u) return HSRLE_ERR_UNSUPPORTED;
+  if (outCapacity < bounds32(inSize)) return HSRLE_ERR_CAPACITY;
+  if (!device_ok()) return HSRLE_ERR_DEVICE;
+  const MonoEncPlan m = plan_mono_encode(inSize);
+  if (workspaceSize < m.total) return HSRLE_ERR_CAPACITY;
+  return mono_encode_dev(codec, (const uint8_t *)dIn, inSize, (uint8_t *)dOut, (uint8_t *)dWorkspace, m, pStreamSize, pChunks, (hipStream_t)stream);
 }
 
 uint64_t hsrle_decompress_mono_workspace_size(int codec, uint32_t uncompressedSize, uint32_t compressedSize)

@@ -23,11 +23,21 @@
 
 namespace hsrle {
 
-template <int FAM>
+// MONO = true: the lanes encode consecutive CHUNKS of ONE monolithic reference stream instead of independent blocks (hsrle_mono_encode.hip.h
+// finds the chunk boundaries).  Chunk c covers the input bytes [monoStarts[c], monoStarts[c + 1]); every boundary is the end of a run
+// that every encoder state emits (count >= LONG: SURVEY.md A.4 "reset points"), so the state in front of a chunk is known without the
+// chunks before it -- lastRLE = the boundary, lastSymbol = that run's symbol (monoSyms) -- and the chunk's packets are exactly the
+// packets the sequential encoder writes for these bytes.  A chunk writes no stream header and (unless it reaches the end of the input)
+// no terminator, its rules see the TRUE end of the input (the AVX2 body / tail split of A.5 q1 counts from there), and its output goes
+// to slots + monoSlotOff[c].  Families without a move-to-front list only (the list behind a boundary is not known).
+template <int FAM, bool MONO = false>
 __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t nBlocks,
-                                                       uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes)
+                                                       uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes,
+                                                       const uint64_t *__restrict__ monoStarts, const uint8_t *__restrict__ monoSyms,
+                                                       const uint64_t *__restrict__ monoSlotOff, uint32_t monoSteps)
 {
   using TR = Traits<FAM, 1, 0>;
+  static_assert(!MONO || !TR::kMtf, "a monolithic stream is cut only for codecs whose state behind a long run is known");
   constexpr int Q = 64;                      // input bytes per lane and step
 #ifndef HSRLE_ENC8_RING
 #define HSRLE_ENC8_RING 256
@@ -63,13 +73,24 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
   const uint32_t hbase = (lane * (uint32_t)H) ^ hsw_of(lane);
 
   uint32_t n = 0;
+  [[maybe_unused]] uint32_t nTrueV = 0;                                 // MONO: bytes from the chunk start to the end of the input
+  uint64_t blockAt = (uint64_t)b * B;
   if (active)
   {
-    const uint64_t start = (uint64_t)b * B;
-    n = (uint32_t)((U - start) < (uint64_t)B ? (U - start) : (uint64_t)B);
+    if constexpr (MONO)
+    {
+      blockAt = monoStarts[b];
+      n = (uint32_t)(monoStarts[b + 1] - blockAt);
+      nTrueV = (uint32_t)(U - blockAt);
+    }
+    else
+    {
+      const uint64_t start = (uint64_t)b * B;
+      n = (uint32_t)((U - start) < (uint64_t)B ? (U - start) : (uint64_t)B);
+    }
   }
-  const uint64_t blockAt = (uint64_t)b * B;
-  uint8_t *const slot = slots + (uint64_t)b * slotStride;
+  const uint32_t nTrue = MONO ? nTrueV : n;
+  uint8_t *const slot = MONO ? slots + (active ? monoSlotOff[b] : 0ull) : slots + (uint64_t)b * slotStride;
 
   // ---- per-lane encoder state ----
   uint32_t avail = 0;        // input bytes [.., avail) are (or were) in the ring; the ring holds [avail - H, avail)
@@ -77,7 +98,7 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
   bool inRun = false;
   uint32_t runStart = 0, sym = 0;
   uint32_t lastRLE = 0;
-  uint32_t lastSym = 0;      // Packed: lastSymbol (starts 0, A.5 q5)
+  uint32_t lastSym = (MONO && active) ? monoSyms[b] : 0u;      // Packed: lastSymbol (starts 0, A.5 q5)
   [[maybe_unused]] uint64_t lutw = (K == 3) ? 0x0000000000FF7F00ull : 0x00FE807E01FF7F00ull; // LUT: MTF list, entry k in byte k
   bool ended = false;        // the end terminator has been written
   bool finished = !active;   // the whole stream is in the slot
@@ -169,7 +190,7 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
   };
 
   // ---- stream header ----
-  if (active)
+  if (active && !MONO)
   {
     h32(n);
     h32(0);
@@ -184,6 +205,17 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
   u32x4 pf[LPR];
   uint32_t pfAt[LPR];
   uint32_t wantReq = 0;
+  [[maybe_unused]] uint64_t rowAt[LPR];                                 // MONO: input position of the LPR rows this lane serves
+  if constexpr (MONO)
+  {
+#pragma unroll
+    for (int q = 0; q < LPR; q++)
+    {
+      const int r = (int)((uint32_t)q * RPL + lane / LPR);
+      const uint32_t lo32 = (uint32_t)__shfl((int)(uint32_t)blockAt, r, 64), hi32 = (uint32_t)__shfl((int)(uint32_t)(blockAt >> 32), r, 64);
+      rowAt[q] = ((uint64_t)hi32 << 32) | lo32;
+    }
+  }
 
   auto issue = [&]() {
     const uint32_t left = (n > avail) ? (n - avail + 15u) >> 4 : 0u;
@@ -200,7 +232,7 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
       const uint32_t r = (uint32_t)q * RPL + lane / LPR, c = lane % LPR;
       const uint32_t nreq = ri[q] & 15u, e = ri[q] & ~15u;
       const bool valid = c < nreq;
-      const uint64_t g = (uint64_t)(wgFirst + r) * B + e + c * 16u;
+      const uint64_t g = (MONO ? rowAt[q] : (uint64_t)(wgFirst + r) * B) + e + c * 16u;
       u32x4 v = u32x4{ 0, 0, 0, 0 };
       if (valid)
       {
@@ -289,7 +321,7 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
       // body / tail split of the canonical AVX2 encoder
       rng = gap + 1u;
       const int32_t kk = (int32_t)(count - 1u) / 32;
-      body = (e < n) && ((int32_t)p + 1 + 32 * kk < (int32_t)n - 32);
+      body = (e < nTrue) && ((int32_t)p + 1 + 32 * kk < (int32_t)nTrue - 32);
       if (body)
       {
         same = sym == lastSym;
@@ -367,7 +399,7 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
     emit_literals(lastRLE, gap);
     lastRLE = e;
 
-    if (e >= n)
+    if (e >= nTrue)
     {
       // end terminator (rle8_extreme_cpu.h:203-338; rleX_Xsl.h:319-338)
       if constexpr (TR::kShort) { hb(TR::SCINV << TR::SRBP); hb(TR::STB); hb(1); h16(0); h16(0); if (K == 0) hb(0); }   // rleX_Xsl_short.h:470-501
@@ -395,7 +427,7 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
   land();
   wave_sync();
 
-  uint32_t stepsLeft = 2u * (B / (uint32_t)Q) + 64u;                    // bounded: every step scans a window or lands input
+  uint32_t stepsLeft = MONO ? monoSteps : 2u * (B / (uint32_t)Q) + 64u;  // bounded: every step scans a window or lands input
 
   while (__ballot(!finished) != 0ull)
   {
@@ -472,11 +504,11 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
       {
         // end of input: a run that reaches the end is judged now; then the literal terminator unless the stream ended
         if (inRun) { handle_run(runStart, n); inRun = false; }
-        if (!ended) { finish_literals(); ended = true; }
+        if (!ended && n == nTrue) { finish_literals(); ended = true; }      // (a MONO chunk that does not reach the end of the input ends with its boundary run's packet)
         // the last partial chunk, then the stream size (header field compressedLength and the size table)
         if ((opos & 15u) != 0u)
           st128(slot + (opos & ~15u), oacc);
-        st32(slot + 4, opos);
+        if constexpr (!MONO) st32(slot + 4, opos);
         sizes[b] = opos;
         finished = true;
       }

@@ -47,6 +47,12 @@ struct EncodeArgs
   int *residentWorkgroups = nullptr; // query mode, as in DecodeArgs
 };
 
+// chunks of ONE monolithic stream (hsrle_mono_encode.hip.h): EncodeArgs with nBlocks = chunks, plus the chunk table
+struct MonoEncodeArgs
+{
+  const uint64_t *starts; const uint8_t *syms; const uint64_t *slotOff; uint32_t steps;
+};
+typedef hipError_t (*MonoEncodeLaunch)(const EncodeArgs &, const MonoEncodeArgs &, hipStream_t);
 typedef hipError_t (*DecodeLaunch)(const DecodeArgs &, hipStream_t);
 typedef hipError_t (*EncodeLaunch)(const EncodeArgs &, hipStream_t);
 
@@ -69,13 +75,16 @@ constexpr int kDecodeStep = HSRLE_DECODE_STEP; // output bytes per lane and deco
 constexpr int kDecodeTile = HSRLE_DECODE_TILE; // bytes produced per lane and round (k_decode_blocks T)
 constexpr int kDecodeRing = HSRLE_DECODE_RING; // per-lane stream ring in LDS (k_decode_blocks R)
 
-void register_w8(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub);
+void register_w8(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub, MonoEncodeLaunch *menc);
 void register_w16(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub);
 void register_w24(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub);
 void register_w32(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub);
 void register_w48(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub);
 void register_w64(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub);
 void register_w128(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub);
+
+template <typename... A>
+constexpr int kernel_arity(void (*)(A...)) { return (int)sizeof...(A); }
 
 template <typename KERNEL>
 inline hipError_t launch_decode(KERNEL k, const DecodeArgs &a, hipStream_t st)
@@ -98,7 +107,18 @@ inline hipError_t launch_encode(KERNEL k, const EncodeArgs &a, hipStream_t st, i
   static const uint32_t lds8 = [] { const char *e = getenv("HSRLE_ENCODE8_LDS"); return e ? (uint32_t)atoi(e) : 0u; }();   // experiment knob
   if (a.residentWorkgroups != nullptr)
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(a.residentWorkgroups, k, 64, capResidency ? ldsCap : lds8);
-  hipLaunchKernelGGL(k, dim3(grid), dim3(64), capResidency ? ldsCap : lds8, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes);
+  if constexpr (kernel_arity(KERNEL{}) == 11)   // kernels with a MONO mode (hsrle_encode8.hip.h): block mode = no chunk table
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64), capResidency ? ldsCap : lds8, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, (const uint64_t *)nullptr,
+                       (const uint8_t *)nullptr, (const uint64_t *)nullptr, 0u);
+  else
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64), capResidency ? ldsCap : lds8, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes);
+  return hipGetLastError();
+}
+
+template <typename KERNEL>
+inline hipError_t launch_mono_encode(KERNEL k, const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st)
+{
+  hipLaunchKernelGGL(k, dim3((a.nBlocks + 63u) / 64u), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, m.starts, m.syms, m.slotOff, m.steps);
   return hipGetLastError();
 }
 

@@ -1,0 +1,143 @@
+// hsrle_mono_encode.hip.h -- ONE monolithic reference stream encoded by many lanes (the encode side of SURVEY.md 8f-3 / 7 step 7).
+//
+// The reference's encoders are sequential state machines: whether a run is stored depends on where the last stored run ended
+// (`lastRLE`: the range field) and, for the Packed codecs, on its symbol (reference: src/rle8_extreme_cpu.h:974-1001,
+// src/rleX_extreme_cpu_encode.h:174-311).  But a run of LONG bytes or more is stored WHATEVER the state is, and
+// behind it the state is fully known: lastRLE = its end, lastSymbol = its symbol.  So the input can be cut behind such runs and every
+// piece encoded on its own -- by the block kernels in their MONO mode (hsrle_encode8.hip.h) -- into exactly the packets the sequential
+// encoder writes for it.  Codecs with a move-to-front list are not cut (the list behind a long run is not known from the run alone).
+//
+//   k_mono_cuts     one lane per nominal piece of G input bytes: the first maximal run of >= LONG equal symbols that ENDS inside the
+//                   piece (the lane looks LONG bytes back, so a run that began in an earlier piece is seen long enough)
+//   k_mono_scatter  the pieces that found one, compacted: chunk starts, the symbol in front of every chunk, staging slot offsets
+//   k_encode*_blocks<.., MONO>   one lane per chunk
+//   k_compact_var   one wave per chunk: staging slot -> its place behind the 9 / 8 byte stream header
+//   k_mono_finish   the stream header
+// Data without long runs (random bytes) gives few chunks or one: then one lane walks it all, as the block kernel would a huge block.
+#pragma once
+
+#include "hsrle_common.hip.h"
+
+namespace hsrle {
+
+constexpr uint64_t MONO_NO_CUT = ~0ull;
+
+// 8 bit symbols.  cutPos[c] = end (exclusive) of the first maximal run of >= LONGC equal bytes with c * G < end <= (c + 1) * G and
+// end < U, cutSym[c] its byte; MONO_NO_CUT if there is none.  Piece 0 additionally starts the stream: the host adds position 0.
+__global__ __launch_bounds__(64) void k_mono_cuts8(const uint8_t *__restrict__ in, uint64_t U, uint32_t G, uint32_t pieces, uint32_t LONGC, uint64_t *__restrict__ cutPos,
+                                                   uint8_t *__restrict__ cutSym, uint32_t *__restrict__ flags)
+{
+  const uint32_t c = blockIdx.x * 64u + threadIdx.x;
+  if (c >= pieces) return;
+  const uint64_t x = (uint64_t)c * G;
+  const uint64_t hiEnd = (x + G < U) ? x + G : U;
+  uint64_t i = (x > LONGC) ? x - LONGC : 0;
+  uint64_t st = i;
+  uint32_t sy = in[i];
+  uint64_t found = MONO_NO_CUT;
+  uint32_t fsym = 0;
+  i++;
+  // a run [st, i) ends when in[i] differs; it is a cut iff it is long enough and ends inside (x, hiEnd] (and in front of the input's end)
+  const uint64_t lastCut = (U > 64u) ? U - 64u : 0u;
+  while (i <= lastCut && i <= hiEnd)
+  {
+    // fast path: 8 positions without two equal neighbours (x ^ (x >> 8) has no zero byte): the open run ends at i, nothing else starts
+    if (i + 9u <= U && i + 8u <= hiEnd)
+    {
+      const uint64_t w = ld64(in + i - 1), w1 = ld64(in + i);
+      const uint64_t d = w ^ w1;                                        // byte k: in[i - 1 + k] ^ in[i + k]
+      const uint64_t z = ((d & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | d;
+      if ((~z & 0x8080808080808080ull) == 0ull)
+      {
+        if (i - st >= LONGC && i > x) { found = i; fsym = sy; break; }
+        st = i + 7u; sy = in[i + 7u]; i += 8u;
+        continue;
+      }
+    }
+    const uint32_t v = in[i];
+    if (v != sy)
+    {
+      if (i - st >= LONGC && i > x) { found = i; fsym = sy; break; }
+      st = i; sy = v;
+    }
+    i++;
+  }
+  cutPos[c] = found;
+  cutSym[c] = (uint8_t)fsym;
+  flags[c] = (found != MONO_NO_CUT) ? 1u : 0u;
+}
+
+// idx = exclusive scan of flags (idx[pieces] = number of cuts).  Chunk 0 starts at 0 with symbol 0; cut j starts chunk j + 1.
+__global__ __launch_bounds__(256) void k_mono_scatter(const uint64_t *__restrict__ cutPos, const uint8_t *__restrict__ cutSym, const uint32_t *__restrict__ flags,
+                                                      const uint64_t *__restrict__ idx, uint32_t pieces, uint64_t U, uint64_t *__restrict__ starts, uint8_t *__restrict__ syms,
+                                                      uint64_t *__restrict__ slotOff, uint32_t *__restrict__ ctrl)
+{
+  const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+  auto slot_of = [](uint64_t at, uint64_t k) -> uint64_t { return (at + (at >> 7) + 256ull * k + 15ull) & ~15ull; };
+  if (c == 0u)
+  {
+    const uint64_t cuts = idx[pieces];
+    starts[0] = 0; syms[0] = 0; slotOff[0] = 0;
+    starts[cuts + 1ull] = U;
+    ctrl[0] = (uint32_t)(cuts + 1ull);                                  // chunks
+  }
+  if (c < pieces && flags[c] != 0u)
+  {
+    const uint64_t k = idx[c] + 1ull;
+    starts[k] = cutPos[c]; syms[k] = cutSym[c]; slotOff[k] = slot_of(cutPos[c], k);
+  }
+}
+
+// longest chunk (for the encode kernel's step bound) -- one workgroup
+__global__ __launch_bounds__(256) void k_mono_longest(const uint64_t *__restrict__ starts, uint32_t *__restrict__ ctrl)
+{
+  __shared__ uint32_t best;
+  if (threadIdx.x == 0) best = 0;
+  __syncthreads();
+  const uint32_t chunks = ctrl[0];
+  uint32_t m = 0;
+  for (uint32_t k = threadIdx.x; k < chunks; k += 256u)
+  {
+    const uint64_t n = starts[k + 1u] - starts[k];
+    m = (n > 0xFFFFFFFFull) ? 0xFFFFFFFFu : ((uint32_t)n > m ? (uint32_t)n : m);
+  }
+  atomicMax(&best, m);
+  __syncthreads();
+  if (threadIdx.x == 0) ctrl[1] = best;
+}
+
+// one wave per chunk: staging slot -> dst + offsets[c]
+__global__ __launch_bounds__(256) void k_compact_var(const uint8_t *__restrict__ slots, const uint64_t *__restrict__ slotOff, const uint64_t *__restrict__ offsets,
+                                                     uint8_t *__restrict__ dst, uint32_t chunks)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t c = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (c >= chunks) return;
+  const uint64_t off = offsets[c];
+  const uint64_t size = offsets[c + 1u] - off;
+  const uint8_t *src = slots + slotOff[c];
+  uint8_t *d = dst + off;
+  uint64_t head = (16u - ((uintptr_t)d & 15u)) & 15u;
+  if (head > size) head = size;
+  if (lane < head) d[lane] = src[lane];
+  const uint64_t body = (size - head) & ~15ull;
+  for (uint64_t k = (uint64_t)lane * 16u; k < body; k += 64u * 16u)
+    st128(d + head + k, ld128(src + head + k));
+  const uint64_t tail = size - head - body;
+  if (lane < tail) d[head + body + lane] = src[head + body + lane];
+}
+
+// stream header: {u32 uncompressed, u32 compressed (header included), [u8 mode = 0]}; ctrl[2..3] = the stream's size
+__global__ void k_mono_finish(uint8_t *__restrict__ out, uint32_t U, uint32_t headerSize, const uint64_t *__restrict__ offsets, const uint32_t *__restrict__ ctrlIn, uint32_t *__restrict__ ctrl)
+{
+  if (threadIdx.x == 0)
+  {
+    const uint64_t total = offsets[ctrlIn[0]] + headerSize;
+    st32(out, U);
+    st32(out + 4, (uint32_t)total);
+    if (headerSize == 9u) out[8] = 0;
+    ctrl[2] = (uint32_t)total; ctrl[3] = (uint32_t)(total >> 32);
+  }
+}
+
+} // namespace hsrle

@@ -60,8 +60,13 @@ static hipError_t sub_short3(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hi
 static hipError_t sub_short7(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<SHORT7, 1, 0>(a, SB, 0u, rec, st); }
 static hipError_t sub_short_single(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<SHORT_SINGLE, 1, 0>(a, SB, 0u, rec, st); }
 
-void register_w8(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub)
+static hipError_t menc_plain(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode(k_encode8_blocks<PLAIN, true>, a, m, st); }
+static hipError_t menc_packed(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode(k_encode8_blocks<PACKED, true>, a, m, st); }
+static hipError_t menc_short0(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode(k_encode8_blocks<SHORT0, true>, a, m, st); }
+
+void register_w8(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub, MonoEncodeLaunch *menc)
 {
+  menc[0] = menc_plain; menc[1] = menc_packed; menc[kShortBase8 + 0] = menc_short0;
   sub[0] = sub_plain; sub[1] = sub_packed; sub[2] = sub_lut3; sub[3] = sub_lut7; sub[4] = sub_plain_any; sub[5] = sub_packed_any;
   sub[kShortBase8 + 0] = sub_short0; sub[kShortBase8 + 1] = sub_short1; sub[kShortBase8 + 2] = sub_short3; sub[kShortBase8 + 3] = sub_short7;
   sub[kSingleShort] = sub_short_single;

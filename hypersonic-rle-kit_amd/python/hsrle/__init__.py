@@ -106,6 +106,10 @@ def _lib():
     L.hsrle_decompress_mono_workspace_size.argtypes = [ci, u32, u32]
     L.hsrle_decompress_mono_dev.restype = ci
     L.hsrle_decompress_mono_dev.argtypes = [ci, vp, u32, vp, u64, vp, u64, ctypes.POINTER(u32), ctypes.POINTER(u32), vp]
+    L.hsrle_compress_mono_workspace_size.restype = u64
+    L.hsrle_compress_mono_workspace_size.argtypes = [ci, u32]
+    L.hsrle_compress_mono_dev.restype = ci
+    L.hsrle_compress_mono_dev.argtypes = [ci, vp, u32, vp, u64, vp, u64, ctypes.POINTER(u32), ctypes.POINTER(u32), vp]
     L.hsrle_mono_tuning.restype = None
     L.hsrle_mono_tuning.argtypes = [u32, u32, u32]
     L.hsrle_split_sub_block_size.restype = u32
@@ -191,6 +195,29 @@ def mono_decompress(codec, stream, out_size=None):
 def mono_tuning(block=0, region=0, lookback=0):
     """Knobs of the monolithic decode (hsrle_mono_tuning): any values give the same output; 0 = the library's choice."""
     _lib().hsrle_mono_tuning(block, region, lookback)
+
+
+def mono_compress_dev(codec, src, dst=None, workspace=None, return_chunks=False):
+    """ONE monolithic reference stream of the CUDA uint8 tensor `src`, written by many lanes (hsrle_compress_mono_dev; the codecs
+    whose encoder state is known behind a long run: rle8_multi, rle8_packed_multi, rle8_multi_short).  Returns the stream tensor."""
+    import torch
+
+    _check_u8_cuda(src, "src")
+    cid = codec_id(codec)
+    n = src.numel()
+    if dst is None:
+        dst = torch.empty(compress_bounds(n) + 64, dtype=torch.uint8, device=src.device)
+    need = _lib().hsrle_compress_mono_workspace_size(cid, n)
+    if need == 0:
+        raise HsrleError(ERR_UNSUPPORTED, "hsrle_compress_mono_dev")
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=src.device)
+    size, chunks = ctypes.c_uint32(0), ctypes.c_uint32(0)
+    rc = _lib().hsrle_compress_mono_dev(cid, ctypes.c_void_p(src.data_ptr()), n, ctypes.c_void_p(dst.data_ptr()), dst.numel(), ctypes.c_void_p(workspace.data_ptr()),
+                                        workspace.numel(), ctypes.byref(size), ctypes.byref(chunks), _stream_ptr())
+    if rc != OK:
+        raise HsrleError(rc, "hsrle_compress_mono_dev")
+    return (dst[: size.value], chunks.value) if return_chunks else dst[: size.value]
 
 
 def mono_decompress_dev(codec, stream_tensor, dst=None, workspace=None, return_stats=False):

@@ -190,6 +190,16 @@ uint32_t hsrle_decompress_mono(int codec, const uint8_t *pIn, uint32_t inSize, u
  * repair rounds, regions walked again, final look-back of the entry guess.  Returns HSRLE_OK, HSRLE_ERR_FORMAT (malformed stream / sizes do not match the header), ...
  */
 uint64_t hsrle_decompress_mono_workspace_size(int codec, uint32_t uncompressedSize, uint32_t compressedSize);
+/*
+ * Device-resident form of <codec>_compress for the codecs whose encoder state is known behind a long run (rle8_multi, rle8_packed_multi,
+ * rle8_multi_short): ONE monolithic reference stream, byte-identical with the reference encoder's (src/rle8_extreme_cpu.h:86-344,
+ * :936-1099), written by many lanes -- the input is cut behind runs that every encoder state stores, and the pieces are encoded by the
+ * block kernels (csrc/hsrle_mono_encode.hip.h).  HSRLE_ERR_UNSUPPORTED for the other codecs (their drop-in functions use one lane).
+ * dOut capacity >= rle_compress_bounds(inSize); dWorkspace >= hsrle_compress_mono_workspace_size(); synchronises `stream`.
+ */
+uint64_t hsrle_compress_mono_workspace_size(int codec, uint32_t inSize);
+int hsrle_compress_mono_dev(int codec, const void *dIn, uint32_t inSize, void *dOut, uint64_t outCapacity, void *dWorkspace, uint64_t workspaceSize, uint32_t *pStreamSize,
+                            uint32_t *pChunks, void *stream);
 int hsrle_decompress_mono_dev(int codec, const void *dStream, uint32_t streamSize, void *dOut, uint64_t outCapacity, void *dWorkspace, uint64_t workspaceSize,
                               uint32_t *pUncompressedSize, uint32_t *pStats, void *stream);
 /* tuning / test knob of the monolithic decode: output bytes per decode lane (multiple of 128), stream bytes per index lane, look-back

@@ -69,3 +69,18 @@ def test_monolithic_stream_of_the_reference_decodes_on_the_gpu(hs, oracle, name)
     out, stats = hs.mono_decompress_dev(e["codec"], t, return_stats=True)
     src = hs.synth(e["kind"], codec.S, e["seed"], e["size"], device="cuda")
     assert torch.equal(out, src), f"{name}: monolithic decode differs (index stats {stats})"
+
+
+def test_config2_monolithic_stream_written_by_the_gpu(hs):
+    """BASELINE config 2 as ONE stream: the GPU's many-lane encoder writes the 1 GiB buffer's monolithic rle8_packed stream; its size
+    and sha256 are the ones the COMPILED REFERENCE minted (tests/golden/big/manifest.json); then the GPU decodes its own stream."""
+    import torch
+
+    e = big_manifest()["cases"]["config2_1GiB"]
+    src = hs.synth(e["kind"], 1, e["seed"], e["size"], device="cuda")
+    stream = hs.mono_compress_dev(e["codec"], src)
+    assert stream.numel() == e["mono"]["size"]
+    assert hashlib.sha256(stream.cpu().numpy().data).hexdigest() == e["mono"]["sha256"]
+    t = torch.zeros(stream.numel() + 64, dtype=torch.uint8, device="cuda")
+    t[: stream.numel()] = stream
+    assert torch.equal(hs.mono_decompress_dev(e["codec"], t), src)

@@ -153,21 +153,47 @@ def test_device_resident_mono_decode_of_synthetic_workloads(hs, oracle, key, kin
     assert rounds <= 64, f"{key}: {rounds} repair rounds ({rewalked} of {regions} regions guessed wrong, look-back {lookback})"
 
 
-def test_monolithic_manifest_against_the_reference(hs, oracle):
-    """tests/golden/mono_manifest.json (minted by make_golden.py from the COMPILED REFERENCE): sha256 of the monolithic stream of the
-    deterministic synthetic buffers.  The oracle's stream must hash the same (so the bytes the GPU decodes are the reference's), and the
-    GPU's decode of it must be the generator's bytes."""
+# ---- the encode side: ONE stream written by many lanes (csrc/hsrle_mono_encode.hip.h) ----
+
+MONO_ENC_KEYS = ["rle8_multi", "rle8_packed_multi", "rle8_multi_short"]
+
+
+def _run_mix(seed, size, counts):
+    """Runs whose lengths sit around the thresholds of the emit rules, separated by 0 .. 140 literal bytes (range field 1 / 4 bytes)."""
+    rng = random.Random(seed)
+    out = bytearray()
+    while len(out) < size:
+        out += bytes(rng.randrange(256) for _ in range(rng.choice([0, 1, 2, 5, 20, 60, 126, 127, 128, 140, 254, 255, 256, 300])))
+        out += bytes([rng.choice([0, 7, 7, 200, rng.randrange(256)])]) * rng.choice(counts)
+    return bytes(out[:size])
+
+
+@pytest.mark.parametrize("key", MONO_ENC_KEYS)
+def test_mono_encode_is_the_reference_stream(hs, oracle, key):
+    """Byte-identical with the sequential encoder, whatever the piece size: tiny pieces put a cut behind nearly every long run."""
+    codec = CODEC_BY_KEY[key]
+    rng = random.Random(11)
+    cases = [_mixed_input(1 + k, n) for k, n in enumerate((70, 130, 500, 3000, 40000, 150000))]
+    cases += [_run_mix(5, 60000, [1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 40]), _run_mix(6, 60000, [11, 12, 13, 30, 64, 65, 300]),
+              bytes(200000), bytes(rng.randrange(256) for _ in range(100000)), b"\x05" * 70 + bytes(range(256)) * 100 + b"\x06" * 40,
+              _run_mix(7, 30000, [12, 13]) + b"\x09" * 20, _run_mix(8, 30000, [12, 13]) + b"\x09" * 20 + b"abc", _run_mix(9, 5000, [20]) + bytes(50)]
+    for tune in ((0, 0, 0), (0, 64, 0), (0, 100, 0), (0, 1000, 0), (0, 5000, 0)):
+        hs.mono_tuning(*tune)
+        for d in cases:
+            size, stream = hs.call_dropin(codec.cname, d, hs.compress_bounds(len(d)))
+            expect = oracle.compress(codec, d)
+            assert size == len(expect) and stream == expect, f"{key} len {len(d)} tuning {tune}"
+    hs.mono_tuning(0, 0, 0)
+
+
+@pytest.mark.parametrize("key,kind,size", [("rle8_packed_multi", SYNTH_RUNS, 64 << 20), ("rle8_packed_multi", SYNTH_VIDEO, 88473600), ("rle8_multi", SYNTH_RUNS, 32 << 20),
+                                           ("rle8_multi_short", SYNTH_VIDEO, 32 << 20)])
+def test_device_resident_mono_encode(hs, oracle, key, kind, size):
     import torch
 
-    path = os.path.join(GOLDEN, "mono_manifest.json")
-    if not os.path.exists(path):
-        pytest.skip("mono manifest not minted")
-    for case in json.load(open(path))["cases"]:
-        if case["size"] > (96 << 20):
-            continue                                                       # the 1 GiB cases: test_full_size_mono_stream
-        codec = CODEC_BY_KEY[case["codec"]]
-        data = oracle.synth(case["kind"], codec.S, case["seed"], case["size"])
-        stream = oracle.compress(codec, data.tobytes())
-        assert hashlib.sha256(stream).hexdigest() == case["stream_sha256"], case
-        out = hs.mono_decompress_dev(codec.key, _dev_stream(stream))
-        assert hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest() == case["input_sha256"]
+    codec = CODEC_BY_KEY[key]
+    src = hs.synth(kind, 1, 2, size, device="cuda")
+    stream, chunks = hs.mono_compress_dev(key, src, return_chunks=True)
+    expect = oracle.compress(codec, src.cpu().numpy().tobytes())
+    assert stream.cpu().numpy().tobytes() == expect, f"{key}: stream differs from the oracle's ({chunks} chunks)"
+    assert chunks > size // 8192

@@ -60,8 +60,23 @@ def main():
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
         ok = torch.equal(res.cpu(), torch.from_numpy(data))
+        enc = ""
+        if hsrle.lib().hsrle_compress_mono_workspace_size(hsrle.codec_id(key), size):
+            src = torch.from_numpy(data).cuda()
+            ews = torch.empty(hsrle.lib().hsrle_compress_mono_workspace_size(hsrle.codec_id(key), size), dtype=torch.uint8, device="cuda")
+            edst = torch.empty(hsrle.compress_bounds(size) + 64, dtype=torch.uint8, device="cuda")
+            eb = None
+            for _ in range(args.reps + 1):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                st, chunks = hsrle.mono_compress_dev(key, src, dst=edst, workspace=ews, return_chunks=True)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                eb = dt if eb is None else min(eb, dt)
+            same = st.cpu().numpy().tobytes() == stream
+            enc = f"  | mono ENCODE {size / 2**30 / eb:7.1f} GiB/s {eb * 1e3:8.3f} ms chunks {chunks} identical {same}"
         print(f"{name:24s} {key:28s} U {size >> 20:5d} MiB C/U {len(stream) / size:.3f}  {size / 2**30 / best:8.1f} GiB/s  {best * 1e3:8.3f} ms  regions {stats[0]} rounds {stats[1]} rewalked {stats[2]} lookback {stats[3]}"
-              f"  exact {ok}  (host encode {enc_s:.1f} s)", flush=True)
+              f"  exact {ok}{enc}  (host encode {enc_s:.1f} s)", flush=True)
 
 
 if __name__ == "__main__":
