@@ -9,6 +9,7 @@
 #include "hsrle_launch.h"
 #include "hsrle_index.hip.h"
 #include "hsrle_mono_encode.hip.h"
+#include "hsrle_encode8w.hip.h"
 #include "hsrle_rle8m.hip.h"
 
 #include <stdlib.h>
@@ -53,12 +54,13 @@ static EncodeLaunch g_enc[kCodecCount];
 static IndexLaunch g_idx[kCodecCount];
 static SubBlockLaunch g_sub[kCodecCount];
 static MonoEncodeLaunch g_menc[kCodecCount];
+static WaveEncodeLaunch g_wenc[kCodecCount];
 static std::once_flag g_tableOnce;
 
 static void init_tables()
 {
   std::call_once(g_tableOnce, [] {
-    register_w8(g_dec, g_enc, g_idx, g_sub, g_menc);
+    register_w8(g_dec, g_enc, g_idx, g_sub, g_menc, g_wenc);
     register_w16(g_dec, g_enc, g_idx, g_sub);
     register_w24(g_dec, g_enc, g_idx, g_sub);
     register_w32(g_dec, g_enc, g_idx, g_sub);
@@ -425,7 +427,7 @@ static Workspace plan_workspace(uint64_t U, uint32_t B)
   w.t2 = (w.t1 + kScanTile - 1) / kScanTile;
   w.t3 = (w.t2 + kScanTile - 1) / kScanTile;
   uint64_t at = 0;
-  w.offSlots = at; at += align_up(slotBlocks * (uint64_t)slot_stride(B), 256);
+  w.offSlots = at; at += align_up(slotBlocks * (uint64_t)slot_stride(B) + kTicketBytes, 256);    // (+ the wave encoder's counters: hsrle_encode8w.hip.h)
   w.offSizes = at; at += align_up(w.nBlocks * 4ull, 256);
   w.offL1 = at; at += align_up((w.t1 + 1) * 8ull, 256);
   w.offL2 = at; at += align_up((w.t2 + 1) * 8ull, 256);
@@ -515,8 +517,24 @@ static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, ui
   uint32_t *sizes = (uint32_t *)(ws + w.offSizes);
   int rc = HSRLE_OK;
 
+  // HSRLE_ENCODE_WAVE=1: rle8_multi / rle8_packed_multi with blocks of at most 4 KiB by ONE WAVE PER BLOCK (hsrle_encode8w.hip.h: position
+  // parallel run detection, offsets by decoupled look-back, the payload written once, no staging slots and no compaction pass).  Bit-exact
+  // (every block of the 8 GiB buffer against the reference manifest), but OFF by default: at 4 KiB per wave the kernel is bound by the
+  // latency chain of one block, not by traffic -- 8 GiB: 13.5 ms against 7.4 ms of the lane-per-block kernel + compaction (input load + masks
+  // 2.1 ms, run list 0.7, decisions 2.1, packets 2.6, look-back 1.4 .. 5.9 ms).
+  static const bool waveEncode = env_u32("HSRLE_ENCODE_WAVE", 0) != 0u;
   hipStream_t aux = w.nChunks > 1 ? aux_stream() : nullptr;
-  if (w.nChunks > 1 && aux == nullptr)
+  if (waveEncode && g_wenc[codec] && B <= kWaveEncodeMaxBlock)
+  {
+    // (the slot area of the lane-per-block path is not needed: the tile words and the ticket counters live at its start)
+    uint32_t *ticket = (uint32_t *)(ws + w.offSlots);
+    unsigned long long *tiles = (unsigned long long *)(ws + w.offSlots + kTicketBytes);
+    WaveEncodeArgs wa{ (const uint8_t *)dIn, U, B, nBlocks, offsets, payload, tiles, ticket };
+    if (w.offSizes - w.offSlots < kTicketBytes + 8ull * nBlocks) rc = HSRLE_ERR_CAPACITY;
+    else if (hipMemsetAsync(ticket, 0, kTicketBytes + 8ull * nBlocks, st) != hipSuccess || g_wenc[codec](wa, st) != hipSuccess)
+      rc = HSRLE_ERR_DEVICE;
+  }
+  else if (w.nChunks > 1 && aux == nullptr)
     rc = HSRLE_ERR_DEVICE;
   else if (w.nChunks <= 1)
   {

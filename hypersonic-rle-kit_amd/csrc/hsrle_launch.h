@@ -53,6 +53,15 @@ struct MonoEncodeArgs
   const uint64_t *starts; const uint8_t *syms; const uint64_t *slotOff; uint32_t steps;
 };
 typedef hipError_t (*MonoEncodeLaunch)(const EncodeArgs &, const MonoEncodeArgs &, hipStream_t);
+// wave-per-block encoder (hsrle_encode8w.hip.h): writes offsets and payload of the container directly
+struct WaveEncodeArgs
+{
+  const uint8_t *in; uint64_t U; uint32_t B, nBlocks;
+  uint64_t *offsets; uint8_t *payload;
+  unsigned long long *tiles; uint32_t *ticket;      // zeroed by the caller: one word per block, one counter
+  int *residentWorkgroups = nullptr;                // query mode
+};
+typedef hipError_t (*WaveEncodeLaunch)(const WaveEncodeArgs &, hipStream_t);
 typedef hipError_t (*DecodeLaunch)(const DecodeArgs &, hipStream_t);
 typedef hipError_t (*EncodeLaunch)(const EncodeArgs &, hipStream_t);
 
@@ -75,7 +84,7 @@ constexpr int kDecodeStep = HSRLE_DECODE_STEP; // output bytes per lane and deco
 constexpr int kDecodeTile = HSRLE_DECODE_TILE; // bytes produced per lane and round (k_decode_blocks T)
 constexpr int kDecodeRing = HSRLE_DECODE_RING; // per-lane stream ring in LDS (k_decode_blocks R)
 
-void register_w8(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub, MonoEncodeLaunch *menc);
+void register_w8(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub, MonoEncodeLaunch *menc, WaveEncodeLaunch *wenc);
 void register_w16(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub);
 void register_w24(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub);
 void register_w32(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub);
@@ -112,6 +121,26 @@ inline hipError_t launch_encode(KERNEL k, const EncodeArgs &a, hipStream_t st, i
                        (const uint8_t *)nullptr, (const uint64_t *)nullptr, 0u);
   else
     hipLaunchKernelGGL(k, dim3(grid), dim3(64), capResidency ? ldsCap : lds8, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes);
+  return hipGetLastError();
+}
+
+template <typename KERNEL>
+inline hipError_t launch_wave_encode(KERNEL k, const WaveEncodeArgs &a, hipStream_t st)
+{
+  static int perCu = 0, cus = 0;
+  if (perCu == 0)
+  {
+    int dev = 0, n = 0, c = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, 64, 0) != hipSuccess ||
+        hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0 || c <= 0)
+      return hipErrorInvalidValue;
+    perCu = n; cus = c;
+  }
+  if (a.residentWorkgroups != nullptr) { *a.residentWorkgroups = perCu; return hipSuccess; }
+  // resident waves take blocks in ticket order
+  const uint64_t resident = (uint64_t)perCu * (uint64_t)cus;
+  const uint32_t grid = (uint32_t)(a.nBlocks < resident ? a.nBlocks : resident);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.offsets, a.payload, a.tiles, a.ticket);
   return hipGetLastError();
 }
 

@@ -4,6 +4,7 @@
 #include "hsrle_decode.hip.h"
 #include "hsrle_encode.hip.h"
 #include "hsrle_encode8.hip.h"
+#include "hsrle_encode8w.hip.h"
 #include "hsrle_encode_greedy.hip.h"
 #include "hsrle_index.hip.h"
 #include "hsrle_launch.h"
@@ -64,8 +65,12 @@ static hipError_t menc_plain(const EncodeArgs &a, const MonoEncodeArgs &m, hipSt
 static hipError_t menc_packed(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode(k_encode8_blocks<PACKED, true>, a, m, st); }
 static hipError_t menc_short0(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode(k_encode8_blocks<SHORT0, true>, a, m, st); }
 
-void register_w8(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub, MonoEncodeLaunch *menc)
+static hipError_t wenc_plain(const WaveEncodeArgs &a, hipStream_t st) { return launch_wave_encode(k_encode8_wave<PLAIN>, a, st); }
+static hipError_t wenc_packed(const WaveEncodeArgs &a, hipStream_t st) { return launch_wave_encode(k_encode8_wave<PACKED>, a, st); }
+
+void register_w8(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub, MonoEncodeLaunch *menc, WaveEncodeLaunch *wenc)
 {
+  wenc[0] = wenc_plain; wenc[1] = wenc_packed;
   menc[0] = menc_plain; menc[1] = menc_packed; menc[kShortBase8 + 0] = menc_short0;
   sub[0] = sub_plain; sub[1] = sub_packed; sub[2] = sub_lut3; sub[3] = sub_lut7; sub[4] = sub_plain_any; sub[5] = sub_packed_any;
   sub[kShortBase8 + 0] = sub_short0; sub[kShortBase8 + 1] = sub_short1; sub[kShortBase8 + 2] = sub_short3; sub[kShortBase8 + 3] = sub_short7;
