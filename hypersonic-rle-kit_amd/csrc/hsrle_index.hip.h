@@ -38,6 +38,7 @@ constexpr uint32_t IDX_OLD = 0x80000000u;    // transformer entry: slot (v & 15)
 constexpr uint32_t IDX_INIT = 0xC0000000u;   // resolved state entry: entry (v & 15) of the list a decoder starts with
 
 constexpr int kResolveThreads = 512;
+constexpr uint32_t HSRLE_TAIL_PAD_BYTES = 32u;   // zero bytes behind a container's payload (include/hsrle.h: HSRLE_CONTAINER_TAIL_PAD)
 
 enum IndexStatus : uint32_t
 {
@@ -62,11 +63,34 @@ struct Pkt
   bool hasSym, last, bad;
 };
 
+// Where a walk reads its stream from: global memory (one 16-byte window per packet hop: a memory latency per hop), or a copy of a
+// piece of the payload in LDS (k_container_records: the streams of the blocks a wave walks are one contiguous piece).  LDS accesses must
+// be naturally aligned to be fast (tools/ubench/lds_align.hip), so the LDS reader funnels three aligned 8-byte reads.
+struct GlobalReader
+{
+  const uint8_t *s;
+  __device__ __forceinline__ void load16(uint32_t p, uint64_t &lo, uint64_t &hi) const { lo = ld64(s + p); hi = ld64(s + p + 8); }
+  __device__ __forceinline__ uint32_t load32(uint32_t p) const { return ld32(s + p); }
+  __device__ __forceinline__ u32x4 load128(uint32_t p) const { return ld128(s + p); }
+};
+struct LdsReader
+{
+  const uint8_t *lds;      // 16-byte aligned
+  uint32_t delta;          // LDS offset of the stream's byte 0
+  __device__ __forceinline__ u32x4 load128(uint32_t p) const { return lds_read16_w8(lds, delta + p); }
+  __device__ __forceinline__ void load16(uint32_t p, uint64_t &lo, uint64_t &hi) const
+  {
+    const u32x4 v = load128(p);
+    lo = (uint64_t)v.x | ((uint64_t)v.y << 32); hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+  }
+  __device__ __forceinline__ uint32_t load32(uint32_t p) const { return load128(p).x; }
+};
+
 // One packet header at stream offset p (the stream is readable up to C + 32).  The field rules are those of the decoder
 // (hsrle_decode.hip.h): the two must agree on every stream, which tests/test_gpu_mono.py checks by decoding through
 // the index what the block kernel decodes on its own.
-template <int FAM, int S, int AL>
-__device__ __forceinline__ Pkt parse_packet(const uint8_t *__restrict__ s, uint32_t p, uint32_t C, bool single)
+template <int FAM, int S, int AL, typename READER>
+__device__ __forceinline__ Pkt parse_packet(const READER &rd, uint32_t p, uint32_t C, bool single)
 {
   using TR = Traits<FAM, S, AL>;
   constexpr int KE = IndexState<FAM>::KE;
@@ -74,8 +98,9 @@ __device__ __forceinline__ Pkt parse_packet(const uint8_t *__restrict__ s, uint3
   k.used = 1; k.lit = 0; k.run = 0; k.op = 0; k.symAt = p; k.hasSym = false; k.last = false; k.bad = false;
   if (p + 2u > C) { k.bad = true; return k; }
 
-  const uint64_t lo = ld64(s + p), hi = ld64(s + p + 8);
-  auto u32at = [&](uint32_t pos) -> uint32_t { return pos <= 12u ? ex32(lo, hi, pos) : ld32(s + p + pos); };
+  uint64_t lo, hi;
+  rd.load16(p, lo, hi);
+  auto u32at = [&](uint32_t pos) -> uint32_t { return pos <= 12u ? ex32(lo, hi, pos) : rd.load32(p + pos); };
 
   uint32_t cnt, range, pos;
   bool endNow = false, hbad = false;
@@ -232,7 +257,7 @@ __global__ __launch_bounds__(64) void k_index_walk(const uint8_t *__restrict__ s
   {
     if (guessing && x >= start) { guessing = false; q = x; }
     if (!guessing && x >= endr) { ex = x; break; }
-    const Pkt k = parse_packet<FAM, S, AL>(s, x, C, sgl);      // the one parse site of the loop: guessing and walking lanes share it
+    const Pkt k = parse_packet<FAM, S, AL>(GlobalReader{ s }, x, C, sgl);      // the one parse site of the loop: guessing and walking lanes share it
     if (guessing)
     {
       const bool truth = fromStart && t == p0;
@@ -473,8 +498,8 @@ __global__ __launch_bounds__(kResolveThreads) void k_index_resolve(const uint32_
 }
 
 // symbol of a resolved state entry as the decoder keeps it: masked to S bytes in up to four dwords
-template <int S>
-__device__ __forceinline__ u32x4 index_symbol(const uint8_t *__restrict__ s, uint32_t v, bool packedInit)
+template <int S, typename READER>
+__device__ __forceinline__ u32x4 index_symbol(const READER &rd, uint32_t v, bool packedInit)
 {
   if ((v >> 30) == 3u)
   {
@@ -489,7 +514,7 @@ __device__ __forceinline__ u32x4 index_symbol(const uint8_t *__restrict__ s, uin
     else if constexpr (S == 8) m = u32x4{ b, b, 0, 0 };
     return m;
   }
-  const u32x4 x = ld128(s + v);
+  const u32x4 x = rd.load128(v);
   if constexpr (S == 1) return u32x4{ x.x & 0xFFu, 0, 0, 0 };
   else if constexpr (S == 2) return u32x4{ x.x & 0xFFFFu, 0, 0, 0 };
   else if constexpr (S == 3) return u32x4{ x.x & 0xFFFFFFu, 0, 0, 0 };
@@ -505,8 +530,8 @@ __device__ __forceinline__ u32x4 index_symbol(const uint8_t *__restrict__ s, uin
 //   record dwords: [0..1] stream position (relative to `payload`), [2] literal bytes left, [3] run bytes left, [4] phase | flags,
 //   [5] bytes from that position to the stream's end, [6..9] current symbol, [10..] move-to-front list
 // Returns 0 (stopped at endr), 1 (the stream's last packet was walked) or 2 (malformed packet); o = output position behind the walk.
-template <int FAM, int S, int AL>
-__device__ __forceinline__ uint32_t walk_emit_records(const uint8_t *__restrict__ s, uint64_t sBase, uint32_t C, uint32_t x, uint32_t endr, uint64_t &o,
+template <int FAM, int S, int AL, typename READER>
+__device__ __forceinline__ uint32_t walk_emit_records(const READER &s, uint64_t sBase, uint32_t C, uint32_t x, uint32_t endr, uint64_t &o,
                                                       uint32_t (&st)[IndexState<FAM>::KE > 0 ? IndexState<FAM>::KE : 1], bool sgl, uint32_t singleSym,
                                                       uint64_t limit, uint32_t B, uint32_t *__restrict__ rec)
 {
@@ -514,6 +539,8 @@ __device__ __forceinline__ uint32_t walk_emit_records(const uint8_t *__restrict_
   constexpr int KE = IndexState<FAM>::KE;
   constexpr int SW = TR::SW;
   uint32_t curSym = IDX_INIT;      // offset / tag of the current packet's symbol (families without a list)
+  // the next output position that gets a record (kept incrementally: a 64 bit division per packet hop was most of this function's time)
+  uint64_t nextRec = (o + B - 1u) / B * (uint64_t)B;
   while (x < endr)
   {
     const Pkt k = parse_packet<FAM, S, AL>(s, x, C, sgl);
@@ -522,9 +549,10 @@ __device__ __forceinline__ uint32_t walk_emit_records(const uint8_t *__restrict_
     if (k.hasSym) curSym = k.symAt;
     const uint64_t outEnd = o + (uint64_t)k.lit + (uint64_t)k.run;
     const uint32_t body = x + k.used;
-    for (uint64_t b = (o + B - 1u) / B; b * B < outEnd && b * B < limit; b++)
+    for (; nextRec < outEnd && nextRec < limit; nextRec += B)
     {
-      const uint64_t into = b * B - o;
+      const uint64_t into = nextRec - o;
+      const uint64_t b = (B & (B - 1u)) == 0u ? nextRec >> __builtin_ctz(B) : nextRec / B;
       uint32_t *const w = rec + b * (uint64_t)kEntryRecDwords;
       uint32_t rsp, rlit, rrun, phase = 0;
       if (into < (uint64_t)k.lit) { rsp = body + (uint32_t)into; rlit = k.lit - (uint32_t)into; rrun = k.run; }
@@ -578,26 +606,46 @@ __global__ __launch_bounds__(64) void k_index_records(const uint8_t *__restrict_
   uint32_t st[KS];
 #pragma unroll
   for (int j = 0; j < KS; j++) st[j] = (KE > 0) ? stateIn[(uint64_t)r * KS + j] : 0u;
-  (void)walk_emit_records<FAM, S, AL>(s, 0ull, C, x, p0 + (r + 1u) * G, o, st, single != 0u, singleSym, U, B, rec);   // (cannot meet a malformed packet: k_index_walk walked this chain)
+  (void)walk_emit_records<FAM, S, AL>(GlobalReader{ s }, 0ull, C, x, p0 + (r + 1u) * G, o, st, single != 0u, singleSym, U, B, rec);   // (cannot meet a malformed packet: k_index_walk walked this chain)
 }
 
 // ---- the same for a block container: one lane per block walks the block's stream from its first packet (known: no guessing, no
 //      resolve pass) and writes the decoder state at every SB output bytes, so that k_decode_blocks can put B / SB lanes on a block.
 //      What the block kernel checks in its prologue (table entry, stream header, mode byte) is checked here.
+//      The streams of the NB consecutive blocks a wave walks are one contiguous piece of the payload: the wave copies it into LDS first
+//      (coalesced 16-byte loads) and the lanes walk their chains from there -- a packet hop then costs an LDS round trip instead of a
+//      global-memory latency (the 88 MB frame: 100-130 -> ~30 us).  A piece that does not fit the LDS window is walked from global memory.
 template <int FAM, int S, int AL>
 __global__ __launch_bounds__(64) void k_container_records(const uint8_t *__restrict__ payload, const uint64_t *__restrict__ offsets, const uint8_t *__restrict__ payloadEnd,
                                                           uint64_t U, uint32_t B, uint32_t firstBlock, uint32_t blockCount, uint32_t SB, uint32_t allowSingle,
-                                                          uint32_t *__restrict__ rec, uint32_t *__restrict__ status)
+                                                          uint32_t NB, uint32_t ldsBytes, uint32_t *__restrict__ rec, uint32_t *__restrict__ status)
 {
   using TR = Traits<FAM, S, AL>;
   constexpr int KE = IndexState<FAM>::KE;
   constexpr int KS = KE > 0 ? KE : 1;
-  const uint32_t i = xcd_tile(blockIdx.x, gridDim.x) * 64u + threadIdx.x;
-  if (i >= blockCount) return;
-  const uint32_t b = firstBlock + i;
+  extern __shared__ __attribute__((aligned(16))) uint8_t window[];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t i0 = xcd_tile(blockIdx.x, gridDim.x) * NB;
+  if (i0 >= blockCount) return;
+  const uint32_t cnt = (blockCount - i0 < NB) ? blockCount - i0 : NB;
+  const uint64_t payloadBytes = (uint64_t)(payloadEnd - payload);
+
+  // the wave's piece of the payload -> LDS (only if the table entries are sane and the piece fits)
+  const uint64_t w0raw = offsets[firstBlock + i0], w1 = offsets[firstBlock + i0 + cnt];
+  const uint64_t w0 = w0raw & ~15ull;
+  const bool staged = w0raw <= w1 && w1 <= payloadBytes && w1 - w0 + 96u <= (uint64_t)ldsBytes;   // (+ what the aligned reads of a parse near the end may touch)
+  if (staged)
+  {
+    const uint32_t total = (uint32_t)(w1 - w0) + 64u;                    // (+ what a parse may read behind the last packet; beyond the payload's 32-byte tail pad: zeros)
+    for (uint32_t c = lane * 16u; c < total; c += 64u * 16u)
+      lds_st128(window + c, (w0 + c + 16u <= payloadBytes + HSRLE_TAIL_PAD_BYTES) ? ld128(payload + w0 + c) : u32x4{ 0, 0, 0, 0 });
+  }
+  wave_sync();
+  if (lane >= cnt) return;
+
+  const uint32_t b = firstBlock + i0 + lane;
   uint32_t err = 0;
   const uint64_t off0 = offsets[b], off1 = offsets[b + 1];
-  const uint64_t payloadBytes = (uint64_t)(payloadEnd - payload);
   const uint64_t start = (uint64_t)b * B;
   const uint32_t blen = (uint32_t)((U - start) < (uint64_t)B ? (U - start) : (uint64_t)B);
   if (off0 > off1 || off1 > payloadBytes || off1 - off0 > 0xFFFFFF00ull) err = DEC_ERR_HEADER;
@@ -620,7 +668,11 @@ __global__ __launch_bounds__(64) void k_container_records(const uint8_t *__restr
 #pragma unroll
       for (int j = 0; j < KS; j++) st[j] = IDX_INIT | (uint32_t)j;
       uint64_t o = start;
-      const uint32_t how = walk_emit_records<FAM, S, AL>(s, off0, C, p0, 0xFFFFFFF0u, o, st, sgl != 0u, sym, start + blen, SB, rec);
+      uint32_t how;
+      if (staged && off0 >= w0 && off1 <= w1)
+        how = walk_emit_records<FAM, S, AL>(LdsReader{ window, (uint32_t)(off0 - w0) }, off0, C, p0, 0xFFFFFFF0u, o, st, sgl != 0u, sym, start + blen, SB, rec);
+      else
+        how = walk_emit_records<FAM, S, AL>(GlobalReader{ s }, off0, C, p0, 0xFFFFFFF0u, o, st, sgl != 0u, sym, start + blen, SB, rec);
       if (how != 1u || o != start + blen) err = DEC_ERR_STREAM;
     }
   }
@@ -647,8 +699,17 @@ inline hipError_t launch_index(const IndexArgs &a, int records, hipStream_t st)
 template <int FAM, int S, int AL>
 inline hipError_t launch_container_records(const DecodeArgs &a, uint32_t SB, uint32_t allowSingle, uint32_t *rec, hipStream_t st)
 {
-  hipLaunchKernelGGL((k_container_records<FAM, S, AL>), dim3((a.blockCount + 63u) / 64u), dim3(64), 0, st, a.payload, a.offsets, a.payloadEnd, a.U, a.B, a.firstBlock, a.blockCount, SB,
-                     allowSingle, rec, a.status);
+  // blocks per wave and LDS window: the average block stream x 1.5 per block, at most 48 KB (three waves per CU)
+  const uint64_t payloadBytes = (uint64_t)(a.payloadEnd - a.payload);
+  const uint64_t total = a.firstBlock + (uint64_t)a.blockCount;          // (the average over the whole container is what the host knows)
+  const uint64_t avg = payloadBytes / (total ? total : 1u) + 16u;
+  uint32_t NB = 64u;
+  while (NB > 8u && (uint64_t)NB * avg * 3u / 2u > 49152ull) NB /= 2u;
+  uint64_t lds = (uint64_t)NB * avg * 3u / 2u + 128u;
+  lds = lds > 49152ull ? 49152ull : (lds < 4096ull ? 4096ull : lds);
+  lds = (lds + 255ull) & ~255ull;
+  hipLaunchKernelGGL((k_container_records<FAM, S, AL>), dim3((a.blockCount + NB - 1u) / NB), dim3(64), (uint32_t)lds, st, a.payload, a.offsets, a.payloadEnd, a.U, a.B, a.firstBlock,
+                     a.blockCount, SB, allowSingle, NB, (uint32_t)lds, rec, a.status);
   return hipGetLastError();
 }
 
