@@ -936,12 +936,14 @@ static int mono_encode_dev(int codec, const uint8_t *dIn, uint32_t U, uint8_t *d
   Workspace w{};
   w.offL1 = m.offL1; w.offL2 = m.offL2; w.offL3 = m.offL3;
 
+  if (hipMemsetAsync(ctrl, 0, 64, st) != hipSuccess)
+    return HSRLE_ERR_DEVICE;
   hipLaunchKernelGGL(k_mono_cuts8, dim3((m.pieces + 63u) / 64u), dim3(64), 0, st, dIn, (uint64_t)U, m.G, m.pieces, longc, cutPos, cutSym, flags);
   if (scan_sizes(flags, m.pieces, idx, ws, w, st) != hipSuccess)
     return HSRLE_ERR_DEVICE;
   hipLaunchKernelGGL(k_mono_scatter, dim3((m.pieces + 255u) / 256u), dim3(256), 0, st, (const uint64_t *)cutPos, (const uint8_t *)cutSym, (const uint32_t *)flags, (const uint64_t *)idx,
                      m.pieces, (uint64_t)U, starts, syms, slotOff, ctrl);
-  hipLaunchKernelGGL(k_mono_longest, dim3(1), dim3(256), 0, st, (const uint64_t *)starts, ctrl);
+  hipLaunchKernelGGL(k_mono_longest, dim3((m.pieces + 1u + 255u) / 256u), dim3(256), 0, st, (const uint64_t *)starts, ctrl);
   uint32_t head[2] = { 0, 0 };
   if (hipMemcpyAsync(head, ctrl, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
     return HSRLE_ERR_DEVICE;

@@ -314,7 +314,8 @@ __global__ __launch_bounds__(kResolveThreads) void k_index_resolve(const uint32_
   constexpr int KS = KE > 0 ? KE : 1;
   constexpr uint8_t F_NONE = 0, F_OK = 1, F_SKIP = 2, F_DIRTY = 3;
   __shared__ uint32_t sg[NT], se[NT];
-  __shared__ uint8_t sflag[NT], sok[NT];
+  __shared__ uint8_t sflag[NT];
+  __shared__ uint64_t sokMask[NT / 64];                                 // bit: the region passed the parallel check
   __shared__ uint64_t swave[NT / 64];
   __shared__ uint32_t sT1[2 * NT * KS];
 #define HS_ST(buf, t, j) sT1[((uint32_t)(buf) * NT + (uint32_t)(t)) * KS + (uint32_t)(j)]
@@ -331,11 +332,28 @@ __global__ __launch_bounds__(kResolveThreads) void k_index_resolve(const uint32_
   }
   __syncthreads();
 
+  // the next batch's walk results are requested while this batch is worked on (the pass is one workgroup: nothing else hides the latency)
+  uint32_t nG = (tid < R) ? g[tid] : 0u, nE = (tid < R) ? e[tid] : 0u;
+  uint64_t nOl = (tid < R) ? olen[tid] : 0ull;
+  uint32_t nT[KS];
+#pragma unroll
+  for (int j = 0; j < KS; j++) nT[j] = (KE > 0 && tid < R) ? tIn[(uint64_t)tid * KS + j] : (IDX_OLD | (uint32_t)j);
+
   for (uint32_t base = 0; base < R; base += NT)
   {
     const uint32_t r = base + tid;
     const bool valid = r < R;
-    const uint32_t gg = valid ? g[r] : 0u, ee = valid ? e[r] : 0u;
+    const uint32_t gg = nG, ee = nE;
+    const uint64_t myOl = nOl;
+    uint32_t myT[KS];
+#pragma unroll
+    for (int j = 0; j < KS; j++) myT[j] = nT[j];
+    {
+      const uint32_t rn = r + NT;
+      nG = (rn < R) ? g[rn] : 0u; nE = (rn < R) ? e[rn] : 0u; nOl = (rn < R) ? olen[rn] : 0ull;
+#pragma unroll
+      for (int j = 0; j < KS; j++) nT[j] = (KE > 0 && rn < R) ? tIn[(uint64_t)rn * KS + j] : (IDX_OLD | (uint32_t)j);
+    }
     sg[tid] = gg; se[tid] = ee;
     __syncthreads();
     const uint32_t cur0 = sCur, ended0 = sEnded;                        // (read in front of the barrier below: thread 0 writes them behind it)
@@ -344,7 +362,10 @@ __global__ __launch_bounds__(kResolveThreads) void k_index_resolve(const uint32_
     const bool ok = !valid || (ended0 == 0u && prev == gg && gg < endr && ee < IDX_SKIP);
     const int allok = __syncthreads_and(ok ? 1 : 0);
     const uint32_t n = (R - base < (uint32_t)NT) ? R - base : (uint32_t)NT;
-    sok[tid] = ok ? 1 : 0;
+    {
+      const uint64_t m = __ballot(ok);
+      if ((tid & 63u) == 0u) sokMask[tid >> 6] = m;
+    }
     const bool allSkipped = ended0 != 0u || cur0 >= p0 + (base + n) * G;   // the chain is over, or jumps over the whole batch
 
     if (allok)
@@ -368,10 +389,17 @@ __global__ __launch_bounds__(kResolveThreads) void k_index_resolve(const uint32_
       auto next_guess = [&](uint32_t k, uint32_t rr) -> uint32_t { (void)k; return g[rr + 1u]; };
       for (uint32_t k = 0; k < n; k++)
       {
-        if (insync && !ended && sok[k])
+        if (insync && !ended && ((sokMask[k >> 6] >> (k & 63u)) & 1ull) != 0ull)
         {
-          uint32_t j = k + 1u;
-          while (j < n && sok[j]) j++;
+          // first region at or behind k that did NOT pass: one word of the mask at a time
+          uint32_t j = n;
+          for (uint32_t wd = k >> 6; wd < (uint32_t)(NT / 64); wd++)
+          {
+            uint64_t bad = ~sokMask[wd];
+            if (wd == (k >> 6)) bad &= ~0ull << (k & 63u);
+            if (bad != 0ull) { j = wd * 64u + (uint32_t)__builtin_ctzll(bad); break; }
+          }
+          if (j > n) j = n;
           cur = se[j - 1u];                                                // regions k .. j-1 keep F_OK
           k = j - 1u;
           continue;
@@ -406,7 +434,7 @@ __global__ __launch_bounds__(kResolveThreads) void k_index_resolve(const uint32_
 
     const uint8_t fl = sflag[tid];
     // exclusive scan of the output sizes
-    const uint64_t v = (fl == F_OK) ? olen[r] : 0ull;
+    const uint64_t v = (fl == F_OK) ? myOl : 0ull;
     uint64_t xsum = v;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
 #pragma unroll
@@ -420,7 +448,7 @@ __global__ __launch_bounds__(kResolveThreads) void k_index_resolve(const uint32_
     if constexpr (KE > 0)
     {
 #pragma unroll
-      for (int j = 0; j < KE; j++) HS_ST(0, tid, j) = (fl == F_OK) ? tIn[(uint64_t)r * KE + j] : (IDX_OLD | (uint32_t)j);
+      for (int j = 0; j < KE; j++) HS_ST(0, tid, j) = (fl == F_OK) ? myT[j] : (IDX_OLD | (uint32_t)j);
     }
     __syncthreads();
     uint64_t wbase = 0, wall = 0;

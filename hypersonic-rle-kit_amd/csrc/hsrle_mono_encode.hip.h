@@ -88,22 +88,23 @@ __global__ __launch_bounds__(256) void k_mono_scatter(const uint64_t *__restrict
   }
 }
 
-// longest chunk (for the encode kernel's step bound) -- one workgroup
+// longest chunk (for the encode kernel's step bound): ctrl[1] (zeroed by the host) = max over the chunks
 __global__ __launch_bounds__(256) void k_mono_longest(const uint64_t *__restrict__ starts, uint32_t *__restrict__ ctrl)
 {
-  __shared__ uint32_t best;
-  if (threadIdx.x == 0) best = 0;
-  __syncthreads();
-  const uint32_t chunks = ctrl[0];
+  const uint32_t k = blockIdx.x * 256u + threadIdx.x;
   uint32_t m = 0;
-  for (uint32_t k = threadIdx.x; k < chunks; k += 256u)
+  if (k < ctrl[0])
   {
     const uint64_t n = starts[k + 1u] - starts[k];
-    m = (n > 0xFFFFFFFFull) ? 0xFFFFFFFFu : ((uint32_t)n > m ? (uint32_t)n : m);
+    m = (n > 0xFFFFFFFFull) ? 0xFFFFFFFFu : (uint32_t)n;
   }
-  atomicMax(&best, m);
-  __syncthreads();
-  if (threadIdx.x == 0) ctrl[1] = best;
+#pragma unroll
+  for (int dd = 32; dd >= 1; dd >>= 1)
+  {
+    const uint32_t y = (uint32_t)__shfl_xor((int)m, dd, 64);
+    m = y > m ? y : m;
+  }
+  if ((threadIdx.x & 63u) == 0u && m != 0u) atomicMax(ctrl + 1, m);
 }
 
 // one wave per chunk: staging slot -> dst + offsets[c]
