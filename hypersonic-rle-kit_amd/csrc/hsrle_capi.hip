@@ -61,11 +61,11 @@ static void init_tables()
 {
   std::call_once(g_tableOnce, [] {
     register_w8(g_dec, g_enc, g_idx, g_sub, g_menc, g_wenc);
-    register_w16(g_dec, g_enc, g_idx, g_sub);
-    register_w24(g_dec, g_enc, g_idx, g_sub);
-    register_w32(g_dec, g_enc, g_idx, g_sub);
-    register_w48(g_dec, g_enc, g_idx, g_sub);
-    register_w64(g_dec, g_enc, g_idx, g_sub);
+    register_w16(g_dec, g_enc, g_idx, g_sub, g_menc);
+    register_w24(g_dec, g_enc, g_idx, g_sub, g_menc);
+    register_w32(g_dec, g_enc, g_idx, g_sub, g_menc);
+    register_w48(g_dec, g_enc, g_idx, g_sub, g_menc);
+    register_w64(g_dec, g_enc, g_idx, g_sub, g_menc);
     register_w128(g_dec, g_enc, g_idx, g_sub);
   });
 }
@@ -879,12 +879,37 @@ static int mono_decode_dev(const MonoHeader &mh, const uint8_t *dStream, uint8_t
 // monolithic stream encode by many lanes (hsrle_mono_encode.hip.h): cut behind long runs, block kernels in MONO mode, compaction
 
 // the run length every state of the codec's encoder stores (SURVEY.md A.2 LONG / the Short family's SMINL); 0 = the codec is not cut
-static uint32_t mono_cut_long(int codec)
+// (move-to-front list, Single, 128 bit).  *pS / *pAligned: symbol bytes and sym-alignment of the codec.
+static uint32_t mono_cut_long(int codec, int *pS = nullptr, int *pAligned = nullptr)
 {
-  if (codec == HSRLE_RLE8_MULTI) return 6u;              // rle8_extreme_cpu.h:974: count >= 6 whatever the range
-  if (codec == HSRLE_RLE8_PACKED_MULTI) return 11u;      // :978 (body) and :122 (tail)
-  if (codec == HSRLE_RLE8_MULTI_SHORT) return 13u;       // rleX_Xsl_short.h: RLEX_EXTREME_MIN_LONG of the 0-symbol codec (S + 12)
-  return 0u;
+  int S = 1, al = 0;
+  uint32_t longc = 0;
+  if (codec == HSRLE_RLE8_MULTI) longc = 6u;                    // rle8_extreme_cpu.h:974: count >= 6 whatever the range
+  else if (codec == HSRLE_RLE8_PACKED_MULTI) longc = 11u;       // :978 (body) and :122 (tail)
+  else if (codec == HSRLE_RLE8_MULTI_SHORT) longc = 13u;        // rleX_Xsl_short.h: always stored from S + 12 on (0-symbol codec)
+  else
+  {
+    static const int widths[5] = { 2, 3, 4, 6, 8 };
+    if (codec >= 6 && codec < 46)
+    {
+      const int k = (codec - 6) & 7;
+      S = widths[(codec - 6) >> 3];
+      al = k < 4 ? 1 : 0;
+      if (k == 0 || k == 4) longc = (uint32_t)S + 11u;                                  // plain: rleX_extreme_cpu.h:10-11
+      else if (k == 1) longc = (uint32_t)S + 10u;                                       // sym-aligned Packed: the hybrid of A.5 q10
+      else if (k == 5) longc = (uint32_t)S + 11u;                                       // byte-aligned Packed
+    }
+    else if (codec >= kShortBaseW && codec < kGreedyBase)
+    {
+      const int k = (codec - kShortBaseW) & 7;
+      S = widths[(codec - kShortBaseW) >> 3];
+      al = k < 4 ? 1 : 0;
+      if (k == 0 || k == 4) longc = (uint32_t)S + 12u;                                  // 0-symbol Short codecs
+    }
+  }
+  if (pS) *pS = S;
+  if (pAligned) *pAligned = al;
+  return longc;
 }
 
 struct MonoEncPlan
@@ -904,11 +929,11 @@ static MonoEncPlan plan_mono_encode(uint32_t U)
   const uint64_t t1 = (n + 2 + kScanTile - 1) / kScanTile, t2 = (t1 + kScanTile - 1) / kScanTile, t3 = (t2 + kScanTile - 1) / kScanTile;
   uint64_t at = 0;
   m.offCutPos = at; at += align_up(8ull * n, 256);
-  m.offCutSym = at; at += align_up(n, 256);
+  m.offCutSym = at; at += align_up(8ull * n, 256);
   m.offFlags = at; at += align_up(4ull * n, 256);
   m.offIdx = at; at += align_up(8ull * (n + 1), 256);
   m.offStarts = at; at += align_up(8ull * (n + 2), 256);
-  m.offSyms = at; at += align_up(n + 1, 256);
+  m.offSyms = at; at += align_up(8ull * (n + 1), 256);
   m.offSlotOff = at; at += align_up(8ull * (n + 1), 256);
   m.offSizes = at; at += align_up(4ull * (n + 1), 256);
   m.offOffsets = at; at += align_up(8ull * (n + 2), 256);
@@ -925,23 +950,37 @@ static MonoEncPlan plan_mono_encode(uint32_t U)
 static int mono_encode_dev(int codec, const uint8_t *dIn, uint32_t U, uint8_t *dOut, uint8_t *ws, const MonoEncPlan &m, uint32_t *pSize, uint32_t *pChunks, hipStream_t st)
 {
   init_tables();
-  const uint32_t longc = mono_cut_long(codec);
+  int S = 1, aligned = 0;
+  const uint32_t longc = mono_cut_long(codec, &S, &aligned);
   if (!g_menc[codec] || longc == 0u)
     return HSRLE_ERR_UNSUPPORTED;
   const uint32_t hs = codec_header_size(codec);
   uint64_t *cutPos = (uint64_t *)(ws + m.offCutPos), *idx = (uint64_t *)(ws + m.offIdx), *starts = (uint64_t *)(ws + m.offStarts), *slotOff = (uint64_t *)(ws + m.offSlotOff);
   uint64_t *offsets = (uint64_t *)(ws + m.offOffsets);
-  uint8_t *cutSym = ws + m.offCutSym, *syms = ws + m.offSyms;
+  uint64_t *cutSym = (uint64_t *)(ws + m.offCutSym), *syms = (uint64_t *)(ws + m.offSyms);
   uint32_t *flags = (uint32_t *)(ws + m.offFlags), *sizes = (uint32_t *)(ws + m.offSizes), *ctrl = (uint32_t *)(ws + m.offCtrl);
   Workspace w{};
   w.offL1 = m.offL1; w.offL2 = m.offL2; w.offL3 = m.offL3;
 
   if (hipMemsetAsync(ctrl, 0, 64, st) != hipSuccess)
     return HSRLE_ERR_DEVICE;
-  hipLaunchKernelGGL(k_mono_cuts8, dim3((m.pieces + 63u) / 64u), dim3(64), 0, st, dIn, (uint64_t)U, m.G, m.pieces, longc, cutPos, cutSym, flags);
+  const dim3 cgrid((m.pieces + 63u) / 64u);
+#define HSRLE_CUTS(SS) \
+  if (aligned) hipLaunchKernelGGL((k_mono_cutsS<SS, 1>), cgrid, dim3(64), 0, st, dIn, (uint64_t)U, m.G, m.pieces, longc, cutPos, cutSym, flags); \
+  else hipLaunchKernelGGL((k_mono_cutsS<SS, 0>), cgrid, dim3(64), 0, st, dIn, (uint64_t)U, m.G, m.pieces, longc, cutPos, cutSym, flags)
+  switch (S)
+  {
+  case 1: hipLaunchKernelGGL(k_mono_cuts8, cgrid, dim3(64), 0, st, dIn, (uint64_t)U, m.G, m.pieces, longc, cutPos, cutSym, flags); break;
+  case 2: HSRLE_CUTS(2); break;
+  case 3: HSRLE_CUTS(3); break;
+  case 4: HSRLE_CUTS(4); break;
+  case 6: HSRLE_CUTS(6); break;
+  default: HSRLE_CUTS(8); break;
+  }
+#undef HSRLE_CUTS
   if (scan_sizes(flags, m.pieces, idx, ws, w, st) != hipSuccess)
     return HSRLE_ERR_DEVICE;
-  hipLaunchKernelGGL(k_mono_scatter, dim3((m.pieces + 255u) / 256u), dim3(256), 0, st, (const uint64_t *)cutPos, (const uint8_t *)cutSym, (const uint32_t *)flags, (const uint64_t *)idx,
+  hipLaunchKernelGGL(k_mono_scatter, dim3((m.pieces + 255u) / 256u), dim3(256), 0, st, (const uint64_t *)cutPos, (const uint64_t *)cutSym, (const uint32_t *)flags, (const uint64_t *)idx,
                      m.pieces, (uint64_t)U, starts, syms, slotOff, ctrl);
   hipLaunchKernelGGL(k_mono_longest, dim3((m.pieces + 1u + 255u) / 256u), dim3(256), 0, st, (const uint64_t *)starts, ctrl);
   uint32_t head[2] = { 0, 0 };

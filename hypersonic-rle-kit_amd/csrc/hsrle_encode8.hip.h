@@ -33,7 +33,7 @@ namespace hsrle {
 template <int FAM, bool MONO = false>
 __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t nBlocks,
                                                        uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes,
-                                                       const uint64_t *__restrict__ monoStarts, const uint8_t *__restrict__ monoSyms,
+                                                       const uint64_t *__restrict__ monoStarts, const uint64_t *__restrict__ monoSyms,
                                                        const uint64_t *__restrict__ monoSlotOff, uint32_t monoSteps)
 {
   using TR = Traits<FAM, 1, 0>;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
   bool inRun = false;
   uint32_t runStart = 0, sym = 0;
   uint32_t lastRLE = 0;
-  uint32_t lastSym = (MONO && active) ? monoSyms[b] : 0u;      // Packed: lastSymbol (starts 0, A.5 q5)
+  uint32_t lastSym = (MONO && active) ? (uint32_t)(monoSyms[b] & 0xFFull) : 0u;      // Packed: lastSymbol (starts 0, A.5 q5)
   [[maybe_unused]] uint64_t lutw = (K == 3) ? 0x0000000000FF7F00ull : 0x00FE807E01FF7F00ull; // LUT: MTF list, entry k in byte k
   bool ended = false;        // the end terminator has been written
   bool finished = !active;   // the whole stream is in the slot

@@ -19,10 +19,17 @@
 
 namespace hsrle {
 
-template <int FAM, int S, int AL>
+// MONO = true: the lanes encode consecutive chunks of ONE monolithic stream (hsrle_mono_encode.hip.h; see k_encode8_blocks): chunk table
+// instead of b * B, the symbol in front of the chunk as lastSymbol, no stream header, no terminator unless the chunk reaches the end of
+// the input, and the rules that look at the end of the input (the partial-symbol extension of the byte-aligned variants, the end
+// terminator) see the TRUE end.
+template <int FAM, int S, int AL, bool MONO = false>
 __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t nBlocks,
-                                                       uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes)
+                                                       uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes,
+                                                       const uint64_t *__restrict__ monoStarts, const uint64_t *__restrict__ monoSyms,
+                                                       const uint64_t *__restrict__ monoSlotOff, uint32_t monoSteps)
 {
+  static_assert(!MONO || !Traits<FAM, S, AL>::kMtf, "a monolithic stream is cut only for codecs whose state behind a long run is known");
   using TR = Traits<FAM, S, AL>;
   static_assert(S == 2 || S == 3 || S == 4 || S == 6 || S == 8, "8 bit and 128 bit symbols have their own kernels");
   static_assert(FAM == PLAIN || FAM == PACKED || FAM == LUT3 || FAM == LUT7 || (FAM >= SHORT0 && FAM <= SHORT7), "multi-symbol families only");
@@ -59,13 +66,24 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
   const uint32_t hbase = (lane * (uint32_t)H) ^ hsw_of(lane);
 
   uint32_t n = 0;
+  [[maybe_unused]] uint32_t nTrueV = 0;
+  uint64_t blockAt = (uint64_t)b * B;
   if (active)
   {
-    const uint64_t start = (uint64_t)b * B;
-    n = (uint32_t)((U - start) < (uint64_t)B ? (U - start) : (uint64_t)B);
+    if constexpr (MONO)
+    {
+      blockAt = monoStarts[b];
+      n = (uint32_t)(monoStarts[b + 1] - blockAt);
+      nTrueV = (uint32_t)(U - blockAt);
+    }
+    else
+    {
+      const uint64_t start = (uint64_t)b * B;
+      n = (uint32_t)((U - start) < (uint64_t)B ? (U - start) : (uint64_t)B);
+    }
   }
-  const uint64_t blockAt = (uint64_t)b * B;
-  uint8_t *const slot = slots + (uint64_t)b * slotStride;
+  const uint32_t nTrue = MONO ? nTrueV : n;
+  uint8_t *const slot = MONO ? slots + (active ? monoSlotOff[b] : 0ull) : slots + (uint64_t)b * slotStride;
 
   // ---- per-lane encoder state ----
   uint32_t avail = 0;        // input bytes [.., avail) are (or were) in the ring; the ring holds [avail - H, avail)
@@ -76,6 +94,7 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
   uint32_t sy0 = 0, sy1 = 0; // the symbol at sStart (low S bytes)
   uint32_t lastRLE = 0;
   [[maybe_unused]] uint32_t la0 = 0, la1 = 0;  // Packed: last emitted symbol (starts as zeros)
+  if constexpr (MONO) { if (active) { const uint64_t v = monoSyms[b]; la0 = (uint32_t)v; la1 = (uint32_t)(v >> 32); } }
   bool ended = false;        // the end terminator has been written
   bool finished = !active;   // the whole stream is in the slot
 
@@ -181,7 +200,7 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
   };
 
   // ---- stream header ----
-  if (active)
+  if (active && !MONO)
   {
     h32(n);
     h32(0);
@@ -195,6 +214,17 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
   u32x4 pf[LPR];
   uint32_t pfAt[LPR];
   uint32_t wantReq = 0;
+  [[maybe_unused]] uint64_t rowAt[LPR];                                 // MONO: input position of the LPR rows this lane serves
+  if constexpr (MONO)
+  {
+#pragma unroll
+    for (int q = 0; q < LPR; q++)
+    {
+      const int r = (int)((uint32_t)q * RPL + lane / LPR);
+      const uint32_t lo32 = (uint32_t)__shfl((int)(uint32_t)blockAt, r, 64), hi32 = (uint32_t)__shfl((int)(uint32_t)(blockAt >> 32), r, 64);
+      rowAt[q] = ((uint64_t)hi32 << 32) | lo32;
+    }
+  }
 
   auto issue = [&]() {
     const uint32_t left = (n > avail) ? (n - avail + 15u) >> 4 : 0u;
@@ -211,7 +241,7 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
       const uint32_t r = (uint32_t)q * RPL + lane / LPR, c = lane % LPR;
       const uint32_t nreq = ri[q] & 15u, e = ri[q] & ~15u;
       const bool valid = c < nreq;
-      const uint64_t g = (uint64_t)(wgFirst + r) * B + e + c * 16u;
+      const uint64_t g = (MONO ? rowAt[q] : (uint64_t)(wgFirst + r) * B) + e + c * 16u;
       u32x4 v = u32x4{ 0, 0, 0, 0 };
       if (valid)
       {
@@ -370,7 +400,7 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
     emit_literals(lastRLE, gap);
     lastRLE = e;
 
-    if (e >= n)
+    if (e >= nTrue)
     {
       // end terminator (rleX_extreme_cpu_encode.h:373-609; rleX_Xsl_multibyte_encoder.h:329-370)
       if constexpr (TR::kShort) { hb(TR::SCINV << TR::SRBP); hb(TR::STB); hb(1); h16(0); h16(0); if (K == 0) hb(0); }   // one zero byte, whatever S
@@ -406,7 +436,7 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
     const uint32_t whole = sStart + SU + SU * (L / SU);
     uint32_t e = whole;
     if constexpr (!TR::kAligned)
-      if (whole + SU <= n) e = sStart + SU + L;
+      if (whole + SU <= nTrue) e = sStart + SU + L;
     handle_run(sStart, e, sy0, sy1);
     return e;
   };
@@ -416,7 +446,7 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
   land();
   wave_sync();
 
-  uint32_t stepsLeft = 2u * (B / (uint32_t)Q) + 64u;                    // bounded: every step scans a window or lands input
+  uint32_t stepsLeft = MONO ? monoSteps : 2u * (B / (uint32_t)Q) + 64u;  // bounded: every step scans a window or lands input
 
   while (__ballot(!finished) != 0ull)
   {
@@ -500,11 +530,11 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
       if (cb >= n && avail >= n)
       {
         // end of input: the literal terminator unless the stream ended with a run
-        if (!ended) { finish_literals(); ended = true; }
+        if (!ended && n == nTrue) { finish_literals(); ended = true; }
         // the last partial chunk, then the stream size (header field compressedLength and the size table)
         if ((opos & 15u) != 0u)
           st128(slot + (opos & ~15u), oacc);
-        st32(slot + 4, opos);
+        if constexpr (!MONO) st32(slot + 4, opos);
         sizes[b] = opos;
         finished = true;
       }

@@ -50,7 +50,7 @@ struct EncodeArgs
 // chunks of ONE monolithic stream (hsrle_mono_encode.hip.h): EncodeArgs with nBlocks = chunks, plus the chunk table
 struct MonoEncodeArgs
 {
-  const uint64_t *starts; const uint8_t *syms; const uint64_t *slotOff; uint32_t steps;
+  const uint64_t *starts; const uint64_t *syms; const uint64_t *slotOff; uint32_t steps;
 };
 typedef hipError_t (*MonoEncodeLaunch)(const EncodeArgs &, const MonoEncodeArgs &, hipStream_t);
 // wave-per-block encoder (hsrle_encode8w.hip.h): writes offsets and payload of the container directly
@@ -85,11 +85,11 @@ constexpr int kDecodeTile = HSRLE_DECODE_TILE; // bytes produced per lane and ro
 constexpr int kDecodeRing = HSRLE_DECODE_RING; // per-lane stream ring in LDS (k_decode_blocks R)
 
 void register_w8(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub, MonoEncodeLaunch *menc, WaveEncodeLaunch *wenc);
-void register_w16(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub);
-void register_w24(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub);
-void register_w32(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub);
-void register_w48(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub);
-void register_w64(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub);
+void register_w16(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub, MonoEncodeLaunch *menc);
+void register_w24(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub, MonoEncodeLaunch *menc);
+void register_w32(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub, MonoEncodeLaunch *menc);
+void register_w48(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub, MonoEncodeLaunch *menc);
+void register_w64(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub, MonoEncodeLaunch *menc);
 void register_w128(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub);
 
 template <typename... A>
@@ -118,7 +118,7 @@ inline hipError_t launch_encode(KERNEL k, const EncodeArgs &a, hipStream_t st, i
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(a.residentWorkgroups, k, 64, capResidency ? ldsCap : lds8);
   if constexpr (kernel_arity(KERNEL{}) == 11)   // kernels with a MONO mode (hsrle_encode8.hip.h): block mode = no chunk table
     hipLaunchKernelGGL(k, dim3(grid), dim3(64), capResidency ? ldsCap : lds8, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, (const uint64_t *)nullptr,
-                       (const uint8_t *)nullptr, (const uint64_t *)nullptr, 0u);
+                       (const uint64_t *)nullptr, (const uint64_t *)nullptr, 0u);
   else
     hipLaunchKernelGGL(k, dim3(grid), dim3(64), capResidency ? ldsCap : lds8, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes);
   return hipGetLastError();

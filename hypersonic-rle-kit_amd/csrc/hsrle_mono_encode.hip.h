@@ -25,7 +25,7 @@ constexpr uint64_t MONO_NO_CUT = ~0ull;
 // 8 bit symbols.  cutPos[c] = end (exclusive) of the first maximal run of >= LONGC equal bytes with c * G < end <= (c + 1) * G and
 // end < U, cutSym[c] its byte; MONO_NO_CUT if there is none.  Piece 0 additionally starts the stream: the host adds position 0.
 __global__ __launch_bounds__(64) void k_mono_cuts8(const uint8_t *__restrict__ in, uint64_t U, uint32_t G, uint32_t pieces, uint32_t LONGC, uint64_t *__restrict__ cutPos,
-                                                   uint8_t *__restrict__ cutSym, uint32_t *__restrict__ flags)
+                                                   uint64_t *__restrict__ cutSym, uint32_t *__restrict__ flags)
 {
   const uint32_t c = blockIdx.x * 64u + threadIdx.x;
   if (c >= pieces) return;
@@ -63,13 +63,71 @@ __global__ __launch_bounds__(64) void k_mono_cuts8(const uint8_t *__restrict__ i
     i++;
   }
   cutPos[c] = found;
-  cutSym[c] = (uint8_t)fsym;
+  cutSym[c] = (uint64_t)fsym;
+  flags[c] = (found != MONO_NO_CUT) ? 1u : 0u;
+}
+
+// Symbols of S = 2, 3, 4, 6, 8 bytes (reference: src/rleX_extreme_cpu_encode.h:315-366 run search, :79-163 extension; restated in
+// hsrle_encodeS.hip.h).  With the match bits m[j] = (d[j] == d[j + S]) a run is a maximal stretch [q, q + L) of set bits with L >= S: it
+// starts at the first searched position in it and ends at e = q + S + L (byte-aligned) or q + S * floor((L + S) / S) (sym-aligned).  The
+// search resumes at the previous run's end, which may lie up to S - 1 bytes INSIDE the next stretch (then that run starts later, with a
+// rotated symbol); so a stretch is a cut only if its start is CLEAN: no stretch of >= S set bits ends within the S positions in front
+// of it (then the encoder's search position is at or in front of q when it gets there, and the run is [q, e) with symbol d[q, q + S)).
+// cutSym[c] = that symbol (low S bytes).  Stretches that begin in front of the lane's look-back are not used.
+template <int S, int ALIGNED>
+__global__ __launch_bounds__(64) void k_mono_cutsS(const uint8_t *__restrict__ in, uint64_t U, uint32_t G, uint32_t pieces, uint32_t LONGC, uint64_t *__restrict__ cutPos,
+                                                   uint64_t *__restrict__ cutSym, uint32_t *__restrict__ flags)
+{
+  const uint32_t c = blockIdx.x * 64u + threadIdx.x;
+  if (c >= pieces) return;
+  constexpr uint64_t SU = (uint64_t)S;
+  const uint64_t x = (uint64_t)c * G;
+  const uint64_t hiEnd = (x + G < U) ? x + G : U;
+  const uint64_t lastCut = (U > 64u + 4u * SU) ? U - 64u - 4u * SU : 0u;     // no cut near the end of the input (its rules look at the end)
+  const uint64_t back = (uint64_t)LONGC + 4u * SU + 16u;
+  uint64_t j = (x > back) ? x - back : 0;
+  // state of the scan over the match bits: length of the current stretch of set bits and its start; whether that stretch is usable (its
+  // start was seen and is clean); position of the zero bit that ended the last stretch of >= S set bits
+  uint64_t ones = (j == 0) ? 0 : SU;            // (a stretch that is open where the scan begins counts as long and is not usable)
+  uint64_t q = j;
+  bool usable = false;
+  uint64_t zLong = (j == 0) ? ~0ull : j;        // ~0: none yet.  Scan start: unknown history -> as if a long stretch had just ended here
+  uint64_t found = MONO_NO_CUT, fsym = 0;
+  const uint64_t symMask = (S >= 8) ? ~0ull : ((1ull << (8 * S)) - 1ull);
+  while (j + SU < U)
+  {
+    const bool m = in[j] == in[j + SU];
+    if (m)
+    {
+      if (ones == 0)
+      {
+        q = j;
+        usable = (zLong == ~0ull) || (zLong + SU <= q);                 // clean start: the last long stretch ended >= S positions in front
+      }
+      ones++;
+    }
+    else
+    {
+      if (ones >= SU)
+      {
+        const uint64_t L = ones;
+        const uint64_t e = ALIGNED ? q + SU * ((L + SU) / SU) : q + SU + L;
+        if (usable && e - q >= LONGC && e > x && e <= hiEnd && e <= lastCut) { found = e; fsym = ld64(in + q) & symMask; break; }
+        zLong = j;
+      }
+      ones = 0;
+      if (j > hiEnd) break;                                              // every later stretch ends behind this piece
+    }
+    j++;
+  }
+  cutPos[c] = found;
+  cutSym[c] = fsym;
   flags[c] = (found != MONO_NO_CUT) ? 1u : 0u;
 }
 
 // idx = exclusive scan of flags (idx[pieces] = number of cuts).  Chunk 0 starts at 0 with symbol 0; cut j starts chunk j + 1.
-__global__ __launch_bounds__(256) void k_mono_scatter(const uint64_t *__restrict__ cutPos, const uint8_t *__restrict__ cutSym, const uint32_t *__restrict__ flags,
-                                                      const uint64_t *__restrict__ idx, uint32_t pieces, uint64_t U, uint64_t *__restrict__ starts, uint8_t *__restrict__ syms,
+__global__ __launch_bounds__(256) void k_mono_scatter(const uint64_t *__restrict__ cutPos, const uint64_t *__restrict__ cutSym, const uint32_t *__restrict__ flags,
+                                                      const uint64_t *__restrict__ idx, uint32_t pieces, uint64_t U, uint64_t *__restrict__ starts, uint64_t *__restrict__ syms,
                                                       uint64_t *__restrict__ slotOff, uint32_t *__restrict__ ctrl)
 {
   const uint32_t c = blockIdx.x * 256u + threadIdx.x;

@@ -155,7 +155,25 @@ def test_device_resident_mono_decode_of_synthetic_workloads(hs, oracle, key, kin
 
 # ---- the encode side: ONE stream written by many lanes (csrc/hsrle_mono_encode.hip.h) ----
 
-MONO_ENC_KEYS = ["rle8_multi", "rle8_packed_multi", "rle8_multi_short"]
+MONO_ENC_KEYS = ["rle8_multi", "rle8_packed_multi", "rle8_multi_short"] + [f"rle{w}_{v}" for w in (16, 24, 32, 48, 64) for v in ("sym", "sym_packed", "byte", "byte_packed", "sym_short", "byte_short")]
+
+
+def _wide_run_mix(seed, size, S):
+    """Runs of S-byte symbols with lengths around the thresholds, cut mid-symbol, butting against each other with shared bytes (the
+    overlapping periodic stretches that make a run start later, with a rotated symbol) and separated by 0 .. 300 literal bytes."""
+    rng = random.Random(seed)
+    out = bytearray()
+    while len(out) < size:
+        out += bytes(rng.randrange(256) for _ in range(rng.choice([0, 0, 1, 2, 5, 20, 60, 126, 127, 128, 140, 254, 255, 256, 300])))
+        sym = bytes(rng.choice([0, 7, 200, rng.randrange(256)]) for _ in range(S)) if rng.random() < 0.7 else bytes([rng.randrange(4)]) * S
+        k = rng.choice([2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 20, 40, 100]) * S // rng.choice([1, 1, 2]) + rng.randrange(S)
+        piece = (sym * (k // S + 2))[:k]
+        out += piece
+        if rng.random() < 0.3:                                            # a second run that shares its first bytes with the end of the first
+            rot = rng.randrange(1, S + 1)
+            sym2 = piece[-rot:] + bytes(rng.randrange(256) for _ in range(S - rot)) if rot < S else piece[-S:]
+            out += (sym2 * 30)[rot : rot + rng.choice([S * 3, S * 12, S * 20 + 1])]
+    return bytes(out[:size])
 
 
 def _run_mix(seed, size, counts):
@@ -177,6 +195,9 @@ def test_mono_encode_is_the_reference_stream(hs, oracle, key):
     cases += [_run_mix(5, 60000, [1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 40]), _run_mix(6, 60000, [11, 12, 13, 30, 64, 65, 300]),
               bytes(200000), bytes(rng.randrange(256) for _ in range(100000)), b"\x05" * 70 + bytes(range(256)) * 100 + b"\x06" * 40,
               _run_mix(7, 30000, [12, 13]) + b"\x09" * 20, _run_mix(8, 30000, [12, 13]) + b"\x09" * 20 + b"abc", _run_mix(9, 5000, [20]) + bytes(50)]
+    if codec.S > 1:
+        cases += [_wide_run_mix(20 + k, n, codec.S) for k, n in enumerate((300, 5000, 60000, 60000, 150000))]
+        cases += [_wide_run_mix(30, 40000, 1), bytes(range(7)) * 9000]
     for tune in ((0, 0, 0), (0, 64, 0), (0, 100, 0), (0, 1000, 0), (0, 5000, 0)):
         hs.mono_tuning(*tune)
         for d in cases:
@@ -187,12 +208,14 @@ def test_mono_encode_is_the_reference_stream(hs, oracle, key):
 
 
 @pytest.mark.parametrize("key,kind,size", [("rle8_packed_multi", SYNTH_RUNS, 64 << 20), ("rle8_packed_multi", SYNTH_VIDEO, 88473600), ("rle8_multi", SYNTH_RUNS, 32 << 20),
-                                           ("rle8_multi_short", SYNTH_VIDEO, 32 << 20)])
+                                           ("rle8_multi_short", SYNTH_VIDEO, 32 << 20), ("rle16_sym_packed", SYNTH_RUNS, 32 << 20), ("rle24_byte", SYNTH_RUNS, 32 << 20),
+                                           ("rle32_byte_packed", SYNTH_RUNS, 32 << 20), ("rle48_sym", SYNTH_RUNS, 32 << 20), ("rle64_byte_short", SYNTH_RUNS, 32 << 20),
+                                           ("rle64_sym_packed", SYNTH_VIDEO, 32 << 20)])
 def test_device_resident_mono_encode(hs, oracle, key, kind, size):
     import torch
 
     codec = CODEC_BY_KEY[key]
-    src = hs.synth(kind, 1, 2, size, device="cuda")
+    src = hs.synth(kind, codec.S, 2, size, device="cuda")
     stream, chunks = hs.mono_compress_dev(key, src, return_chunks=True)
     expect = oracle.compress(codec, src.cpu().numpy().tobytes())
     assert stream.cpu().numpy().tobytes() == expect, f"{key}: stream differs from the oracle's ({chunks} chunks)"
