@@ -713,7 +713,8 @@ struct MonoPlan
 {
   uint32_t G, M, B, R, KE;
   uint64_t nb;
-  uint64_t offG, offE, offOlen, offT, offEntry, offOutStart, offStateIn, offFix, offList, offCtrl, offRec, total;
+  uint64_t offG, offE, offOlen, offT, offEntry, offOutStart, offStateIn, offFix, offList, offMark, offCtrl, offRec, total;
+  bool range7;
 };
 
 
@@ -739,6 +740,7 @@ static MonoPlan plan_mono(int codec, uint32_t U, uint32_t C, uint32_t p0)
   // too many guesses turn out wrong.
   const bool range7 = (codec == 1 || (codec >= 6 && codec < 50 && (codec == 49 || (codec < 46 && ((codec - 6) & 7) == 5))));
   m.M = tM ? tM : (range7 ? 1024u : 4096u);
+  m.range7 = range7;
   m.R = (uint32_t)(((uint64_t)(C - p0) + G - 1u) / G);
   if (m.R == 0u) m.R = 1u;
   m.KE = (uint32_t)codec_state_slots(codec);
@@ -754,19 +756,20 @@ static MonoPlan plan_mono(int codec, uint32_t U, uint32_t C, uint32_t p0)
   m.offStateIn = at; at += align_up(4ull * m.R * ks, 256);
   m.offFix = at; at += align_up(4ull * m.R, 256);
   m.offList = at; at += align_up(4ull * m.R, 256);
+  m.offMark = at; at += align_up(4ull * m.R, 256);
   m.offCtrl = at; at += 256;
   m.offRec = at; at += align_up(4ull * kEntryRecDwords * m.nb, 256);
   m.total = at;
   return m;
 }
 
-static hipError_t launch_resolve(const MonoPlan &m, uint8_t *ws, uint32_t p0, uint64_t U, hipStream_t st)
+static hipError_t launch_resolve(const MonoPlan &m, uint8_t *ws, uint32_t p0, uint64_t U, uint32_t roundTag, hipStream_t st)
 {
 #define HSRLE_RESOLVE(KE)                                                                                                                                        \
   hipLaunchKernelGGL(k_index_resolve<KE>, dim3(1), dim3(kResolveThreads), 0, st, (const uint32_t *)(ws + m.offG), (const uint32_t *)(ws + m.offE),               \
                      (const uint64_t *)(ws + m.offOlen), (const uint32_t *)(ws + m.offT), m.R, p0, m.G, U, (uint32_t *)(ws + m.offEntry),                         \
                      (uint64_t *)(ws + m.offOutStart), (uint32_t *)(ws + m.offStateIn), (uint32_t *)(ws + m.offFix), (uint32_t *)(ws + m.offList),                \
-                     (uint32_t *)(ws + m.offCtrl))
+                     (uint32_t *)(ws + m.offCtrl), (uint32_t *)(ws + m.offMark), roundTag)
   switch (m.KE)
   {
   case 0: HSRLE_RESOLVE(0); break;
@@ -819,7 +822,8 @@ static int mono_decode_dev(const MonoHeader &mh, const uint8_t *dStream, uint8_t
   if (!g_dec[mh.codec] || !g_idx[mh.codec])
     return HSRLE_ERR_UNSUPPORTED;
   uint32_t *ctrl = (uint32_t *)(ws + m.offCtrl);
-  if (hipMemsetAsync(ctrl, 0, 256, st) != hipSuccess || hipMemsetAsync(ws + m.offRec, 0, 4ull * kEntryRecDwords * m.nb, st) != hipSuccess)
+  if (hipMemsetAsync(ctrl, 0, 256, st) != hipSuccess || hipMemsetAsync(ws + m.offRec, 0, 4ull * kEntryRecDwords * m.nb, st) != hipSuccess ||
+      hipMemsetAsync(ws + m.offMark, 0, 4ull * m.R, st) != hipSuccess)
     return HSRLE_ERR_DEVICE;
 
   IndexArgs ia{};
@@ -829,13 +833,30 @@ static int mono_decode_dev(const MonoHeader &mh, const uint8_t *dStream, uint8_t
   ia.entry = (const uint32_t *)(ws + m.offEntry); ia.outStart = (const uint64_t *)(ws + m.offOutStart); ia.stateIn = (const uint32_t *)(ws + m.offStateIn);
   ia.U = mh.U; ia.B = m.B; ia.rec = (uint32_t *)(ws + m.offRec);
 
+  ia.mark = (uint32_t *)(ws + m.offMark); ia.roundTag = 0;
+  { static const uint32_t ext = env_u32("HSRLE_MONO_REPAIR_EXTEND", 48); ia.extMax = ext; }
+  if (!m.range7 && m.R > 256u && g_monoTune[2] == 0u)
+  {
+    // formats whose junk walks do not die: does the short look-back find the chain on THIS stream?  A pilot over the first 128 regions
+    // tells (data with little entropy synchronises within bytes, random literals need ~16 KiB): each wrong guess costs a repair later
+    uint32_t pg[128], pe[128];
+    IndexArgs pilot = ia;
+    pilot.R = 128u;
+    if (g_idx[mh.codec](pilot, 0, st) != hipSuccess || hipMemcpyAsync(pg, ia.g, sizeof(pg), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(pe, ia.e, sizeof(pe), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+      return HSRLE_ERR_DEVICE;
+    uint32_t agree = 0;
+    for (uint32_t r = 1; r < 128u; r++) agree += (pe[r - 1] == pg[r]) ? 1u : 0u;
+    if (agree < 120u) ia.M = 16384u;
+  }
   if (g_idx[mh.codec](ia, 0, st) != hipSuccess)
     return HSRLE_ERR_DEVICE;
-  uint32_t rounds = 0, rewalked = 0;
+  uint32_t rounds = 0, rewalked = 0, roundTag = 0;
   uint32_t verdict[4] = { 0, 0, 0, 0 };
   for (;;)
   {
-    if (launch_resolve(m, ws, mh.p0, mh.U, st) != hipSuccess)
+    roundTag++;
+    if (launch_resolve(m, ws, mh.p0, mh.U, roundTag, st) != hipSuccess)
       return HSRLE_ERR_DEVICE;
     if (hipMemcpyAsync(verdict, ctrl, sizeof(verdict), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
       return HSRLE_ERR_DEVICE;
@@ -852,7 +873,7 @@ static int mono_decode_dev(const MonoHeader &mh, const uint8_t *dStream, uint8_t
       ia.list = nullptr; ia.listCount = 0;
       rounds = 0;
     }
-    else { ia.list = (const uint32_t *)(ws + m.offList); ia.listCount = verdict[0]; }
+    else { ia.list = (const uint32_t *)(ws + m.offList); ia.listCount = verdict[0]; ia.roundTag = roundTag; }
     if (g_idx[mh.codec](ia, 0, st) != hipSuccess)
       return HSRLE_ERR_DEVICE;
   }

@@ -225,6 +225,7 @@ __device__ __forceinline__ void state_apply(uint32_t (&t)[K > 0 ? K : 1], uint32
 template <int FAM, int S, int AL>
 __global__ __launch_bounds__(64) void k_index_walk(const uint8_t *__restrict__ s, uint32_t C, uint32_t p0, uint32_t G, uint32_t M, uint32_t R, uint32_t single,
                                                    const uint32_t *__restrict__ list, uint32_t listCount, const uint32_t *__restrict__ fix,
+                                                   uint32_t *__restrict__ mark, uint32_t roundTag, uint32_t extMax,
                                                    uint32_t *__restrict__ gOut, uint32_t *__restrict__ eOut, uint64_t *__restrict__ olenOut, uint32_t *__restrict__ tOut)
 {
   constexpr int KE = IndexState<FAM>::KE;
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(64) void k_index_walk(const uint8_t *__restrict__ s
   if (list != nullptr) { if (i >= listCount) return; r = list[i]; }
   else { if (i >= R) return; r = i; }
 
-  const uint32_t start = p0 + r * G, endr = start + G;
+  uint32_t start = p0 + r * G, endr = start + G;
   const bool sgl = single != 0u;
 
   // ONE loop, one packet per trip, whatever a lane is doing (guessing or walking its region): nested loops would make the whole wave
@@ -253,6 +254,11 @@ __global__ __launch_bounds__(64) void k_index_walk(const uint8_t *__restrict__ s
 #pragma unroll
   for (int j = 0; j < (KE > 0 ? KE : 1); j++) tr[j] = IDX_OLD | (uint32_t)j;
 
+  // A REPAIR walk (list != nullptr) goes on into the regions behind its own while the chain does not arrive at their recorded guesses:
+  // wrong guesses come in streaks, and a streak would otherwise cost one round per region.  It stops in front of a region that is on this
+  // round's list itself or that another repair walk has claimed (mark == roundTag: one writer per record -- two could tear it).
+  for (uint32_t ext = 0;; ext++)
+  {
   for (;;)
   {
     if (guessing && x >= start) { guessing = false; q = x; }
@@ -282,6 +288,16 @@ __global__ __launch_bounds__(64) void k_index_walk(const uint8_t *__restrict__ s
 #pragma unroll
     for (int j = 0; j < KE; j++) tOut[(uint64_t)r * KE + j] = tr[j];
   }
+  if (list == nullptr || ex >= IDX_SKIP || ext >= extMax) break;
+  const uint32_t next = (ex - p0) / G;                                  // the region the chain enters next (ex >= endr: next > r)
+  // claim the region for this round (its record must have ONE writer: the chain may have jumped over listed regions whose lanes walk
+  // on into the same region): whoever raises mark[next] to this round's tag first owns it
+  if (next >= R || atomicMax(mark + next, roundTag) >= roundTag || gOut[next] == ex) break;
+  r = next; start = p0 + r * G; endr = start + G;
+  x = ex; q = ex; ol = 0;
+#pragma unroll
+  for (int j = 0; j < (KE > 0 ? KE : 1); j++) tr[j] = IDX_OLD | (uint32_t)j;
+  }
 }
 
 // ---- pass 2: chain the regions, scan sizes and states.  ONE workgroup. ----
@@ -308,7 +324,8 @@ template <int KE>
 __global__ __launch_bounds__(kResolveThreads) void k_index_resolve(const uint32_t *__restrict__ g, const uint32_t *__restrict__ e, const uint64_t *__restrict__ olen,
                                                                    const uint32_t *__restrict__ tIn, uint32_t R, uint32_t p0, uint32_t G, uint64_t U,
                                                                    uint32_t *__restrict__ entry, uint64_t *__restrict__ outStart, uint32_t *__restrict__ stateIn,
-                                                                   uint32_t *__restrict__ fix, uint32_t *__restrict__ list, uint32_t *__restrict__ ctrl)
+                                                                   uint32_t *__restrict__ fix, uint32_t *__restrict__ list, uint32_t *__restrict__ ctrl,
+                                                                   uint32_t *__restrict__ mark, uint32_t roundTag)
 {
   constexpr int NT = kResolveThreads;
   constexpr int KS = KE > 0 ? KE : 1;
@@ -422,6 +439,7 @@ __global__ __launch_bounds__(kResolveThreads) void k_index_resolve(const uint32_
           // from the next region's own guess so that further wrong guesses are found (and repaired) in the same round.
           sflag[k] = F_DIRTY;
           fix[rr] = cur;
+          mark[rr] = roundTag;
           list[sDirty++] = rr;
           trusted = 0;
           if (rr + 1u < R) cur = next_guess(k, rr);
@@ -718,8 +736,8 @@ inline hipError_t launch_index(const IndexArgs &a, int records, hipStream_t st)
   {
     const uint32_t n = a.list ? a.listCount : a.R;
     if (n == 0u) return hipSuccess;
-    hipLaunchKernelGGL((k_index_walk<FAM, S, AL>), dim3((n + 63u) / 64u), dim3(64), 0, st, a.stream, a.C, a.p0, a.G, a.M, a.R, a.single, a.list, a.listCount, a.fix, a.g, a.e,
-                       a.olen, a.t);
+    hipLaunchKernelGGL((k_index_walk<FAM, S, AL>), dim3((n + 63u) / 64u), dim3(64), 0, st, a.stream, a.C, a.p0, a.G, a.M, a.R, a.single, a.list, a.listCount, a.fix, a.mark, a.roundTag, a.extMax,
+                       a.g, a.e, a.olen, a.t);
   }
   return hipGetLastError();
 }

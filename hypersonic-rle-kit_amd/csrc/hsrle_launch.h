@@ -29,6 +29,7 @@ struct IndexArgs
   uint32_t C, p0, G, M, R;      // stream bytes, first packet, region size, look-back of the guess, regions
   uint32_t single, singleSym;   // 8 bit Single mode / rle8_single_short: mode flag and the stream's one symbol
   const uint32_t *list; uint32_t listCount; const uint32_t *fix;   // repair pass: regions to walk again and their true entries
+  uint32_t *mark; uint32_t roundTag; uint32_t extMax;                           //              mark[r] == roundTag: region r is on this round's list
   uint32_t *g, *e; uint64_t *olen; uint32_t *t;                       // walk results per region
   const uint32_t *entry; const uint64_t *outStart; const uint32_t *stateIn; uint64_t U; uint32_t B; uint32_t *rec;   // record pass
 };

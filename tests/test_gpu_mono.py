@@ -72,6 +72,21 @@ def test_every_codec_through_the_index(hs, oracle, codec):
     hs.mono_tuning(0, 0, 0)
 
 
+@pytest.mark.parametrize("key", ["rle8_7symlut", "rle8_3symlut", "rle16_7symlut_sym", "rle8_multi", "rle64_7symlut_byte_short", "rle24_sym_packed"])
+def test_repair_streaks_with_tiny_regions(hs, oracle, key):
+    """Formats whose wrong walks do not die + regions far smaller than the look-back they would need: most guesses are wrong, the chain
+    jumps over listed regions, repair walks run on into their neighbours (one writer per region record: claimed through the mark word)."""
+    codec = CODEC_BY_KEY[key]
+    for seed in range(8):
+        data = _mixed_input(977 + CODECS.index(codec) + seed * 1000, 40000)
+        stream = oracle.compress(codec, data)
+        for tune in ((128, 64, 40), (256, 300, 16), (128, 32, 1024), (128, 48, 8)):
+            hs.mono_tuning(*tune)
+            size, dec = hs.call_dropin(codec.dname, stream, len(data))
+            assert size == len(data) and dec == data, f"{key} seed {seed} tuning {tune}"
+    hs.mono_tuning(0, 0, 0)
+
+
 @pytest.mark.parametrize("key", ["rle8_single", "rle8_packed_single", "rle8_single_short"])
 def test_single_symbol_streams(hs, oracle, key):
     codec = CODEC_BY_KEY[key]
