@@ -835,7 +835,7 @@ static int mono_decode_dev(const MonoHeader &mh, const uint8_t *dStream, uint8_t
 
   ia.mark = (uint32_t *)(ws + m.offMark); ia.roundTag = 0;
   { static const uint32_t ext = env_u32("HSRLE_MONO_REPAIR_EXTEND", 48); ia.extMax = ext; }
-  if (!m.range7 && m.R > 256u && g_monoTune[2] == 0u)
+  if (!m.range7 && m.R >= 16384u && g_monoTune[2] == 0u)                  // (small streams: the pilot's launch + read costs more than a widened second try)
   {
     // formats whose junk walks do not die: does the short look-back find the chain on THIS stream?  A pilot over the first 128 regions
     // tells (data with little entropy synchronises within bytes, random literals need ~16 KiB): each wrong guess costs a repair later
