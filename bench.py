@@ -115,6 +115,73 @@ def cpu_baseline(container_prefix, n_blocks, block_size, codec_key, expect):
     return res
 
 
+def side_measurements(hsrle, torch, src, dev):
+    """Not `value`: (1) BASELINE config 3 -- rle64_3symlut_byte on the 88 473 600-byte video-shaped frame in 4 KiB blocks, decoded plain
+    and split (one lane per 1 KiB sub-block; the container is untouched); (2) BASELINE config 2 as ONE monolithic stream: the first
+    1 GiB of the headline buffer written by the many-lane encoder and read back through the entry-point index."""
+    import ctypes
+
+    def timed(fn, reps):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    out = {}
+    fsize = 88473600
+    frame = hsrle.synth(hsrle.SYNTH_VIDEO, 8, 2, fsize, device=dev)
+    cont, info = hsrle.compress("rle64_3symlut_byte", frame, block_size=4096)
+    dec = torch.empty(fsize, dtype=torch.uint8, device=dev)
+    st = torch.zeros(16, dtype=torch.int32, device=dev)
+    ws = torch.empty(max(hsrle.split_workspace_size(info, None, 0), 16), dtype=torch.uint8, device=dev)
+    plain_ms = timed(lambda: hsrle.decompress_async(cont, info, dec, st), 10)
+    split_ms = timed(lambda: hsrle.decompress_split_async(cont, info, dec, ws, st, sub_block=0), 10)
+    ok = int(st[0].item()) == 0 and torch.equal(dec, frame)
+    out["config3_frame"] = {"codec": "rle64_3symlut_byte", "bytes": fsize, "block_size": 4096, "ratio": round(info.totalSize / fsize, 4), "decode_us": round(plain_ms * 1e3, 1),
+                            "split_decode_us": round(split_ms * 1e3, 1), "split_GiBps": round(fsize / 2**30 / (split_ms * 1e-3), 1),
+                            "split_algorithmic_TBps": round((fsize + info.totalSize) / (split_ms * 1e-3) / 1e12, 3), "exact": bool(ok)}
+    del frame, cont, dec, ws
+
+    n = 1 << 30
+    part = src[:n]
+    stream = hsrle.mono_compress_dev("rle8_packed_multi", part)
+    t = torch.zeros(stream.numel() + 64, dtype=torch.uint8, device=dev)
+    t[: stream.numel()] = stream
+    L = hsrle.lib()
+    ews = torch.empty(L.hsrle_compress_mono_workspace_size(1, n), dtype=torch.uint8, device=dev)
+    edst = torch.empty(hsrle.compress_bounds(n) + 64, dtype=torch.uint8, device=dev)
+    dws = torch.empty(L.hsrle_decompress_mono_workspace_size(1, n, stream.numel()), dtype=torch.uint8, device=dev)
+    dout = torch.empty(n, dtype=torch.uint8, device=dev)
+    import time
+
+    def wall(fn, reps):
+        fn(); torch.cuda.synchronize()
+        best = None
+        for _ in range(reps):
+            t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return best * 1e3
+
+    enc_ms = wall(lambda: hsrle.mono_compress_dev("rle8_packed_multi", part, dst=edst, workspace=ews), 3)
+    dec_ms = wall(lambda: hsrle.mono_decompress_dev("rle8_packed_multi", t, dst=dout, workspace=dws), 3)
+    from hsrle_testlib import big_manifest
+
+    import hashlib
+
+    man = big_manifest()
+    want = man["cases"]["config2_1GiB"]["mono"] if man else None
+    same = None
+    if want is not None:
+        same = stream.numel() == want["size"] and hashlib.sha256(stream.cpu().numpy().data).hexdigest() == want["sha256"]
+    out["mono_1GiB"] = {"codec": "rle8_packed_multi", "stream_bytes": int(stream.numel()), "encode_ms": round(enc_ms, 3), "encode_GiBps": round(1024 / enc_ms, 1),
+                        "decode_ms": round(dec_ms, 3), "decode_GiBps": round(1024 / dec_ms, 1), "stream_is_the_references": same, "decode_exact": bool(torch.equal(dout, part)),
+                        "note": "one monolithic reference stream, device resident, host verdict reads included"}
+    return out
+
+
 def kernel_name(codec_key):
     """The decode kernel instantiation behind a codec id (hsrle_decode.hip.h: k_decode_blocks<FAM, S, AL, T, R, Q, SGL>)."""
     from hsrle_testlib import CODEC_BY_KEY, FAMILY_NAMES
@@ -176,6 +243,7 @@ def main():
     ap.add_argument("--codec", default="rle8_packed_multi")
     ap.add_argument("--synth", choices=["runs", "video"], default="runs", help="synthetic generator: run-distributed (headline) or video-shaped (BASELINE config 3)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (config 3 frame, monolithic 1 GiB stream)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -303,6 +371,15 @@ def main():
     torch.cuda.synchronize()
     enc_ms = e0.elapsed_time(e1) / enc_steps
 
+    # ---- side measurements on rank 0 (untimed for `value`): BASELINE config 3 at its own size (split decode of the 4 KiB-block container),
+    #      and ONE monolithic 1 GiB reference stream written and read by the GPU (what the rle.h drop-in functions do, without PCIe) ----
+    extras = {}
+    if rank == 0 and args.codec == "rle8_packed_multi" and args.synth == "runs" and not args.no_extras:
+        try:
+            extras = side_measurements(hsrle, torch, src, dev)
+        except Exception as ex:  # noqa: BLE001 -- a side measurement must never cost the headline line
+            extras = {"error": repr(ex)[:200]}
+
     # ---- the one exchange step of the sharded path: gather the per-rank compressed segments into one stream ----
     gather_ms = None
     if distributed:
@@ -355,6 +432,8 @@ def main():
         }
         if gather_ms is not None:
             line["gather_ms"] = round(gather_ms, 3)
+        if extras:
+            line["extras"] = extras
         if not args.no_cpu and world == 1:
             nb = min(info.blockCount, (1 << 30) // args.block)
             prefix_end = p0 + int(container[64 + 8 * nb : 64 + 8 * nb + 8].view(torch.int64).item()) + 64

@@ -640,7 +640,7 @@ static uint32_t split_sub_block(const hsrle_container_info_t *info, uint32_t wan
   const uint32_t B = info->blockSize;
   if (want == 0u)
   {
-    want = pow2_floor(info->uncompressedSize >> 18);                 // >= 2^18 lanes where the buffer allows it
+    want = pow2_floor(info->uncompressedSize >> 16);                 // ~2^16 .. 2^17 lanes (measured on the 88 MB frame: 1 KiB sub-blocks 187 us, 512 / 256 bytes 206)
     want = want < 256u ? 256u : want;
   }
   if (want >= B || (want % 128u) != 0u || (B % want) != 0u)
@@ -1504,13 +1504,20 @@ int hsrle_decompress_dev(const void *dContainer, uint64_t containerSize, void *d
   int rc = hsrle_container_info_dev(dContainer, containerSize, &info, stream);
   if (rc != HSRLE_OK) return rc;
 
-  uint32_t *dStatus = (uint32_t *)scratch_alloc(4, (hipStream_t)stream);
+  // a container with too few blocks to fill the GPU with one lane per block is decoded split (one lane per sub-block):
+  // this call owns its scratch, so it can afford the records
+  const uint64_t recBytes = (info.blockCount < 131072u) ? hsrle_decompress_split_workspace_size(&info, info.blockCount, 0) : 0;
+  uint8_t *scratch = (uint8_t *)scratch_alloc(256 + recBytes, (hipStream_t)stream);
+  uint32_t *dStatus = (uint32_t *)scratch;
   if (!dStatus) return HSRLE_ERR_DEVICE;
   uint32_t status = 0;
   bool ok = hipMemsetAsync(dStatus, 0, 4, (hipStream_t)stream) == hipSuccess;
   if (ok)
   {
-    rc = decompress_blocks_async(dContainer, &info, 0, info.blockCount, dOut, outCapacity, dStatus, (hipStream_t)stream);
+    if (recBytes != 0)
+      rc = decompress_split_async(dContainer, &info, 0, info.blockCount, dOut, outCapacity, dStatus, scratch + 256, recBytes, 0, (hipStream_t)stream);
+    else
+      rc = decompress_blocks_async(dContainer, &info, 0, info.blockCount, dOut, outCapacity, dStatus, (hipStream_t)stream);
     ok = hipMemcpyAsync(&status, dStatus, 4, hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess && hipStreamSynchronize((hipStream_t)stream) == hipSuccess;
   }
   scratch_free(dStatus, (hipStream_t)stream);
