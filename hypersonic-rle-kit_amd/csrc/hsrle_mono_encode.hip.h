@@ -37,22 +37,34 @@ __global__ __launch_bounds__(64) void k_mono_cuts8(const uint8_t *__restrict__ i
   uint64_t found = MONO_NO_CUT;
   uint32_t fsym = 0;
   i++;
-  // a run [st, i) ends when in[i] differs; it is a cut iff it is long enough and ends inside (x, hiEnd] (and in front of the input's end)
+  // a run [st, i) ends when in[i] differs; it is a cut iff it is long enough and ends inside (x, hiEnd] (and in front of the input's end).
+  // Eight positions per trip from two 8-byte loads: w1 byte k = in[i + k], w byte k = its left neighbour
   const uint64_t lastCut = (U > 64u) ? U - 64u : 0u;
-  while (i <= lastCut && i <= hiEnd)
+  const uint64_t stop = (hiEnd < lastCut) ? hiEnd : lastCut;             // run ends behind `stop` are of no use
+  while (i <= stop)
   {
-    // fast path: 8 positions without two equal neighbours (x ^ (x >> 8) has no zero byte): the open run ends at i, nothing else starts
-    if (i + 9u <= U && i + 8u <= hiEnd)
+    if (i + 9u <= U)
     {
       const uint64_t w = ld64(in + i - 1), w1 = ld64(in + i);
       const uint64_t d = w ^ w1;                                        // byte k: in[i - 1 + k] ^ in[i + k]
       const uint64_t z = ((d & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | d;
-      if ((~z & 0x8080808080808080ull) == 0ull)
+      const uint64_t eq = ~z & 0x8080808080808080ull;                   // 0x80 in byte k: in[i + k] continues the run of its left neighbour
+      if (eq == 0x8080808080808080ull) { i += 8u; continue; }           // the open run goes on through all eight
+      // positions where a run ends = bytes that do NOT continue: visit them in order (all from registers)
+      uint64_t brk = ~eq & 0x8080808080808080ull;
+      bool hit = false;
+      while (brk != 0ull)
       {
-        if (i - st >= LONGC && i > x) { found = i; fsym = sy; break; }
-        st = i + 7u; sy = in[i + 7u]; i += 8u;
-        continue;
+        const uint32_t k = (uint32_t)__builtin_ctzll(brk) >> 3;
+        brk &= brk - 1ull;
+        const uint64_t at = i + k;
+        if (at > stop) break;
+        if (at - st >= LONGC && at > x) { found = at; fsym = sy; hit = true; break; }
+        st = at; sy = (uint32_t)(w1 >> (8u * k)) & 0xFFu;
       }
+      if (hit) break;
+      i += 8u;
+      continue;
     }
     const uint32_t v = in[i];
     if (v != sy)
