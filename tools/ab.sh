@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/.."
 run() {
   echo "== $1"
-  timeout 200 python tools/gpu_probe6.py rle8_packed_multi,rle8_multi,rle8_3symlut,rle16_sym,rle64_3symlut_byte 2>&1 | grep -v amdgpu.ids | tail -3
+  timeout 200 python tools/probe_correctness.py rle8_packed_multi,rle8_multi,rle8_3symlut,rle16_sym,rle64_3symlut_byte 2>&1 | grep -v amdgpu.ids | tail -3
   for rep in $(seq 1 ${REPS:-3}); do timeout 300 python bench.py --no-cpu --steps 10 --warmup 3 2>&1 | grep -v amdgpu.ids | python -c "
 import sys, json
 for l in sys.stdin:

@@ -1,4 +1,4 @@
-# small correctness probe with status reporting (for debugging a decoder): python tools/gpu_probe6.py
+# small correctness probe with status reporting (for debugging a decoder): python tools/probe_correctness.py
 import sys, os, random
 sys.path.insert(0,'tests'); sys.path.insert(0,'hypersonic-rle-kit_amd/python')
 import torch, hsrle

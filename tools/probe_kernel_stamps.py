@@ -1,4 +1,4 @@
-# in-kernel phase stamps (diagnostic build): HSRLE_LIB=variants/libhsrle_stamps.so python tools/gpu_probe5.py
+# in-kernel phase stamps (diagnostic build): HSRLE_LIB=variants/libhsrle_stamps.so python tools/probe_kernel_stamps.py
 import sys, os
 sys.path.insert(0,'tests'); sys.path.insert(0,'hypersonic-rle-kit_amd/python')
 import torch, hsrle

@@ -1,4 +1,4 @@
-# decode/encode only, for profiling: python tools/gpu_probe3.py [size_mib] [bs] [codec] [iters]
+# decode/encode only, for profiling: python tools/probe_profile_run.py [size_mib] [bs] [codec] [iters]
 import sys, os
 sys.path.insert(0,'tests'); sys.path.insert(0,'hypersonic-rle-kit_amd/python')
 import torch, hsrle
