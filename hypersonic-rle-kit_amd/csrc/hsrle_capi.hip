@@ -1132,9 +1132,9 @@ static int rle8m_decode_async(const void *dStream, uint64_t streamSize, uint32_t
   // video-shaped bytes, 618 against 629 on bytes that do not compress; 1 KiB sections: 841 / 501 against 737 / 617)
   const bool wave = forced ? forced == 2 : (sections < kRle8mWaveBelow || uncompressedSize / sections >= 4096u);
   if (wave)
-    hipLaunchKernelGGL(k_rle8m_decode_wave, dim3(sections), dim3(64), 0, st, (const uint8_t *)dStream, streamSize, (uint8_t *)dOut, dStatus);
+    hipLaunchKernelGGL(k_rle8m_decode_wave, dim3(sections), dim3(64), 0, st, (const uint8_t *)dStream, streamSize, (uint8_t *)dOut, dStatus, uncompressedSize, sections);
   else
-    hipLaunchKernelGGL(k_rle8m_decode, dim3((sections + 63u) / 64u), dim3(64), 0, st, (const uint8_t *)dStream, streamSize, (uint8_t *)dOut, dStatus);
+    hipLaunchKernelGGL(k_rle8m_decode, dim3((sections + 63u) / 64u), dim3(64), 0, st, (const uint8_t *)dStream, streamSize, (uint8_t *)dOut, dStatus, uncompressedSize, sections);
   return hipGetLastError() == hipSuccess ? HSRLE_OK : HSRLE_ERR_DEVICE;
 }
 

@@ -70,7 +70,8 @@ __device__ __forceinline__ uint32_t rle8m_tables(const uint8_t *__restrict__ s, 
   return hdr[0];
 }
 
-__global__ __launch_bounds__(64) void k_rle8m_decode(const uint8_t *__restrict__ s, uint64_t streamBytes, uint8_t *__restrict__ out, uint32_t *__restrict__ status)
+__global__ __launch_bounds__(64) void k_rle8m_decode(const uint8_t *__restrict__ s, uint64_t streamBytes, uint8_t *__restrict__ out, uint32_t *__restrict__ status,
+                                                      uint32_t wantOut, uint32_t wantSections)
 {
   __shared__ uint32_t rleBits[8];          // bit b: symbol b is followed by a repeat code
   __shared__ uint8_t codeToCount[256];     // repeat code -> count (rle8_low_entropy_cpu.c:569-600)
@@ -82,7 +83,8 @@ __global__ __launch_bounds__(64) void k_rle8m_decode(const uint8_t *__restrict__
   const uint32_t expIn = ld32(s), expOut = ld32(s + 4), sections = ld32(s + 8);
   const uint32_t dataStart = rle8m_tables(s, streamBytes, lane, rleBits, codeToCount, listed, hdr);
   const uint32_t k = blockIdx.x * 64u + lane;
-  if (dataStart == 0u)
+  // the grid and the output capacity were sized from the caller's info: a stream header that says something else is an error, not a write
+  if (dataStart == 0u || expOut != wantOut || sections != wantSections)
   {
     if (k == 0u && status) atomicOr(status, RLE8M_ERR_HEADER);
     return;
@@ -173,7 +175,8 @@ __global__ __launch_bounds__(64) void k_rle8m_decode(const uint8_t *__restrict__
 //     flagged).  The run length below a lane comes from the ballot of the flagged lanes, its parity across windows is one carried bit;
 //   * a flagged symbol in lane 63 has its code in the next window: it emits its own byte now, lane 0 of the next window the repeats;
 //   * output offsets = exclusive wave scan of the packet lengths (1 + count); every lane writes its own packet.
-__global__ __launch_bounds__(64) void k_rle8m_decode_wave(const uint8_t *__restrict__ s, uint64_t streamBytes, uint8_t *__restrict__ out, uint32_t *__restrict__ status)
+__global__ __launch_bounds__(64) void k_rle8m_decode_wave(const uint8_t *__restrict__ s, uint64_t streamBytes, uint8_t *__restrict__ out, uint32_t *__restrict__ status,
+                                                      uint32_t wantOut, uint32_t wantSections)
 {
   __shared__ uint32_t rleBits[8];
   __shared__ uint8_t codeToCount[256];
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(64) void k_rle8m_decode_wave(const uint8_t *__restr
   const uint32_t expIn = ld32(s), expOut = ld32(s + 4), sections = ld32(s + 8);
   const uint32_t dataStart = rle8m_tables(s, streamBytes, lane, rleBits, codeToCount, listed, hdr);
   const uint32_t k = blockIdx.x;
-  if (dataStart == 0u)
+  if (dataStart == 0u || expOut != wantOut || sections != wantSections)    // (see k_rle8m_decode)
   {
     if (k == 0u && lane == 0u && status) atomicOr(status, RLE8M_ERR_HEADER);
     return;

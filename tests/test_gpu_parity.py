@@ -477,3 +477,24 @@ print("WAVE_OK")
 """ % (os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hypersonic-rle-kit_amd", "python"), os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HSRLE_ENCODE_WAVE="1"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "WAVE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_rle8m_info_that_disagrees_with_the_stream_is_an_error(hs, oracle):
+    """The decode grid and the capacity check come from the caller's info struct; the kernels read the sizes from the stream again.  A
+    hand-built / stale info must end as an error bit, not as sections left undecoded or bytes written past what was checked."""
+    import torch
+
+    rng = random.Random(3)
+    data = mixed_runs(rng, 60000, alphabet=4)
+    st = oracle.rle8m_compress(16, data)
+    dev = torch.zeros(len(st) + 64, dtype=torch.uint8, device="cuda")
+    dev[: len(st)] = torch.frombuffer(bytearray(st), dtype=torch.uint8).cuda()
+    info = hs.rle8m_info(dev)
+    for field, value in (("sections", 8), ("uncompressedSize", len(data) - 100)):
+        bad = hs.Rle8mInfo(info.compressedSize, info.uncompressedSize, info.sections)
+        setattr(bad, field, value)
+        out = torch.full((len(data) + 4096,), 0xA5, dtype=torch.uint8, device="cuda")
+        status = torch.zeros(1, dtype=torch.int32, device="cuda")
+        hs.rle8m_decompress_async(dev, bad, out[: len(data)], status)
+        torch.cuda.synchronize()
+        assert int(status.item()) != 0 and bool((out[len(data):] == 0xA5).all())
