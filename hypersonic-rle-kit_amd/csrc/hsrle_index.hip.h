@@ -37,7 +37,7 @@ constexpr uint32_t IDX_SKIP = 0xFFFFFFFDu;   // entry: no packet of the chain st
 constexpr uint32_t IDX_OLD = 0x80000000u;    // transformer entry: slot (v & 15) of the incoming list; otherwise the stream offset of the symbol (< 2^31)
 constexpr uint32_t IDX_INIT = 0xC0000000u;   // resolved state entry: entry (v & 15) of the list a decoder starts with
 
-constexpr int kResolveThreads = 512;
+constexpr int kResolveThreads = 1024;
 constexpr uint32_t HSRLE_TAIL_PAD_BYTES = 32u;   // zero bytes behind a container's payload (include/hsrle.h: HSRLE_CONTAINER_TAIL_PAD)
 
 enum IndexStatus : uint32_t
@@ -334,8 +334,7 @@ __global__ __launch_bounds__(kResolveThreads) void k_index_resolve(const uint32_
   __shared__ uint8_t sflag[NT];
   __shared__ uint64_t sokMask[NT / 64];                                 // bit: the region passed the parallel check
   __shared__ uint64_t swave[NT / 64];
-  __shared__ uint32_t sT1[2 * NT * KS];
-#define HS_ST(buf, t, j) sT1[((uint32_t)(buf) * NT + (uint32_t)(t)) * KS + (uint32_t)(j)]
+  __shared__ uint32_t sWaveT[(NT / 64) * KS];                            // per wave: composition of its regions' state transformers
   __shared__ uint32_t sCur, sEnded, sTrusted, sDirty, sStatus;
   __shared__ uint32_t sCarryState[KS];
   __shared__ uint64_t sCarryOut;
@@ -462,11 +461,30 @@ __global__ __launch_bounds__(kResolveThreads) void k_index_resolve(const uint32_
       if ((int)lane >= d) xsum += y;
     }
     if (lane == 63u) swave[wave] = xsum;
-    // inclusive scan of the state transformers (Hillis-Steele through LDS)
+    // inclusive scan of the state transformers: inside the wave with shuffles, across the waves through their totals in LDS
+    uint32_t tInc[KS];                                                  // composition of the regions of this wave up to and including mine
+#pragma unroll
+    for (int j = 0; j < KS; j++) tInc[j] = (KE > 0 && fl == F_OK) ? myT[j] : (IDX_OLD | (uint32_t)j);
     if constexpr (KE > 0)
     {
 #pragma unroll
-      for (int j = 0; j < KE; j++) HS_ST(0, tid, j) = (fl == F_OK) ? myT[j] : (IDX_OLD | (uint32_t)j);
+      for (int d = 1; d < 64; d <<= 1)
+      {
+        uint32_t left[KS], tmp[KS];
+#pragma unroll
+        for (int j = 0; j < KE; j++) left[j] = (uint32_t)__shfl_up((int)tInc[j], d, 64);
+        state_compose<KE>(tmp, left, tInc);
+        if ((int)lane >= d)
+        {
+#pragma unroll
+          for (int j = 0; j < KE; j++) tInc[j] = tmp[j];
+        }
+      }
+      if (lane == 63u)
+      {
+#pragma unroll
+        for (int j = 0; j < KE; j++) sWaveT[wave * KS + j] = tInc[j];
+      }
     }
     __syncthreads();
     uint64_t wbase = 0, wall = 0;
@@ -477,25 +495,42 @@ __global__ __launch_bounds__(kResolveThreads) void k_index_resolve(const uint32_
       if ((uint32_t)w < wave) wbase += t;
       wall += t;
     }
-    int cb = 0;
+    // composition of the waves in front of mine, and of all waves (every wave scans the NT / 64 wave totals itself: lane w holds wave w's)
+    uint32_t tWaves[KS], tAll[KS];
+#pragma unroll
+    for (int j = 0; j < KS; j++) { tWaves[j] = IDX_OLD | (uint32_t)j; tAll[j] = IDX_OLD | (uint32_t)j; }
     if constexpr (KE > 0)
     {
-      for (int d = 1; d < NT; d <<= 1)
-      {
-        uint32_t tmp[KS], mine[KS], before[KS];
+      uint32_t wt[KS];
 #pragma unroll
-        for (int j = 0; j < KE; j++) { mine[j] = HS_ST(cb, tid, j); before[j] = HS_ST(cb, (int)tid >= d ? tid - d : tid, j); }
-        state_compose<KE>(tmp, before, mine);
-        if ((int)tid < d)
+      for (int j = 0; j < KE; j++) wt[j] = (lane < (uint32_t)(NT / 64)) ? sWaveT[lane * KS + j] : (IDX_OLD | (uint32_t)j);
+#pragma unroll
+      for (int d = 1; d < NT / 64; d <<= 1)
+      {
+        uint32_t left[KS], tmp[KS];
+#pragma unroll
+        for (int j = 0; j < KE; j++) left[j] = (uint32_t)__shfl_up((int)wt[j], d, 64);
+        state_compose<KE>(tmp, left, wt);
+        if ((int)lane >= d)
         {
 #pragma unroll
-          for (int j = 0; j < KE; j++) tmp[j] = mine[j];
+          for (int j = 0; j < KE; j++) wt[j] = tmp[j];
         }
-#pragma unroll
-        for (int j = 0; j < KE; j++) HS_ST(cb ^ 1, tid, j) = tmp[j];
-        __syncthreads();
-        cb ^= 1;
       }
+#pragma unroll
+      for (int j = 0; j < KE; j++)
+      {
+        const uint32_t before = (uint32_t)__shfl((int)wt[j], (int)(wave > 0u ? wave - 1u : 0u), 64);
+        tWaves[j] = (wave > 0u) ? before : (IDX_OLD | (uint32_t)j);
+        tAll[j] = (uint32_t)__shfl((int)wt[j], NT / 64 - 1, 64);
+      }
+    }
+    uint32_t tExcl[KS];                                                 // my wave's lanes in front of me (all lanes take part in the shuffle)
+#pragma unroll
+    for (int j = 0; j < KS; j++)
+    {
+      const uint32_t prevLane = (uint32_t)__shfl_up((int)tInc[j], 1, 64);
+      tExcl[j] = (lane == 0u) ? (IDX_OLD | (uint32_t)j) : prevLane;
     }
     if (valid)
     {
@@ -503,10 +538,12 @@ __global__ __launch_bounds__(kResolveThreads) void k_index_resolve(const uint32_
       outStart[r] = sCarryOut + wbase + xsum - v;
       if constexpr (KE > 0)
       {
-        uint32_t st[KS], carry[KS], excl[KS];
+        // the regions in front of mine: the batches before (carry), the waves before mine, my wave's lanes before me
+        uint32_t st[KS], carry[KS], upto[KS];
 #pragma unroll
-        for (int j = 0; j < KE; j++) { carry[j] = sCarryState[j]; excl[j] = (tid == 0) ? (IDX_OLD | (uint32_t)j) : HS_ST(cb, tid - 1, j); }
-        state_compose<KE>(st, carry, excl);
+        for (int j = 0; j < KE; j++) carry[j] = sCarryState[j];
+        state_compose<KE>(upto, carry, tWaves);
+        state_compose<KE>(st, upto, tExcl);
 #pragma unroll
         for (int j = 0; j < KE; j++) stateIn[(uint64_t)r * KE + j] = st[j];
       }
@@ -517,10 +554,10 @@ __global__ __launch_bounds__(kResolveThreads) void k_index_resolve(const uint32_
       sCarryOut += wall;
       if constexpr (KE > 0)
       {
-        uint32_t st[KS], carry[KS], all[KS];
+        uint32_t st[KS], carry[KS];
 #pragma unroll
-        for (int j = 0; j < KE; j++) { carry[j] = sCarryState[j]; all[j] = HS_ST(cb, NT - 1, j); }
-        state_compose<KE>(st, carry, all);
+        for (int j = 0; j < KE; j++) carry[j] = sCarryState[j];
+        state_compose<KE>(st, carry, tAll);
 #pragma unroll
         for (int j = 0; j < KE; j++) sCarryState[j] = st[j];
       }
