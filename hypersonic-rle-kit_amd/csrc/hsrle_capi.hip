@@ -944,7 +944,7 @@ struct MonoEncPlan
 static MonoEncPlan plan_mono_encode(uint32_t U)
 {
   MonoEncPlan m;
-  uint32_t G = 4096u;
+  uint32_t G = (U >= (256u << 20)) ? 8192u : 4096u;                        // (1 GiB: 8 KiB pieces 780 GiB/s, 4 KiB 720)
   if (g_monoTune[1] >= 32u && g_monoTune[1] <= (1u << 24)) G = g_monoTune[1];
   m.G = G;
   m.pieces = (uint32_t)(((uint64_t)U + G - 1u) / G);
