@@ -903,13 +903,16 @@ static int mono_decode_dev(const MonoHeader &mh, const uint8_t *dStream, uint8_t
 
 // the run length every state of the codec's encoder stores (SURVEY.md A.2 LONG / the Short family's SMINL); 0 = the codec is not cut
 // (move-to-front list, Single, 128 bit).  *pS / *pAligned: symbol bytes and sym-alignment of the codec.
-static uint32_t mono_cut_long(int codec, int *pS = nullptr, int *pAligned = nullptr)
+static uint32_t mono_cut_long(int codec, int *pS = nullptr, int *pAligned = nullptr, int *pListK = nullptr)
 {
-  int S = 1, al = 0;
+  int S = 1, al = 0, K = 0;
   uint32_t longc = 0;
+  static const int shortK[4] = { 0, 1, 3, 7 };
   if (codec == HSRLE_RLE8_MULTI) longc = 6u;                    // rle8_extreme_cpu.h:974: count >= 6 whatever the range
   else if (codec == HSRLE_RLE8_PACKED_MULTI) longc = 11u;       // :978 (body) and :122 (tail)
+  else if (codec == 2 || codec == 3) { longc = 11u; K = codec == 2 ? 3 : 7; }   // rle8 3 / 7 symbol LUT: rleX_Xsl.h:132 with S = 1
   else if (codec == HSRLE_RLE8_MULTI_SHORT) longc = 13u;        // rleX_Xsl_short.h: always stored from S + 12 on (0-symbol codec)
+  else if (codec > kShortBase8 && codec < kShortBase8 + 4) { longc = 12u; K = shortK[codec - kShortBase8]; }   // ... from S + 11 on with a list
   else
   {
     static const int widths[5] = { 2, 3, 4, 6, 8 };
@@ -921,6 +924,7 @@ static uint32_t mono_cut_long(int codec, int *pS = nullptr, int *pAligned = null
       if (k == 0 || k == 4) longc = (uint32_t)S + 11u;                                  // plain: rleX_extreme_cpu.h:10-11
       else if (k == 1) longc = (uint32_t)S + 10u;                                       // sym-aligned Packed: the hybrid of A.5 q10
       else if (k == 5) longc = (uint32_t)S + 11u;                                       // byte-aligned Packed
+      else { longc = (uint32_t)S + 10u; K = (k & 1) ? 7 : 3; }                          // LUT: rleX_Xsl.h:132
     }
     else if (codec >= kShortBaseW && codec < kGreedyBase)
     {
@@ -928,23 +932,31 @@ static uint32_t mono_cut_long(int codec, int *pS = nullptr, int *pAligned = null
       S = widths[(codec - kShortBaseW) >> 3];
       al = k < 4 ? 1 : 0;
       if (k == 0 || k == 4) longc = (uint32_t)S + 12u;                                  // 0-symbol Short codecs
+      else { longc = (uint32_t)S + 11u; K = shortK[k & 3]; }                            // 1 / 3 / 7 symbol Short codecs
     }
   }
   if (pS) *pS = S;
   if (pAligned) *pAligned = al;
+  if (pListK) *pListK = K;
   return longc;
 }
+
+constexpr uint32_t kMonoListRounds = 64u;     // repair rounds of the guessed move-to-front lists before the caller falls back to one lane
+static thread_local uint32_t g_monoEncLast[4] = { 0, 0, 0, 0 };   // this thread's last list-codec encode: extra rounds, chunks encoded again in rounds 1, 2, chunks the proof rejected (hsrle_mono_encode_stats)
 
 struct MonoEncPlan
 {
   uint32_t G, pieces;
   uint64_t offCutPos, offCutSym, offFlags, offIdx, offStarts, offSyms, offSlotOff, offSizes, offOffsets, offL1, offL2, offL3, offCtrl, offSlots, total;
+  uint64_t offGuess, offListOut, offRoll1, offRoll2;   // codecs with a move-to-front list: 8 words per chunk / per 64 / per 4096 chunks
 };
 
-static MonoEncPlan plan_mono_encode(uint32_t U)
+static MonoEncPlan plan_mono_encode(uint32_t U, bool lists = true)
 {
   MonoEncPlan m;
-  uint32_t G = (U >= (256u << 20)) ? 8192u : 4096u;                        // (1 GiB: 8 KiB pieces 780 GiB/s, 4 KiB 720)
+  // ~131 072 pieces (= lanes) keep the device busy: 1 GiB: 8 KiB pieces 780 GiB/s, 4 KiB 720; 256 MiB: 2 KiB 523, 4 KiB 321; 88 MB: 1 KiB 286, 2 KiB 224
+  uint32_t G = 1024u;
+  while (G < 8192u && ((uint64_t)U + G - 1u) / G > 131072ull) G *= 2u;
   if (g_monoTune[1] >= 32u && g_monoTune[1] <= (1u << 24)) G = g_monoTune[1];
   m.G = G;
   m.pieces = (uint32_t)(((uint64_t)U + G - 1u) / G);
@@ -964,6 +976,14 @@ static MonoEncPlan plan_mono_encode(uint32_t U)
   m.offL2 = at; at += align_up(8ull * (t2 + 1), 256);
   m.offL3 = at; at += align_up(8ull * (t3 + 1), 256);
   m.offCtrl = at; at += 256;
+  m.offGuess = m.offListOut = m.offRoll1 = m.offRoll2 = at;
+  if (lists)
+  {
+    m.offGuess = at; at += align_up(64ull * (n + 1), 256);
+    m.offListOut = at; at += align_up(64ull * (n + 1), 256);
+    m.offRoll1 = at; at += align_up(64ull * ((n + 1) / 64 + 1), 256);
+    m.offRoll2 = at; at += align_up(64ull * ((n + 1) / 4096 + 1), 256);
+  }
   m.offSlots = at; at += align_up((uint64_t)U + ((uint64_t)U >> 7) + 256ull * (n + 2) + 4096ull, 256);
   m.total = at;
   return m;
@@ -973,8 +993,8 @@ static MonoEncPlan plan_mono_encode(uint32_t U)
 static int mono_encode_dev(int codec, const uint8_t *dIn, uint32_t U, uint8_t *dOut, uint8_t *ws, const MonoEncPlan &m, uint32_t *pSize, uint32_t *pChunks, hipStream_t st)
 {
   init_tables();
-  int S = 1, aligned = 0;
-  const uint32_t longc = mono_cut_long(codec, &S, &aligned);
+  int S = 1, aligned = 0, listK = 0;
+  const uint32_t longc = mono_cut_long(codec, &S, &aligned, &listK);
   if (!g_menc[codec] || longc == 0u)
     return HSRLE_ERR_UNSUPPORTED;
   const uint32_t hs = codec_header_size(codec);
@@ -1016,7 +1036,67 @@ static int mono_encode_dev(int codec, const uint8_t *dIn, uint32_t U, uint8_t *d
 
   EncodeArgs ea{ dIn, (uint64_t)U, 0u, chunks, ws + m.offSlots, 0u, sizes };
   MonoEncodeArgs ma{ starts, syms, slotOff, 2u * (longest / 64u) + 64u };
-  if (g_menc[codec](ea, ma, st) != hipSuccess || scan_sizes(sizes, chunks, offsets, ws, w, st) != hipSuccess)
+  if (listK == 0)
+  {
+    if (g_menc[codec](ea, ma, st) != hipSuccess)
+      return HSRLE_ERR_DEVICE;
+  }
+  else
+  {
+    // move-to-front list: dry pass -> guessed lists -> encode -> verify, repeat for the chunks whose guess was wrong (hsrle_mono_encode.hip.h)
+    uint64_t *guess = (uint64_t *)(ws + m.offGuess), *listOut = (uint64_t *)(ws + m.offListOut), *roll1 = (uint64_t *)(ws + m.offRoll1), *roll2 = (uint64_t *)(ws + m.offRoll2);
+    const uint32_t n1 = (chunks + 63u) / 64u, n2 = (n1 + 63u) / 64u;
+    ma.syms = guess; ma.listOut = listOut;
+    hipLaunchKernelGGL(k_mono_list_default, dim3((chunks + 255u) / 256u), dim3(256), 0, st, chunks, (uint32_t)listK, (uint32_t)S, guess);
+    ma.dry = 1u;
+    if (g_menc[codec](ea, ma, st) != hipSuccess)
+      return HSRLE_ERR_DEVICE;
+    ma.dry = 0u;
+    uint32_t rounds = 0;
+    g_monoEncLast[0] = g_monoEncLast[1] = g_monoEncLast[2] = g_monoEncLast[3] = 0u;
+    for (;; rounds++)
+    {
+      // lists from what the chunks did in the last pass; chunks whose list changed (first time: all) are encoded from it
+      if (rounds > kMonoListRounds)
+        return HSRLE_ERR_UNSUPPORTED;                                    // (callers fall back to one lane)
+      if (hipMemsetAsync(ctrl + 4, 0, 4, st) != hipSuccess)
+        return HSRLE_ERR_DEVICE;
+      hipLaunchKernelGGL(k_mono_list_tiles, dim3((n1 + 63u) / 64u), dim3(64), 0, st, (const uint64_t *)listOut, chunks, (uint32_t)listK, roll1);
+      hipLaunchKernelGGL(k_mono_list_tiles, dim3((n2 + 63u) / 64u), dim3(64), 0, st, (const uint64_t *)roll1, n1, (uint32_t)listK, roll2);
+      hipLaunchKernelGGL(k_mono_list_guess, dim3((chunks + 63u) / 64u), dim3(64), 0, st, (const uint64_t *)listOut, (const uint64_t *)roll1, (const uint64_t *)roll2, chunks,
+                         (uint32_t)listK, (uint32_t)S, guess, rounds == 0u ? 1u : 0u, ctrl + 4);
+      if (rounds > 0u)
+      {
+        uint32_t todo = 0;
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&todo, ctrl + 4, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+          return HSRLE_ERR_DEVICE;
+        g_monoEncLast[0] = rounds - 1u;
+        if (rounds <= 2u) g_monoEncLast[rounds] = todo;
+        if (todo == 0u)
+          break;
+      }
+      if (g_menc[codec](ea, ma, st) != hipSuccess)
+        return HSRLE_ERR_DEVICE;
+    }
+    for (;; rounds++)
+    {
+      // the proof (and, should the fixed point above not be one, the repair)
+      if (hipMemsetAsync(ctrl + 4, 0, 4, st) != hipSuccess)
+        return HSRLE_ERR_DEVICE;
+      hipLaunchKernelGGL(k_mono_list_verify, dim3((chunks + 255u) / 256u), dim3(256), 0, st, guess, (const uint64_t *)listOut, chunks, (uint32_t)listK, ctrl + 4);
+      uint32_t bad = 0;
+      if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&bad, ctrl + 4, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return HSRLE_ERR_DEVICE;
+      g_monoEncLast[3] += bad;
+      if (bad == 0u)
+        break;
+      if (rounds > kMonoListRounds)
+        return HSRLE_ERR_UNSUPPORTED;
+      if (g_menc[codec](ea, ma, st) != hipSuccess)
+        return HSRLE_ERR_DEVICE;
+    }
+  }
+  if (scan_sizes(sizes, chunks, offsets, ws, w, st) != hipSuccess)
     return HSRLE_ERR_DEVICE;
   hipLaunchKernelGGL(k_compact_var, dim3((chunks + 3u) / 4u), dim3(256), 0, st, (const uint8_t *)(ws + m.offSlots), (const uint64_t *)slotOff, (const uint64_t *)offsets, dOut + hs, chunks);
   hipLaunchKernelGGL(k_mono_finish, dim3(1), dim3(64), 0, st, dOut, U, hs, (const uint64_t *)offsets, (const uint32_t *)ctrl, ctrl);
@@ -1063,11 +1143,15 @@ static uint32_t mono_compress(int codec, const uint8_t *pIn, uint32_t inSize, ui
       if (hipMemcpy(D.monoIn, pIn, inSize, hipMemcpyHostToDevice) != hipSuccess)
         return 0;
       uint32_t size = 0;
-      if (mono_encode_dev(codec, (const uint8_t *)D.monoIn, inSize, (uint8_t *)D.monoOut, (uint8_t *)D.monoWs, m, &size, nullptr, nullptr) != HSRLE_OK || size == 0 || size > outSize)
+      const int rc = mono_encode_dev(codec, (const uint8_t *)D.monoIn, inSize, (uint8_t *)D.monoOut, (uint8_t *)D.monoWs, m, &size, nullptr, nullptr);
+      if (rc == HSRLE_OK)
+      {
+        if (size == 0 || size > outSize || hipMemcpy(pOut, D.monoOut, size, hipMemcpyDeviceToHost) != hipSuccess)
+          return 0;
+        return size;
+      }
+      if (rc != HSRLE_ERR_UNSUPPORTED)                                   // (UNSUPPORTED: the list guesses did not settle -- one lane, below)
         return 0;
-      if (hipMemcpy(pOut, D.monoOut, size, hipMemcpyDeviceToHost) != hipSuccess)
-        return 0;
-      return size;
     }
   }
   if (!D.monoAux && hipMalloc(&D.monoAux, 256) != hipSuccess)
@@ -1581,6 +1665,11 @@ int hsrle_decompress_host(const void *pContainer, uint64_t containerSize, void *
 void hsrle_mono_tuning(uint32_t blockSize, uint32_t regionSize, uint32_t lookBack)
 {
   g_monoTune[0] = blockSize; g_monoTune[1] = regionSize; g_monoTune[2] = lookBack;
+}
+
+void hsrle_mono_encode_stats(uint32_t stats[4])
+{
+  for (int k = 0; k < 4; k++) stats[k] = g_monoEncLast[k];
 }
 
 uint64_t hsrle_compress_mono_workspace_size(int codec, uint32_t inSize)

@@ -29,15 +29,18 @@ namespace hsrle {
 // chunks before it -- lastRLE = the boundary, lastSymbol = that run's symbol (monoSyms) -- and the chunk's packets are exactly the
 // packets the sequential encoder writes for these bytes.  A chunk writes no stream header and (unless it reaches the end of the input)
 // no terminator, its rules see the TRUE end of the input (the AVX2 body / tail split of A.5 q1 counts from there), and its output goes
-// to slots + monoSlotOff[c].  Families without a move-to-front list only (the list behind a boundary is not known).
+// to slots + monoSlotOff[c].
 template <int FAM, bool MONO = false>
 __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t nBlocks,
                                                        uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes,
                                                        const uint64_t *__restrict__ monoStarts, const uint64_t *__restrict__ monoSyms,
-                                                       const uint64_t *__restrict__ monoSlotOff, uint32_t monoSteps)
+                                                       const uint64_t *__restrict__ monoSlotOff, uint32_t monoSteps, uint64_t *__restrict__ monoListOut, uint32_t monoDry)
 {
   using TR = Traits<FAM, 1, 0>;
-  static_assert(!MONO || !TR::kMtf, "a monolithic stream is cut only for codecs whose state behind a long run is known");
+  // Codecs with a move-to-front list: the list in front of a chunk is NOT known from the boundary run; the host hands every chunk a list
+  // (monoSyms[8 * c + k]: entry k; [8 * c + 7]: encode this chunk?), gets the list behind it back (monoListOut[8 * c + k]; [.. + 7]: mtfDepth) and repeats the chunks whose
+  // incoming list was not what the chunk in front left behind (hsrle_capi.hip: mono_encode_dev).  monoDry: no stores, only the list.
+  [[maybe_unused]] const bool dry = MONO && monoDry != 0u;
   constexpr int Q = 64;                      // input bytes per lane and step
 #ifndef HSRLE_ENC8_RING
 #define HSRLE_ENC8_RING 256
@@ -66,7 +69,8 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
   const uint32_t lane = threadIdx.x;
   const uint32_t wgFirst = xcd_tile(blockIdx.x, gridDim.x) * 64u;    // XCD-aware tile order (hsrle_common.hip.h)
   const uint32_t b = wgFirst + lane;
-  const bool active = b < nBlocks;
+  bool active = b < nBlocks;
+  if constexpr (MONO && Traits<FAM, 1, 0>::kMtf) { if (active) active = monoSyms[8ull * b + 7] != 0ull; }   // the host's repair rounds switch most chunks off
 
   // ring byte x of row r lives at hist[(r * H) ^ hsw(r) ^ (x & HM)]: chunks XOR-swizzled by the row index (bank spread without pad)
   auto hsw_of = [](uint32_t r) -> uint32_t { return (r & 7u) << 4; };
@@ -98,8 +102,20 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
   bool inRun = false;
   uint32_t runStart = 0, sym = 0;
   uint32_t lastRLE = 0;
-  uint32_t lastSym = (MONO && active) ? (uint32_t)(monoSyms[b] & 0xFFull) : 0u;      // Packed: lastSymbol (starts 0, A.5 q5)
+  uint32_t lastSym = (MONO && active && !TR::kMtf) ? (uint32_t)(monoSyms[b] & 0xFFull) : 0u;      // Packed: lastSymbol (starts 0, A.5 q5)
   [[maybe_unused]] uint64_t lutw = (K == 3) ? 0x0000000000FF7F00ull : 0x00FE807E01FF7F00ull; // LUT: MTF list, entry k in byte k
+  // MONO: how many leading list entries were put there by runs of this chunk (the rest is what the chunk was handed, in its order): the
+  // list behind a chunk as a function of the list in front of it, as far as the chunk's own decisions did not depend on it
+  [[maybe_unused]] uint32_t mtfDepth = 0;
+  if constexpr (MONO && TR::kMtf)
+  {
+    if (active)
+    {
+      lutw = 0ull;
+#pragma unroll
+      for (int j = 0; j < K; j++) lutw |= (monoSyms[8ull * b + j] & 0xFFull) << (8 * j);
+    }
+  }
   bool ended = false;        // the end terminator has been written
   bool finished = !active;   // the whole stream is in the slot
   uint64_t winStarts = 0;    // current window: run-start bits
@@ -116,7 +132,7 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
     const u32x4 w = HS_EMERGE(oacc, lowp, c);
     if (c + nb >= 16u)
     {
-      st128(slot + (opos & ~15u), w);
+      if (!dry) st128(slot + (opos & ~15u), w);
       oacc = (c == 0u) ? zero4 : funnel16(hv, zero4, 16u - c);          // hv >> (16 - c) bytes
     }
     else
@@ -165,7 +181,7 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
       uint32_t k = 0;
       while (k + 16u <= total)
       {
-        st128(dst + k, w);
+        if (!dry) st128(dst + k, w);
         k += 16u;
         if (k < total) w = ring_win(srcp + k);
       }
@@ -177,7 +193,7 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
       uint32_t k = 0;
       while (k + 16u <= total)
       {
-        st128(dst + k, w);
+        if (!dry) st128(dst + k, w);
         k += 16u;
         if (k < total) w = global_window16(in, blockAt, U, srcp + k);
       }
@@ -350,6 +366,7 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
         const uint64_t keepHi = lutw & ~((1ull << (8u * (limit + 1u))) - 1ull);
         const uint64_t low = lutw & ((1ull << (8u * limit)) - 1ull);
         lutw = keepHi | (low << 8) | (uint64_t)sym;
+        if (m >= mtfDepth && mtfDepth < (uint32_t)K) mtfDepth++;
       }
       const uint32_t mi = (K > 0) ? m << (TR::SCB + TR::SRBP) : 0u;
       if (pack1)
@@ -373,6 +390,7 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
       const uint64_t keepHi = lutw & ~((1ull << (8u * (limit + 1u))) - 1ull);
       const uint64_t low = lutw & ((1ull << (8u * limit)) - 1ull);
       lutw = keepHi | (low << 8) | (uint64_t)sym;
+      if (m >= mtfDepth && mtfDepth < (uint32_t)K) mtfDepth++;
       h16((m << (K == 3 ? 14 : 13)) | (c7 << TR::RB) | r7);
       if (m == (uint32_t)K) hb(sym);
       if (cst != c7) { if (cst <= 0xFFFFu) h16(cst); else h32(cst); }
@@ -506,10 +524,16 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
         if (inRun) { handle_run(runStart, n); inRun = false; }
         if (!ended && n == nTrue) { finish_literals(); ended = true; }      // (a MONO chunk that does not reach the end of the input ends with its boundary run's packet)
         // the last partial chunk, then the stream size (header field compressedLength and the size table)
-        if ((opos & 15u) != 0u)
+        if ((opos & 15u) != 0u && !dry)
           st128(slot + (opos & ~15u), oacc);
         if constexpr (!MONO) st32(slot + 4, opos);
-        sizes[b] = opos;
+        if (!dry) sizes[b] = opos;
+        if constexpr (MONO && TR::kMtf)
+        {
+#pragma unroll
+          for (int j = 0; j < K; j++) monoListOut[8ull * b + j] = (lutw >> (8 * j)) & 0xFFull;
+          monoListOut[8ull * b + 7] = mtfDepth;
+        }
         finished = true;
       }
     }

@@ -27,9 +27,11 @@ template <int FAM, int S, int AL, bool MONO = false>
 __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t nBlocks,
                                                        uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes,
                                                        const uint64_t *__restrict__ monoStarts, const uint64_t *__restrict__ monoSyms,
-                                                       const uint64_t *__restrict__ monoSlotOff, uint32_t monoSteps)
+                                                       const uint64_t *__restrict__ monoSlotOff, uint32_t monoSteps, uint64_t *__restrict__ monoListOut, uint32_t monoDry)
 {
-  static_assert(!MONO || !Traits<FAM, S, AL>::kMtf, "a monolithic stream is cut only for codecs whose state behind a long run is known");
+  // (codecs with a move-to-front list: monoSyms[8 * c + k] = entry k of the list in front of chunk c, monoListOut likewise the list behind it;
+  //  monoDry: no stores, only the list -- see k_encode8_blocks)
+  [[maybe_unused]] const bool dry = MONO && monoDry != 0u;
   using TR = Traits<FAM, S, AL>;
   static_assert(S == 2 || S == 3 || S == 4 || S == 6 || S == 8, "8 bit and 128 bit symbols have their own kernels");
   static_assert(FAM == PLAIN || FAM == PACKED || FAM == LUT3 || FAM == LUT7 || (FAM >= SHORT0 && FAM <= SHORT7), "multi-symbol families only");
@@ -59,7 +61,8 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
   const uint32_t lane = threadIdx.x;
   const uint32_t wgFirst = xcd_tile(blockIdx.x, gridDim.x) * 64u;    // XCD-aware tile order (hsrle_common.hip.h)
   const uint32_t b = wgFirst + lane;
-  const bool active = b < nBlocks;
+  bool active = b < nBlocks;
+  if constexpr (MONO && Traits<FAM, S, AL>::kMtf) { if (active) active = monoSyms[8ull * b + 7] != 0ull; }   // repair rounds switch most chunks off
 
   // ring byte x of row r lives at hist[(r * H) ^ hsw(r) ^ (x & HM)]: chunks XOR-swizzled by the row index (bank spread without pad)
   auto hsw_of = [](uint32_t r) -> uint32_t { return (r & 7u) << 4; };
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
   uint32_t sy0 = 0, sy1 = 0; // the symbol at sStart (low S bytes)
   uint32_t lastRLE = 0;
   [[maybe_unused]] uint32_t la0 = 0, la1 = 0;  // Packed: last emitted symbol (starts as zeros)
-  if constexpr (MONO) { if (active) { const uint64_t v = monoSyms[b]; la0 = (uint32_t)v; la1 = (uint32_t)(v >> 32); } }
+  if constexpr (MONO && !Traits<FAM, S, AL>::kMtf) { if (active) { const uint64_t v = monoSyms[b]; la0 = (uint32_t)v; la1 = (uint32_t)(v >> 32); } }
   bool ended = false;        // the end terminator has been written
   bool finished = !active;   // the whole stream is in the slot
 
@@ -111,6 +114,16 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
     }
   }
 
+  [[maybe_unused]] uint32_t mtfDepth = 0;   // MONO: leading list entries that came from runs of this chunk (see k_encode8_blocks)
+  if constexpr (MONO && TR::kMtf)
+  {
+    if (active)
+    {
+#pragma unroll
+      for (int k = 0; k < K; k++) { const uint64_t v = monoSyms[8ull * b + k]; lut0[k] = (uint32_t)v; lut1[k] = (uint32_t)(v >> 32); }
+    }
+  }
+
   // ---- output: 16-byte accumulator + stream position; completed chunks go to the slot ----
   const u32x4 zero4 = u32x4{ 0, 0, 0, 0 };
   u32x4 oacc = zero4;        // the chunk that contains stream position opos (its low opos & 15 bytes are valid)
@@ -123,7 +136,7 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
     const u32x4 w = HS_SMERGE(oacc, lowp, c);
     if (c + nb >= 16u)
     {
-      st128(slot + (opos & ~15u), w);
+      if (!dry) st128(slot + (opos & ~15u), w);
       oacc = (c == 0u) ? zero4 : funnel16(hv, zero4, 16u - c);          // hv >> (16 - c) bytes
     }
     else
@@ -175,7 +188,7 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
       uint32_t k = 0;
       while (k + 16u <= total)
       {
-        st128(dst + k, w);
+        if (!dry) st128(dst + k, w);
         k += 16u;
         if (k < total) w = ring_win(srcp + k);
       }
@@ -187,7 +200,7 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
       uint32_t k = 0;
       while (k + 16u <= total)
       {
-        st128(dst + k, w);
+        if (!dry) st128(dst + k, w);
         k += 16u;
         if (k < total) w = global_window16(in, blockAt, U, srcp + k);
       }
@@ -310,6 +323,7 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
         for (int k = K - 1; k >= 1; k--)
           if ((uint32_t)k <= limit) { lut0[k] = lut0[k - 1]; lut1[k] = lut1[k - 1]; }
         lut0[0] = s0; lut1[0] = s1;
+        if (m >= mtfDepth && mtfDepth < (uint32_t)K) mtfDepth++;
       }
 
       const uint32_t mi = (K > 0) ? m << (TR::SCB + TR::SRBP) : 0u;
@@ -351,6 +365,7 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
       for (int k = K - 1; k >= 1; k--)
         if ((uint32_t)k <= limit) { lut0[k] = lut0[k - 1]; lut1[k] = lut1[k - 1]; }
       lut0[0] = s0; lut1[0] = s1;
+      if (m >= mtfDepth && mtfDepth < (uint32_t)K) mtfDepth++;
 
       const uint32_t c7 = (c <= MAXC) ? c : (c <= 0xFFFFu ? 1u : 0u);
       const uint32_t r7 = (range <= MAXR) ? range : (range <= 0xFFFFu ? 1u : 0u);
@@ -532,10 +547,16 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
         // end of input: the literal terminator unless the stream ended with a run
         if (!ended && n == nTrue) { finish_literals(); ended = true; }
         // the last partial chunk, then the stream size (header field compressedLength and the size table)
-        if ((opos & 15u) != 0u)
+        if ((opos & 15u) != 0u && !dry)
           st128(slot + (opos & ~15u), oacc);
         if constexpr (!MONO) st32(slot + 4, opos);
-        sizes[b] = opos;
+        if (!dry) sizes[b] = opos;
+        if constexpr (MONO && TR::kMtf)
+        {
+#pragma unroll
+          for (int k = 0; k < K; k++) monoListOut[8ull * b + k] = (uint64_t)lut0[k] | ((uint64_t)lut1[k] << 32);
+          monoListOut[8ull * b + 7] = mtfDepth;
+        }
         finished = true;
       }
     }

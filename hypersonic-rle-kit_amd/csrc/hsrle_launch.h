@@ -52,6 +52,7 @@ struct EncodeArgs
 struct MonoEncodeArgs
 {
   const uint64_t *starts; const uint64_t *syms; const uint64_t *slotOff; uint32_t steps;
+  uint64_t *listOut = nullptr; uint32_t dry = 0;     // codecs with a move-to-front list: syms / listOut hold 8 words per chunk
 };
 typedef hipError_t (*MonoEncodeLaunch)(const EncodeArgs &, const MonoEncodeArgs &, hipStream_t);
 // wave-per-block encoder (hsrle_encode8w.hip.h): writes offsets and payload of the container directly
@@ -117,9 +118,9 @@ inline hipError_t launch_encode(KERNEL k, const EncodeArgs &a, hipStream_t st, i
   static const uint32_t lds8 = [] { const char *e = getenv("HSRLE_ENCODE8_LDS"); return e ? (uint32_t)atoi(e) : 0u; }();   // experiment knob
   if (a.residentWorkgroups != nullptr)
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(a.residentWorkgroups, k, 64, capResidency ? ldsCap : lds8);
-  if constexpr (kernel_arity(KERNEL{}) == 11)   // kernels with a MONO mode (hsrle_encode8.hip.h): block mode = no chunk table
+  if constexpr (kernel_arity(KERNEL{}) == 13)   // kernels with a MONO mode (hsrle_encode8.hip.h): block mode = no chunk table
     hipLaunchKernelGGL(k, dim3(grid), dim3(64), capResidency ? ldsCap : lds8, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, (const uint64_t *)nullptr,
-                       (const uint64_t *)nullptr, (const uint64_t *)nullptr, 0u);
+                       (const uint64_t *)nullptr, (const uint64_t *)nullptr, 0u, (uint64_t *)nullptr, 0u);
   else
     hipLaunchKernelGGL(k, dim3(grid), dim3(64), capResidency ? ldsCap : lds8, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes);
   return hipGetLastError();
@@ -148,7 +149,7 @@ inline hipError_t launch_wave_encode(KERNEL k, const WaveEncodeArgs &a, hipStrea
 template <typename KERNEL>
 inline hipError_t launch_mono_encode(KERNEL k, const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st)
 {
-  hipLaunchKernelGGL(k, dim3((a.nBlocks + 63u) / 64u), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, m.starts, m.syms, m.slotOff, m.steps);
+  hipLaunchKernelGGL(k, dim3((a.nBlocks + 63u) / 64u), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, m.starts, m.syms, m.slotOff, m.steps, m.listOut, m.dry);
   return hipGetLastError();
 }
 

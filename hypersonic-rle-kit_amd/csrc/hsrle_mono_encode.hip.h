@@ -5,7 +5,7 @@
 // src/rleX_extreme_cpu_encode.h:174-311).  But a run of LONG bytes or more is stored WHATEVER the state is, and
 // behind it the state is fully known: lastRLE = its end, lastSymbol = its symbol.  So the input can be cut behind such runs and every
 // piece encoded on its own -- by the block kernels in their MONO mode (hsrle_encode8.hip.h) -- into exactly the packets the sequential
-// encoder writes for it.  Codecs with a move-to-front list are not cut (the list behind a long run is not known from the run alone).
+// encoder writes for it.  Codecs with a move-to-front list: the list in front of a chunk is guessed, checked and repaired (below).
 //
 //   k_mono_cuts     one lane per nominal piece of G input bytes: the first maximal run of >= LONG equal symbols that ENDS inside the
 //                   piece (the lane looks LONG bytes back, so a run that began in an earlier piece is seen long enough)
@@ -175,6 +175,124 @@ __global__ __launch_bounds__(256) void k_mono_longest(const uint64_t *__restrict
     m = y > m ? y : m;
   }
   if ((threadIdx.x & 63u) == 0u && m != 0u) atomicMax(ctrl + 1, m);
+}
+
+// ---- codecs with a move-to-front list (LUT3 / LUT7, Short1 / 3 / 7) -------------------------------------------------------------
+// A run of >= LONG bytes fixes lastRLE, not the list: the list in front of a chunk is whatever the runs stored before it left.  A
+// move-to-front list is an LRU stack, so what a chunk does to it is "these d symbols (most recent first) now lead, the older entries
+// follow in their order" -- IF the chunk stores the same runs whatever list it is handed, which is nearly always so (the list only
+// enters the decision through a penalty of one symbol's worth of bytes for an absent symbol).  So:
+//   1. every chunk is walked DRY (no stores) from the default list: its d leading symbols (k_encode*_blocks<.., MONO>, mtfDepth)
+//   2. k_mono_list_tiles x 2 + k_mono_list_guess: the lists in front of all chunks by composing those (64 / 4096 chunk roll-ups)
+//   3. every chunk is encoded from its guessed list and reports the list it ends with and its d -- now from (nearly) the right list
+//   4. 2 again with those: chunks whose list comes out different are encoded again (3, they only), until no list changes.  A change
+//      travels any distance in one round as long as the chunks in between keep their decisions.
+//   5. k_mono_list_verify, the proof: is every chunk's list the one its predecessor ended with?  Chunk 0's is (the default list), so
+//      if all agree the stream is the sequential encoder's by induction.  (A fixed point of 4 passes; chunks that fail would get the
+//      right list and go through 3 again.)
+// Lists are 8 words per chunk: entry k (the symbol, S bytes, zero-extended) in word k, word 7 = d (results) / "encode me" (guesses).
+
+__device__ __forceinline__ uint64_t mono_default_entry(uint32_t k, uint32_t S)
+{
+  // 0x00, 0x7F, 0xFF, 0x01, 0x7E, 0x80, 0xFE in every symbol byte (rleX_Xsl.h: the initial list)
+  const uint64_t b = (0xFE807E01FF7F00ull >> (8u * k)) & 0xFFull;
+  const uint64_t all = b * 0x0101010101010101ull;
+  return (S >= 8u) ? all : (all & ((1ull << (8u * S)) - 1ull));
+}
+
+// newest-first accumulation of at most K distinct symbols
+struct MonoListAcc
+{
+  uint64_t e[7];
+  uint32_t n;
+  __device__ __forceinline__ void add_one(uint64_t v, uint32_t K)
+  {
+    bool have = false;
+#pragma unroll
+    for (int k = 0; k < 7; k++) have = have || ((uint32_t)k < n && e[k] == v);
+    if (!have && n < K)
+    {
+#pragma unroll
+      for (int k = 0; k < 7; k++) if ((uint32_t)k == n) e[k] = v;
+      n++;
+    }
+  }
+  __device__ __forceinline__ void add(const uint64_t *__restrict__ t, uint32_t K)
+  {
+    const uint32_t d = (uint32_t)t[7];
+#pragma unroll
+    for (int j = 0; j < 7; j++)
+      if ((uint32_t)j < d && n < K) add_one(t[j], K);
+  }
+};
+
+// roll-ups: out[t] = the transformers src[64 t .. 64 t + 63] composed (one lane each)
+__global__ __launch_bounds__(64) void k_mono_list_tiles(const uint64_t *__restrict__ src, uint32_t count, uint32_t K, uint64_t *__restrict__ out)
+{
+  const uint32_t t = blockIdx.x * 64u + threadIdx.x;
+  const uint32_t first = t * 64u;
+  if (first >= count) return;
+  const uint32_t last = (first + 64u < count) ? first + 64u : count;
+  MonoListAcc a; a.n = 0;
+#pragma unroll
+  for (int k = 0; k < 7; k++) a.e[k] = 0;
+  for (uint32_t i = last; i > first && a.n < K; i--) a.add(src + 8ull * (i - 1u), K);
+#pragma unroll
+  for (int k = 0; k < 7; k++) out[8ull * t + k] = a.e[k];
+  out[8ull * t + 7] = a.n;
+}
+
+// guess[c] = the list behind chunks 0 .. c - 1 applied to the default list; word 7 = 1 (encode) if that is not the list the chunk was
+// last encoded from (or `force`), *todo counts those
+__global__ __launch_bounds__(64) void k_mono_list_guess(const uint64_t *__restrict__ t0, const uint64_t *__restrict__ t1, const uint64_t *__restrict__ t2, uint32_t chunks, uint32_t K,
+                                                        uint32_t S, uint64_t *__restrict__ guess, uint32_t force, uint32_t *__restrict__ todo)
+{
+  const uint32_t c = blockIdx.x * 64u + threadIdx.x;
+  if (c >= chunks) return;
+  MonoListAcc a; a.n = 0;
+#pragma unroll
+  for (int k = 0; k < 7; k++) a.e[k] = 0;
+  for (uint32_t i = c; i > (c & ~63u) && a.n < K; i--) a.add(t0 + 8ull * (i - 1u), K);
+  const uint32_t t = c >> 6;
+  for (uint32_t i = t; i > (t & ~63u) && a.n < K; i--) a.add(t1 + 8ull * (i - 1u), K);
+  for (uint32_t i = t >> 6; i > 0u && a.n < K; i--) a.add(t2 + 8ull * (i - 1u), K);
+  for (uint32_t k = 0; k < K && a.n < K; k++) a.add_one(mono_default_entry(k, S), K);
+  bool changed = force != 0u;
+#pragma unroll
+  for (int k = 0; k < 7; k++)
+    if ((uint32_t)k < K && guess[8ull * c + k] != a.e[k]) { changed = true; guess[8ull * c + k] = a.e[k]; }
+  guess[8ull * c + 7] = changed ? 1ull : 0ull;
+  if (changed) atomicAdd(todo, 1u);
+}
+
+// all chunks start from the default list (the dry pass)
+__global__ __launch_bounds__(256) void k_mono_list_default(uint32_t chunks, uint32_t K, uint32_t S, uint64_t *__restrict__ guess)
+{
+  const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+  if (c >= chunks) return;
+#pragma unroll
+  for (int k = 0; k < 7; k++) guess[8ull * c + k] = ((uint32_t)k < K) ? mono_default_entry((uint32_t)k, S) : 0ull;
+  guess[8ull * c + 7] = 1ull;
+}
+
+// chunk c's guess against the list chunk c - 1 ended with; wrong ones are corrected and marked for another pass; *bad counts them
+__global__ __launch_bounds__(256) void k_mono_list_verify(uint64_t *__restrict__ guess, const uint64_t *__restrict__ listOut, uint32_t chunks, uint32_t K, uint32_t *__restrict__ bad)
+{
+  const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+  if (c >= chunks) return;
+  bool wrong = false;
+  if (c > 0u)
+  {
+#pragma unroll
+    for (int k = 0; k < 7; k++)
+      if ((uint32_t)k < K)
+      {
+        const uint64_t want = listOut[8ull * (c - 1u) + k];
+        if (guess[8ull * c + k] != want) { wrong = true; guess[8ull * c + k] = want; }
+      }
+  }
+  guess[8ull * c + 7] = wrong ? 1ull : 0ull;
+  if (wrong) atomicAdd(bad, 1u);
 }
 
 // one wave per chunk: staging slot -> dst + offsets[c]

@@ -64,6 +64,11 @@ static hipError_t sub_short_single(const DecodeArgs &a, uint32_t SB, uint32_t *r
 static hipError_t menc_plain(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode(k_encode8_blocks<PLAIN, true>, a, m, st); }
 static hipError_t menc_packed(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode(k_encode8_blocks<PACKED, true>, a, m, st); }
 static hipError_t menc_short0(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode(k_encode8_blocks<SHORT0, true>, a, m, st); }
+static hipError_t menc_lut3(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode(k_encode8_blocks<LUT3, true>, a, m, st); }
+static hipError_t menc_lut7(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode(k_encode8_blocks<LUT7, true>, a, m, st); }
+static hipError_t menc_short1(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode(k_encode8_blocks<SHORT1, true>, a, m, st); }
+static hipError_t menc_short3(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode(k_encode8_blocks<SHORT3, true>, a, m, st); }
+static hipError_t menc_short7(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode(k_encode8_blocks<SHORT7, true>, a, m, st); }
 
 static hipError_t wenc_plain(const WaveEncodeArgs &a, hipStream_t st) { return launch_wave_encode(k_encode8_wave<PLAIN>, a, st); }
 static hipError_t wenc_packed(const WaveEncodeArgs &a, hipStream_t st) { return launch_wave_encode(k_encode8_wave<PACKED>, a, st); }
@@ -72,6 +77,7 @@ void register_w8(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBloc
 {
   wenc[0] = wenc_plain; wenc[1] = wenc_packed;
   menc[0] = menc_plain; menc[1] = menc_packed; menc[kShortBase8 + 0] = menc_short0;
+  menc[2] = menc_lut3; menc[3] = menc_lut7; menc[kShortBase8 + 1] = menc_short1; menc[kShortBase8 + 2] = menc_short3; menc[kShortBase8 + 3] = menc_short7;
   sub[0] = sub_plain; sub[1] = sub_packed; sub[2] = sub_lut3; sub[3] = sub_lut7; sub[4] = sub_plain_any; sub[5] = sub_packed_any;
   sub[kShortBase8 + 0] = sub_short0; sub[kShortBase8 + 1] = sub_short1; sub[kShortBase8 + 2] = sub_short3; sub[kShortBase8 + 3] = sub_short7;
   sub[kSingleShort] = sub_short_single;

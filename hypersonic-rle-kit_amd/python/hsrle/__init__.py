@@ -112,6 +112,8 @@ def _lib():
     L.hsrle_compress_mono_dev.argtypes = [ci, vp, u32, vp, u64, vp, u64, ctypes.POINTER(u32), ctypes.POINTER(u32), vp]
     L.hsrle_mono_tuning.restype = None
     L.hsrle_mono_tuning.argtypes = [u32, u32, u32]
+    L.hsrle_mono_encode_stats.restype = None
+    L.hsrle_mono_encode_stats.argtypes = [ctypes.POINTER(u32)]
     L.hsrle_split_sub_block_size.restype = u32
     L.hsrle_split_sub_block_size.argtypes = [ctypes.POINTER(ContainerInfo), u32]
     L.hsrle_decompress_split_workspace_size.restype = u64
@@ -198,8 +200,8 @@ def mono_tuning(block=0, region=0, lookback=0):
 
 
 def mono_compress_dev(codec, src, dst=None, workspace=None, return_chunks=False):
-    """ONE monolithic reference stream of the CUDA uint8 tensor `src`, written by many lanes (hsrle_compress_mono_dev; the codecs
-    whose encoder state is known behind a long run: rle8_multi, rle8_packed_multi, rle8_multi_short).  Returns the stream tensor."""
+    """ONE monolithic reference stream of the CUDA uint8 tensor `src`, written by many lanes (hsrle_compress_mono_dev; the multi-symbol
+    codecs of 8 .. 64 bit symbols: not Single, 128 bit, Greedy).  Returns the stream tensor."""
     import torch
 
     _check_u8_cuda(src, "src")
@@ -218,6 +220,13 @@ def mono_compress_dev(codec, src, dst=None, workspace=None, return_chunks=False)
     if rc != OK:
         raise HsrleError(rc, "hsrle_compress_mono_dev")
     return (dst[: size.value], chunks.value) if return_chunks else dst[: size.value]
+
+
+def mono_encode_stats():
+    """Of this thread's last monolithic encode with a move-to-front-list codec: (repair rounds, wrong list guesses in round 0, 1, later)."""
+    stats = (ctypes.c_uint32 * 4)()
+    _lib().hsrle_mono_encode_stats(stats)
+    return tuple(int(v) for v in stats)
 
 
 def mono_decompress_dev(codec, stream_tensor, dst=None, workspace=None, return_stats=False):

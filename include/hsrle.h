@@ -191,15 +191,21 @@ uint32_t hsrle_decompress_mono(int codec, const uint8_t *pIn, uint32_t inSize, u
  */
 uint64_t hsrle_decompress_mono_workspace_size(int codec, uint32_t uncompressedSize, uint32_t compressedSize);
 /*
- * Device-resident form of <codec>_compress for the codecs whose encoder state is known behind a long run (rle8_multi, rle8_packed_multi,
- * rle8_multi_short): ONE monolithic reference stream, byte-identical with the reference encoder's (src/rle8_extreme_cpu.h:86-344,
- * :936-1099), written by many lanes -- the input is cut behind runs that every encoder state stores, and the pieces are encoded by the
- * block kernels (csrc/hsrle_mono_encode.hip.h).  HSRLE_ERR_UNSUPPORTED for the other codecs (their drop-in functions use one lane).
+ * Device-resident form of <codec>_compress for the multi-symbol codecs of 8 to 64 bit symbols (plain, Packed, 3 / 7 symbol LUT and
+ * the Short family; not Single, 128 bit, Greedy): ONE monolithic reference stream, byte-identical with the reference encoder's
+ * (src/rle8_extreme_cpu.h:86-344, :936-1099, src/rleX_extreme_cpu_encode.h, src/rleX_Xsl.h, src/rleX_Xsl_short.h), written by many
+ * lanes -- the input is cut behind runs that every encoder state stores, and the pieces are encoded by the block kernels
+ * (csrc/hsrle_mono_encode.hip.h).  The codecs with a move-to-front list get the list in front of every piece from a dry pass, and the
+ * result is checked piece by piece (wrong guesses are encoded again); HSRLE_ERR_UNSUPPORTED if that does not settle, and for the other
+ * codecs (the drop-in functions then use one lane).
  * dOut capacity >= rle_compress_bounds(inSize); dWorkspace >= hsrle_compress_mono_workspace_size(); synchronises `stream`.
+ * hsrle_mono_encode_stats: of the calling thread's last list-codec encode: extra rounds, pieces encoded again in rounds 1 and 2,
+ * pieces the final check rejected (0 unless the library is wrong).
  */
 uint64_t hsrle_compress_mono_workspace_size(int codec, uint32_t inSize);
 int hsrle_compress_mono_dev(int codec, const void *dIn, uint32_t inSize, void *dOut, uint64_t outCapacity, void *dWorkspace, uint64_t workspaceSize, uint32_t *pStreamSize,
                             uint32_t *pChunks, void *stream);
+void hsrle_mono_encode_stats(uint32_t stats[4]);
 int hsrle_decompress_mono_dev(int codec, const void *dStream, uint32_t streamSize, void *dOut, uint64_t outCapacity, void *dWorkspace, uint64_t workspaceSize,
                               uint32_t *pUncompressedSize, uint32_t *pStats, void *stream);
 /* tuning / test knob of the monolithic decode: output bytes per decode lane (multiple of 128), stream bytes per index lane, look-back

@@ -170,7 +170,9 @@ def test_device_resident_mono_decode_of_synthetic_workloads(hs, oracle, key, kin
 
 # ---- the encode side: ONE stream written by many lanes (csrc/hsrle_mono_encode.hip.h) ----
 
-MONO_ENC_KEYS = ["rle8_multi", "rle8_packed_multi", "rle8_multi_short"] + [f"rle{w}_{v}" for w in (16, 24, 32, 48, 64) for v in ("sym", "sym_packed", "byte", "byte_packed", "sym_short", "byte_short")]
+# every multi-symbol codec of 8 .. 64 bit symbols: plain, Packed, LUT and the Short family (not Single, 128 bit, Greedy)
+MONO_ENC_KEYS = [c.key for c in CODECS if "single" not in c.key and "greedy" not in c.key and not c.key.startswith("rle128")]
+MONO_LIST_KEYS = [k for k in MONO_ENC_KEYS if "symlut" in k]
 
 
 def _wide_run_mix(seed, size, S):
@@ -222,7 +224,41 @@ def test_mono_encode_is_the_reference_stream(hs, oracle, key):
     hs.mono_tuning(0, 0, 0)
 
 
-@pytest.mark.parametrize("key,kind,size", [("rle8_packed_multi", SYNTH_RUNS, 64 << 20), ("rle8_packed_multi", SYNTH_VIDEO, 88473600), ("rle8_multi", SYNTH_RUNS, 32 << 20),
+def _few_symbols(seed, size, S, symbols, counts):
+    """Runs of a handful of symbols: the move-to-front list in front of a piece is whatever far earlier pieces left in it."""
+    rng = random.Random(seed)
+    syms = [bytes(rng.randrange(256) for _ in range(S)) for _ in range(symbols)]
+    out = bytearray()
+    while len(out) < size:
+        out += bytes(rng.randrange(256) for _ in range(rng.choice([0, 1, 3, 9, 40])))
+        # mostly the two favourites, now and then another one: most pieces see fewer distinct symbols than the list holds
+        s = syms[rng.randrange(min(2, symbols))] if rng.random() < 0.97 else syms[rng.randrange(symbols)]
+        out += s * rng.choice(counts)
+    return bytes(out[:size])
+
+
+@pytest.mark.parametrize("key", MONO_LIST_KEYS)
+def test_mono_encode_lists_from_far_back(hs, oracle, key):
+    """The guessed lists come from roll-ups over 64 and 4096 pieces: inputs where a list entry survives thousands of pieces."""
+    codec = CODEC_BY_KEY[key]
+    S = codec.S
+    cases = [_few_symbols(3, 700000, S, 9, [1, 2, 3, 4, 12 // S + 3, 30]), _few_symbols(4, 300000, S, 3, [2, 3, 4, 5, 20]),
+             _few_symbols(5, 300000, S, 1, [3, 14]), bytes(10000) + _few_symbols(6, 200000, S, 12, [3, 4, 5])]
+    for tune in ((0, 64, 0), (0, 0, 0)):
+        hs.mono_tuning(*tune)
+        for d in cases:
+            size, stream = hs.call_dropin(codec.cname, d, hs.compress_bounds(len(d)))
+            expect = oracle.compress(codec, d)
+            assert size == len(expect) and stream == expect, f"{key} len {len(d)} tuning {tune}"
+            rounds, bad0, bad1, bad2 = hs.mono_encode_stats()
+            assert rounds <= 8, f"{key}: {rounds} repair rounds ({bad0}, {bad1}, {bad2} wrong guesses)"
+    hs.mono_tuning(0, 0, 0)
+
+
+@pytest.mark.parametrize("key,kind,size", [("rle8_3symlut", SYNTH_RUNS, 32 << 20), ("rle8_7symlut_short", SYNTH_VIDEO, 32 << 20), ("rle16_3symlut_sym", SYNTH_RUNS, 32 << 20),
+                                           ("rle24_7symlut_byte", SYNTH_RUNS, 32 << 20), ("rle32_1symlut_sym_short", SYNTH_RUNS, 32 << 20), ("rle48_3symlut_byte_short", SYNTH_VIDEO, 32 << 20),
+                                           ("rle64_7symlut_sym", SYNTH_RUNS, 32 << 20),
+                                           ("rle8_packed_multi", SYNTH_RUNS, 64 << 20), ("rle8_packed_multi", SYNTH_VIDEO, 88473600), ("rle8_multi", SYNTH_RUNS, 32 << 20),
                                            ("rle8_multi_short", SYNTH_VIDEO, 32 << 20), ("rle16_sym_packed", SYNTH_RUNS, 32 << 20), ("rle24_byte", SYNTH_RUNS, 32 << 20),
                                            ("rle32_byte_packed", SYNTH_RUNS, 32 << 20), ("rle48_sym", SYNTH_RUNS, 32 << 20), ("rle64_byte_short", SYNTH_RUNS, 32 << 20),
                                            ("rle64_sym_packed", SYNTH_VIDEO, 32 << 20)])

@@ -23,6 +23,9 @@ CASES = {
     "plain8_runs_256m": ("rle8_multi", 0, 256 << 20),
     "sympacked16_runs_256m": ("rle16_sym_packed", 0, 256 << 20),
     "short32_video_256m": ("rle32_7symlut_byte_short", 1, 256 << 20),
+    "lut8_runs_1g": ("rle8_3symlut", 0, 1 << 30),
+    "lut16_7_runs_256m": ("rle16_7symlut_sym", 0, 256 << 20),
+    "short8_1_video_256m": ("rle8_1symlut_short", 1, 256 << 20),
 }
 
 
@@ -74,7 +77,8 @@ def main():
                 dt = time.perf_counter() - t0
                 eb = dt if eb is None else min(eb, dt)
             same = st.cpu().numpy().tobytes() == stream
-            enc = f"  | mono ENCODE {size / 2**30 / eb:7.1f} GiB/s {eb * 1e3:8.3f} ms chunks {chunks} identical {same}"
+            lst = f" list rounds/again/again/rejected {hsrle.mono_encode_stats()}" if "symlut" in key else ""
+            enc = f"  | mono ENCODE {size / 2**30 / eb:7.1f} GiB/s {eb * 1e3:8.3f} ms chunks {chunks} identical {same}{lst}"
         print(f"{name:24s} {key:28s} U {size >> 20:5d} MiB C/U {len(stream) / size:.3f}  {size / 2**30 / best:8.1f} GiB/s  {best * 1e3:8.3f} ms  regions {stats[0]} rounds {stats[1]} rewalked {stats[2]} lookback {stats[3]}"
               f"  exact {ok}{enc}  (host encode {enc_s:.1f} s)", flush=True)
 
