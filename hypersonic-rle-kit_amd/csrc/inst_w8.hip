@@ -5,6 +5,7 @@
 #include "hsrle_encode.hip.h"
 #include "hsrle_encode8.hip.h"
 #include "hsrle_encode8w.hip.h"
+#include "hsrle_encode8s.hip.h"
 #include "hsrle_encode_greedy.hip.h"
 #include "hsrle_index.hip.h"
 #include "hsrle_launch.h"
@@ -36,8 +37,25 @@ static hipError_t enc_plain(const EncodeArgs &a, hipStream_t st) { return launch
 static hipError_t enc_packed(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode8_blocks<PACKED>, a, st, 0); }
 static hipError_t enc_lut3(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode8_blocks<LUT3>, a, st, 0); }
 static hipError_t enc_lut7(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode8_blocks<LUT7>, a, st, 0); }
-static hipError_t enc_single(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<SINGLE, 1, 0>, a, st, 0); }            // no residency cap: +40 % on run data, +20 % on noise, -8 % on video-shaped
-static hipError_t enc_packed_single(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<PACKED_SINGLE, 1, 0>, a, st, 0); }
+// Single: symbol pick by one wave per block, then the ring encoder (hsrle_encode8s.hip.h).  Blocks above kSinglePickMaxBlock (the one-lane
+// drop-in path spans the whole input with one block) and HSRLE_SINGLE_V1=1 (A/B runs) use the first-generation kernel.
+template <bool PACKED_S>
+static hipError_t enc_single_any(const EncodeArgs &a, hipStream_t st)
+{
+  static const bool v1 = [] { const char *e = getenv("HSRLE_SINGLE_V1"); return e && atoi(e) != 0; }();
+  if (v1 || a.B > kSinglePickMaxBlock)
+    return launch_encode(k_encode_blocks<PACKED_S ? PACKED_SINGLE : SINGLE, 1, 0>, a, st, 0);   // no residency cap: +40 % on run data, +20 % on noise, -8 % on video-shaped
+  if (a.residentWorkgroups == nullptr)
+  {
+    const uint32_t padded = (a.B + 63u) & ~63u;
+    const uint32_t lds = 1024u + padded + 64u + (padded / 64u + 1u) * 8u;
+    hipLaunchKernelGGL(k_single_pick, dim3(a.nBlocks), dim3(64), lds, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride);
+    if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
+  }
+  return launch_encode(k_encode8_single_blocks<PACKED_S>, a, st, 0);
+}
+static hipError_t enc_single(const EncodeArgs &a, hipStream_t st) { return enc_single_any<false>(a, st); }
+static hipError_t enc_packed_single(const EncodeArgs &a, hipStream_t st) { return enc_single_any<true>(a, st); }
 
 static hipError_t idx_plain(const IndexArgs &a, int records, hipStream_t st) { return launch_index<PLAIN, 1, 0>(a, records, st); }
 static hipError_t idx_packed(const IndexArgs &a, int records, hipStream_t st) { return launch_index<PACKED, 1, 0>(a, records, st); }

@@ -498,3 +498,50 @@ def test_rle8m_info_that_disagrees_with_the_stream_is_an_error(hs, oracle):
         hs.rle8m_decompress_async(dev, bad, out[: len(data)], status)
         torch.cuda.synchronize()
         assert int(status.item()) != 0 and bool((out[len(data):] == 0xA5).all())
+
+
+def _single_stress(seed, n):
+    """What the Single encoders' state machine branches on: literal gaps around 255 bytes in front of runs of the favourite symbol around
+    SHORT / MEDIUM / LONG (wasted chances and the back-track to the first of them), runs through several 16-byte scan windows, runs of
+    other symbols (they only matter to the symbol pick), the favourite sprinkled through the literals (the search's skip rule)."""
+    rng = random.Random(seed)
+    fav = rng.randrange(256)
+    other = [rng.randrange(256) for _ in range(3)]
+    out = bytearray()
+    while len(out) < n:
+        gap = rng.choice([0, 1, 3, 14, 15, 16, 17, 40, 200, 250, 253, 254, 255, 256, 257, 270, 300, 600])
+        lit = bytearray(rng.randrange(256) for _ in range(gap))
+        for k in range(len(lit)):
+            if rng.random() < 0.08:
+                lit[k] = fav
+        out += lit
+        for _ in range(rng.choice([1, 1, 2, 3, 4, 6])):
+            s = fav if rng.random() < 0.8 else rng.choice(other)
+            out += bytes([s]) * rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 15, 16, 17, 18, 31, 32, 33, 34, 48, 49, 50, 65, 100, 257, 700])
+            out += bytes(rng.randrange(256) for _ in range(rng.choice([0, 1, 1, 2, 3, 7, 20, 60])))
+    return bytes(out[:n])
+
+
+@pytest.mark.parametrize("key", ["rle8_single", "rle8_packed_single"])
+def test_single_blocks_stress(hs, oracle, key):
+    """The Single encoders (wave-parallel symbol pick + ring encoder, csrc/hsrle_encode8s.hip.h) against the oracle's literal restatement,
+    block sizes up to the first-generation kernel's range (> 32 KiB); one-block streams of odd sizes through the rle.h names."""
+    codec = CODEC_BY_KEY[key]
+    rng = random.Random(99)
+    for seed, size, blocks in ((1, 300001, (128, 256, 1024, 4096)), (2, 700013, (384, 640, 3968, 16384)), (3, 400000, (128, 32768, 65536))):
+        data = _single_stress(seed, size) if seed != 3 else single_symbol_mix(rng, size)
+        src = _to_dev(data)
+        for block_size in blocks:
+            container, info = hs.compress(key, src, block_size=block_size)
+            cinfo, streams = hs.split_container(container.cpu().numpy().tobytes())
+            assert len(streams) == (len(data) + block_size - 1) // block_size
+            step = 1 if len(streams) < 3000 else 7
+            for i in list(range(0, len(streams), step)) + [len(streams) - 1]:
+                expect = oracle.compress(codec, data[i * block_size : (i + 1) * block_size])
+                assert streams[i] == expect, f"{key} block {i} of size {block_size} (input seed {seed}) differs from the oracle"
+            assert hs.decompress(container).cpu().numpy().tobytes() == data
+    for k, n in enumerate((17, 31, 33, 47, 48, 49, 257, 1000, 4095, 4097, 20001, 32767, 32768, 32769, 50000)):
+        d = _single_stress(10 + k, n)
+        size, stream = hs.call_dropin(codec.cname, d, hs.compress_bounds(len(d)))
+        expect = oracle.compress(codec, d)
+        assert size == len(expect) and stream == expect, f"{key}: one-block stream of {n} bytes differs from the oracle"
