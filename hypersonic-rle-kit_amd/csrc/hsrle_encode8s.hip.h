@@ -23,6 +23,9 @@
 
 namespace hsrle {
 
+#ifndef HSRLE_SINGLE_RING
+#define HSRLE_SINGLE_RING 256   // (128: 12 instead of 9 waves per CU, run data 14.2 -> 13.1 ms, video-shaped 13.8 -> 18.9: lanes that lag get fewer chunks per step)
+#endif
 constexpr uint32_t kSinglePickMaxBlock = 32768u;   // larger blocks use the first-generation kernel (hsrle_encode.hip.h)
 
 // dynamic LDS: [0, 1024) table (prob | pcount << 16), then n bytes of the block (padded to 64), then the equality bits
@@ -218,8 +221,10 @@ template <bool PACKED>
 __global__ __launch_bounds__(64) void k_encode8_single_blocks(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t nBlocks, uint8_t *__restrict__ slots, uint32_t slotStride,
                                                               uint32_t *__restrict__ sizes)
 {
+  // (every lambda below is always_inline: one that stays a function -- match16 did, with its five call sites -- keeps all it captures by
+  //  reference in scratch memory: 2x the kernel time)
   constexpr int Q = 64;                      // input bytes per lane and step
-  constexpr int H = 256;                     // history ring per lane
+  constexpr int H = HSRLE_SINGLE_RING;       // history ring per lane
   constexpr int LPR = Q / 16, RPL = 64 / LPR;
   constexpr uint32_t HM = (uint32_t)H - 1u;
   constexpr int32_t SHORT = PACKED ? 2 : 4, MEDIUM = 6, LONG = PACKED ? 10 : 8;
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(64) void k_encode8_single_blocks(const uint8_t *__r
   const uint32_t wgFirst = xcd_tile(blockIdx.x, gridDim.x) * 64u;
   const uint32_t b = wgFirst + lane;
   const bool active = b < nBlocks;
-  auto hsw_of = [](uint32_t r) -> uint32_t { return (r & 7u) << 4; };
+  auto hsw_of = [](uint32_t r) __attribute__((always_inline)) -> uint32_t { return (r & 7u) << 4; };
   const uint32_t hbase = (lane * (uint32_t)H) ^ hsw_of(lane);
 
   uint32_t n = 0;
@@ -260,13 +265,25 @@ __global__ __launch_bounds__(64) void k_encode8_single_blocks(const uint8_t *__r
   const u32x4 zero4 = u32x4{ 0, 0, 0, 0 };
   u32x4 oacc = zero4;
   uint32_t opos = 0;
-  auto append = [&](u32x4 hv, uint32_t nb) {
+  // The bytes below accLow of the accumulator's chunk are not the accumulator's: they are the end of a literal stretch that the wave copies
+  // later (emit_literals).  Such a chunk is stored byte by byte from accLow on; in all other chunks accLow is 0.
+  uint32_t accLow = 0;
+  auto store_bytes = [&](uint8_t *p, u32x4 w, uint32_t lo, uint32_t hi) __attribute__((always_inline)) {
+    const uint64_t w0 = (uint64_t)w.x | ((uint64_t)w.y << 32), w1 = (uint64_t)w.z | ((uint64_t)w.w << 32);
+    for (uint32_t k = lo; k < hi; k++)
+      p[k] = (uint8_t)((k < 8u ? w0 >> (8u * k) : w1 >> (8u * (k - 8u))) & 0xFFull);
+  };
+  auto store_chunk = [&](uint8_t *p, u32x4 w) __attribute__((always_inline)) {
+    if (__builtin_expect(accLow == 0u, 1)) st128(p, w);
+    else { store_bytes(p, w, accLow, 16u); accLow = 0u; }
+  };
+  auto append = [&](u32x4 hv, uint32_t nb) __attribute__((always_inline)) {
     const uint32_t c = opos & 15u;
     const u32x4 lowp = (c == 0u) ? hv : funnel16(zero4, hv, 16u - c);
     const u32x4 w = HS_SMERGE1(oacc, lowp, c);
     if (c + nb >= 16u)
     {
-      st128(slot + (opos & ~15u), w);
+      store_chunk(slot + (opos & ~15u), w);
       oacc = (c == 0u) ? zero4 : funnel16(hv, zero4, 16u - c);
     }
     else
@@ -275,7 +292,7 @@ __global__ __launch_bounds__(64) void k_encode8_single_blocks(const uint8_t *__r
   };
   uint64_t hlo = 0;
   uint32_t hhi = 0, hn = 0;
-  auto hpush = [&](uint32_t v, uint32_t k) {
+  auto hpush = [&](uint32_t v, uint32_t k) __attribute__((always_inline)) {
     const uint32_t sh = hn * 8u;
     if (hn < 8u)
     {
@@ -286,25 +303,26 @@ __global__ __launch_bounds__(64) void k_encode8_single_blocks(const uint8_t *__r
       hhi |= v << (sh - 64u);
     hn += k;
   };
-  auto hb = [&](uint32_t v) { hpush(v & 0xFFu, 1u); };
-  auto h32 = [&](uint32_t v) { hpush(v, 4u); };
-  auto hflush = [&]() {
+  auto hb = [&](uint32_t v) __attribute__((always_inline)) { hpush(v & 0xFFu, 1u); };
+  auto h32 = [&](uint32_t v) __attribute__((always_inline)) { hpush(v, 4u); };
+  auto hflush = [&]() __attribute__((always_inline)) {
     append(u32x4{ (uint32_t)hlo, (uint32_t)(hlo >> 32), hhi, 0u }, hn);
     hlo = 0; hhi = 0; hn = 0;
   };
-  auto ring_win = [&](uint32_t p) -> u32x4 {
+  auto ring_win = [&](uint32_t p) __attribute__((always_inline)) -> u32x4 {
     const uint32_t a0 = p & ~15u;
     return funnel16(lds_ld128(hist + (hbase ^ (a0 & HM))), lds_ld128(hist + (hbase ^ ((a0 + 16u) & HM))), p & 15u);
   };
   // is the 16-byte window at block position p still in the ring?
-  auto in_ring = [&](uint32_t p) -> bool { return p + (uint32_t)H >= avail + 16u; };
+  auto in_ring = [&](uint32_t p) __attribute__((always_inline)) -> bool { return p + (uint32_t)H >= avail + 16u; };
   // Literal bytes [from, from + len) of the block.  The Single codecs store few runs, so literal stretches are long and have mostly left the
-  // ring when their packet is written.  Fetching them 16 bytes at a time per lane pays one memory latency per chunk (a 4 KiB block without a
-  // stored run: 256 of them -- 4x the time of everything else), so the 16-byte aligned middle of such a stretch is only NOTED here
-  // (pendSrc / pendDst / pendBytes) and copied by the whole wave at the next point where the wave is converged (coop_flush): 1 KiB per
-  // load / store pair.  At most one stretch is pending per lane: every trip of the scanner and every round of the tail stores at most one run.
-  uint32_t pendSrc = 0, pendDst = 0, pendBytes = 0;
-  auto emit_literals = [&](uint32_t from, uint32_t len) {
+  // ring when their packet is written.  Fetching them from global memory inside the lane's own code pays a memory latency per 16 bytes with
+  // ONE lane of the wave active (a 4 KiB block without a stored run: 256 of them -- 4x the time of everything else; and even a single such
+  // load per packet was 2/3 of the kernel), so such a stretch is only NOTED here (two note slots per lane) and copied by the whole wave at
+  // a point where the wave is converged (coop_flush): 1 KiB per load / store pair, any alignment.  Every trip of the scanner and every
+  // round of the tail stores at most one run, and a flush follows as soon as a lane has both slots in use.
+  uint32_t pendSrc = 0, pendDst = 0, pendBytes = 0, pend2Src = 0, pend2Dst = 0, pend2Bytes = 0;
+  auto emit_literals = [&](uint32_t from, uint32_t len) __attribute__((always_inline)) {
     if (len == 0u) return;
     if (__builtin_expect(in_ring(from), 1))
     {
@@ -315,7 +333,7 @@ __global__ __launch_bounds__(64) void k_encode8_single_blocks(const uint8_t *__r
       uint32_t k = 0;
       while (k + 16u <= total)
       {
-        st128(dst + k, w);
+        store_chunk(dst + k, w);
         k += 16u;
         if (k < total) w = ring_win(srcp + k);
       }
@@ -324,65 +342,66 @@ __global__ __launch_bounds__(64) void k_encode8_single_blocks(const uint8_t *__r
     }
     else
     {
-      // up to the next 16-byte boundary of the stream | whole chunks, noted for the wave | the rest
-      const uint32_t head = umin(len, (16u - (opos & 15u)) & 15u);
-      const uint32_t mid = ((len - head) & ~15u) >= 64u ? ((len - head) & ~15u) : 0u;
-#pragma unroll 1
-      for (uint32_t piece = 0; piece < 2u; piece++)
-      {
-        uint32_t f = from, l = (mid != 0u) ? head : len;
-        if (piece == 1u)
-        {
-          if (mid == 0u) break;
-          pendSrc = from + head; pendDst = opos; pendBytes = mid;
-          opos += mid;                                                  // (a multiple of 16: the accumulator is empty here and stays so)
-          f = from + head + mid; l = len - head - mid;
-        }
-        if (l == 0u) continue;
-        const uint32_t c = opos & 15u, total = c + l;
-        const uint32_t srcp = f - c;
-        uint8_t *const dst = slot + (opos & ~15u);
-        u32x4 w = HS_SMERGE1(oacc, global_window16(in, blockAt, U, srcp), c);
-        uint32_t k = 0;
-        while (k + 16u <= total)
-        {
-          st128(dst + k, w);
-          k += 16u;
-          if (k < total) w = global_window16(in, blockAt, U, srcp + k);
-        }
-        lds_st128(accScratch + lane * 16u, w);                          // (see k_encode8_blocks: keeps vmcnt waits out of the common path)
-        oacc = lds_ld128(accScratch + lane * 16u);
-        opos += l;
-      }
+      // what the accumulator holds goes out now; the stretch is noted; the accumulator starts again behind it
+      const uint32_t c = opos & 15u;
+      if (c > accLow) store_bytes(slot + (opos & ~15u), oacc, accLow, c);
+      if (pendBytes == 0u) { pendSrc = from; pendDst = opos; pendBytes = len; }
+      else { pend2Src = from; pend2Dst = opos; pend2Bytes = len; }
+      opos += len;
+      accLow = opos & 15u;
+      oacc = zero4;
     }
   };
-  // wave-converged: copy the noted stretches, one after the other, 16 bytes per lane and trip (source at any alignment)
-  auto coop_flush = [&]() {
-    uint64_t todo = __ballot(pendBytes != 0u);
-    while (todo != 0ull)
+  // wave-converged: copy the noted stretches, 16 bytes per lane and load (source at any alignment), two stretches in flight.  Source and
+  // destination are private to the lane's block and stay as they are, so the copies can wait: coop_flush(false) only acts when some lane
+  // has both of its note slots in use -- by then most lanes have a note or two, and a flush pays one memory latency for all of them.
+  auto coop_copy2 = [&](uint32_t l0, uint32_t s0, uint32_t d0, uint32_t n0, uint32_t l1, uint32_t s1, uint32_t d1, uint32_t n1) __attribute__((always_inline)) {
+    const uint8_t *const sp0 = in + (uint64_t)(wgFirst + l0) * B + s0, *const sp1 = in + (uint64_t)(wgFirst + l1) * B + s1;
+    uint8_t *const dp0 = slots + (uint64_t)(wgFirst + l0) * slotStride + d0, *const dp1 = slots + (uint64_t)(wgFirst + l1) * slotStride + d1;
+    const uint32_t f0 = n0 & ~15u, f1 = n1 & ~15u;
+    const uint32_t nmax = f0 > f1 ? f0 : f1;
+    for (uint32_t k = lane * 16u; k < nmax; k += 2048u)
     {
-      const uint32_t l = (uint32_t)__builtin_ctzll(todo);
-      todo &= todo - 1ull;
-      const uint32_t src = (uint32_t)__builtin_amdgcn_readlane((int)pendSrc, (int)l), dstOff = (uint32_t)__builtin_amdgcn_readlane((int)pendDst, (int)l);
-      const uint32_t bytes = (uint32_t)__builtin_amdgcn_readlane((int)pendBytes, (int)l);
-      const uint8_t *const sp = in + (uint64_t)(wgFirst + l) * B + src;
-      uint8_t *const dp = slots + (uint64_t)(wgFirst + l) * slotStride + dstOff;
-      for (uint32_t k = lane * 16u; k < bytes; k += 4096u)
+      u32x4 a0, a1, b0, b1;
+      const bool ha0 = k < f0, ha1 = k + 1024u < f0, hb0 = k < f1, hb1 = k + 1024u < f1;
+      if (ha0) a0 = ld128(sp0 + k);
+      if (ha1) a1 = ld128(sp0 + k + 1024u);
+      if (hb0) b0 = ld128(sp1 + k);
+      if (hb1) b1 = ld128(sp1 + k + 1024u);
+      if (ha0) st128(dp0 + k, a0);
+      if (ha1) st128(dp0 + k + 1024u, a1);
+      if (hb0) st128(dp1 + k, b0);
+      if (hb1) st128(dp1 + k + 1024u, b1);
+    }
+    // the last n & 15 bytes: lanes 0..15 for the first stretch, 16..31 for the second
+    const uint32_t r = lane & 15u;
+    if (lane < 16u) { if (r < (n0 & 15u)) dp0[f0 + r] = sp0[f0 + r]; }
+    else if (lane < 32u) { if (r < (n1 & 15u)) dp1[f1 + r] = sp1[f1 + r]; }
+  };
+  auto coop_flush = [&](bool all) __attribute__((always_inline)) {
+    if (!all && __ballot(pendBytes != 0u && pend2Bytes != 0u) == 0ull) return;
+#pragma unroll 1
+    for (int slotNo = 0; slotNo < 2; slotNo++)
+    {
+      const uint32_t ps = slotNo ? pend2Src : pendSrc, pd = slotNo ? pend2Dst : pendDst, pb = slotNo ? pend2Bytes : pendBytes;
+      uint64_t todo = __ballot(pb != 0u);
+      while (todo != 0ull)
       {
-        // four loads in flight (bytes is a multiple of 16)
-        u32x4 v[4];
-#pragma unroll
-        for (uint32_t q = 0; q < 4u; q++)
-          if (k + q * 1024u < bytes) v[q] = ld128(sp + k + q * 1024u);
-#pragma unroll
-        for (uint32_t q = 0; q < 4u; q++)
-          if (k + q * 1024u < bytes) st128(dp + k + q * 1024u, v[q]);
+        const uint32_t l0 = (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        uint32_t l1 = l0;
+        if (todo != 0ull) { l1 = (uint32_t)__builtin_ctzll(todo); todo &= todo - 1ull; }
+        const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)ps, (int)l0), d0 = (uint32_t)__builtin_amdgcn_readlane((int)pd, (int)l0);
+        const uint32_t n0 = (uint32_t)__builtin_amdgcn_readlane((int)pb, (int)l0);
+        const uint32_t s1 = (uint32_t)__builtin_amdgcn_readlane((int)ps, (int)l1), d1 = (uint32_t)__builtin_amdgcn_readlane((int)pd, (int)l1);
+        const uint32_t n1 = (l1 != l0) ? (uint32_t)__builtin_amdgcn_readlane((int)pb, (int)l1) : 0u;
+        coop_copy2(l0, s0, d0, n0, l1, s1, d1, n1);
       }
     }
-    pendBytes = 0u;
+    pendBytes = 0u; pend2Bytes = 0u;
   };
   // match bits of the 16 bytes at p: bit k = (d[p + k] == sym)
-  auto match16 = [&](uint32_t p) -> uint32_t {
+  auto match16 = [&](uint32_t p) __attribute__((always_inline)) -> uint32_t {
     u32x4 x;
     if (__builtin_expect(in_ring(p), 1)) x = ring_win(p);
     else
@@ -404,10 +423,13 @@ __global__ __launch_bounds__(64) void k_encode8_single_blocks(const uint8_t *__r
   }
 
   // ---- input top-up (as k_encode8_blocks) ----
-  auto publish = [&](uint32_t v) { rinfo[(lane % (uint32_t)RPL) * (uint32_t)LPR + lane / (uint32_t)RPL] = v; };
+  auto publish = [&](uint32_t v) __attribute__((always_inline)) { rinfo[(lane % (uint32_t)RPL) * (uint32_t)LPR + lane / (uint32_t)RPL] = v; };
   u32x4 pf[LPR];
   uint32_t pfAt[LPR];
   uint32_t wantReq = 0;
+  uint32_t landedAt = 0, landedChunks = 0;
+  uint64_t M0 = 0, M1 = 0;
+  uint32_t mEnd = 0;
 
   // ---- the scanner (rle8_extreme_cpu.h:1140-1312) ----
   const int32_t end = (int32_t)n - 16;
@@ -415,7 +437,7 @@ __global__ __launch_bounds__(64) void k_encode8_single_blocks(const uint8_t *__r
   bool searching = false;                    // in the "find the next candidate block" loop
   bool bodyDone = !(0 < end);
 
-  auto issue = [&]() {
+  auto issue = [&]() __attribute__((always_inline)) {
     const uint32_t left = (n > avail) ? (n - avail + 15u) >> 4 : 0u;
     wantReq = umin((uint32_t)LPR, left);
     publish(wantReq != 0u ? (avail | wantReq) : 0u);
@@ -448,7 +470,7 @@ __global__ __launch_bounds__(64) void k_encode8_single_blocks(const uint8_t *__r
       pfAt[q] = (r * (uint32_t)H) ^ hsw_of(r) ^ ((e + c * 16u) & HM);
     }
   };
-  auto land = [&]() {
+  auto land = [&]() __attribute__((always_inline)) {
     // the ring keeps the chunk the scanner stands in and the one before it; a scanner that was sent back behind the ring (it reads global
     // memory there) gets no new bytes until it has caught up
     const uint32_t pos = (uint32_t)i;
@@ -466,12 +488,51 @@ __global__ __launch_bounds__(64) void k_encode8_single_blocks(const uint8_t *__r
     for (int q = 0; q < LPR; q++)
       if (lane % LPR < ri[q])
         lds_st128(hist + pfAt[q], pf[q]);
+    landedAt = avail; landedChunks = take;
     avail = umin(avail + (take << 4), n);
+  };
+  // Match bits of the last 128 landed positions, [mEnd - 128, mEnd), in two registers: the scanner's windows are bit fields of them (16
+  // bytes of ring + funnel + compare per window was most of the kernel).  Called behind every land(), once the row's chunks are visible.
+  auto extend_masks = [&]() __attribute__((always_inline)) {
+    uint64_t fresh = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < (uint32_t)LPR; j++)
+    {
+      const uint32_t at = landedAt + 16u * j;
+      const u32x4 x = lds_ld128(hist + (hbase ^ (at & HM)));
+      const uint32_t z0 = zero_bytes(x.x ^ sym4), z1 = zero_bytes(x.y ^ sym4), z2 = zero_bytes(x.z ^ sym4), z3 = zero_bytes(x.w ^ sym4);
+      const uint32_t b0 = (((z0 >> 7) * 0x00204081u) >> 21) & 0xFu, b1 = (((z1 >> 7) * 0x00204081u) >> 21) & 0xFu;
+      const uint32_t b2 = (((z2 >> 7) * 0x00204081u) >> 21) & 0xFu, b3 = (((z3 >> 7) * 0x00204081u) >> 21) & 0xFu;
+      uint32_t bits = b0 | (b1 << 4) | (b2 << 8) | (b3 << 12);
+      const uint32_t left = (n > at) ? n - at : 0u;                     // bytes at or beyond n never match
+      if (left < 16u) bits &= (1u << left) - 1u;
+      if (j >= landedChunks) bits = 0u;
+      fresh |= (uint64_t)bits << (16u * j);
+    }
+    const uint32_t sh = 16u * landedChunks;                             // 0, 16, 32, 48 or 64
+    if (sh == 64u) { M0 = M1; M1 = fresh; }
+    else if (sh != 0u)
+    {
+      M0 = (M0 >> sh) | (M1 << (64u - sh));
+      M1 = (M1 >> sh) | (fresh << (64u - sh));
+    }
+    mEnd += sh;
+  };
+  // match bits of the 16 bytes at pos: from the registers, or -- a scanner that was sent back -- from the ring / global memory
+  auto win16 = [&](int32_t pos) __attribute__((always_inline)) -> uint32_t {
+    const int32_t sft = pos - ((int32_t)mEnd - 128);
+    if (__builtin_expect(sft >= 0, 1))
+    {
+      const uint32_t u = (uint32_t)sft;
+      const uint64_t v = (u < 64u) ? ((M0 >> u) | ((u != 0u) ? (M1 << (64u - u)) : 0ull)) : (M1 >> (u - 64u));
+      return (uint32_t)v & 0xFFFFu;
+    }
+    return match16((uint32_t)pos);
   };
 
   // kind 0: short form (range in one byte), 1: long form, 2: the forced packet of the back-track (count byte without the 32 bit escape)
-  auto emit = [&](int kind, int32_t at, int32_t cnt) {
-    const uint32_t range = (uint32_t)(at - lastRLE - cnt + 1);
+  auto emit = [&](int kind, int32_t at, int32_t cnt, int32_t from) __attribute__((always_inline)) {
+    const uint32_t range = (uint32_t)(at - from - cnt + 1);
     const uint32_t c = (uint32_t)(cnt - SHORT + 1);
     if (kind == 2) hb(c);
     else if (c <= 255u) hb(c);
@@ -479,13 +540,19 @@ __global__ __launch_bounds__(64) void k_encode8_single_blocks(const uint8_t *__r
     if (kind == 0) hb(range);
     else { hb(0); h32(range); }
     hflush();
-    emit_literals((uint32_t)lastRLE, (uint32_t)(at - cnt - lastRLE));
-    lastRLE = at;
+    emit_literals((uint32_t)from, (uint32_t)(at - cnt - from));
   };
+  // Writing a packet is ~250 instructions, and where few runs are stored every lane comes to it in another trip: one lane active, all
+  // others waiting (measured: 29 k of the 58 k vector instructions of a wave at 1/64 utilisation).  The DECISION only needs lastRLE, so
+  // the scanner notes the packet (queue of one + the one it stands at) and goes on; the packets are written when a lane comes to its
+  // second one, when half of the lanes have one, or at the end -- by all lanes that have one, together.
+  int32_t qKind = -1, qAt = 0, qCnt = 0, qFrom = 0;      // noted packet
+  int32_t bKind = -1, bAt = 0, bCnt = 0, bFrom = 0;      // the packet the lane is blocked at (queue full)
 
   issue();
   land();
   wave_sync();
+  extend_masks();
 
   uint32_t stepsLeft = 2u * (B / (uint32_t)Q) + 64u;
   uint32_t tripsLeft = 8u * B + 1024u;       // the back-track re-scans at most 255 bytes per three runs: bounded, and bounded here again
@@ -495,86 +562,112 @@ __global__ __launch_bounds__(64) void k_encode8_single_blocks(const uint8_t *__r
     if (stepsLeft-- == 0u) break;
     issue();
 
-    // (no lane is masked off around this loop: the copies of coop_flush are done by all 64 lanes; finished and unused lanes have bodyDone set)
+    // One trip of the wave = per lane: the search up to the next candidate, the run through its full windows, ONE run end (the only part
+    // that may write a packet).  (No lane is masked off around this loop: the copies of coop_flush are done by all 64 lanes; finished and
+    // unused lanes have bodyDone set.)
+    for (;;)
     {
-      for (;;)
+      const bool can = !bodyDone && bKind < 0 && (uint32_t)i + 16u <= avail && tripsLeft != 0u;
+      if (__ballot(can) == 0ull)
       {
-        const bool can = !bodyDone && (uint32_t)i + 16u <= avail && tripsLeft != 0u;
-        if (__ballot(can) == 0ull) break;
-        if (can)
+        // nobody can scan on.  Write the noted packets?  (always at the end of the input: the tail needs an empty queue)
+        const uint64_t noted = __ballot(qKind >= 0);
+        if (noted == 0ull) break;
+        if (__ballot(bKind >= 0 || (qKind >= 0 && (bodyDone || avail >= n))) == 0ull && __builtin_popcountll(noted) < 32) break;
+        while (__ballot(qKind >= 0) != 0ull)
         {
-          tripsLeft--;
-          const uint32_t m = match16((uint32_t)i);
-          if (!searching)
+          if (qKind >= 0)
           {
-            if (m == 0xFFFFu) { count += 16; i += 16; }                  // (i += 15 and the loop's i++)
-            else
+            emit(qKind, qAt, qCnt, qFrom);
+            qKind = bKind; qAt = bAt; qCnt = bCnt; qFrom = bFrom;
+            bKind = -1;
+          }
+          coop_flush(false);
+        }
+        continue;
+      }
+      if (can)
+      {
+        if (searching)
+        {
+          // find the next candidate block (:1291-1312): windows without the symbol, or with fewer than SHORT of it and not at their end, are skipped
+          for (;;)
+          {
+            if (!(i < end)) { searching = false; i += 1; break; }
+            if ((uint32_t)i + 16u > avail || tripsLeft == 0u) break;
+            tripsLeft--;
+            const uint32_t m = win16(i);
+            if (m == 0u || ((m & 0x8000u) == 0u && (uint32_t)__builtin_popcount(m) < (uint32_t)SHORT)) { i += 16; continue; }
+            i += (int32_t)__builtin_ctz(m) + 1;
+            count = 1;
+            searching = false;
+            break;
+          }
+        }
+        if (!searching && i < end && (uint32_t)i + 16u <= avail && tripsLeft != 0u)
+        {
+          uint32_t m = win16(i);
+          while (m == 0xFFFFu)                                            // (i += 15 and the loop's i++)
+          {
+            count += 16; i += 16;
+            if (!(i < end) || (uint32_t)i + 16u > avail || tripsLeft == 0u) break;
+            tripsLeft--;
+            m = win16(i);
+          }
+          if (m != 0xFFFFu)
+          {
+            tripsLeft--;
+            if (m != 0u || count > 1)
             {
-              if (m != 0u || count > 1)
+              const int32_t z = (int32_t)__builtin_ctz(~m);
+              count += z; i += z;
+              const int32_t range = i - lastRLE - count + 1;
+              int ek = -1;                                               // the packet to write: one emit site (the code is inlined)
+              if (count >= SHORT)
               {
-                const int32_t z = (int32_t)__builtin_ctz(~m);
-                count += z; i += z;
-                const int32_t range = i - lastRLE - count + 1;
-                int ek = -1;                                             // the packet to write: one emit site (the code is inlined)
-                if (count >= SHORT)
+                if (range <= 255) { ek = 0; wasted = 0; }
+                else if (count >= LONG || (PACKED && count - SHORT + 1 <= 255 && count >= MEDIUM)) { ek = 1; wasted = 0; }
+                else
                 {
-                  if (range <= 255) { ek = 0; wasted = 0; }
-                  else if (count >= LONG || (PACKED && count - SHORT + 1 <= 255 && count >= MEDIUM)) { ek = 1; wasted = 0; }
-                  else
+                  wasted++;
+                  if (wasted == 1 || i - firstW > 255) { firstW = i - count; wasted = 1; }
+                  else if (wasted > 2)
                   {
-                    wasted++;
-                    if (wasted == 1 || i - firstW > 255) { firstW = i - count; wasted = 1; }
-                    else if (wasted > 2)
+                    // back to the first skipped run: it is stored with a long range whatever its length (:1244-1285)
+                    i = firstW; wasted = 0; count = 0;
+                    for (;;)
                     {
-                      // back to the first skipped run: it is stored with a long range whatever its length (:1244-1285)
-                      i = firstW; wasted = 0; count = 0;
-                      for (;;)
-                      {
-                        if (!(i < end)) break;
-                        const uint32_t mm = match16((uint32_t)i);
-                        int32_t zz = (int32_t)__builtin_ctz(~mm | 0x10000u);
-                        if (zz > end - i) zz = end - i;
-                        count += zz; i += zz;
-                        if (zz < 16) break;
-                      }
-                      ek = 2;
+                      if (!(i < end)) break;
+                      const uint32_t mm = win16(i);
+                      int32_t zz = (int32_t)__builtin_ctz(~mm | 0x10000u);
+                      if (zz > end - i) zz = end - i;
+                      count += zz; i += zz;
+                      if (zz < 16) break;
                     }
+                    ek = 2;
                   }
                 }
-                if (ek >= 0) emit(ek, i, count);
               }
-              count = 0;
-              searching = true;                                          // the search starts at this i, in the next trip (if i < end)
-              if (!(i < end)) { searching = false; i += 1; }
+              if (ek >= 0)
+              {
+                if (qKind < 0) { qKind = ek; qAt = i; qCnt = count; qFrom = lastRLE; }
+                else { bKind = ek; bAt = i; bCnt = count; bFrom = lastRLE; }
+                lastRLE = i;
+              }
             }
+            count = 0;
+            searching = true;                                            // the search starts at this i (if i < end)
+            if (!(i < end)) { searching = false; i += 1; }
           }
-          else
-          {
-            const uint32_t pop = (uint32_t)__builtin_popcount(m);
-            if (m == 0u || ((m & 0x8000u) == 0u && pop < (uint32_t)SHORT))
-            {
-              i += 16;
-              if (!(i < end)) { searching = false; i += 1; }
-            }
-            else
-            {
-              i += (int32_t)__builtin_ctz(m);
-              count = 1;
-              searching = false;
-              i += 1;
-            }
-          }
-          if (!searching && !(i < end)) bodyDone = true;
         }
-        coop_flush();
+        if (!searching && !(i < end)) bodyDone = true;
       }
-
     }
 
     // scalar tail (:392-470: no wasted-chances logic, no MEDIUM clause) and final block (:472-560), in rounds of at most one stored run
     // per lane so that the wave can copy the noted literal stretches in between
     {
-      bool inTail = !finished && bodyDone && avail >= n;
+      bool inTail = !finished && bodyDone && avail >= n && qKind < 0;
       while (__ballot(inTail) != 0ull)
       {
         if (inTail)
@@ -604,7 +697,7 @@ __global__ __launch_bounds__(64) void k_encode8_single_blocks(const uint8_t *__r
             else if (count >= LONG) ek = 1;
             at = i; cnt = count;
           }
-          if (ek >= 0) emit(ek, at, cnt);
+          if (ek >= 0) { emit(ek, at, cnt, lastRLE); lastRLE = at; }
           if (fin)
           {
             if (ek >= 0) { hb(0); h32(0); hb(0); h32(0); hflush(); }
@@ -614,22 +707,27 @@ __global__ __launch_bounds__(64) void k_encode8_single_blocks(const uint8_t *__r
               hflush();
               emit_literals((uint32_t)lastRLE, (uint32_t)(i - lastRLE));
             }
-            if ((opos & 15u) != 0u)
-              st128(slot + (opos & ~15u), oacc);
+            if ((opos & 15u) > accLow)
+            {
+              if (accLow == 0u) st128(slot + (opos & ~15u), oacc);
+              else store_bytes(slot + (opos & ~15u), oacc, accLow, opos & 15u);
+            }
             st32(slot + 4, opos);
             sizes[b] = opos;
             finished = true;
             inTail = false;
           }
         }
-        coop_flush();
+        coop_flush(false);
       }
     }
 
     wave_sync();
     land();
     wave_sync();
+    extend_masks();
   }
+  coop_flush(true);
 #undef HS_SMERGE1
 }
 
