@@ -128,6 +128,17 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
   const u32x4 zero4 = u32x4{ 0, 0, 0, 0 };
   u32x4 oacc = zero4;        // the chunk that contains stream position opos (its low opos & 15 bytes are valid)
   uint32_t opos = 0;         // stream bytes produced so far
+  // Literal stretches that have left the ring are not fetched by the lane (one memory latency per 16 bytes with one lane of the wave
+  // active: incompressible input ran at 0.45 TiB/s) but NOTED -- two slots per lane -- and copied by the whole wave where it is converged
+  // (coop_flush below; first done for the Single encoders, hsrle_encode8s.hip.h).  A noted stretch ends at a 16-byte boundary of the
+  // stream; the bytes behind it (< 16) are fetched into the accumulator.
+  uint32_t pendSrc = 0, pendDst = 0, pendBytes = 0, pend2Src = 0, pend2Dst = 0, pend2Bytes = 0;
+  auto store_bytes = [&](uint8_t *p, u32x4 w, uint32_t lo, uint32_t hi) __attribute__((always_inline)) {
+    const uint64_t w0 = (uint64_t)w.x | ((uint64_t)w.y << 32), w1 = (uint64_t)w.z | ((uint64_t)w.w << 32);
+    if (!dry)
+      for (uint32_t k = lo; k < hi; k++)
+        p[k] = (uint8_t)((k < 8u ? w0 >> (8u * k) : w1 >> (8u * (k - 8u))) & 0xFFull);
+  };
 
   // append the low nb (<= 16) bytes of hv
   auto append = [&](u32x4 hv, uint32_t nb) {
@@ -194,6 +205,20 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
       }
       oacc = w;
     }
+    else if (__builtin_expect(len >= 48u && (pendBytes == 0u || pend2Bytes == 0u), 0))
+    {
+      // what the accumulator holds goes out now; the stretch is noted up to the last 16-byte boundary of the stream it reaches; the
+      // bytes behind that boundary come into the accumulator (through LDS: see below)
+      if (c != 0u) store_bytes(dst, oacc, 0u, c);
+      const uint32_t tail = (opos + len) & 15u, noted = len - tail;
+      if (!dry)
+      {
+        if (pendBytes == 0u) { pendSrc = at; pendDst = opos; pendBytes = noted; }
+        else { pend2Src = at; pend2Dst = opos; pend2Bytes = noted; }
+      }
+      lds_st128(accScratch + lane * 16u, tail != 0u ? global_window16(in, blockAt, U, at + noted) : zero4);
+      oacc = lds_ld128(accScratch + lane * 16u);
+    }
     else
     {
       u32x4 w = HS_SMERGE(oacc, global_window16(in, blockAt, U, srcp), c);
@@ -210,6 +235,54 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
       oacc = lds_ld128(accScratch + lane * 16u);
     }
     opos += len;
+  };
+
+  // wave-converged: copy the noted stretches, 16 bytes per lane and load (any alignment), two stretches in flight; coop_flush(false) only
+  // acts once some lane has both of its slots in use
+  const uint64_t slotOff = (uint64_t)(slot - slots);
+  auto coop_flush = [&](bool all) __attribute__((always_inline)) {
+    if (__builtin_expect(__ballot(pendBytes != 0u && (all || pend2Bytes != 0u)) == 0ull, 1)) return;
+#pragma unroll 1
+    for (int slotNo = 0; slotNo < 2; slotNo++)
+    {
+      const uint32_t ps = slotNo ? pend2Src : pendSrc, pd = slotNo ? pend2Dst : pendDst, pb = slotNo ? pend2Bytes : pendBytes;
+      uint64_t todo = __ballot(pb != 0u);
+      while (todo != 0ull)
+      {
+        const uint32_t l0 = (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        uint32_t l1 = l0;
+        if (todo != 0ull) { l1 = (uint32_t)__builtin_ctzll(todo); todo &= todo - 1ull; }
+        auto lane64 = [&](uint64_t v, uint32_t l) __attribute__((always_inline)) -> uint64_t {
+          return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)l) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)l) << 32);
+        };
+        const uint8_t *const sp0 = in + lane64(blockAt, l0) + (uint32_t)__builtin_amdgcn_readlane((int)ps, (int)l0);
+        const uint8_t *const sp1 = in + lane64(blockAt, l1) + (uint32_t)__builtin_amdgcn_readlane((int)ps, (int)l1);
+        uint8_t *const dp0 = slots + lane64(slotOff, l0) + (uint32_t)__builtin_amdgcn_readlane((int)pd, (int)l0);
+        uint8_t *const dp1 = slots + lane64(slotOff, l1) + (uint32_t)__builtin_amdgcn_readlane((int)pd, (int)l1);
+        const uint32_t n0 = (uint32_t)__builtin_amdgcn_readlane((int)pb, (int)l0);
+        const uint32_t n1 = (l1 != l0) ? (uint32_t)__builtin_amdgcn_readlane((int)pb, (int)l1) : 0u;
+        const uint32_t f0 = n0 & ~15u, f1 = n1 & ~15u;
+        const uint32_t nmax = f0 > f1 ? f0 : f1;
+        for (uint32_t k = lane * 16u; k < nmax; k += 2048u)
+        {
+          u32x4 a0, a1, b0, b1;
+          const bool ha0 = k < f0, ha1 = k + 1024u < f0, hb0 = k < f1, hb1 = k + 1024u < f1;
+          if (ha0) a0 = ld128(sp0 + k);
+          if (ha1) a1 = ld128(sp0 + k + 1024u);
+          if (hb0) b0 = ld128(sp1 + k);
+          if (hb1) b1 = ld128(sp1 + k + 1024u);
+          if (ha0) st128(dp0 + k, a0);
+          if (ha1) st128(dp0 + k + 1024u, a1);
+          if (hb0) st128(dp1 + k, b0);
+          if (hb1) st128(dp1 + k + 1024u, b1);
+        }
+        const uint32_t r = lane & 15u;                                    // the last n & 15 bytes: lanes 0..15 / 16..31
+        if (lane < 16u) { if (r < (n0 & 15u)) dp0[f0 + r] = sp0[f0 + r]; }
+        else if (lane < 32u) { if (r < (n1 & 15u)) dp1[f1 + r] = sp1[f1 + r]; }
+      }
+    }
+    pendBytes = 0u; pend2Bytes = 0u;
   };
 
   // ---- stream header ----
@@ -561,10 +634,12 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
       }
     }
 
+    coop_flush(false);                                                  // (all lanes are here: the scan above is the only masked part)
     wave_sync();
     land();
     wave_sync();
   }
+  coop_flush(true);
 }
 
 } // namespace hsrle
