@@ -530,6 +530,19 @@ __global__ __launch_bounds__(64) void k_encode8_single_blocks(const uint8_t *__r
     return match16((uint32_t)pos);
   };
 
+  // 64 match bits from pos on (bits behind the landed positions read 0); wmax: how many 16-bit windows the value is good for
+  auto win64 = [&](int32_t pos, uint32_t &wmax) __attribute__((always_inline)) -> uint64_t {
+    const int32_t sft = pos - ((int32_t)mEnd - 128);
+    if (__builtin_expect(sft >= 0, 1))
+    {
+      const uint32_t u = (uint32_t)sft;
+      wmax = 4u;
+      return (u < 64u) ? ((M0 >> u) | ((u != 0u) ? (M1 << (64u - u)) : 0ull)) : (M1 >> (u - 64u));
+    }
+    wmax = 1u;
+    return (uint64_t)match16((uint32_t)pos);
+  };
+
   // kind 0: short form (range in one byte), 1: long form, 2: the forced packet of the back-track (count byte without the 32 bit escape)
   auto emit = [&](int kind, int32_t at, int32_t cnt, int32_t from) __attribute__((always_inline)) {
     const uint32_t range = (uint32_t)(at - from - cnt + 1);
@@ -588,31 +601,58 @@ __global__ __launch_bounds__(64) void k_encode8_single_blocks(const uint8_t *__r
       }
       if (can)
       {
+        // the windows at i, i + 16, ... that may be looked at now: their 16 bytes have landed and they start in front of `end`
+        auto windows_at = [&](int32_t pos, uint32_t wmax) __attribute__((always_inline)) -> uint32_t {
+          const uint32_t wa = (avail - (uint32_t)pos) >> 4, we = ((uint32_t)(end - pos) + 15u) >> 4;
+          return umin(wmax, umin(wa, we));
+        };
         if (searching)
         {
-          // find the next candidate block (:1291-1312): windows without the symbol, or with fewer than SHORT of it and not at their end, are skipped
-          for (;;)
+          // find the next candidate block (:1291-1312): windows without the symbol, or with fewer than SHORT of it and not at their end,
+          // are skipped -- up to four windows per pass, from one 64-bit field of the match masks
+          if (!(i < end)) { searching = false; i += 1; }
+          else
           {
-            if (!(i < end)) { searching = false; i += 1; break; }
-            if ((uint32_t)i + 16u > avail || tripsLeft == 0u) break;
+            uint32_t wmax;
+            const uint64_t v = win64(i, wmax);
+            const uint32_t w = windows_at(i, wmax);
             tripsLeft--;
-            const uint32_t m = win16(i);
-            if (m == 0u || ((m & 0x8000u) == 0u && (uint32_t)__builtin_popcount(m) < (uint32_t)SHORT)) { i += 16; continue; }
-            i += (int32_t)__builtin_ctz(m) + 1;
-            count = 1;
-            searching = false;
-            break;
+            uint32_t hit = 4u, mh = 0u;                                   // the first window that is not skipped
+#pragma unroll
+            for (int k = 3; k >= 0; k--)
+            {
+              const uint32_t m = (uint32_t)(v >> (16 * k)) & 0xFFFFu;
+              const bool skip = m == 0u || ((m & 0x8000u) == 0u && (uint32_t)__builtin_popcount(m) < (uint32_t)SHORT);
+              if (!skip && (uint32_t)k < w) { hit = (uint32_t)k; mh = m; }
+            }
+            if (hit < 4u)
+            {
+              i += (int32_t)(16u * hit + (uint32_t)__builtin_ctz(mh) + 1u);
+              count = 1;
+              searching = false;
+            }
+            else
+            {
+              i += (int32_t)(16u * w);
+              if (!(i < end)) { searching = false; i += 1; }
+            }
           }
         }
         if (!searching && i < end && (uint32_t)i + 16u <= avail && tripsLeft != 0u)
         {
-          uint32_t m = win16(i);
-          while (m == 0xFFFFu)                                            // (i += 15 and the loop's i++)
+          // the run through its full windows (count += 16 each: i += 15 and the loop's i++), then the window where it ends
+          uint32_t wmax;
+          const uint64_t v = win64(i, wmax);
+          const uint32_t w = windows_at(i, wmax);
+          tripsLeft--;
+          const uint32_t t = (wmax == 1u) ? (uint32_t)__builtin_ctz(~(uint32_t)v | 0x10000u) : (v == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~v));
+          uint32_t m = 0xFFFFu;
+          if (t >= 16u * w) { count += (int32_t)(16u * w); i += (int32_t)(16u * w); }
+          else
           {
-            count += 16; i += 16;
-            if (!(i < end) || (uint32_t)i + 16u > avail || tripsLeft == 0u) break;
-            tripsLeft--;
-            m = win16(i);
+            const uint32_t full = t & ~15u;
+            m = (uint32_t)(v >> full) & 0xFFFFu;
+            count += (int32_t)full; i += (int32_t)full;
           }
           if (m != 0xFFFFu)
           {

@@ -545,3 +545,31 @@ def test_single_blocks_stress(hs, oracle, key):
         size, stream = hs.call_dropin(codec.cname, d, hs.compress_bounds(len(d)))
         expect = oracle.compress(codec, d)
         assert size == len(expect) and stream == expect, f"{key}: one-block stream of {n} bytes differs from the oracle"
+
+
+@pytest.mark.parametrize("key", ["rle8_multi", "rle8_packed_multi", "rle8_3symlut", "rle8_7symlut_short", "rle16_sym", "rle24_byte_packed", "rle32_7symlut_sym", "rle48_byte",
+                                 "rle64_3symlut_byte", "rle64_sym_short", "rle8_single", "rle8_packed_single"])
+def test_long_literal_stretches(hs, oracle, key):
+    """Literal stretches that have left the encoders' 256-byte ring are noted and copied by the whole wave (hsrle_encode8.hip.h: coop_flush):
+    input without runs, one run per KiB, runs in bursts with gaps of 250 .. 3000 bytes, stretches that end on every byte of a 16-byte chunk."""
+    codec = CODEC_BY_KEY[key]
+    rng = random.Random(4711)
+    S = codec.S
+    noise = bytes(rng.randrange(256) for _ in range(150000))
+    sparse = bytearray(noise)
+    for at in range(500, len(sparse) - 100, 1024):
+        sparse[at : at + 5 * S + 3] = (bytes([7]) * S) * 6
+    bursts = bytearray()
+    while len(bursts) < 200000:
+        bursts += bytes(rng.randrange(256) for _ in range(rng.choice([250, 257, 271, 300, 500, 1000, 1001, 1002, 1003, 1017, 3000])))
+        for _ in range(rng.randrange(1, 4)):
+            sym = bytes(rng.randrange(256) for _ in range(S))
+            bursts += sym * rng.choice([3, 4, 8, 20]) + bytes(rng.randrange(256) for _ in range(rng.randrange(0, 18)))
+    for data, block_size in ((noise, 4096), (bytes(sparse), 4096), (bytes(bursts), 4096), (bytes(bursts[:70001]), 16384), (bytes(sparse), 1024)):
+        src = _to_dev(data)
+        container, info = hs.compress(key, src, block_size=block_size)
+        cinfo, streams = hs.split_container(container.cpu().numpy().tobytes())
+        for i, s in enumerate(streams):
+            expect = oracle.compress(codec, data[i * block_size : (i + 1) * block_size])
+            assert s == expect, f"{key} block {i} (size {block_size}) differs from the oracle"
+        assert hs.decompress(container).cpu().numpy().tobytes() == data
