@@ -1,6 +1,7 @@
 // 128 bit symbols: rle128_{sym,byte}[_packed]  (reference: src/rle.h:124-125, :146-147, :168-169, :194-195)
 #include "hsrle_decode.hip.h"
 #include "hsrle_encode.hip.h"
+#include "hsrle_encode128.hip.h"
 #include "hsrle_index.hip.h"
 #include "hsrle_launch.h"
 
@@ -11,10 +12,18 @@ static hipError_t dec_sym_packed(const DecodeArgs &a, hipStream_t st) { return l
 static hipError_t dec_byte(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PLAIN, 16, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
 static hipError_t dec_byte_packed(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PACKED, 16, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
 
-static hipError_t enc_sym(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<PLAIN, 16, 1>, a, st); }
-static hipError_t enc_sym_packed(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<PACKED, 16, 1>, a, st); }
-static hipError_t enc_byte(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<PLAIN, 16, 0>, a, st); }
-static hipError_t enc_byte_packed(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_blocks<PACKED, 16, 0>, a, st); }
+// ring encoder (hsrle_encode128.hip.h); HSRLE_ENCODE128_V1=1 selects the first-generation kernel (A/B runs)
+template <int FAM, int AL>
+static hipError_t enc_any(const EncodeArgs &a, hipStream_t st)
+{
+  static const bool v1 = [] { const char *e = getenv("HSRLE_ENCODE128_V1"); return e && atoi(e) != 0; }();
+  if (v1) return launch_encode(k_encode_blocks<FAM, 16, AL>, a, st);
+  return launch_encode(k_encode128_blocks<FAM == PACKED, AL>, a, st, 0);
+}
+static hipError_t enc_sym(const EncodeArgs &a, hipStream_t st) { return enc_any<PLAIN, 1>(a, st); }
+static hipError_t enc_sym_packed(const EncodeArgs &a, hipStream_t st) { return enc_any<PACKED, 1>(a, st); }
+static hipError_t enc_byte(const EncodeArgs &a, hipStream_t st) { return enc_any<PLAIN, 0>(a, st); }
+static hipError_t enc_byte_packed(const EncodeArgs &a, hipStream_t st) { return enc_any<PACKED, 0>(a, st); }
 
 static hipError_t idx_sym(const IndexArgs &a, int records, hipStream_t st) { return launch_index<PLAIN, 16, 1>(a, records, st); }
 static hipError_t idx_sym_packed(const IndexArgs &a, int records, hipStream_t st) { return launch_index<PACKED, 16, 1>(a, records, st); }

@@ -573,3 +573,47 @@ def test_long_literal_stretches(hs, oracle, key):
             expect = oracle.compress(codec, data[i * block_size : (i + 1) * block_size])
             assert s == expect, f"{key} block {i} (size {block_size}) differs from the oracle"
         assert hs.decompress(container).cpu().numpy().tobytes() == data
+
+
+def _runs128(seed, size):
+    """16-byte symbols: runs of 2 .. 40 symbols cut mid-symbol, runs that butt against each other sharing bytes (a later start with a rotated
+    symbol), byte runs (every 16-byte window of them is a symbol), gaps of 0 .. 300 bytes; the same near every block end."""
+    rng = random.Random(seed)
+    out = bytearray()
+    while len(out) < size:
+        out += bytes(rng.randrange(256) for _ in range(rng.choice([0, 0, 1, 2, 5, 15, 16, 17, 31, 33, 60, 127, 128, 255, 300])))
+        kind = rng.random()
+        if kind < 0.2:
+            out += bytes([rng.choice([0, 0, 7, rng.randrange(256)])]) * rng.choice([16, 17, 31, 32, 33, 34, 47, 48, 49, 64, 100, 500])
+        else:
+            sym = bytes(rng.choice([0, 7, rng.randrange(256)]) for _ in range(16)) if rng.random() < 0.5 else bytes(rng.randrange(256) for _ in range(16))
+            k = rng.choice([16, 18, 19, 20, 26, 27, 28, 31, 32, 33, 34, 35, 36, 42, 43, 44, 47, 48, 49, 64, 65, 80, 160, 640, 3000]) + rng.choice([0, 0, 1, 3, 15])
+            piece = (sym * (k // 16 + 2))[:k]
+            out += piece
+            if rng.random() < 0.3:
+                rot = rng.randrange(1, 17)
+                sym2 = piece[-rot:] + bytes(rng.randrange(256) for _ in range(16 - rot)) if rot < 16 else piece[-16:]
+                out += (sym2 * 30)[rot : rot + rng.choice([48, 50, 200, 321])]
+    return bytes(out[:size])
+
+
+@pytest.mark.parametrize("key", ["rle128_sym", "rle128_sym_packed", "rle128_byte", "rle128_byte_packed"])
+def test_rle128_blocks_stress(hs, oracle, key):
+    """The 128 bit ring encoder (bit scanner up to n - 48, the reference's loop as it is behind that: csrc/hsrle_encode128.hip.h)."""
+    codec = CODEC_BY_KEY[key]
+    for seed, size, blocks in ((1, 300001, (128, 256, 1024, 4096)), (2, 500017, (384, 640, 3968, 16384)), (3, 200000, (128, 65536))):
+        data = _runs128(seed, size)
+        src = _to_dev(data)
+        for block_size in blocks:
+            container, info = hs.compress(key, src, block_size=block_size)
+            cinfo, streams = hs.split_container(container.cpu().numpy().tobytes())
+            step = 1 if len(streams) < 3000 else 5
+            for i in list(range(0, len(streams), step)) + [len(streams) - 1]:
+                expect = oracle.compress(codec, data[i * block_size : (i + 1) * block_size])
+                assert streams[i] == expect, f"{key} block {i} of size {block_size} (input seed {seed}) differs from the oracle"
+            assert hs.decompress(container).cpu().numpy().tobytes() == data
+    for k, n in enumerate(list(range(1, 100)) + [127, 128, 129, 255, 257, 1000, 4095, 4097, 20001, 50000]):
+        d = _runs128(100 + k, n)
+        size, stream = hs.call_dropin(codec.cname, d, hs.compress_bounds(len(d)))
+        expect = oracle.compress(codec, d)
+        assert size == len(expect) and stream == expect, f"{key}: one-block stream of {n} bytes differs from the oracle"
