@@ -6,8 +6,9 @@
 // One lane = one block, the ring encoders' top-up and output accumulator (hsrle_encode8.hip.h), literal stretches that have left the ring
 // noted and copied by the wave (hsrle_encode8s.hip.h).  Run detection on bits: E[j] = (d[j] == d[j + 16]), sixteen bits per landed pair
 // of neighbouring chunks (the chunks are aligned: one SWAR compare), kept in two registers per lane for the last 128 positions.
-//   * a run starts at the first p >= the search position with E[p .. p + 16) all set (the reference's pair search with its skip rule,
-//     :233-268, reaches exactly this p); with L = the set bits from p on, it ends at p + 16 + L (byte-aligned: the matching leading
+//   * a run starts at the first p >= the search position with E[p .. p + 16) all set (the reference's pair search, :233-268, hops there:
+//     behind the highest differing byte of its window each time; the hops are replayed on the bits -- where they stand at n - 32
+//     matters); with L = the set bits from p on, it ends at p + 16 + L (byte-aligned: the matching leading
 //     bytes of the next symbol count, :214-228) or at p + 16 + 16 (L / 16) (sym-aligned);
 //   * the block starts INSIDE a run of its first symbol (count 0, symbol not inverted: q4), i.e. a run at p = 0 that needs no pair.
 // This holds as long as the end of the block is far: the extension wants i < n - 16, the pair search i < n - 32, and behind that the
@@ -371,25 +372,28 @@ __global__ __launch_bounds__(64) void k_encode128_blocks(const uint8_t *__restri
         if (!haveSymbol) { symbol = ring_win(0u); haveSymbol = true; }
         if (!inRun)
         {
-          // the first p >= i with E[p .. p + 16) set, among the windows that are known and start below bulkEnd (i < bulkEnd here)
+          // The pair search (:233-268) as it hops: at i the window E[i .. i + 16) is all set (a run starts), or i moves behind the highest
+          // byte that differs.  The hops end at the first all-set window whatever their way there -- but WHERE the search stands when it
+          // reaches n - 32 decides what the byte-wise loop behind it sees, so the hops are taken exactly (from one 64-bit field per pass).
           const uint64_t v = bits64(i);
-          uint64_t y = v & (v >> 1);
-          y &= y >> 2; y &= y >> 4; y &= y >> 8;                             // bit p: v[p .. p + 16) all set (p <= 48)
-          const uint32_t known = umin(49u, mEnd - (uint32_t)i - 15u);       // windows at i .. i + known - 1 are complete
-          const uint32_t lim = umin(known, (uint32_t)(bulkEnd - i));
-          const uint64_t ym = y & ((1ull << lim) - 1ull);                   // (lim <= 49)
-          if (ym != 0ull)
+          const uint32_t known = umin(64u, mEnd - (uint32_t)i);             // bits of v that are known (>= 16 here)
+          uint32_t off = 0;
+          bool found = false;
+          while (off + 16u <= known && i + (int32_t)off < bulkEnd)
           {
-            runP = i + (int32_t)__builtin_ctzll(ym);
+            const uint32_t w = (uint32_t)(v >> off) & 0xFFFFu;
+            if (w == 0xFFFFu) { found = true; break; }
+            off += 32u - (uint32_t)__builtin_clz((~w) & 0xFFFFu);            // highest differing byte + 1
+          }
+          i += (int32_t)off;
+          if (found)
+          {
+            runP = i;
             symbol = bytes16((uint32_t)runP);
             i = runP + 16;                                                  // set bits are known on [runP, i)
             inRun = true;
           }
-          else
-          {
-            i += (int32_t)lim;
-            if (!(i < bulkEnd)) { bulkDone = true; tailMode = 1; }          // the pair search goes on in the tail
-          }
+          else if (!(i < bulkEnd)) { bulkDone = true; tailMode = 1; }       // the pair search goes on in the tail, from exactly here
         }
         if (inRun && !bulkDone)
         {

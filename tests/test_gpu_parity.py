@@ -11,6 +11,7 @@ import struct
 import pytest
 
 from hsrle_testlib import CODECS, CODEC_BY_KEY, FUZZ_LENGTHS, Oracle, fuzz_sections, mixed_runs, single_symbol_mix
+from hsrle_testlib import SYNTH_VIDEO as SYNTH_VIDEO_KIND
 
 pytestmark = pytest.mark.gpu
 
@@ -612,6 +613,15 @@ def test_rle128_blocks_stress(hs, oracle, key):
                 expect = oracle.compress(codec, data[i * block_size : (i + 1) * block_size])
                 assert streams[i] == expect, f"{key} block {i} of size {block_size} (input seed {seed}) differs from the oracle"
             assert hs.decompress(container).cpu().numpy().tobytes() == data
+    # video-shaped data: byte runs of 10 .. 160 zeros with a few other bytes in between -- near a block's end the reference's byte-wise
+    # loop finds (or misses) 16-byte "symbols" in them depending on where its pair search stood when it reached n - 32
+    video = hs.synth(SYNTH_VIDEO_KIND, 16, 2, 4 << 20, device="cuda")
+    vdata = video.cpu().numpy().tobytes()
+    for block_size in (4096, 1024):
+        container, info = hs.compress(key, video, block_size=block_size)
+        cinfo, streams = hs.split_container(container.cpu().numpy().tobytes())
+        for i, s in enumerate(streams):
+            assert s == oracle.compress(codec, vdata[i * block_size : (i + 1) * block_size]), f"{key} video-shaped block {i} of size {block_size} differs from the oracle"
     for k, n in enumerate(list(range(1, 100)) + [127, 128, 129, 255, 257, 1000, 4095, 4097, 20001, 50000]):
         d = _runs128(100 + k, n)
         size, stream = hs.call_dropin(codec.cname, d, hs.compress_bounds(len(d)))
