@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64) void k_encode128_blocks(const uint8_t *__restri
       }
       oacc = w;
     }
-    else if (len >= 48u && (pendBytes == 0u || pend2Bytes == 0u))
+    else if (len >= kNotedLiteralMin && (pendBytes == 0u || pend2Bytes == 0u))
     {
       if (c != 0u) store_bytes(dst, oacc, 0u, c);
       const uint32_t tail = (opos + len) & 15u, noted = len - tail;

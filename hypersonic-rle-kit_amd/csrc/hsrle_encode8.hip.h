@@ -198,7 +198,7 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
       }
       oacc = w;
     }
-    else if (__builtin_expect(len >= 48u && (pendBytes == 0u || pend2Bytes == 0u), 0))
+    else if (__builtin_expect(len >= kNotedLiteralMin && (pendBytes == 0u || pend2Bytes == 0u), 0))
     {
       // what the accumulator holds goes out now; the stretch is noted up to the last 16-byte boundary of the stream it reaches; the
       // bytes behind that boundary come into the accumulator (through LDS: see below)
