@@ -163,8 +163,7 @@ __device__ __forceinline__ u32x4 global_window16(const uint8_t *in, uint64_t blo
 
 // Ring encoders: a literal stretch that has left the ring is copied by the whole wave (hsrle_encode8.hip.h: coop_flush) if it is at least
 // this long, else fetched by its lane.  A wave-wide copy costs every lane of the wave a memory latency, so it only pays for stretches
-// a lane would need many loads for: with 48 the 16 - 64 bit codecs lost 30 % on run data (literals of <= 63 bytes in front of runs longer
-// than the ring were copied one by one by the wave: rle64_sym 1 432 -> 991 GiB/s); with 256 they are where they were.
+// a lane would need many loads for (with 48, and noting between stored runs too, the 16 - 64 bit codecs lost 30 % on run data).
 constexpr uint32_t kNotedLiteralMin = 256;
 
 constexpr uint32_t kLaneRingStride = 132;  // bytes per lane in the input ring: 128 + one dword, so that the lanes' rows start in different banks

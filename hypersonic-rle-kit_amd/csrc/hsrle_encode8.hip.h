@@ -124,10 +124,12 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
   const u32x4 zero4 = u32x4{ 0, 0, 0, 0 };
   u32x4 oacc = zero4;        // the chunk that contains stream position opos (its low opos & 15 bytes are valid)
   uint32_t opos = 0;         // stream bytes produced so far
-  // Literal stretches that have left the ring are not fetched by the lane (one memory latency per 16 bytes with one lane of the wave
-  // active: incompressible input ran at 0.45 TiB/s) but NOTED -- two slots per lane -- and copied by the whole wave where it is converged
-  // (coop_flush below; first done for the Single encoders, hsrle_encode8s.hip.h).  A noted stretch ends at a 16-byte boundary of the
-  // stream; the bytes behind it (< 16) are fetched into the accumulator.
+  // The literals behind the last stored run (input without runs: the whole block) have mostly left the ring when the block is through.
+  // Fetching them in the lane's own code costs a memory latency per 16 bytes with one lane of the wave active (random bytes: 0.45 TiB/s),
+  // so finish_literals only NOTES a stretch of >= kNotedLiteralMin bytes and the whole wave copies the noted stretches when all its lanes
+  // are through (coop_flush; first done for the Single encoders, hsrle_encode8s.hip.h).  A noted stretch ends at a 16-byte boundary of
+  // the stream; the bytes behind it (< 16) are fetched into the accumulator.  Literals between two stored runs are NOT noted: with
+  // the noting code inlined into handle_run the encoders lost 4 - 7 % on every input (same-box A/B), whatever the threshold.
   uint32_t pendSrc = 0, pendDst = 0, pendBytes = 0, pend2Src = 0, pend2Dst = 0, pend2Bytes = 0;
   auto store_bytes = [&](uint8_t *p, u32x4 w, uint32_t lo, uint32_t hi) __attribute__((always_inline)) {
     const uint64_t w0 = (uint64_t)w.x | ((uint64_t)w.y << 32), w1 = (uint64_t)w.z | ((uint64_t)w.w << 32);
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
   // literal bytes [from, from + len) of the block: from the ring while they are still there.  Literals that have left the ring (a long
   // stretch of runs too short to be stored) are read from global memory by a function that is kept out of line: with the two
   // sources selected per chunk inside one loop the rare path cost the common one 10 % of the kernel.
-  auto emit_literals = [&](uint32_t from, uint32_t len) {
+  auto emit_literals = [&](uint32_t from, uint32_t len, bool mayNote) {
     if (len == 0u) return;
     const uint32_t c = opos & 15u, total = c + len;
     const uint32_t srcp = from - c;
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
       }
       oacc = w;
     }
-    else if (__builtin_expect(len >= kNotedLiteralMin && (pendBytes == 0u || pend2Bytes == 0u), 0))
+    else if (mayNote && len >= kNotedLiteralMin && (pendBytes == 0u || pend2Bytes == 0u))
     {
       // what the accumulator holds goes out now; the stretch is noted up to the last 16-byte boundary of the stream it reaches; the
       // bytes behind that boundary come into the accumulator (through LDS: see below)
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
     hflush();
 
     // ---- literals ----
-    emit_literals(lastRLE, gap);
+    emit_literals(lastRLE, gap, false);
     lastRLE = e;
 
     if (e >= nTrue)
@@ -510,7 +512,7 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
     else if constexpr (TR::kPacked) { hb(0x80); h32(0); h32(((kLit + 1u) << 1) | 1u); }
     else { hb(0); hb(0); h32(0); hb(0); h32(kLit + 1u); }
     hflush();
-    emit_literals(lastRLE, kLit);
+    emit_literals(lastRLE, kLit, true);    // (the one place that notes: see above)
   };
 
   // ---- main loop ----
@@ -611,7 +613,6 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
       }
     }
 
-    coop_flush(false);                                                  // (all lanes are here: the scan above is the only masked part)
     wave_sync();
     land();
     wave_sync();
