@@ -693,6 +693,34 @@ static int decompress_split_async(const void *dContainer, const hsrle_container_
   return g_dec[info->codec](da, st) == hipSuccess ? HSRLE_OK : HSRLE_ERR_DEVICE;
 }
 
+// one WAVE per block (hsrle_decode_wave.hip.h): for containers with too few blocks to fill the chip with one lane each
+constexpr uint32_t kWaveDecodeBelow = 65536u;     // blocks: above, one lane per block has the waves it needs
+static int decompress_wave_async(const void *dContainer, const hsrle_container_info_t *info, uint32_t first, uint32_t count, void *dOut, uint64_t cap, uint32_t *dStatus, hipStream_t st)
+{
+  if (dContainer == nullptr || info == nullptr || dOut == nullptr)
+    return HSRLE_ERR_ARGUMENT;
+  if (info->codec >= (uint32_t)kCodecCount || !valid_block_size(info->blockSize) || info->blockCount != block_count(info->uncompressedSize, info->blockSize))
+    return HSRLE_ERR_FORMAT;
+  if (info->blockSize > 16384u)
+    return HSRLE_ERR_UNSUPPORTED;
+  if ((uint64_t)first + count > info->blockCount)
+    return HSRLE_ERR_ARGUMENT;
+  if (cap < info->uncompressedSize)
+    return HSRLE_ERR_CAPACITY;
+  if (!device_ok())
+    return HSRLE_ERR_DEVICE;
+  if (count == 0)
+    return HSRLE_OK;
+  init_tables();
+  if (!g_sub[info->codec])
+    return HSRLE_ERR_UNSUPPORTED;
+  const uint8_t *container = (const uint8_t *)dContainer;
+  const uint8_t *payload = container + HSRLE_CONTAINER_HEADER_SIZE + 8ull * ((uint64_t)info->blockCount + 1ull);
+  DecodeArgs da{ payload, (const uint64_t *)(container + HSRLE_CONTAINER_HEADER_SIZE), payload + info->payloadSize + HSRLE_CONTAINER_TAIL_PAD,
+                 (uint8_t *)dOut, info->uncompressedSize, info->blockSize, first, count, dStatus };
+  return g_sub[info->codec](da, 0u, nullptr, st) == hipSuccess ? HSRLE_OK : HSRLE_ERR_DEVICE;     // (sub-block size 0 = the wave decoder)
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // monolithic stream decode: index passes (hsrle_index.hip.h) + the block kernel started from entry records
 
@@ -1584,6 +1612,12 @@ int hsrle_decompress_split_dev_async(const void *dContainer, const hsrle_contain
   return decompress_split_async(dContainer, info, firstBlock, blockCount, dOut, outCapacity, dStatus, dWorkspace, workspaceSize, subBlockSize, (hipStream_t)stream);
 }
 
+int hsrle_decompress_wave_dev_async(const void *dContainer, const hsrle_container_info_t *info, uint32_t firstBlock, uint32_t blockCount, void *dOut, uint64_t outCapacity,
+                                    uint32_t *dStatus, void *stream)
+{
+  return decompress_wave_async(dContainer, info, firstBlock, blockCount, dOut, outCapacity, dStatus, (hipStream_t)stream);
+}
+
 int hsrle_decompress_dev(const void *dContainer, uint64_t containerSize, void *dOut, uint64_t outCapacity, uint64_t *pUncompressedSize, void *stream)
 {
   hsrle_container_info_t info;
@@ -1592,7 +1626,13 @@ int hsrle_decompress_dev(const void *dContainer, uint64_t containerSize, void *d
 
   // a container with too few blocks to fill the GPU with one lane per block is decoded split (one lane per sub-block):
   // this call owns its scratch, so it can afford the records
-  const uint64_t recBytes = (info.blockCount < 131072u) ? hsrle_decompress_split_workspace_size(&info, info.blockCount, 0) : 0;
+  // ... or, for blocks of up to 16 KiB, by one WAVE per block (hsrle_decode_wave.hip.h): no records, no second kernel
+  // (opt-in: measured on the 88 MB frame it is the slower of the two -- 427 us against 189 us split: the packet hops of ONE lane per
+  //  wave are a latency chain of ~1 us per packet that the other 63 lanes wait for, while the split decode's record walk runs 64 such
+  //  chains per wave)
+  static const int waveMode = [] { const char *e = getenv("HSRLE_WAVE_DECODE"); return e ? atoi(e) : 0; }();
+  const bool wave = waveMode != 0 && info.blockCount < kWaveDecodeBelow && info.blockSize <= 16384u && info.codec < (uint32_t)kCodecCount;
+  const uint64_t recBytes = (!wave && info.blockCount < 131072u) ? hsrle_decompress_split_workspace_size(&info, info.blockCount, 0) : 0;
   uint8_t *scratch = (uint8_t *)scratch_alloc(256 + recBytes, (hipStream_t)stream);
   uint32_t *dStatus = (uint32_t *)scratch;
   if (!dStatus) return HSRLE_ERR_DEVICE;
@@ -1600,7 +1640,9 @@ int hsrle_decompress_dev(const void *dContainer, uint64_t containerSize, void *d
   bool ok = hipMemsetAsync(dStatus, 0, 4, (hipStream_t)stream) == hipSuccess;
   if (ok)
   {
-    if (recBytes != 0)
+    if (wave)
+      rc = decompress_wave_async(dContainer, &info, 0, info.blockCount, dOut, outCapacity, dStatus, (hipStream_t)stream);
+    else if (recBytes != 0)
       rc = decompress_split_async(dContainer, &info, 0, info.blockCount, dOut, outCapacity, dStatus, scratch + 256, recBytes, 0, (hipStream_t)stream);
     else
       rc = decompress_blocks_async(dContainer, &info, 0, info.blockCount, dOut, outCapacity, dStatus, (hipStream_t)stream);

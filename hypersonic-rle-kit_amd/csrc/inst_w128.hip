@@ -3,6 +3,7 @@
 #include "hsrle_encode.hip.h"
 #include "hsrle_encode128.hip.h"
 #include "hsrle_index.hip.h"
+#include "hsrle_decode_wave.hip.h"
 #include "hsrle_launch.h"
 
 namespace hsrle {
@@ -30,10 +31,10 @@ static hipError_t idx_sym_packed(const IndexArgs &a, int records, hipStream_t st
 static hipError_t idx_byte(const IndexArgs &a, int records, hipStream_t st) { return launch_index<PLAIN, 16, 0>(a, records, st); }
 static hipError_t idx_byte_packed(const IndexArgs &a, int records, hipStream_t st) { return launch_index<PACKED, 16, 0>(a, records, st); }
 
-static hipError_t sub_sym(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<PLAIN, 16, 1>(a, SB, 0u, rec, st); }
-static hipError_t sub_sym_packed(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<PACKED, 16, 1>(a, SB, 0u, rec, st); }
-static hipError_t sub_byte(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<PLAIN, 16, 0>(a, SB, 0u, rec, st); }
-static hipError_t sub_byte_packed(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<PACKED, 16, 0>(a, SB, 0u, rec, st); }
+static hipError_t sub_sym(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_sub_or_wave<PLAIN, 16, 1>(a, SB, 0u, rec, st); }
+static hipError_t sub_sym_packed(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_sub_or_wave<PACKED, 16, 1>(a, SB, 0u, rec, st); }
+static hipError_t sub_byte(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_sub_or_wave<PLAIN, 16, 0>(a, SB, 0u, rec, st); }
+static hipError_t sub_byte_packed(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_sub_or_wave<PACKED, 16, 0>(a, SB, 0u, rec, st); }
 
 void register_w128(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub)
 {

@@ -8,6 +8,7 @@
 #include "hsrle_encode8s.hip.h"
 #include "hsrle_encode_greedy.hip.h"
 #include "hsrle_index.hip.h"
+#include "hsrle_decode_wave.hip.h"
 #include "hsrle_launch.h"
 
 namespace hsrle {
@@ -67,17 +68,17 @@ static hipError_t idx_short3(const IndexArgs &a, int records, hipStream_t st) { 
 static hipError_t idx_short7(const IndexArgs &a, int records, hipStream_t st) { return launch_index<SHORT7, 1, 0>(a, records, st); }
 static hipError_t idx_short_single(const IndexArgs &a, int records, hipStream_t st) { return launch_index<SHORT_SINGLE, 1, 0>(a, records, st); }
 
-static hipError_t sub_plain(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<PLAIN, 1, 0>(a, SB, 0u, rec, st); }
-static hipError_t sub_packed(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<PACKED, 1, 0>(a, SB, 0u, rec, st); }
-static hipError_t sub_plain_any(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<PLAIN, 1, 0>(a, SB, 1u, rec, st); }
-static hipError_t sub_packed_any(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<PACKED, 1, 0>(a, SB, 1u, rec, st); }
-static hipError_t sub_lut3(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<LUT3, 1, 0>(a, SB, 0u, rec, st); }
-static hipError_t sub_lut7(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<LUT7, 1, 0>(a, SB, 0u, rec, st); }
-static hipError_t sub_short0(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<SHORT0, 1, 0>(a, SB, 0u, rec, st); }
-static hipError_t sub_short1(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<SHORT1, 1, 0>(a, SB, 0u, rec, st); }
-static hipError_t sub_short3(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<SHORT3, 1, 0>(a, SB, 0u, rec, st); }
-static hipError_t sub_short7(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<SHORT7, 1, 0>(a, SB, 0u, rec, st); }
-static hipError_t sub_short_single(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_container_records<SHORT_SINGLE, 1, 0>(a, SB, 0u, rec, st); }
+static hipError_t sub_plain(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_sub_or_wave<PLAIN, 1, 0>(a, SB, 0u, rec, st); }
+static hipError_t sub_packed(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_sub_or_wave<PACKED, 1, 0>(a, SB, 0u, rec, st); }
+static hipError_t sub_plain_any(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_sub_or_wave<PLAIN, 1, 0>(a, SB, 1u, rec, st); }
+static hipError_t sub_packed_any(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_sub_or_wave<PACKED, 1, 0>(a, SB, 1u, rec, st); }
+static hipError_t sub_lut3(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_sub_or_wave<LUT3, 1, 0>(a, SB, 0u, rec, st); }
+static hipError_t sub_lut7(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_sub_or_wave<LUT7, 1, 0>(a, SB, 0u, rec, st); }
+static hipError_t sub_short0(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_sub_or_wave<SHORT0, 1, 0>(a, SB, 0u, rec, st); }
+static hipError_t sub_short1(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_sub_or_wave<SHORT1, 1, 0>(a, SB, 0u, rec, st); }
+static hipError_t sub_short3(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_sub_or_wave<SHORT3, 1, 0>(a, SB, 0u, rec, st); }
+static hipError_t sub_short7(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_sub_or_wave<SHORT7, 1, 0>(a, SB, 0u, rec, st); }
+static hipError_t sub_short_single(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_sub_or_wave<SHORT_SINGLE, 1, 0>(a, SB, 0u, rec, st); }
 
 static hipError_t menc_plain(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode(k_encode8_blocks<PLAIN, true>, a, m, st); }
 static hipError_t menc_packed(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode(k_encode8_blocks<PACKED, true>, a, m, st); }

@@ -120,6 +120,8 @@ def _lib():
     L.hsrle_decompress_split_workspace_size.argtypes = [ctypes.POINTER(ContainerInfo), u32, u32]
     L.hsrle_decompress_split_dev_async.restype = ci
     L.hsrle_decompress_split_dev_async.argtypes = [vp, ctypes.POINTER(ContainerInfo), u32, u32, vp, u64, vp, vp, u64, u32, vp]
+    L.hsrle_decompress_wave_dev_async.restype = ci
+    L.hsrle_decompress_wave_dev_async.argtypes = [vp, ctypes.POINTER(ContainerInfo), u32, u32, vp, u64, vp, vp]
     L.hsrle_hash_blocks_dev_async.restype = ci
     L.hsrle_hash_blocks_dev_async.argtypes = [vp, ctypes.POINTER(ContainerInfo), u32, u32, vp, vp]
     L.hsrle_synth_dev_async.restype = ci
@@ -369,6 +371,19 @@ def decompress_split_async(container, info, dst, workspace, status=None, sub_blo
                                                  sp, wp, wn, sub_block, _stream_ptr(stream))
     if rc != OK:
         raise HsrleError(rc, "hsrle_decompress_split_dev_async")
+
+
+def decompress_wave_async(container, info, dst, status=None, first_block=0, block_count=None, stream=None):
+    """Wave decode (hsrle_decompress_wave_dev_async): one wave per block, for containers with few blocks."""
+    _check_u8_cuda(container, "container")
+    _check_u8_cuda(dst, "dst")
+    if block_count is None:
+        block_count = info.blockCount - first_block
+    sp = ctypes.c_void_p(status.data_ptr()) if status is not None else None
+    rc = _lib().hsrle_decompress_wave_dev_async(ctypes.c_void_p(container.data_ptr()), ctypes.byref(info), first_block, block_count, ctypes.c_void_p(dst.data_ptr()), dst.numel(),
+                                                sp, _stream_ptr(stream))
+    if rc != OK:
+        raise HsrleError(rc, "hsrle_decompress_wave_dev_async")
 
 
 def decompress(container, dst=None):

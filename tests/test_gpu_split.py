@@ -106,3 +106,29 @@ def test_config3_frame_split_decode(hs, oracle):
     for sub in (0, 1024, 256):
         out, status = _split(hs, container, info, size, sub)
         assert status == 0 and torch.equal(out[:size], src), f"sub {sub}"
+
+
+@pytest.mark.parametrize("codec", CODECS, ids=lambda c: c.key)
+def test_wave_decode_every_codec(hs, codec):
+    """One wave per block (hsrle_decompress_wave_dev_async, csrc/hsrle_decode_wave.hip.h): every grammar, block sizes 128 .. 16 KiB, blocks with
+    more packets than a descriptor batch holds, a range of blocks, the bytes behind the output untouched."""
+    import torch
+
+    rng = random.Random(31 + CODECS.index(codec))
+    data = b"".join(d for d in (mixed_runs(rng, rng.choice([1, 17, 333, 3000, 9000])) for _ in range(12)) if d) + bytes(rng.randrange(4) for _ in range(40000))
+    src = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    for block_size in (128, 4096, 16384):
+        container, info = hs.compress(codec.key, src, block_size=block_size)
+        out = torch.full((len(data) + 256,), 0xA5, dtype=torch.uint8, device="cuda")
+        status = torch.zeros(1, dtype=torch.int32, device="cuda")
+        hs.decompress_wave_async(container, info, out[: len(data)], status)
+        torch.cuda.synchronize()
+        assert int(status.item()) == 0
+        assert out[: len(data)].cpu().numpy().tobytes() == data, f"{codec.key}: wave decode differs (block size {block_size})"
+        assert bool((out[len(data):] == 0xA5).all())
+    if info.blockCount > 2:
+        out.fill_(0xA5)
+        hs.decompress_wave_async(container, info, out[: len(data)], status, first_block=1, block_count=1)
+        torch.cuda.synchronize()
+        bs = info.blockSize
+        assert out[bs : 2 * bs].cpu().numpy().tobytes()[: len(data) - bs] == data[bs : 2 * bs] and bool((out[:bs] == 0xA5).all()) and bool((out[2 * bs : len(data)] == 0xA5).all())

@@ -46,6 +46,22 @@ def main():
         ms = e0.elapsed_time(e1) / args.reps
         ok = int(status.item()) == 0 and torch.equal(out, src)
         print(f"  sub-block {sub:5d} (-> {eff:5d}): {ms * 1e3:8.1f} us  {args.size / 2**30 / (ms * 1e-3):8.1f} GiB/s  {(args.size + info.totalSize) / (ms * 1e-3) / 1e12:6.3f} TB/s algorithmic  exact {ok}", flush=True)
+    # one wave per block (hsrle_decompress_wave_dev_async)
+    if args.block <= 16384:
+        run = lambda: hsrle.decompress_wave_async(container, info, out, status)
+        out.zero_()
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.reps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / args.reps
+        ok = int(status.item()) == 0 and torch.equal(out, src)
+        print(f"  wave per block          : {ms * 1e3:8.1f} us  {args.size / 2**30 / (ms * 1e-3):8.1f} GiB/s  {(args.size + info.totalSize) / (ms * 1e-3) / 1e12:6.3f} TB/s algorithmic  exact {ok}", flush=True)
 
 
 if __name__ == "__main__":
