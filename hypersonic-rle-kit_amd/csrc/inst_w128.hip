@@ -13,12 +13,12 @@ static hipError_t dec_sym_packed(const DecodeArgs &a, hipStream_t st) { return l
 static hipError_t dec_byte(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PLAIN, 16, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
 static hipError_t dec_byte_packed(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PACKED, 16, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
 
-// ring encoder (hsrle_encode128.hip.h); HSRLE_ENCODE128_V1=1 selects the first-generation kernel (A/B runs)
+// ring encoder (hsrle_encode128.hip.h) for block sizes up to 64 KiB; HSRLE_ENCODE128_V1=1 selects the first-generation kernel (A/B runs)
 template <int FAM, int AL>
 static hipError_t enc_any(const EncodeArgs &a, hipStream_t st)
 {
   static const bool v1 = [] { const char *e = getenv("HSRLE_ENCODE128_V1"); return e && atoi(e) != 0; }();
-  if (v1) return launch_encode(k_encode_blocks<FAM, 16, AL>, a, st);
+  if (v1 || a.B > 65536u) return launch_encode(k_encode_blocks<FAM, 16, AL>, a, st);   // (the one-block drop-in path spans the whole input with one block: one lane either way)
   return launch_encode(k_encode128_blocks<FAM == PACKED, AL>, a, st, 0);
 }
 static hipError_t enc_sym(const EncodeArgs &a, hipStream_t st) { return enc_any<PLAIN, 1>(a, st); }

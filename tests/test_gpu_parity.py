@@ -622,7 +622,7 @@ def test_rle128_blocks_stress(hs, oracle, key):
         cinfo, streams = hs.split_container(container.cpu().numpy().tobytes())
         for i, s in enumerate(streams):
             assert s == oracle.compress(codec, vdata[i * block_size : (i + 1) * block_size]), f"{key} video-shaped block {i} of size {block_size} differs from the oracle"
-    for k, n in enumerate(list(range(1, 100)) + [127, 128, 129, 255, 257, 1000, 4095, 4097, 20001, 50000]):
+    for k, n in enumerate(list(range(1, 100)) + [127, 128, 129, 255, 257, 1000, 4095, 4097, 20001, 50000, 65536, 65537, 150001]):   # (> 64 KiB: the first-generation kernel)
         d = _runs128(100 + k, n)
         size, stream = hs.call_dropin(codec.cname, d, hs.compress_bounds(len(d)))
         expect = oracle.compress(codec, d)
