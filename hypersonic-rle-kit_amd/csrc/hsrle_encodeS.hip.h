@@ -36,7 +36,16 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
   static_assert(S == 2 || S == 3 || S == 4 || S == 6 || S == 8, "8 bit and 128 bit symbols have their own kernels");
   static_assert(FAM == PLAIN || FAM == PACKED || FAM == LUT3 || FAM == LUT7 || (FAM >= SHORT0 && FAM <= SHORT7), "multi-symbol families only");
   constexpr int Q = 64;                      // input bytes per lane and step
-  constexpr int H = 256;                     // history ring per lane (power of two)
+  // History ring per lane (power of two).  The kernel is a latency chain, so LDS is waves: 128 bytes per lane give 16 instead of 9 waves
+  // per CU -- and cost the literals in front of a run whose end lies more than ~100 bytes behind them a fetch from global memory.  With
+  // symbols of 3 bytes and more the runs are that long anyway (8 GiB, same-box A/B, run-distributed / video-shaped: rle32_byte_packed
+  // +17 % / +32 %, rle64_3symlut_byte +21 % / +26 %); with 1 and 2 byte symbols the run-distributed data loses (rle16_sym -11 %,
+  // the 8 bit codecs -17 %) what the video-shaped data gains (+28 ... +31 %): those keep 256.  HSRLE_ENCS_RING overrides (A/B builds).
+#ifdef HSRLE_ENCS_RING
+  constexpr int H = HSRLE_ENCS_RING;
+#else
+  constexpr int H = (S >= 3) ? 128 : 256;
+#endif
   constexpr int LPR = Q / 16, RPL = 64 / LPR;
   constexpr uint32_t HM = (uint32_t)H - 1u;
   constexpr int K = TR::K;
