@@ -539,6 +539,7 @@ static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, ui
   else if (w.nChunks <= 1)
   {
     EncodeArgs ea{ (const uint8_t *)dIn, U, B, nBlocks, ws + w.offSlots, stride, sizes };
+    ea.ringSel = (uint32_t *)(ws + w.offSlots + align_up((uint64_t)nBlocks * stride, 256));   // (in the wave encoder's counter area behind the slots: unused on this path)
     if (g_enc[codec](ea, st) != hipSuccess || scan_sizes(sizes, nBlocks, offsets, ws, w, st) != hipSuccess)
       rc = HSRLE_ERR_DEVICE;
     else

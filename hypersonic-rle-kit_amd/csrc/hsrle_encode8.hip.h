@@ -21,8 +21,13 @@
 #include "hsrle_common.hip.h"
 #include "hsrle_decode.hip.h" // funnel16, merge_low, wave_sync
 
+#ifndef HSRLE_ENC8_RING
+#define HSRLE_ENC8_RING 256
+#endif
+
 namespace hsrle {
 
+// (which ring the encoders of 1 and 2 byte symbols use for an input: hsrle_ring_probe.hip.h)
 // MONO = true: the lanes encode consecutive CHUNKS of ONE monolithic reference stream instead of independent blocks (hsrle_mono_encode.hip.h
 // finds the chunk boundaries).  Chunk c covers the input bytes [monoStarts[c], monoStarts[c + 1]); every boundary is the end of a run
 // that every encoder state emits (count >= LONG: SURVEY.md A.4 "reset points"), so the state in front of a chunk is known without the
@@ -30,22 +35,23 @@ namespace hsrle {
 // packets the sequential encoder writes for these bytes.  A chunk writes no stream header and (unless it reaches the end of the input)
 // no terminator, its rules see the TRUE end of the input (the AVX2 body / tail split of A.5 q1 counts from there), and its output goes
 // to slots + monoSlotOff[c].
-template <int FAM, bool MONO = false>
+// RING: bytes of history ring per lane (256, or 128 for 16 instead of 9 waves per CU).  ringSel != nullptr: the host launches both
+// instantiations and this one only runs if ringSel[0] == RING (k_ring_probe / k_ring_decide below chose from a sample of the input).
+template <int FAM, bool MONO = false, int RING = HSRLE_ENC8_RING>
 __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t nBlocks,
                                                        uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes,
                                                        const uint64_t *__restrict__ monoStarts, const uint64_t *__restrict__ monoSyms,
-                                                       const uint64_t *__restrict__ monoSlotOff, uint32_t monoSteps, uint64_t *__restrict__ monoListOut, uint32_t monoDry)
+                                                       const uint64_t *__restrict__ monoSlotOff, uint32_t monoSteps, uint64_t *__restrict__ monoListOut, uint32_t monoDry,
+                                                       const uint32_t *__restrict__ ringSel)
 {
+  if (ringSel != nullptr && ringSel[0] != (uint32_t)RING) return;
   using TR = Traits<FAM, 1, 0>;
   // Codecs with a move-to-front list: the list in front of a chunk is NOT known from the boundary run; the host hands every chunk a list
   // (monoSyms[8 * c + k]: entry k; [8 * c + 7]: encode this chunk?), gets the list behind it back (monoListOut[8 * c + k]; [.. + 7]: mtfDepth) and repeats the chunks whose
   // incoming list was not what the chunk in front left behind (hsrle_capi.hip: mono_encode_dev).  monoDry: no stores, only the list.
   [[maybe_unused]] const bool dry = MONO && monoDry != 0u;
   constexpr int Q = 64;                      // input bytes per lane and step
-#ifndef HSRLE_ENC8_RING
-#define HSRLE_ENC8_RING 256
-#endif
-  constexpr int H = HSRLE_ENC8_RING;         // history ring per lane (power of two)
+  constexpr int H = RING;                    // history ring per lane (power of two)
   constexpr int LPR = Q / 16, RPL = 64 / LPR;
   constexpr uint32_t HM = (uint32_t)H - 1u;
   constexpr int K = TR::K;

@@ -23,12 +23,19 @@ namespace hsrle {
 // instead of b * B, the symbol in front of the chunk as lastSymbol, no stream header, no terminator unless the chunk reaches the end of
 // the input, and the rules that look at the end of the input (the partial-symbol extension of the byte-aligned variants, the end
 // terminator) see the TRUE end.
-template <int FAM, int S, int AL, bool MONO = false>
+#ifdef HSRLE_ENCS_RING
+#define HSRLE_ENCS_RING_OF(S) HSRLE_ENCS_RING
+#else
+#define HSRLE_ENCS_RING_OF(S) ((S) >= 3 ? 128 : 256)
+#endif
+template <int FAM, int S, int AL, bool MONO = false, int RING = HSRLE_ENCS_RING_OF(S)>
 __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t nBlocks,
                                                        uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes,
                                                        const uint64_t *__restrict__ monoStarts, const uint64_t *__restrict__ monoSyms,
-                                                       const uint64_t *__restrict__ monoSlotOff, uint32_t monoSteps, uint64_t *__restrict__ monoListOut, uint32_t monoDry)
+                                                       const uint64_t *__restrict__ monoSlotOff, uint32_t monoSteps, uint64_t *__restrict__ monoListOut, uint32_t monoDry,
+                                                       const uint32_t *__restrict__ ringSel)
 {
+  if (ringSel != nullptr && ringSel[0] != (uint32_t)RING) return;          // (S = 2: the host launches both rings, k_ring_decide chose: hsrle_encode8.hip.h)
   // (codecs with a move-to-front list: monoSyms[8 * c + k] = entry k of the list in front of chunk c, monoListOut likewise the list behind it;
   //  monoDry: no stores, only the list -- see k_encode8_blocks)
   [[maybe_unused]] const bool dry = MONO && monoDry != 0u;
@@ -40,12 +47,9 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
   // per CU -- and cost the literals in front of a run whose end lies more than ~100 bytes behind them a fetch from global memory.  With
   // symbols of 3 bytes and more the runs are that long anyway (8 GiB, same-box A/B, run-distributed / video-shaped: rle32_byte_packed
   // +17 % / +32 %, rle64_3symlut_byte +21 % / +26 %); with 1 and 2 byte symbols the run-distributed data loses (rle16_sym -11 %,
-  // the 8 bit codecs -17 %) what the video-shaped data gains (+28 ... +31 %): those keep 256.  HSRLE_ENCS_RING overrides (A/B builds).
-#ifdef HSRLE_ENCS_RING
-  constexpr int H = HSRLE_ENCS_RING;
-#else
-  constexpr int H = (S >= 3) ? 128 : 256;
-#endif
+  // the 8 bit codecs -17 %) what the video-shaped data gains (+28 ... +31 %): those choose per input.  HSRLE_ENCS_RING overrides (A/B builds).
+  // For S = 2 the host chooses per input (RING).
+  constexpr int H = RING;
   constexpr int LPR = Q / 16, RPL = 64 / LPR;
   constexpr uint32_t HM = (uint32_t)H - 1u;
   constexpr int K = TR::K;

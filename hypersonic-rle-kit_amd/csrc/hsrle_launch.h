@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include "hsrle_ring_probe.hip.h"
 
 namespace hsrle {
 
@@ -46,6 +47,7 @@ struct EncodeArgs
   uint32_t slotStride;
   uint32_t *sizes;
   int *residentWorkgroups = nullptr; // query mode, as in DecodeArgs
+  uint32_t *ringSel = nullptr;       // 16 bytes of device scratch: the encoders of 1 / 2 byte symbols choose their history ring per input (hsrle_encode8.hip.h)
 };
 
 // chunks of ONE monolithic stream (hsrle_mono_encode.hip.h): EncodeArgs with nBlocks = chunks, plus the chunk table
@@ -118,11 +120,33 @@ inline hipError_t launch_encode(KERNEL k, const EncodeArgs &a, hipStream_t st, i
   static const uint32_t lds8 = [] { const char *e = getenv("HSRLE_ENCODE8_LDS"); return e ? (uint32_t)atoi(e) : 0u; }();   // experiment knob
   if (a.residentWorkgroups != nullptr)
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(a.residentWorkgroups, k, 64, capResidency ? ldsCap : lds8);
-  if constexpr (kernel_arity(KERNEL{}) == 13)   // kernels with a MONO mode (hsrle_encode8.hip.h): block mode = no chunk table
+  if constexpr (kernel_arity(KERNEL{}) == 14)   // kernels with a MONO mode (hsrle_encode8.hip.h): block mode = no chunk table
     hipLaunchKernelGGL(k, dim3(grid), dim3(64), capResidency ? ldsCap : lds8, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, (const uint64_t *)nullptr,
-                       (const uint64_t *)nullptr, (const uint64_t *)nullptr, 0u, (uint64_t *)nullptr, 0u);
+                       (const uint64_t *)nullptr, (const uint64_t *)nullptr, 0u, (uint64_t *)nullptr, 0u, (const uint32_t *)nullptr);
   else
     hipLaunchKernelGGL(k, dim3(grid), dim3(64), capResidency ? ldsCap : lds8, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes);
+  return hipGetLastError();
+}
+
+// the encoders of 1 / 2 byte symbols: probe a sample of the input, then both instantiations -- the one that was not chosen returns at once.
+// HSRLE_ENC_RING=128 / 256 in the environment forces one (tests, A/B).  Without scratch (a.ringSel == nullptr): the 256-byte ring.
+template <int S, typename K256, typename K128>
+inline hipError_t launch_encode_ring(K256 k256, K128 k128, const EncodeArgs &a, hipStream_t st)
+{
+  static const int forced = [] { const char *e = getenv("HSRLE_ENC_RING"); return e ? atoi(e) : 0; }();
+  if (a.residentWorkgroups != nullptr || forced == 256 || (forced == 0 && (a.ringSel == nullptr || a.nBlocks < 4096u)))
+    return launch_encode(k256, a, st, 0);
+  if (forced == 128)
+    return launch_encode(k128, a, st, 0);
+  if (hipMemsetAsync(a.ringSel, 0, 16, st) != hipSuccess) return hipErrorUnknown;
+  const uint32_t samples = a.nBlocks < 256u ? a.nBlocks : 256u;
+  hipLaunchKernelGGL((k_ring_probe<S>), dim3(samples), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.ringSel);
+  hipLaunchKernelGGL((k_ring_decide<S>), dim3(1), dim3(64), 0, st, a.ringSel);
+  const uint32_t grid = (a.nBlocks + 63u) / 64u;
+  hipLaunchKernelGGL(k256, dim3(grid), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, (const uint64_t *)nullptr, (const uint64_t *)nullptr, (const uint64_t *)nullptr, 0u,
+                     (uint64_t *)nullptr, 0u, (const uint32_t *)a.ringSel);
+  hipLaunchKernelGGL(k128, dim3(grid), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, (const uint64_t *)nullptr, (const uint64_t *)nullptr, (const uint64_t *)nullptr, 0u,
+                     (uint64_t *)nullptr, 0u, (const uint32_t *)a.ringSel);
   return hipGetLastError();
 }
 
@@ -149,7 +173,7 @@ inline hipError_t launch_wave_encode(KERNEL k, const WaveEncodeArgs &a, hipStrea
 template <typename KERNEL>
 inline hipError_t launch_mono_encode(KERNEL k, const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st)
 {
-  hipLaunchKernelGGL(k, dim3((a.nBlocks + 63u) / 64u), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, m.starts, m.syms, m.slotOff, m.steps, m.listOut, m.dry);
+  hipLaunchKernelGGL(k, dim3((a.nBlocks + 63u) / 64u), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, m.starts, m.syms, m.slotOff, m.steps, m.listOut, m.dry, (const uint32_t *)nullptr);
   return hipGetLastError();
 }
 

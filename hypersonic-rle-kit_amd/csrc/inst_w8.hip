@@ -26,18 +26,18 @@ static hipError_t dec_short0(const DecodeArgs &a, hipStream_t st) { return launc
 static hipError_t dec_short1(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<SHORT1, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
 static hipError_t dec_short3(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<SHORT3, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
 static hipError_t dec_short7(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<SHORT7, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
-static hipError_t enc_short0(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode8_blocks<SHORT0>, a, st, 0); }
-static hipError_t enc_short1(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode8_blocks<SHORT1>, a, st, 0); }
-static hipError_t enc_short3(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode8_blocks<SHORT3>, a, st, 0); }
-static hipError_t enc_short7(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode8_blocks<SHORT7>, a, st, 0); }
+static hipError_t enc_short0(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<SHORT0, false, 256>, k_encode8_blocks<SHORT0, false, 128>, a, st); }
+static hipError_t enc_short1(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<SHORT1, false, 256>, k_encode8_blocks<SHORT1, false, 128>, a, st); }
+static hipError_t enc_short3(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<SHORT3, false, 256>, k_encode8_blocks<SHORT3, false, 128>, a, st); }
+static hipError_t enc_short7(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<SHORT7, false, 256>, k_encode8_blocks<SHORT7, false, 128>, a, st); }
 
 static hipError_t dec_short_single(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<SHORT_SINGLE, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
 static hipError_t enc_short_single(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_single_short_blocks<SHORT_SINGLE>, a, st, 0); }
 
-static hipError_t enc_plain(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode8_blocks<PLAIN>, a, st, 0); }
-static hipError_t enc_packed(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode8_blocks<PACKED>, a, st, 0); }
-static hipError_t enc_lut3(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode8_blocks<LUT3>, a, st, 0); }
-static hipError_t enc_lut7(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode8_blocks<LUT7>, a, st, 0); }
+static hipError_t enc_plain(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<PLAIN, false, 256>, k_encode8_blocks<PLAIN, false, 128>, a, st); }
+static hipError_t enc_packed(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<PACKED, false, 256>, k_encode8_blocks<PACKED, false, 128>, a, st); }
+static hipError_t enc_lut3(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<LUT3, false, 256>, k_encode8_blocks<LUT3, false, 128>, a, st); }
+static hipError_t enc_lut7(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<LUT7, false, 256>, k_encode8_blocks<LUT7, false, 128>, a, st); }
 // Single: symbol pick by one wave per block, then the ring encoder (hsrle_encode8s.hip.h).  Blocks above kSinglePickMaxBlock (the one-lane
 // drop-in path spans the whole input with one block) and HSRLE_SINGLE_V1=1 (A/B runs) use the first-generation kernel.
 template <bool PACKED_S>
