@@ -201,7 +201,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   constexpr int RPL = 64 / LPR;              // rows covered by one top-up instruction
   constexpr uint32_t RMASK = (uint32_t)R - 1u;
   constexpr uint32_t MAXHDR = 1u + 4u + (uint32_t)S + 4u + 2u; // longest packet header of any family (+ slack)
-  static_assert((R & (R - 1)) == 0 && R >= 64 && R % Q == 0 && T % Q == 0 && (Q == 32 || Q == 64 || Q == 128), "ring size must be a power of two and a multiple of Q");
+  static_assert((R & (R - 1)) == 0 && R >= 64 && (R % Q == 0 || Q % R == 0) && T % Q == 0 && (Q == 32 || Q == 64 || Q == 128), "ring size must be a power of two and a multiple (or a divisor: streams that shrink a lot) of Q");
   static_assert(T == 64 || T == 128, "tile rows are flushed as whole 64/128-byte pieces");
   static_assert(TS % 16 == 0 && RS % 16 == 0, "rows are 16-byte aligned");
 
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
       // bit, never as a wild read -- the lane then sees an empty stream at offset 0, which fails the header check
       const uint64_t payloadBytes = (uint64_t)(payloadEnd - payload);
       if (off0 > off1 || off1 > payloadBytes || off1 - off0 > 0xFFFFFF00ull) { off0 = 0; off1 = 0; }   // -> DEC_ERR_HEADER below
-      g0 = (uint32_t)((uintptr_t)(payload + off0) & (uintptr_t)(Q - 1));
+      g0 = (uint32_t)((uintptr_t)(payload + off0) & (uintptr_t)((R < Q ? R : Q) - 1));   // (< R: the header is read from the ring's first fill)
       g0 = umin(g0, (uint32_t)(off0 < 0xFFFFFFFFull ? off0 : 0xFFFFFFFFull) + 64u) & ~15u; // never reach in front of the container (>= 64 header bytes precede the payload)
       base0 = off0 - g0;                                               // may be "negative" for block 0: wraps, added to `payload` again below
       slen = (uint32_t)(off1 - off0) + g0;
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     if (pfPos[q] < rowLim) pf[q] = ld128(payload + myBase[q] + pfPos[q]);
     else pfPos[q] = 0xFFFFFFFFu;
   }
-  for (int k = 0; k < R / Q; k++)
+  for (int k = 0; k < (R / Q > 0 ? R / Q : 1); k++)
   {
     topup();                                                          // ... land (sp is still 0); the next piece is requested and
     wave_sync();                                                      //     flies during the first step's decode
