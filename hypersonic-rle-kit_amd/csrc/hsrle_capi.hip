@@ -1305,7 +1305,15 @@ static int rle8m_encode_async(const void *dIn, uint32_t n, uint32_t sections, vo
   const uint32_t grid = (sections + 63u) / 64u;
   // the statistics are over the whole input: one lane per 4 KiB piece, whatever the section count
   const uint32_t pieces = (n / 4096u > sections) ? n / 4096u : sections;
-  hipLaunchKernelGGL(k_rle8m_stats, dim3((pieces + 63u) / 64u), dim3(64), 0, st, (const uint8_t *)dIn, n, pieces, t);
+  static const uint32_t g_rle8mStatsWaves = getenv("HSRLE_RLE8M_STATS_WAVES") ? (uint32_t)atoi(getenv("HSRLE_RLE8M_STATS_WAVES")) : 32768u;   // (1 GiB run-distributed / video-shaped: 1 024 waves 7.5 / 6.2 ms per encode, 8 192: 3.96 / 4.17, 32 768: 3.75 / 3.98; the byte-walking kernel: 4.03 / 4.60)
+  static const int statsV1 = getenv("HSRLE_RLE8M_STATS") ? atoi(getenv("HSRLE_RLE8M_STATS")) : 0;   // 1 = the byte-walking kernel (A/B runs)
+  if (statsV1 == 1)
+    hipLaunchKernelGGL(k_rle8m_stats, dim3((pieces + 63u) / 64u), dim3(64), 0, st, (const uint8_t *)dIn, n, pieces, t);
+  else
+  {
+    const uint32_t waves = (uint32_t)(((uint64_t)n + 4095u) / 4096u);
+    hipLaunchKernelGGL(k_rle8m_stats_wave, dim3(waves < g_rle8mStatsWaves ? waves : g_rle8mStatsWaves), dim3(64), 0, st, (const uint8_t *)dIn, n, t);
+  }
   hipLaunchKernelGGL(k_rle8m_info, dim3(1), dim3(256), 0, st, t, sections, (uint8_t *)dOut);
   static const int forced = getenv("HSRLE_RLE8M_ENCODE") ? atoi(getenv("HSRLE_RLE8M_ENCODE")) : 0;   // 1 = lane, 2 = wave kernel (A/B runs)
   if (forced ? forced == 2 : sections < kRle8mWaveBelow)

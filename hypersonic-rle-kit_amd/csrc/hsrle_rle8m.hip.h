@@ -398,6 +398,120 @@ __global__ __launch_bounds__(64) void k_rle8m_stats(const uint8_t *__restrict__ 
   }
 }
 
+// The same statistics, position-parallel: persistent waves take 4 KiB pieces of the input.  A piece goes to LDS, 64 positions per lane
+// become equality bits (d[i] == d[i + 1]), run starts are the positions whose predecessor differs, and every lane adds the runs that
+// START in its 64 positions -- length = 1 + the set bits from the start on (followed through the piece and, for the rare run that
+// leaves it, through global memory) -- to LDS histograms; one flush of the histograms per wave.  (k_rle8m_stats above walks a byte
+// per lane and trip: 1.87 ms per GiB, as long as the encode kernel; kept for HSRLE_RLE8M_STATS=1 A/B runs.)
+__global__ __launch_bounds__(64) void k_rle8m_stats_wave(const uint8_t *__restrict__ d, uint32_t n, Rle8mTables *__restrict__ t)
+{
+  constexpr uint32_t P = 4096u;
+  __shared__ __attribute__((aligned(16))) uint8_t bytes[P + 16u];
+  __shared__ uint64_t eqw[P / 64u + 1u];
+  __shared__ uint32_t prob[256], pcount[256];
+  const uint32_t lane = threadIdx.x;
+  for (uint32_t k = lane; k < 256u; k += 64u) { prob[k] = 0; pcount[k] = 0; }
+  const uint32_t pieces = (uint32_t)(((uint64_t)n + P - 1u) / P);
+  for (uint32_t piece = blockIdx.x; piece < pieces; piece += gridDim.x)
+  {
+    const uint32_t a = piece * P;
+    const uint32_t len = (n - a < P) ? n - a : P;
+    __syncthreads();                                                      // (the piece before is done with the buffers)
+    // piece + the byte behind it (zero filled beyond the input: masked below)
+    for (uint32_t q = lane * 16u; q < P + 16u; q += 64u * 16u)
+    {
+      u32x4 v = u32x4{ 0, 0, 0, 0 };
+      if ((uint64_t)a + q + 16u <= (uint64_t)n) v = ld128(d + a + q);
+      else if ((uint64_t)a + q < (uint64_t)n)
+      {
+        uint32_t tt[4] = { 0, 0, 0, 0 };
+        for (uint32_t k = 0; (uint64_t)a + q + k < (uint64_t)n && k < 16u; k++) tt[k >> 2] |= (uint32_t)d[a + q + k] << (8u * (k & 3u));
+        v = u32x4{ tt[0], tt[1], tt[2], tt[3] };
+      }
+      lds_st128(bytes + q, v);
+    }
+    const uint32_t prevByte = (a > 0u) ? (uint32_t)d[a - 1u] : 0x100u;    // (0x100: the input's first byte starts a run)
+    __syncthreads();
+    {
+      // equality bits of my 64 positions: bit i = (d[a + i] == d[a + i + 1]) and a + i + 1 < n
+      const uint32_t w = lane;
+      uint64_t e64 = 0;
+#pragma unroll
+      for (uint32_t j = 0; j < 4u; j++)
+      {
+        const u32x4 x = lds_ld128(bytes + w * 64u + j * 16u);
+        const uint32_t x4 = lds_ld32(bytes + w * 64u + j * 16u + 16u);
+        const uint32_t z0 = zero_bytes(x.x ^ alignbyte(x.y, x.x, 1)), z1 = zero_bytes(x.y ^ alignbyte(x.z, x.y, 1));
+        const uint32_t z2 = zero_bytes(x.z ^ alignbyte(x.w, x.z, 1)), z3 = zero_bytes(x.w ^ alignbyte(x4, x.w, 1));
+        const uint32_t b0 = (((z0 >> 7) * 0x00204081u) >> 21) & 0xFu, b1 = (((z1 >> 7) * 0x00204081u) >> 21) & 0xFu;
+        const uint32_t b2 = (((z2 >> 7) * 0x00204081u) >> 21) & 0xFu, b3 = (((z3 >> 7) * 0x00204081u) >> 21) & 0xFu;
+        e64 |= (uint64_t)(b0 | (b1 << 4) | (b2 << 8) | (b3 << 12)) << (16u * j);
+      }
+      const uint32_t base = w * 64u;
+      const uint64_t left = (uint64_t)n - 1u - a;                         // positions a + i with a + i + 1 < n: i < left
+      const uint32_t valid = (left > base) ? (uint32_t)((left - base < 64u) ? left - base : 64u) : 0u;
+      if (valid < 64u) e64 &= (1ull << valid) - 1ull;
+      eqw[w] = e64;
+    }
+    __syncthreads();
+    {
+      const uint32_t w = lane;
+      const uint32_t base = w * 64u;
+      const uint64_t m = eqw[w];
+      // run starts among my positions: the predecessor differs (position 0 of the piece: the byte in front of the piece)
+      const uint64_t prevEq = (w > 0u) ? eqw[w - 1u] >> 63 : ((prevByte == (uint32_t)bytes[0]) ? 1ull : 0ull);
+      uint64_t starts = ~((m << 1) | prevEq);
+      const uint32_t mine = (len > base) ? ((len - base < 64u) ? len - base : 64u) : 0u;
+      if (mine < 64u) starts &= (mine == 0u) ? 0ull : ((1ull << mine) - 1ull);
+      while (starts != 0ull)
+      {
+        const uint32_t p = (uint32_t)__builtin_ctzll(starts);
+        starts &= starts - 1ull;
+        // set bits from p on
+        const uint64_t sh = m >> p;
+        uint32_t ones = (p == 0u && m == ~0ull) ? 64u : (uint32_t)__builtin_ctzll(~sh | ((p == 0u) ? 0ull : (1ull << (64u - p))));
+        uint64_t L;
+        if (ones < 64u - p) L = 1ull + ones;
+        else
+        {
+          // through the following words of the piece, then through global memory
+          uint32_t w2 = w + 1u;
+          uint64_t total = ones;
+          bool open = true;
+          while (open && w2 < P / 64u)
+          {
+            const uint64_t mm = eqw[w2];
+            if (mm == ~0ull) { total += 64u; w2++; }
+            else { total += (uint32_t)__builtin_ctzll(~mm); open = false; }
+          }
+          if (open)
+          {
+            // the run leaves the piece: d[a + P - 1] == d[a + P]; count on from a + P
+            const uint32_t sy = bytes[base + p];
+            uint64_t g = (uint64_t)a + P;                                 // first position not yet known to belong to the run... it does (the last bit was set)
+            g += 1u;
+            const uint64_t rep = (uint64_t)sy * 0x0101010101010101ull;
+            while (g + 8u <= (uint64_t)n && ld64(d + g) == rep) g += 8u;       // (eight bytes per trip; the walk is one lane's)
+            while (g < (uint64_t)n && (uint32_t)d[g] == sy) g++;
+            total = g - 1u - ((uint64_t)a + base + p);                    // set bits = run length - 1
+          }
+          L = 1ull + total;
+        }
+        const uint32_t sy = bytes[base + p];
+        const bool toEnd = (uint64_t)a + base + p + L == (uint64_t)n;     // the run that reaches the end of the input counts once
+        atomicAdd(&prob[sy], (uint32_t)L);
+        atomicAdd(&pcount[sy], toEnd ? 1u : (uint32_t)(L / 255ull) + 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t s2 = lane; s2 < 256u; s2 += 64u)
+  {
+    if (prob[s2]) atomicAdd(&t->prob[s2], prob[s2]);
+    if (pcount[s2]) atomicAdd(&t->pcount[s2], pcount[s2]);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_rle8m_info(Rle8mTables *__restrict__ t, uint32_t sections, uint8_t *__restrict__ out)
 {
   __shared__ uint32_t pc[256];
