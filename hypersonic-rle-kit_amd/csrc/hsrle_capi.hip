@@ -1312,7 +1312,9 @@ static int rle8m_encode_async(const void *dIn, uint32_t n, uint32_t sections, vo
   else
   {
     const uint32_t waves = (uint32_t)(((uint64_t)n + 4095u) / 4096u);
-    hipLaunchKernelGGL(k_rle8m_stats_wave, dim3(waves < g_rle8mStatsWaves ? waves : g_rle8mStatsWaves), dim3(64), 0, st, (const uint8_t *)dIn, n, t);
+    uint32_t grid = waves < g_rle8mStatsWaves ? waves : g_rle8mStatsWaves;
+    if ((uint64_t)grid * kRle8mStatsPieces < waves) grid = (waves + kRle8mStatsPieces - 1u) / kRle8mStatsPieces;   // (no wave gets more pieces than its packed counters hold)
+    hipLaunchKernelGGL(k_rle8m_stats_wave, dim3(grid), dim3(64), 0, st, (const uint8_t *)dIn, n, t);
   }
   hipLaunchKernelGGL(k_rle8m_info, dim3(1), dim3(256), 0, st, t, sections, (uint8_t *)dOut);
   static const int forced = getenv("HSRLE_RLE8M_ENCODE") ? atoi(getenv("HSRLE_RLE8M_ENCODE")) : 0;   // 1 = lane, 2 = wave kernel (A/B runs)

@@ -403,14 +403,15 @@ __global__ __launch_bounds__(64) void k_rle8m_stats(const uint8_t *__restrict__ 
 // START in its 64 positions -- length = 1 + the set bits from the start on (followed through the piece and, for the rare run that
 // leaves it, through global memory) -- to LDS histograms; one flush of the histograms per wave.  (k_rle8m_stats above walks a byte
 // per lane and trip: 1.87 ms per GiB, as long as the encode kernel; kept for HSRLE_RLE8M_STATS=1 A/B runs.)
+constexpr uint32_t kRle8mStatsPieces = 15;    // 4 KiB pieces per wave at most (15 * 4096 < 65536: the packed LDS counters)
 __global__ __launch_bounds__(64) void k_rle8m_stats_wave(const uint8_t *__restrict__ d, uint32_t n, Rle8mTables *__restrict__ t)
 {
   constexpr uint32_t P = 4096u;
   __shared__ __attribute__((aligned(16))) uint8_t bytes[P + 16u];
   __shared__ uint64_t eqw[P / 64u + 1u];
-  __shared__ uint32_t prob[256], pcount[256];
+  __shared__ uint32_t pk[256];
   const uint32_t lane = threadIdx.x;
-  for (uint32_t k = lane; k < 256u; k += 64u) { prob[k] = 0; pcount[k] = 0; }
+  for (uint32_t k = lane; k < 256u; k += 64u) pk[k] = 0;
   const uint32_t pieces = (uint32_t)(((uint64_t)n + P - 1u) / P);
   for (uint32_t piece = blockIdx.x; piece < pieces; piece += gridDim.x)
   {
@@ -499,16 +500,22 @@ __global__ __launch_bounds__(64) void k_rle8m_stats_wave(const uint8_t *__restri
         }
         const uint32_t sy = bytes[base + p];
         const bool toEnd = (uint64_t)a + base + p + L == (uint64_t)n;     // the run that reaches the end of the input counts once
-        atomicAdd(&prob[sy], (uint32_t)L);
-        atomicAdd(&pcount[sy], toEnd ? 1u : (uint32_t)(L / 255ull) + 1u);
+        // the usual run (< 255 bytes: one count) is ONE LDS atomic into the packed table (pcount << 16 | prob: a wave sees at most
+        // kRle8mStatsPieces * 4096 bytes, so neither half overflows); the others go to the global table directly
+        if (L < 255ull) atomicAdd(&pk[sy], (1u << 16) | (uint32_t)L);
+        else
+        {
+          atomicAdd(&t->prob[sy], (uint32_t)L);
+          atomicAdd(&t->pcount[sy], toEnd ? 1u : (uint32_t)(L / 255ull) + 1u);
+        }
       }
     }
   }
   __syncthreads();
   for (uint32_t s2 = lane; s2 < 256u; s2 += 64u)
   {
-    if (prob[s2]) atomicAdd(&t->prob[s2], prob[s2]);
-    if (pcount[s2]) atomicAdd(&t->pcount[s2], pcount[s2]);
+    const uint32_t v = pk[s2];
+    if (v != 0u) { atomicAdd(&t->prob[s2], v & 0xFFFFu); atomicAdd(&t->pcount[s2], v >> 16); }
   }
 }
 
