@@ -15,23 +15,23 @@ namespace hsrle {
 
 // ids 0 / 1 (rle8_multi, rle8_packed_multi): their encoders only write mode 0 -> the kernel without the Single mode (k_decode_blocks SGL);
 // ids 4 / 5 (the Single codecs) and any stream whose mode byte says 1 (hsrle_capi.hip: mono_decompress) -> the general kernel
-static hipError_t dec_plain(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PLAIN, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep, false>, a, st); }
-static hipError_t dec_packed(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PACKED, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep, false>, a, st); }
-static hipError_t dec_plain_any(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PLAIN, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep, true>, a, st); }
-static hipError_t dec_packed_any(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PACKED, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep, true>, a, st); }
-static hipError_t dec_lut3(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<LUT3, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
-static hipError_t dec_lut7(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<LUT7, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
+static hipError_t dec_plain(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<PLAIN, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep, false>, k_decode_blocks<PLAIN, 1, 0, kDecodeTile, 64, kDecodeStep, false>, a, st); }
+static hipError_t dec_packed(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<PACKED, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep, false>, k_decode_blocks<PACKED, 1, 0, kDecodeTile, 64, kDecodeStep, false>, a, st); }
+static hipError_t dec_plain_any(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<PLAIN, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep, true>, k_decode_blocks<PLAIN, 1, 0, kDecodeTile, 64, kDecodeStep, true>, a, st); }
+static hipError_t dec_packed_any(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<PACKED, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep, true>, k_decode_blocks<PACKED, 1, 0, kDecodeTile, 64, kDecodeStep, true>, a, st); }
+static hipError_t dec_lut3(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<LUT3, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, k_decode_blocks<LUT3, 1, 0, kDecodeTile, 64, kDecodeStep>, a, st); }
+static hipError_t dec_lut7(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<LUT7, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, k_decode_blocks<LUT7, 1, 0, kDecodeTile, 64, kDecodeStep>, a, st); }
 
-static hipError_t dec_short0(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<SHORT0, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
-static hipError_t dec_short1(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<SHORT1, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
-static hipError_t dec_short3(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<SHORT3, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
-static hipError_t dec_short7(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<SHORT7, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
+static hipError_t dec_short0(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<SHORT0, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, k_decode_blocks<SHORT0, 1, 0, kDecodeTile, 64, kDecodeStep>, a, st); }
+static hipError_t dec_short1(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<SHORT1, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, k_decode_blocks<SHORT1, 1, 0, kDecodeTile, 64, kDecodeStep>, a, st); }
+static hipError_t dec_short3(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<SHORT3, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, k_decode_blocks<SHORT3, 1, 0, kDecodeTile, 64, kDecodeStep>, a, st); }
+static hipError_t dec_short7(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<SHORT7, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, k_decode_blocks<SHORT7, 1, 0, kDecodeTile, 64, kDecodeStep>, a, st); }
 static hipError_t enc_short0(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<SHORT0, false, 256>, k_encode8_blocks<SHORT0, false, 128>, a, st); }
 static hipError_t enc_short1(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<SHORT1, false, 256>, k_encode8_blocks<SHORT1, false, 128>, a, st); }
 static hipError_t enc_short3(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<SHORT3, false, 256>, k_encode8_blocks<SHORT3, false, 128>, a, st); }
 static hipError_t enc_short7(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<SHORT7, false, 256>, k_encode8_blocks<SHORT7, false, 128>, a, st); }
 
-static hipError_t dec_short_single(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<SHORT_SINGLE, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
+static hipError_t dec_short_single(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<SHORT_SINGLE, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, k_decode_blocks<SHORT_SINGLE, 1, 0, kDecodeTile, 64, kDecodeStep>, a, st); }
 static hipError_t enc_short_single(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_single_short_blocks<SHORT_SINGLE>, a, st, 0); }
 
 static hipError_t enc_plain(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<PLAIN, false, 256>, k_encode8_blocks<PLAIN, false, 128>, a, st); }
