@@ -175,7 +175,7 @@ __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
 //   launchers use it for the codec ids whose encoders only write mode 0 (rle8_multi, rle8_packed_multi); a mode-1 block in such a
 //   container is reported as DEC_ERR_MODE.  The Single codec ids and the host-pointer drop-in functions (which look at the mode
 //   byte first, like rle8_decompress does) use the general kernel.
-template <int FAM, int S, int AL, int T, int R, int Q = T, bool SGL = true>
+template <int FAM, int S, int AL, int T, int R, int Q = T, bool SGL = true, bool ENT = true>
 __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict__ payload, const uint64_t *__restrict__ offsets,
                                                       const uint8_t *__restrict__ payloadEnd, uint8_t *__restrict__ out, uint64_t U,
                                                       uint32_t B, uint32_t firstBlock, uint32_t blockCount, uint32_t *__restrict__ status,
@@ -188,6 +188,10 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 #ifdef HSRLE_NO_ENTRIES  // A/B builds only: the kernel without the entry-record prologue
   entries = nullptr;
 #endif
+  // ENT = false: the instantiation without the entry-record prologue.  For 8 .. 64 bit symbols the prologue is free (same-box A/B); with
+  // 16-byte symbols it costs 10 % (8 GiB rle128_sym: 3 120 against 3 460 GiB/s run-distributed, 2 011 against 2 260 video-shaped), so the
+  // 128 bit codecs launch this one for plain containers (inst_w128.hip).
+  if constexpr (!ENT) entries = nullptr;
   using TR = Traits<FAM, S, AL>;
   constexpr int TS = T;                      // tile row stride: no pad -- the 16-byte chunks of a row are XOR-swizzled by the row index instead (TSW)
   constexpr int RS = R;                      // ring row stride: no pad, no mirror -- chunks are XOR-swizzled by the row index (rowx), every 8-byte piece is addressed on its own

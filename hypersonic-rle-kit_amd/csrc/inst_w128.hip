@@ -8,10 +8,10 @@
 
 namespace hsrle {
 
-static hipError_t dec_sym(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PLAIN, 16, 1, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
-static hipError_t dec_sym_packed(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PACKED, 16, 1, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
-static hipError_t dec_byte(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PLAIN, 16, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
-static hipError_t dec_byte_packed(const DecodeArgs &a, hipStream_t st) { return launch_decode(k_decode_blocks<PACKED, 16, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st); }
+static hipError_t dec_sym(const DecodeArgs &a, hipStream_t st) { return a.entries ? launch_decode(k_decode_blocks<PLAIN, 16, 1, kDecodeTile, kDecodeRing, kDecodeStep>, a, st) : launch_decode(k_decode_blocks<PLAIN, 16, 1, kDecodeTile, kDecodeRing, kDecodeStep, true, false>, a, st); }
+static hipError_t dec_sym_packed(const DecodeArgs &a, hipStream_t st) { return a.entries ? launch_decode(k_decode_blocks<PACKED, 16, 1, kDecodeTile, kDecodeRing, kDecodeStep>, a, st) : launch_decode(k_decode_blocks<PACKED, 16, 1, kDecodeTile, kDecodeRing, kDecodeStep, true, false>, a, st); }
+static hipError_t dec_byte(const DecodeArgs &a, hipStream_t st) { return a.entries ? launch_decode(k_decode_blocks<PLAIN, 16, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st) : launch_decode(k_decode_blocks<PLAIN, 16, 0, kDecodeTile, kDecodeRing, kDecodeStep, true, false>, a, st); }
+static hipError_t dec_byte_packed(const DecodeArgs &a, hipStream_t st) { return a.entries ? launch_decode(k_decode_blocks<PACKED, 16, 0, kDecodeTile, kDecodeRing, kDecodeStep>, a, st) : launch_decode(k_decode_blocks<PACKED, 16, 0, kDecodeTile, kDecodeRing, kDecodeStep, true, false>, a, st); }
 
 // ring encoder (hsrle_encode128.hip.h) for block sizes up to 64 KiB; HSRLE_ENCODE128_V1=1 selects the first-generation kernel (A/B runs)
 template <int FAM, int AL>
