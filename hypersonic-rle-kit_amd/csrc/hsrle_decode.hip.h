@@ -1073,11 +1073,6 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     //      never includes the flush stores below: vmcnt counts loads and stores in order), then the next piece is requested --
     //      BEFORE the flush stores, so that the prefetch registers are live across the flush (the flush data then cannot share
     //      registers with them, which would force a full `s_waitcnt vmcnt(0)` drain of the stores before every top-up) ----
-#if defined(HSRLE_EXP_PRIO) && HSRLE_EXP_PRIO == 1
-    __builtin_amdgcn_s_setprio(3);
-#elif defined(HSRLE_EXP_PRIO) && HSRLE_EXP_PRIO == 2
-    __builtin_amdgcn_s_setprio(0);
-#endif
     topup();
     HS_STAMP(tLand)
     wave_sync();
@@ -1137,11 +1132,6 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     }
 
     wave_sync();
-#if defined(HSRLE_EXP_PRIO) && HSRLE_EXP_PRIO == 1
-    __builtin_amdgcn_s_setprio(0);
-#elif defined(HSRLE_EXP_PRIO) && HSRLE_EXP_PRIO == 2
-    __builtin_amdgcn_s_setprio(3);
-#endif
     HS_STAMP(tFlush)
   }
 
