@@ -10,9 +10,9 @@
 //                     >= 2 equal bytes: a run of L bytes adds L - (L - 1) / 16 to prob[s] and 1 to pcount[s].  (Closed form checked
 //                     against the oracle on 90 000 inputs: tools/scratch/pick_model.py.)  So: equality bits of the whole block in
 //                     LDS, every lane takes the run starts of 64 positions, LDS atomics into a 256-entry table, the one run that
-//                     reaches n - 16 and the final registration by lane 0, argmax by shuffles.  The symbol goes to byte 9 of the
-//                     block's staging slot -- where the stream keeps it -- and the encoder picks it up there.
-//   k_encode8_single_blocks<PACKED>   one lane per block like the other ring encoders (hsrle_encode8.hip.h: same top-up, same
+//                     reaches n - 16 and the final registration by lane 0, argmax by shuffles.  The symbol goes to byte 9 (rle8_single_short:
+//                     byte 8) of the block's staging slot -- where the stream keeps it -- and the encoder picks it up there.
+//   k_encode8_single_blocks<MODE>     (rle8_single, rle8_packed_single and the Short family's rle8_single_short) one lane per block like the other ring encoders (hsrle_encode8.hip.h: same top-up, same
 //                     output accumulator).  The scanner of the reference is run as it is -- 16-byte windows at its own, data
 //                     dependent phase, the skip rule of the search, the back-track to the first wasted run -- on match bits taken
 //                     from the ring (from global memory for positions that have left it).
@@ -29,7 +29,8 @@ namespace hsrle {
 constexpr uint32_t kSinglePickMaxBlock = 32768u;   // larger blocks use the first-generation kernel (hsrle_encode.hip.h)
 
 // dynamic LDS: [0, 1024) table (prob | pcount << 16), then n bytes of the block (padded to 64), then the equality bits
-__global__ __launch_bounds__(64) void k_single_pick(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t nBlocks, uint8_t *__restrict__ slots, uint32_t slotStride)
+__global__ __launch_bounds__(64) void k_single_pick(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t nBlocks, uint8_t *__restrict__ slots, uint32_t slotStride,
+                                                    uint32_t symAt)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t pickLds[];
   const uint32_t lane = threadIdx.x;
@@ -214,10 +215,13 @@ __global__ __launch_bounds__(64) void k_single_pick(const uint8_t *__restrict__ 
     bestKey = a > bestKey ? a : bestKey;
   }
   if (lane == 0u)
-    slots[(uint64_t)b * slotStride + 9u] = (bestKey >> 8) != 0u ? (uint8_t)(255u - (bestKey & 0xFFu)) : (uint8_t)0;
+    slots[(uint64_t)b * slotStride + symAt] = (bestKey >> 8) != 0u ? (uint8_t)(255u - (bestKey & 0xFFu)) : (uint8_t)0;
 }
 
-template <bool PACKED>
+// MODE 0: rle8_single, 1: rle8_packed_single, 2: rle8_single_short (rleX_Xsl_short.h with SINGLE: wrapper :380-523, body :1058-1120 -- the
+// same estimator and the same kind of scanner: windows with fewer than two occurrences are skipped unless their last byte is one, every
+// run end goes through process_symbol (:152-372, one-byte or three-byte header, no symbol in the packet), no wasted-chances logic)
+template <int MODE>
 __global__ __launch_bounds__(64) void k_encode8_single_blocks(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t nBlocks, uint8_t *__restrict__ slots, uint32_t slotStride,
                                                               uint32_t *__restrict__ sizes)
 {
@@ -227,7 +231,10 @@ __global__ __launch_bounds__(64) void k_encode8_single_blocks(const uint8_t *__r
   constexpr int H = HSRLE_SINGLE_RING;       // history ring per lane
   constexpr int LPR = Q / 16, RPL = 64 / LPR;
   constexpr uint32_t HM = (uint32_t)H - 1u;
-  constexpr int32_t SHORT = PACKED ? 2 : 4, MEDIUM = 6, LONG = PACKED ? 10 : 8;
+  constexpr bool PACKED = MODE == 1, SSHORT = MODE == 2;
+  using TRS = Traits<SHORT_SINGLE, 1, 0>;                                // header parameters of the Short family's Single codec
+  constexpr int32_t SHORT = SSHORT ? 2 : (PACKED ? 2 : 4), MEDIUM = 6, LONG = PACKED ? 10 : 8;
+  constexpr uint32_t SYM_AT = SSHORT ? 8u : 9u;                           // where the stream keeps its symbol (k_single_pick leaves it there)
 
   __shared__ __attribute__((aligned(16))) uint8_t hist[64 * H];
   __shared__ __attribute__((aligned(16))) uint32_t rinfo[64];
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(64) void k_encode8_single_blocks(const uint8_t *__r
   const uint64_t blockAt = (uint64_t)b * B;
   if (active) n = (uint32_t)((U - blockAt) < (uint64_t)B ? (U - blockAt) : (uint64_t)B);
   uint8_t *const slot = slots + (uint64_t)b * slotStride;
-  const uint32_t sym = active ? (uint32_t)slot[9] : 0u;                 // k_single_pick's choice
+  const uint32_t sym = active ? (uint32_t)slot[SYM_AT] : 0u;            // k_single_pick's choice
   const uint32_t sym4 = sym * 0x01010101u;
 
   uint32_t avail = 0;
@@ -418,7 +425,9 @@ __global__ __launch_bounds__(64) void k_encode8_single_blocks(const uint8_t *__r
   // ---- stream header: sizes, mode = single, the symbol ----
   if (active)
   {
-    h32(n); h32(0); hb(1); hb(sym);
+    h32(n); h32(0);
+    if constexpr (!SSHORT) hb(1);                                         // mode = single
+    hb(sym);
     hflush();
   }
 
@@ -544,7 +553,43 @@ __global__ __launch_bounds__(64) void k_encode8_single_blocks(const uint8_t *__r
   };
 
   // kind 0: short form (range in one byte), 1: long form, 2: the forced packet of the back-track (count byte without the 32 bit escape)
+  // rle8_single_short: is the run [at - cnt, at) stored (process_symbol's penalty rule, rleX_Xsl_short.h:152-197)?
+  auto short_stored = [&](int32_t cnt, int32_t gap) __attribute__((always_inline)) -> bool {
+    const uint32_t range = (uint32_t)gap + 2u;
+    const int32_t sc = cnt - (int32_t)TRS::SMINS + 2;
+    const bool pack1 = (uint32_t)gap <= TRS::SMAXPR && (uint32_t)(sc - 2) <= TRS::SMAXPC;
+    uint32_t pen = 0u;
+    if (!pack1)
+    {
+      pen = 2u;
+      if (!(sc <= (int32_t)TRS::SMAXTC && range <= TRS::SMAXTR))
+        pen += ((range <= 0xFFFFFu) ? (range <= TRS::SMAXTR ? 0u : 2u) : 4u) + ((sc <= 0xFFFFF) ? (sc <= (int32_t)TRS::SMAXTC ? 0u : 2u) : 4u);
+    }
+    return cnt >= (int32_t)TRS::SMINL || cnt >= (int32_t)(TRS::SMINS + pen);
+  };
   auto emit = [&](int kind, int32_t at, int32_t cnt, int32_t from) __attribute__((always_inline)) {
+    if constexpr (SSHORT)
+    {
+      // one-byte header [count | range] or the three-byte form with its 16 / 32 bit extensions (:199-357); no symbol
+      const uint32_t gap = (uint32_t)(at - from - cnt), range = gap + 2u;
+      const int32_t sc = cnt - (int32_t)TRS::SMINS + 2;
+      if (gap <= TRS::SMAXPR && (uint32_t)(sc - 2) <= TRS::SMAXPC)
+        hb(((uint32_t)(sc - 2) << TRS::SRBP) | gap);
+      else
+      {
+        const uint32_t scu = (uint32_t)sc;
+        const uint32_t scx = (scu <= TRS::SMAXTC) ? scu : (scu <= 0xFFFFu ? 1u : 0u);
+        const uint32_t rx = (range <= TRS::SMAXTR) ? range : (range <= 0xFFFFu ? 1u : 0u);
+        hb((TRS::SCINV << TRS::SRBP) | ((scx << (TRS::SRB - 8u)) >> 8));
+        hb((scx << (TRS::SRB - 8u)) | (rx >> 8));
+        hb(rx);
+        if (scx != scu) { if (scu <= 0xFFFFu) { hb(scu); hb(scu >> 8); } else h32(scu); }
+        if (rx != range) { if (range <= 0xFFFFu) { hb(range); hb(range >> 8); } else h32(range); }
+      }
+      hflush();
+      emit_literals((uint32_t)from, (uint32_t)(at - cnt - from));
+      return;
+    }
     const uint32_t range = (uint32_t)(at - from - cnt + 1);
     const uint32_t c = (uint32_t)(cnt - SHORT + 1);
     if (kind == 2) hb(c);
@@ -663,7 +708,11 @@ __global__ __launch_bounds__(64) void k_encode8_single_blocks(const uint8_t *__r
               count += z; i += z;
               const int32_t range = i - lastRLE - count + 1;
               int ek = -1;                                               // the packet to write: one emit site (the code is inlined)
-              if (count >= SHORT)
+              if constexpr (SSHORT)
+              {
+                if (short_stored(count, i - lastRLE - count)) ek = 3;
+              }
+              else if (count >= SHORT)
               {
                 if (range <= 255) { ek = 0; wasted = 0; }
                 else if (count >= LONG || (PACKED && count - SHORT + 1 <= 255 && count >= MEDIUM)) { ek = 1; wasted = 0; }
@@ -721,7 +770,8 @@ __global__ __launch_bounds__(64) void k_encode8_single_blocks(const uint8_t *__r
             else
             {
               const int32_t range = i - lastRLE - count + 1;
-              if (range <= 255 && count >= SHORT) ek = 0;
+              if constexpr (SSHORT) { if (short_stored(count, i - lastRLE - count)) ek = 3; }
+              else if (range <= 255 && count >= SHORT) ek = 0;
               else if (count >= LONG) ek = 1;
               at = i; cnt = count;
               count = 0;
@@ -733,14 +783,27 @@ __global__ __launch_bounds__(64) void k_encode8_single_blocks(const uint8_t *__r
           if (fin)
           {
             frange = i - lastRLE - count + 1;
-            if (frange <= 255 && count >= SHORT) ek = 0;
+            if constexpr (SSHORT) { if (short_stored(count, i - lastRLE - count)) ek = 3; }
+            else if (frange <= 255 && count >= SHORT) ek = 0;
             else if (count >= LONG) ek = 1;
             at = i; cnt = count;
           }
           if (ek >= 0) { emit(ek, at, cnt, lastRLE); lastRLE = at; }
           if (fin)
           {
-            if (ek >= 0) { hb(0); h32(0); hb(0); h32(0); hflush(); }
+            if constexpr (SSHORT)
+            {
+              // terminators of the Short family (rleX_Xsl_short.h:470-523)
+              if (ek >= 0) { hb(TRS::SCINV << TRS::SRBP); hb(TRS::STB); hb(1); hb(0); hb(0); hb(0); hb(0); hflush(); }
+              else
+              {
+                const uint32_t kLit = (uint32_t)(i - lastRLE);
+                hb(TRS::SCINV << TRS::SRBP); hb(TRS::STB); hb(0); hb(0); hb(0); h32(kLit + 2u);
+                hflush();
+                emit_literals((uint32_t)lastRLE, kLit);
+              }
+            }
+            else if (ek >= 0) { hb(0); h32(0); hb(0); h32(0); hflush(); }
             else
             {
               hb(0); h32(0); hb(0); h32((uint32_t)(frange + count));

@@ -32,7 +32,6 @@ static hipError_t enc_short3(const EncodeArgs &a, hipStream_t st) { return launc
 static hipError_t enc_short7(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<SHORT7, false, 256>, k_encode8_blocks<SHORT7, false, 128>, a, st); }
 
 static hipError_t dec_short_single(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<SHORT_SINGLE, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, k_decode_blocks<SHORT_SINGLE, 1, 0, kDecodeTile, 64, kDecodeStep>, a, st); }
-static hipError_t enc_short_single(const EncodeArgs &a, hipStream_t st) { return launch_encode(k_encode_single_short_blocks<SHORT_SINGLE>, a, st, 0); }
 
 static hipError_t enc_plain(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<PLAIN, false, 256>, k_encode8_blocks<PLAIN, false, 128>, a, st); }
 static hipError_t enc_packed(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<PACKED, false, 256>, k_encode8_blocks<PACKED, false, 128>, a, st); }
@@ -40,23 +39,27 @@ static hipError_t enc_lut3(const EncodeArgs &a, hipStream_t st) { return launch_
 static hipError_t enc_lut7(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<LUT7, false, 256>, k_encode8_blocks<LUT7, false, 128>, a, st); }
 // Single: symbol pick by one wave per block, then the ring encoder (hsrle_encode8s.hip.h).  Blocks above kSinglePickMaxBlock (the one-lane
 // drop-in path spans the whole input with one block) and HSRLE_SINGLE_V1=1 (A/B runs) use the first-generation kernel.
-template <bool PACKED_S>
+template <int MODE>   // 0 rle8_single, 1 rle8_packed_single, 2 rle8_single_short
 static hipError_t enc_single_any(const EncodeArgs &a, hipStream_t st)
 {
   static const bool v1 = [] { const char *e = getenv("HSRLE_SINGLE_V1"); return e && atoi(e) != 0; }();
   if (v1 || a.B > kSinglePickMaxBlock)
-    return launch_encode(k_encode_blocks<PACKED_S ? PACKED_SINGLE : SINGLE, 1, 0>, a, st, 0);   // no residency cap: +40 % on run data, +20 % on noise, -8 % on video-shaped
+  {
+    if constexpr (MODE == 2) return launch_encode(k_encode_single_short_blocks<SHORT_SINGLE>, a, st, 0);
+    else return launch_encode(k_encode_blocks<MODE == 1 ? PACKED_SINGLE : SINGLE, 1, 0>, a, st, 0);   // no residency cap: +40 % on run data, +20 % on noise, -8 % on video-shaped
+  }
   if (a.residentWorkgroups == nullptr)
   {
     const uint32_t padded = (a.B + 63u) & ~63u;
     const uint32_t lds = 1024u + padded + 64u + (padded / 64u + 1u) * 8u;
-    hipLaunchKernelGGL(k_single_pick, dim3(a.nBlocks), dim3(64), lds, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride);
+    hipLaunchKernelGGL(k_single_pick, dim3(a.nBlocks), dim3(64), lds, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, MODE == 2 ? 8u : 9u);
     if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
   }
-  return launch_encode(k_encode8_single_blocks<PACKED_S>, a, st, 0);
+  return launch_encode(k_encode8_single_blocks<MODE>, a, st, 0);
 }
-static hipError_t enc_single(const EncodeArgs &a, hipStream_t st) { return enc_single_any<false>(a, st); }
-static hipError_t enc_packed_single(const EncodeArgs &a, hipStream_t st) { return enc_single_any<true>(a, st); }
+static hipError_t enc_single(const EncodeArgs &a, hipStream_t st) { return enc_single_any<0>(a, st); }
+static hipError_t enc_packed_single(const EncodeArgs &a, hipStream_t st) { return enc_single_any<1>(a, st); }
+static hipError_t enc_short_single(const EncodeArgs &a, hipStream_t st) { return enc_single_any<2>(a, st); }
 
 static hipError_t idx_plain(const IndexArgs &a, int records, hipStream_t st) { return launch_index<PLAIN, 1, 0>(a, records, st); }
 static hipError_t idx_packed(const IndexArgs &a, int records, hipStream_t st) { return launch_index<PACKED, 1, 0>(a, records, st); }

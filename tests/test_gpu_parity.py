@@ -523,7 +523,7 @@ def _single_stress(seed, n):
     return bytes(out[:n])
 
 
-@pytest.mark.parametrize("key", ["rle8_single", "rle8_packed_single"])
+@pytest.mark.parametrize("key", ["rle8_single", "rle8_packed_single", "rle8_single_short"])
 def test_single_blocks_stress(hs, oracle, key):
     """The Single encoders (wave-parallel symbol pick + ring encoder, csrc/hsrle_encode8s.hip.h) against the oracle's literal restatement,
     block sizes up to the first-generation kernel's range (> 32 KiB); one-block streams of odd sizes through the rle.h names."""
