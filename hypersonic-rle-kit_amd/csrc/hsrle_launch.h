@@ -149,7 +149,9 @@ template <int S, typename K256, typename K128>
 inline hipError_t launch_encode_ring(K256 k256, K128 k128, const EncodeArgs &a, hipStream_t st)
 {
   static const int forced = [] { const char *e = getenv("HSRLE_ENC_RING"); return e ? atoi(e) : 0; }();
-  if (a.residentWorkgroups != nullptr || forced == 256 || (forced == 0 && (a.ringSel == nullptr || a.nBlocks < 4096u)))
+  // (below ~131 072 blocks the device is not full with 9 waves per CU either: more waves bring nothing, and the probe + the second launch
+  //  are ~25 us of a call that short)
+  if (a.residentWorkgroups != nullptr || forced == 256 || (forced == 0 && (a.ringSel == nullptr || a.nBlocks < 131072u)))
     return launch_encode(k256, a, st, 0);
   if (forced == 128)
     return launch_encode(k128, a, st, 0);

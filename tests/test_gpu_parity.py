@@ -631,17 +631,17 @@ def test_rle128_blocks_stress(hs, oracle, key):
 
 @pytest.mark.parametrize("key", ["rle8_multi", "rle8_packed_multi", "rle8_7symlut", "rle8_3symlut_short", "rle16_sym_packed", "rle16_3symlut_byte", "rle16_1symlut_sym_short"])
 def test_ring_chosen_per_input(hs, oracle, key):
-    """Containers of >= 4096 blocks: the encoders of 1 / 2 byte symbols probe the input and run with a 128- or a 256-byte history ring
+    """Containers of >= 131 072 blocks: the encoders of 1 / 2 byte symbols probe the input and run with a 128- or a 256-byte history ring
     (csrc/hsrle_ring_probe.hip.h: video-shaped data gets 128, run-distributed 256).  Whatever the choice, the streams are the oracle's."""
     import torch
 
     codec = CODEC_BY_KEY[key]
     for kind in (SYNTH_VIDEO_KIND, 0):
-        src = hs.synth(kind, codec.S, 9, 24 << 20, device="cuda")
+        src = hs.synth(kind, codec.S, 9, 128 << 20, device="cuda")
         data = src.cpu().numpy().tobytes()
-        container, info = hs.compress(key, src, block_size=4096)
+        container, info = hs.compress(key, src, block_size=1024)
         cinfo, streams = hs.split_container(container.cpu().numpy().tobytes())
-        assert len(streams) == 6144
-        for i in list(range(0, len(streams), 11)) + [len(streams) - 1]:
-            assert streams[i] == oracle.compress(codec, data[i * 4096 : (i + 1) * 4096]), f"{key} kind {kind}: block {i} differs from the oracle"
+        assert len(streams) == 131072
+        for i in list(range(0, len(streams), 97)) + [len(streams) - 1]:
+            assert streams[i] == oracle.compress(codec, data[i * 1024 : (i + 1) * 1024]), f"{key} kind {kind}: block {i} differs from the oracle"
         assert torch.equal(hs.decompress(container), src)
