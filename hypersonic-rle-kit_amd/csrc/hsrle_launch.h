@@ -109,17 +109,20 @@ inline hipError_t launch_decode(KERNEL k, const DecodeArgs &a, hipStream_t st)
   return hipGetLastError();
 }
 
-// Decoders of 1 / 2 byte symbols: containers whose streams shrink to less than a quarter take the instantiation with a 64-byte
+// Decoders: containers whose streams shrink to less than a quarter (1 / 2 byte symbols) or a fifth take the instantiation with a 64-byte
 // stream ring (12 instead of 9 waves per CU; a lane rarely needs more than 64 stream bytes for 128 output bytes there, and one that
 // does finishes in the second pass).  8 GiB video-shaped rle8_packed (ratio 0.18): 3.90 -> 3.34 ms; at ratio 0.43 it would lose 9 %,
 // on run-distributed data 9 - 25 %.  Blocks decoded from entry records (monolithic streams, split decode) keep the 128-byte ring.
 // HSRLE_DEC_RING=64 / 128 in the environment forces one (tests, A/B).
-template <typename K128, typename K64>
+// (PER_MILLE: the ratio below which the small ring is taken.  1 / 2 byte symbols: 250 -- rle16_sym at 0.23 still gains 6 %; wider symbols:
+//  200 -- 8 GiB video-shaped rle32_3symlut_byte (0.17) +16 %, rle24_7symlut_byte_short (0.19) +12 %, but rle64_3symlut_byte (0.24) -9 %,
+//  rle24_sym (0.26) -3 %, rle32_sym (0.30) -8 %)
+template <int PER_MILLE = 250, typename K128, typename K64>
 inline hipError_t launch_decode_ring(K128 k128, K64 k64, const DecodeArgs &a, hipStream_t st)
 {
   static const int forced = [] { const char *e = getenv("HSRLE_DEC_RING"); return e ? atoi(e) : 0; }();
   const uint64_t payloadBytes = (uint64_t)(a.payloadEnd - a.payload);
-  const bool small = forced ? forced == 64 : (a.entries == nullptr && a.residentWorkgroups == nullptr && payloadBytes * 4u < a.U);
+  const bool small = forced ? forced == 64 : (a.entries == nullptr && a.residentWorkgroups == nullptr && payloadBytes * 1000u < a.U * (uint64_t)PER_MILLE);
   if (small && a.entries == nullptr) return launch_decode(k64, a, st);
   return launch_decode(k128, a, st);
 }
