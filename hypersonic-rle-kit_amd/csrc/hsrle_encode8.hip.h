@@ -6,9 +6,14 @@
 //
 // Same execution model as everything else here: one lane = one block = one reference stream, 64 blocks per wavefront, the
 // emit decisions run as the sequential state machine they are.  Data path:
-//   HBM --(top-up: 4 adjacent lanes read 64 contiguous, aligned input bytes of ONE block per step)--> LDS history ring [64][256]
-//   ring --(run detection: 64 positions per step: x ^ (x >> 8) == 0 on aligned 16-byte reads, the GPU form of the
-//           reference's cmpeq + movemask + ctz scan, rle8_extreme_cpu.h:952-1084; bit masks of run starts / run ends)-->
+//   HBM --(top-up: 4 adjacent lanes read 64 contiguous, aligned input bytes of ONE block per trip)--> LDS history ring [64][256]
+//   ring --(match bits: when chunks have landed their lane computes E[i] = (d[i] == d[i - 1]) for them -- SWAR compare + v_dot4
+//           as the movemask, the GPU form of the reference's cmpeq + movemask, rle8_extreme_cpu.h:952-1084 -- into a bit ring
+//           in LDS, 256 positions per lane)-->
+//   trips: the loop is RUN-synchronous, not window-synchronous: in every trip EVERY lane finds its own next run (two 64-bit
+//           windows of the bit ring + ctz: start, end) and judges it, so a wave makes max-over-lanes(runs per block) trips
+//           (~75 on the run-distributed buffer) instead of the sum over 64-byte windows of max-over-lanes(runs per window) (~290):
+//           the lanes drift apart in their blocks by bytes, never by runs, and every row of the ring tops up at its own pace.
 //   packets: header bytes are assembled in registers, literal bytes come from the ring through a 128-bit byte funnel; both are
 //           appended to a 16-byte output accumulator, and every completed 16-byte chunk goes straight to the block's staging
 //           slot in HBM (the compressed side is the small side, so per-lane stores are not what limits the kernel).
@@ -26,6 +31,14 @@
 #endif
 
 namespace hsrle {
+
+#ifdef HSRLE_E8_STATS
+// diagnostic build only (tools/e8_stats.py): what the waves of the last launches executed
+__device__ unsigned long long g_e8stats[32];
+#define E8S(x) x
+#else
+#define E8S(x)
+#endif
 
 // (which ring the encoders of 1 and 2 byte symbols use for an input: hsrle_ring_probe.hip.h)
 // MONO = true: the lanes encode consecutive CHUNKS of ONE monolithic reference stream instead of independent blocks (hsrle_mono_encode.hip.h
@@ -56,9 +69,15 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
   constexpr uint32_t HM = (uint32_t)H - 1u;
   constexpr int K = TR::K;
 
-  __shared__ __attribute__((aligned(16))) uint8_t hist[64 * H];
+  // ring byte x of row r lives at hist[r * RS + (x & HM)]; the row's first chunk is mirrored behind its end, so that the 20-byte window of
+  // a literal copy (five dword reads at ANY dword of the row: ring_win) never wraps
+  constexpr uint32_t RS = (uint32_t)H + 16u;
+  __shared__ __attribute__((aligned(16))) uint8_t hist[64 * RS];
+  // match bits of the ring's positions: bit (i & 31) of ebits[((i >> 5) % EW) * 64 + lane] = (d[i] == d[i - 1]); dword-transposed so
+  // that every lane stays in its own LDS bank whichever dword of its row it reads
+  constexpr uint32_t EW = (uint32_t)H / 32u;
+  __shared__ __attribute__((aligned(16))) uint32_t ebits[EW * 64u];
   __shared__ __attribute__((aligned(16))) uint32_t rinfo[64];
-  __shared__ __attribute__((aligned(16))) uint8_t accScratch[64 * 16];   // see emit_literals
   // merge masks from a 16-entry table (as in k_decode_blocks: one ds_read_b128 instead of ~9 VALU; +1 % encode throughput)
   __shared__ __attribute__((aligned(16))) uint8_t mlut[16 * 16];
   if (threadIdx.x < 16u)
@@ -78,9 +97,7 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
   bool active = b < nBlocks;
   if constexpr (MONO && Traits<FAM, 1, 0>::kMtf) { if (active) active = monoSyms[8ull * b + 7] != 0ull; }   // the host's repair rounds switch most chunks off
 
-  // ring byte x of row r lives at hist[(r * H) ^ hsw(r) ^ (x & HM)]: chunks XOR-swizzled by the row index (bank spread without pad)
-  auto hsw_of = [](uint32_t r) -> uint32_t { return (r & 7u) << 4; };
-  const uint32_t hbase = (lane * (uint32_t)H) ^ hsw_of(lane);
+  uint8_t *const row = hist + lane * RS;
 
   uint32_t n = 0;
   [[maybe_unused]] uint32_t nTrueV = 0;                                 // MONO: bytes from the chunk start to the end of the input
@@ -104,7 +121,9 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
 
   // ---- per-lane encoder state ----
   uint32_t avail = 0;        // input bytes [.., avail) are (or were) in the ring; the ring holds [avail - H, avail)
-  uint32_t cb = 0;           // base of the window scanned next (multiple of 16)
+  uint32_t mk = 0;           // match bits exist for the positions below mk (multiple of 16; == avail rounded up after every landing)
+  uint32_t pd = 0;           // the last dword of the chunk below mk (its top byte is the predecessor of position mk)
+  uint32_t cur = 0;          // scan position: every run that starts below cur has been judged (inRun: the run from runStart reaches cur)
   bool inRun = false;
   uint32_t runStart = 0, sym = 0;
   uint32_t lastRLE = 0;
@@ -124,7 +143,9 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
   }
   bool ended = false;        // the end terminator has been written
   bool finished = !active;   // the whole stream is in the slot
-  uint64_t winStarts = 0;    // current window: run-start bits
+  E8S(uint32_t sTrips = 0; uint32_t sRunLanes = 0; uint32_t sRunTrips = 0; uint32_t sEmitLanes = 0; uint32_t sLitWave = 0; uint32_t sLitLanes = 0; uint32_t sGlobalTrips = 0;
+      uint32_t sMaskPasses = 0; uint32_t sMaskLanes = 0; uint32_t sLoadLanes = 0; uint32_t sStarve = 0; uint32_t sHdrStore = 0; uint32_t tLit = 0; uint32_t tGlob = 0; uint32_t tEmit = 0; uint32_t tHdrSt = 0;
+      uint32_t sFinTrips = 0; uint32_t sActive = 0;)
 
   // ---- output: 16-byte accumulator + stream position; completed chunks go to the slot ----
   const u32x4 zero4 = u32x4{ 0, 0, 0, 0 };
@@ -151,7 +172,10 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
     const u32x4 w = HS_EMERGE(oacc, lowp, c);
     if (c + nb >= 16u)
     {
+      E8S(tHdrSt++;)
+#ifndef HSRLE_X_NOSTORE
       if (!dry) st128(slot + (opos & ~15u), w);
+#endif
       oacc = (c == 0u) ? zero4 : funnel16(hv, zero4, 16u - c);          // hv >> (16 - c) bytes
     }
     else
@@ -181,10 +205,13 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
     hlo = 0; hhi = 0; hn = 0;
   };
 
-  // 16 input bytes at block position p (p may reach below 0 or beyond the input: those bytes are never used)
+  // 16 input bytes at block position p (p may reach below 0 or beyond the input: those bytes are never used): five dwords from the dword
+  // that holds p (ds_read2_b32 / ds_read_b32: full speed at any dword, unlike the wider reads -- tools/ubench/lds_align.hip) and four
+  // v_alignbyte; with two aligned 16-byte reads the dword selection cost 11 v_cndmask per window
   auto ring_win = [&](uint32_t p) -> u32x4 {
-    const uint32_t a0 = p & ~15u;
-    return funnel16(lds_ld128(hist + (hbase ^ (a0 & HM))), lds_ld128(hist + (hbase ^ ((a0 + 16u) & HM))), p & 15u);
+    const uint32_t *const w = reinterpret_cast<const uint32_t *>(__builtin_assume_aligned(row + (p & HM & ~3u), 4));
+    const uint32_t d0 = w[0], d1 = w[1], d2 = w[2], d3 = w[3], d4 = w[4], sh = p & 3u;
+    return u32x4{ alignbyte(d1, d0, sh), alignbyte(d2, d1, sh), alignbyte(d3, d2, sh), alignbyte(d4, d3, sh) };
   };
   // literal bytes [from, from + len) of the block: from the ring while they are still there.  Literals that have left the ring (a long
   // stretch of runs too short to be stored) are read from global memory by a function that is kept out of line: with the two
@@ -200,7 +227,12 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
       uint32_t k = 0;
       while (k + 16u <= total)
       {
+        E8S(tLit++;)
+#ifndef HSRLE_X_NOSTORE
         if (!dry) st128(dst + k, w);
+#else
+        if (w.x == 0x12345678u && w.y == 0x9ABCDEF0u) st128(dst + k, w);
+#endif
         k += 16u;
         if (k < total) w = ring_win(srcp + k);
       }
@@ -217,11 +249,12 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
         if (pendBytes == 0u) { pendSrc = from; pendDst = opos; pendBytes = noted; }
         else { pend2Src = from; pend2Dst = opos; pend2Bytes = noted; }
       }
-      lds_st128(accScratch + lane * 16u, tail != 0u ? global_window16(in, blockAt, U, from + noted) : zero4);
-      oacc = lds_ld128(accScratch + lane * 16u);
+      oacc = tail != 0u ? global_window16(in, blockAt, U, from + noted) : zero4;
+      __builtin_amdgcn_s_waitcnt(0x0F70);                                // vmcnt(0): see below
     }
     else
     {
+      E8S(tGlob = 1;)
       u32x4 w = HS_EMERGE(oacc, global_window16(in, blockAt, U, srcp), c);
       uint32_t k = 0;
       while (k + 16u <= total)
@@ -230,10 +263,11 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
         k += 16u;
         if (k < total) w = global_window16(in, blockAt, U, srcp + k);
       }
-      // the accumulator is handed back through LDS: a register that may hold a pending vector-memory load makes the compiler wait
-      // for ALL outstanding loads -- the input prefetch included -- in front of every store of the common path (-10 % encode)
-      lds_st128(accScratch + lane * 16u, w);
-      oacc = lds_ld128(accScratch + lane * 16u);
+      // the loads are waited for HERE: an accumulator that may still be the target of a pending vector-memory load where the paths join
+      // makes the compiler wait for ALL outstanding loads -- the input prefetch included -- in front of every store of the common path
+      // (-10 % encode; round 2 handed the value back through 1 KB of LDS instead, which the bit ring needs now)
+      __builtin_amdgcn_s_waitcnt(0x0F70);                                // vmcnt(0)
+      oacc = w;
     }
     opos += len;
   };
@@ -301,22 +335,42 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
   // ---- input top-up (4 lanes per row read 64 contiguous bytes; the loads fly during the step's scan) ----
   u32x4 pf[LPR];
   uint32_t pfAt[LPR];
+  bool pfValid[LPR];
   uint32_t wantReq = 0;
-  [[maybe_unused]] uint64_t rowAt[LPR];                                 // MONO: input position of the LPR rows this lane serves
-  if constexpr (MONO)
-  {
+  // per served row: where its input starts (+ this lane's chunk within a 64-byte piece), how many bytes are readable from there, its ring row
+  const uint8_t *rowPtr[LPR];
+  uint32_t rowLim[LPR], rowLds[LPR];
 #pragma unroll
-    for (int q = 0; q < LPR; q++)
+  for (int q = 0; q < LPR; q++)
+  {
+    const uint32_t r = (uint32_t)q * RPL + lane / LPR, c = lane % LPR;
+    uint64_t at = (uint64_t)(wgFirst + r) * B;
+    if constexpr (MONO)
     {
-      const int r = (int)((uint32_t)q * RPL + lane / LPR);
-      const uint32_t lo32 = (uint32_t)__shfl((int)(uint32_t)blockAt, r, 64), hi32 = (uint32_t)__shfl((int)(uint32_t)(blockAt >> 32), r, 64);
-      rowAt[q] = ((uint64_t)hi32 << 32) | lo32;
+      const uint32_t lo32 = (uint32_t)__shfl((int)(uint32_t)blockAt, (int)r, 64), hi32 = (uint32_t)__shfl((int)(uint32_t)(blockAt >> 32), (int)r, 64);
+      at = ((uint64_t)hi32 << 32) | lo32;
     }
+    at += c * 16u;
+    rowPtr[q] = in + at;
+    rowLim[q] = (at < U) ? (uint32_t)(((U - at) < 0xFFFFFFFFull) ? (U - at) : 0xFFFFFFFFull) : 0u;
+    rowLds[q] = r * RS;
   }
 
+  // The ring runs ahead of the scan position AT REQUEST TIME: what a trip requests lands behind the trip, so the scan of the next trip --
+  // which wants its run's start within 64 positions and its end within 64 more -- sees the request's reach minus what this trip consumes
+  // (with a reach of 128 a lane starved in every fourth trip: 101 instead of 84 trips per wave on the run-distributed buffer).  The reach is
+  // counted from lastRLE while that leaves kNeed positions in front of the scan: the literals in front of a run are copied from the ring
+  // when the run ends, and a stretch that has left the ring is fetched from global memory by its lane.  The chunk count is decided BEFORE
+  // the loads are issued, so every chunk is requested exactly once.
+  constexpr uint32_t kReach = (uint32_t)H - 16u, kNeed = ((uint32_t)H >= 256u) ? 144u : (uint32_t)H / 2u + 16u;
   auto issue = [&]() {
     const uint32_t left = (n > avail) ? (n - avail + 15u) >> 4 : 0u;
-    wantReq = umin((uint32_t)LPR, left);
+    const uint32_t ahead = avail - cur;                                // <= kReach
+    const uint32_t fitHard = (kReach - ahead) >> 4;
+    const uint32_t behind = avail - lastRLE;                           // lastRLE <= cur
+    const uint32_t fitSoft = (behind < kReach) ? (kReach - behind) >> 4 : 0u;
+    const uint32_t need = (ahead < kNeed) ? (kNeed - ahead + 15u) >> 4 : 0u;
+    wantReq = umin(umin((uint32_t)LPR, left), umin(fitHard, fitSoft > need ? fitSoft : need));
     publish(wantReq != 0u ? (avail | wantReq) : 0u);                   // avail is a multiple of 16 while chunks are left
     wave_sync();
     uint32_t ri[LPR];
@@ -326,44 +380,75 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
 #pragma unroll
     for (int q = 0; q < LPR; q++)
     {
-      const uint32_t r = (uint32_t)q * RPL + lane / LPR, c = lane % LPR;
+      const uint32_t c = lane % LPR;
       const uint32_t nreq = ri[q] & 15u, e = ri[q] & ~15u;
       const bool valid = c < nreq;
-      const uint64_t g = (MONO ? rowAt[q] : (uint64_t)(wgFirst + r) * B) + e + c * 16u;
       u32x4 v = u32x4{ 0, 0, 0, 0 };
       if (valid)
       {
-        if (g + 16u <= U)
-          v = ld128(in + g);
+        const uint8_t *const g = rowPtr[q] + e;
+        if (__builtin_expect(e + 16u <= rowLim[q], 1))
+#ifdef HSRLE_X_HOTLOAD
+          v = ld128(in + ((uint64_t)(g - in) & 0xFFFF0ull));
+#else
+          v = ld128(g);
+#endif
+        else if (U >= 16u)
+          v = funnel16(ld128(in + U - 16u), v, (uint32_t)((uint64_t)(g - in) + 16u - U));   // the input's last, partial chunk: read at U - 16, shifted down
         else
         {
-          uint32_t t[4] = { 0, 0, 0, 0 };
-          for (uint32_t k = 0; k < 16u && g + k < U; k++)
-            t[k >> 2] |= (uint32_t)in[g + k] << (8u * (k & 3u));
-          v = u32x4{ t[0], t[1], t[2], t[3] };
+          uint64_t t0 = 0, t1 = 0;
+#pragma unroll 1
+          for (uint32_t k = 0; k < 16u && e + k < rowLim[q]; k++)
+            if (k < 8u) t0 |= (uint64_t)g[k] << (8u * k); else t1 |= (uint64_t)g[k] << (8u * (k - 8u));
+          v = u32x4{ (uint32_t)t0, (uint32_t)(t0 >> 32), (uint32_t)t1, (uint32_t)(t1 >> 32) };
         }
       }
       pf[q] = v;
-      pfAt[q] = (r * (uint32_t)H) ^ hsw_of(r) ^ ((e + c * 16u) & HM);
+      pfValid[q] = valid;
+      pfAt[q] = rowLds[q] + ((e + c * 16u) & HM);
     }
   };
 
+  // the requested chunks go into the ring (all of them: issue() asked for no more than fit), then every lane computes the match bits
+  // of the chunks that are new in ITS row: E[i] = (d[i] == d[i - 1]) -- x ^ (x shifted by one byte) per dword, the exact SWAR zero-byte
+  // test, and v_dot4_u32_u8 with the weights 1 2 4 8 / 16 .. 128 as the movemask: 5 VALU per dword.  (Bits of positions at or beyond n are
+  // never looked at: the scan stops at `avail` <= n.)
   auto land = [&]() {
-    // the ring must keep the chunk being scanned (and one before it for the byte funnel)
-    const uint32_t keep = (cb >= 16u) ? cb - 16u : 0u;
-    const uint32_t fit = ((uint32_t)H - (avail - keep)) >> 4;
-    const uint32_t take = umin(wantReq, fit);
-    publish(take);
-    wave_sync();
-    uint32_t ri[LPR];
 #pragma unroll
-    for (int q = 0; q < LPR; q++) ri[q] = rinfo[(lane / LPR) * LPR + q];
+    for (int q = 0; q < LPR; q++)
+      if (pfValid[q])
+      {
+        lds_st128(hist + pfAt[q], pf[q]);
+        if ((pfAt[q] - rowLds[q]) == 0u) lds_st128(hist + pfAt[q] + (uint32_t)H, pf[q]);   // the mirror of the row's first chunk
+      }
+    avail = umin(avail + (wantReq << 4), n);
     wave_sync();
 #pragma unroll
     for (int q = 0; q < LPR; q++)
-      if (lane % LPR < ri[q])
-        lds_st128(hist + pfAt[q], pf[q]);
-    avail = umin(avail + (take << 4), n);
+    {
+      E8S(sMaskPasses += (__ballot(mk < avail) != 0ull) ? 1u : 0u; sMaskLanes += (uint32_t)__builtin_popcountll(__ballot(mk < avail));)
+      if (mk < avail)
+      {
+        const u32x4 x = lds_ld128(row + (mk & HM));
+        const uint32_t t0 = x.x ^ alignbyte(x.x, pd, 3), t1 = x.y ^ alignbyte(x.y, x.x, 3), t2 = x.z ^ alignbyte(x.z, x.y, 3), t3 = x.w ^ alignbyte(x.w, x.z, 3);
+        const uint32_t n0 = (((t0 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t0) & 0x80808080u, n1 = (((t1 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t1) & 0x80808080u;
+        const uint32_t n2 = (((t2 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t2) & 0x80808080u, n3 = (((t3 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t3) & 0x80808080u;
+        // 0x80 per differing byte -> 128 * (8 bit mask) per dword pair
+        const uint32_t a01 = __builtin_amdgcn_udot4(n1, 0x80402010u, __builtin_amdgcn_udot4(n0, 0x08040201u, 0u, false), false);
+        const uint32_t a23 = __builtin_amdgcn_udot4(n3, 0x80402010u, __builtin_amdgcn_udot4(n2, 0x08040201u, 0u, false), false);
+        const uint32_t e16 = ~(((a23 << 8) | a01) >> 7);
+        reinterpret_cast<uint16_t *>(ebits)[(((mk >> 5) & (EW - 1u)) * 64u + lane) * 2u + ((mk >> 4) & 1u)] = (uint16_t)e16;
+        pd = x.w;
+        mk += 16u;
+      }
+    }
+  };
+  // E[c .. c + 64) (the caller knows how many of them exist)
+  auto ewin = [&](uint32_t c) -> uint64_t {
+    const uint32_t k = c >> 5, sh = c & 31u;
+    const uint32_t d0 = ebits[((k) & (EW - 1u)) * 64u + lane], d1 = ebits[((k + 1u) & (EW - 1u)) * 64u + lane], d2 = ebits[((k + 2u) & (EW - 1u)) * 64u + lane];
+    return (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32);
   };
 
   // ---- one finished run [p, e): decide, and if emitted write the packet ----
@@ -436,6 +521,7 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
 
     if (!k)
       return;
+    E8S(tEmit = 1;)
 
     // ---- header ----
     if constexpr (TR::kShort)
@@ -525,84 +611,66 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
   issue();
   land();
   wave_sync();
+  ebits[lane] &= ~1u;                                                  // position 0 has no predecessor
+  wave_sync();
 
-  uint32_t stepsLeft = MONO ? monoSteps : 2u * (B / (uint32_t)Q) + 64u;  // bounded: every step scans a window or lands input
+  // bounded: a trip judges a run (>= 2 bytes), or moves the cursor over >= 16 positions, or waits for a landing that brings >= 16 bytes
+  uint32_t stepsLeft = MONO ? 32u * monoSteps : B + 64u;
 
   while (__ballot(!finished) != 0ull)
   {
     if (stepsLeft-- == 0u) break;
     issue();
 
-    // ---------------- scan what is in the ring ----------------
-    // Phase A (uniform): equality mask of up to 64 positions -> bit masks of run starts and run ends.
-    // Phase B (per lane): one handle_run per run END -- a lane's trip count is the number of runs that end in its window.
+    // ---------------- one run per lane and trip ----------------
     if (!finished)
     {
-      // window [cb, cb + W): every position needs its successor byte (or the end of the input)
-      const uint32_t lastStep = (avail >= n) ? 1u : 0u;
-      uint32_t W = lastStep ? umin(64u, n - cb) : umin(64u, ((avail - 1u - cb) >> 4) << 4);
-      if (cb >= n) W = 0;
-      if (W != 0u)
+      const bool allIn = avail >= n;
+      const uint32_t known = avail;                                     // match bits exist below `known` (avail <= n); allIn: position n does not match
+      if (!inRun)
       {
-        uint64_t e64 = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < 4u; j++)
+        // the next run starts at the first i >= cur with E[i + 1]
+        if (cur + 1u < known)
         {
-          if (j * 16u < W)
+          const uint64_t w = ewin(cur + 1u);
+          const uint32_t lim = umin(known - (cur + 1u), 64u);
+          const uint32_t j = (w != 0ull) ? (uint32_t)__builtin_ctzll(w) : 64u;
+          if (j < lim)
           {
-            const u32x4 x = lds_ld128(hist + (hbase ^ ((cb + j * 16u) & HM)));
-            const uint32_t x4 = lds_ld32(hist + (hbase ^ ((cb + j * 16u + 16u) & HM)));
-            const uint32_t z0 = zero_bytes(x.x ^ alignbyte(x.y, x.x, 1)), z1 = zero_bytes(x.y ^ alignbyte(x.z, x.y, 1));
-            const uint32_t z2 = zero_bytes(x.z ^ alignbyte(x.w, x.z, 1)), z3 = zero_bytes(x.w ^ alignbyte(x4, x.w, 1));
-            // 0x80 flags -> 4 bits per dword
-            const uint32_t b0 = (((z0 >> 7) * 0x00204081u) >> 21) & 0xFu, b1 = (((z1 >> 7) * 0x00204081u) >> 21) & 0xFu;
-            const uint32_t b2 = (((z2 >> 7) * 0x00204081u) >> 21) & 0xFu, b3 = (((z3 >> 7) * 0x00204081u) >> 21) & 0xFu;
-            e64 |= (uint64_t)(b0 | (b1 << 4) | (b2 << 8) | (b3 << 12)) << (16u * j);
+            runStart = cur + j;
+            sym = row[runStart & HM];
+            inRun = true;
+            cur = runStart + 1u;
           }
+          else
+            cur += lim;
         }
-        // position i is a match only if cb + i + 1 < n (bytes at or beyond n never match)
-        const uint32_t validBits = (n - cb > W) ? W : (n - cb - 1u);
-        e64 &= (validBits >= 64u) ? ~0ull : ((1ull << validBits) - 1ull);
-        const uint64_t wmask = (W >= 64u) ? ~0ull : ((1ull << W) - 1ull);
-        const uint64_t prev = (e64 << 1) | (inRun ? 1ull : 0ull);      // "the position before me matched"
-        winStarts = e64 & ~prev;
-        uint64_t pendingEnds = ~e64 & prev & wmask;                     // bit i: a run ends with position i (exclusive end cb + i + 1)
-
-        while (pendingEnds != 0ull)
-        {
-          const uint32_t i = (uint32_t)__builtin_ctzll(pendingEnds);
-          const uint64_t sBelow = winStarts & ((2ull << i) - 1ull);
-          uint32_t st = runStart, sy = sym;
-          if (sBelow != 0ull)
-          {
-            st = cb + (63u - (uint32_t)__builtin_clzll(sBelow));
-            sy = hist[hbase ^ (st & HM)];
-          }
-          sym = sy;
-          handle_run(st, cb + i + 1u);
-          pendingEnds &= pendingEnds - 1ull;
-        }
-
-        // the window is done: remember a run that is still open at its end (its last position matches its successor)
-        if (((e64 >> (W - 1u)) & 1ull) != 0ull)
-        {
-          // the open run is the last one that started in this window; with no start at all the carried run goes on
-          if (winStarts != 0ull)
-          {
-            runStart = cb + (63u - (uint32_t)__builtin_clzll(winStarts));
-            sym = hist[hbase ^ (runStart & HM)];
-          }
-          inRun = true;
-        }
-        else
-          inRun = false;
-        cb += W;
+        else if (allIn)
+          cur = n;
       }
-
-      if (cb >= n && avail >= n)
+      bool haveRun = false;
+      uint32_t runEnd = 0;
+      if (inRun)
       {
-        // end of input: a run that reaches the end is judged now; then the literal terminator unless the stream ended
-        if (inRun) { handle_run(runStart, n); inRun = false; }
+        // ... and ends at the first i >= cur without E[i] (cur > runStart; E[runStart + 1] is set)
+        const uint64_t w = ~ewin(cur);
+        const uint32_t lim = umin(known - cur, 64u);
+        const uint32_t j = (w != 0ull) ? (uint32_t)__builtin_ctzll(w) : 64u;
+        if (j < lim) { haveRun = true; runEnd = cur + j; }
+        else if (allIn && cur + lim >= n) { haveRun = true; runEnd = n; }
+        else cur += lim;
+      }
+      if (haveRun)
+      {
+        handle_run(runStart, runEnd);
+        inRun = false;
+        cur = runEnd;
+      }
+      E8S(if (!haveRun && !(allIn && !inRun && cur >= n)) sStarve += (avail - cur < 64u && !allIn) ? 1u : 0u;)
+
+      if (allIn && !inRun && cur >= n)
+      {
+        // end of input: the literal terminator unless the stream ended with a run's packet
         if (!ended && n == nTrue) { finish_literals(); ended = true; }      // (a MONO chunk that does not reach the end of the input ends with its boundary run's packet)
         // the last partial chunk, then the stream size (header field compressedLength and the size table)
         if ((opos & 15u) != 0u && !dry)
@@ -619,10 +687,44 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
       }
     }
 
+#ifdef HSRLE_E8_STATS
+    {
+      sTrips++;
+      sActive += (uint32_t)__builtin_popcountll(__ballot(!finished));
+      const uint64_t br = __ballot(tEmit != 0u || tLit != 0u || tHdrSt != 0u);
+      (void)br;
+      sEmitLanes += (uint32_t)__builtin_popcountll(__ballot(tEmit != 0u));
+      sGlobalTrips += (__ballot(tGlob != 0u) != 0ull) ? 1u : 0u;
+      uint32_t m = tLit;
+      for (int dd = 32; dd >= 1; dd >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)m, dd, 64); m = m > o ? m : o; }
+      sLitWave += m;
+      uint32_t sum = tLit;
+      for (int dd = 32; dd >= 1; dd >>= 1) sum += (uint32_t)__shfl_xor((int)sum, dd, 64);
+      sLitLanes += sum;
+      uint32_t hs = tHdrSt;
+      for (int dd = 32; dd >= 1; dd >>= 1) hs += (uint32_t)__shfl_xor((int)hs, dd, 64);
+      sHdrStore += hs;
+      sLoadLanes += (uint32_t)__builtin_popcountll(__ballot(wantReq != 0u));
+      tLit = 0; tGlob = 0; tEmit = 0; tHdrSt = 0;
+    }
+#endif
     wave_sync();
     land();
     wave_sync();
   }
+#ifdef HSRLE_E8_STATS
+  {
+    uint32_t st = sStarve;
+    for (int dd = 32; dd >= 1; dd >>= 1) st += (uint32_t)__shfl_xor((int)st, dd, 64);
+    if (lane == 0u)
+    {
+      atomicAdd(&g_e8stats[0], 1ull); atomicAdd(&g_e8stats[1], (unsigned long long)sTrips); atomicAdd(&g_e8stats[2], (unsigned long long)sActive);
+      atomicAdd(&g_e8stats[3], (unsigned long long)sEmitLanes); atomicAdd(&g_e8stats[4], (unsigned long long)sGlobalTrips); atomicAdd(&g_e8stats[5], (unsigned long long)sLitWave);
+      atomicAdd(&g_e8stats[6], (unsigned long long)sLitLanes); atomicAdd(&g_e8stats[7], (unsigned long long)sHdrStore); atomicAdd(&g_e8stats[8], (unsigned long long)sLoadLanes);
+      atomicAdd(&g_e8stats[9], (unsigned long long)st); atomicAdd(&g_e8stats[10], (unsigned long long)sMaskPasses); atomicAdd(&g_e8stats[11], (unsigned long long)sMaskLanes);
+    }
+  }
+#endif
   coop_flush(true);
 }
 

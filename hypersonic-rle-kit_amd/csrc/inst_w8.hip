@@ -121,3 +121,12 @@ void register_w8(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBloc
 }
 
 } // namespace hsrle
+
+#ifdef HSRLE_E8_STATS
+extern "C" void hsrle_debug_e8stats(unsigned long long *out, int reset)
+{
+  (void)hipDeviceSynchronize();
+  if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(hsrle::g_e8stats), sizeof(unsigned long long) * 32);
+  if (reset) { unsigned long long z[32] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(hsrle::g_e8stats), z, sizeof(z)); }
+}
+#endif

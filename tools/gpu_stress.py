@@ -8,6 +8,7 @@ from hsrle_testlib import CODECS, Oracle, fuzz_sections, mixed_runs, single_symb
 budget=float(sys.argv[1]) if len(sys.argv)>1 else 120.0
 seed=int(sys.argv[2]) if len(sys.argv)>2 else 1
 rng=random.Random(seed); ora=Oracle()
+if os.environ.get('STRESS_KEYS'): CODECS=[c for c in CODECS if any(c.key.startswith(k) for k in os.environ['STRESS_KEYS'].split(','))]   # e.g. STRESS_KEYS=rle8_ : only these codecs
 def long_runs(rng,n):
     out=bytearray()
     while len(out)<n:
@@ -31,7 +32,7 @@ while time.time()-t0<budget:
     arr=np.frombuffer(data,dtype=np.uint8)
     src=torch.from_numpy(arr.copy()).cuda()
     for bs in rng.sample([128,256,384,1024,4096,65536],3):
-        for c in rng.sample(CODECS,10):
+        for c in rng.sample(CODECS,min(10,len(CODECS))):
             cont,info=hsrle.compress(c.key,src,block_size=bs)
             _,streams=hsrle.split_container(cont.cpu().numpy().tobytes())
             exp=ora.compress_blocks(c,arr,bs)
