@@ -412,7 +412,7 @@ static uint32_t encode_chunk_blocks()
 struct Workspace
 {
   uint64_t nBlocks, chunk, nChunks, t1, t2, t3;
-  uint64_t offSlots, offSizes, offL1, offL2, offL3, offTiles, total;
+  uint64_t offSlots, offSizes, offL1, offL2, offL3, total;
 };
 
 static Workspace plan_workspace(uint64_t U, uint32_t B)
@@ -432,7 +432,6 @@ static Workspace plan_workspace(uint64_t U, uint32_t B)
   w.offL1 = at; at += align_up((w.t1 + 1) * 8ull, 256);
   w.offL2 = at; at += align_up((w.t2 + 1) * 8ull, 256);
   w.offL3 = at; at += align_up((w.t3 + 1) * 8ull, 256);
-  w.offTiles = at; at += align_up(((w.nBlocks + 63ull) / 64ull + 1ull) * 8ull, 256);   // fused placement: one look-back word per 64 blocks (hsrle_encode8.hip.h)
   w.total = at;
   return w;
 }
@@ -541,19 +540,10 @@ static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, ui
   {
     EncodeArgs ea{ (const uint8_t *)dIn, U, B, nBlocks, ws + w.offSlots, stride, sizes };
     ea.ringSel = (uint32_t *)(ws + w.offSlots + align_up((uint64_t)nBlocks * stride, 256));   // (in the wave encoder's counter area behind the slots: unused on this path)
-    // encoders that place their streams themselves (the 8 bit ring encoders: look-back over one word per 64 blocks) need neither the size
-    // scan nor the compaction pass
-    bool fused = false;
-    ea.fuseOffsets = offsets; ea.fusePayload = payload; ea.fuseTiles = (unsigned long long *)(ws + w.offTiles); ea.fused = &fused;
-    if (hipMemsetAsync(ea.fuseTiles, 0, ((w.nBlocks + 63ull) / 64ull + 1ull) * 8ull, st) != hipSuccess || g_enc[codec](ea, st) != hipSuccess)
+    if (g_enc[codec](ea, st) != hipSuccess || scan_sizes(sizes, nBlocks, offsets, ws, w, st) != hipSuccess)
       rc = HSRLE_ERR_DEVICE;
-    else if (!fused)
-    {
-      if (scan_sizes(sizes, nBlocks, offsets, ws, w, st) != hipSuccess)
-        rc = HSRLE_ERR_DEVICE;
-      else
-        hipLaunchKernelGGL(k_compact, dim3((nBlocks + 3u) / 4u), dim3(256), 0, st, ea.slots, stride, (const uint64_t *)offsets, payload, nBlocks);
-    }
+    else
+      hipLaunchKernelGGL(k_compact, dim3((nBlocks + 3u) / 4u), dim3(256), 0, st, ea.slots, stride, (const uint64_t *)offsets, payload, nBlocks);
   }
   else
   {

@@ -93,6 +93,18 @@ __device__ __forceinline__ uint32_t zero_bytes(uint32_t z)
   return ~t & 0x80808080u;
 }
 
+// movemask of the zero bytes of a 16-byte value (bit k: byte k of t0..t3 is zero): the exact SWAR test leaves 0x80 in every NONZERO byte,
+// v_dot4_u32_u8 with the weights 1 2 4 8 / 16 32 64 128 adds them up to 128 * (8 bit mask) per dword pair -- 6 VALU per dword where
+// shift + multiply + shift + mask per dword took 11 (round 3; the form of cmpeq + movemask in every run detector here)
+__device__ __forceinline__ uint32_t zero_mask16(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3)
+{
+  const uint32_t n0 = (((t0 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t0) & 0x80808080u, n1 = (((t1 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t1) & 0x80808080u;
+  const uint32_t n2 = (((t2 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t2) & 0x80808080u, n3 = (((t3 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t3) & 0x80808080u;
+  const uint32_t a01 = __builtin_amdgcn_udot4(n1, 0x80402010u, __builtin_amdgcn_udot4(n0, 0x08040201u, 0u, false), false);
+  const uint32_t a23 = __builtin_amdgcn_udot4(n3, 0x80402010u, __builtin_amdgcn_udot4(n2, 0x08040201u, 0u, false), false);
+  return ~(((a23 << 8) | a01) >> 7) & 0xFFFFu;
+}
+
 // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs of the MI355X (workgroup i runs on XCD i % 8), each with
 // its own L2 and TLBs.  Mapping workgroup i to tile (i % 8) * (n / 8) + i / 8 gives every XCD one contiguous eighth of the tiles
 // instead of every eighth tile, so the waves resident on an XCD work on one compact region of their buffers: 8x fewer pages and

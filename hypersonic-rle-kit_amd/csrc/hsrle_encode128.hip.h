@@ -284,10 +284,8 @@ __global__ __launch_bounds__(64) void k_encode128_blocks(const uint8_t *__restri
       if (j < landedChunks && at >= 16u)
       {
         const u32x4 x = lds_ld128(hist + (hbase ^ ((at - 16u) & HM))), y = lds_ld128(hist + (hbase ^ (at & HM)));
-        const uint32_t z0 = zero_bytes(x.x ^ y.x), z1 = zero_bytes(x.y ^ y.y), z2 = zero_bytes(x.z ^ y.z), z3 = zero_bytes(x.w ^ y.w);
-        const uint32_t b0 = (((z0 >> 7) * 0x00204081u) >> 21) & 0xFu, b1 = (((z1 >> 7) * 0x00204081u) >> 21) & 0xFu;
-        const uint32_t b2 = (((z2 >> 7) * 0x00204081u) >> 21) & 0xFu, b3 = (((z3 >> 7) * 0x00204081u) >> 21) & 0xFu;
-        fresh |= (uint64_t)(b0 | (b1 << 4) | (b2 << 8) | (b3 << 12)) << (16u * got);
+        const uint32_t zm16 = zero_mask16(x.x ^ y.x, x.y ^ y.y, x.z ^ y.z, x.w ^ y.w);
+        fresh |= (uint64_t)zm16 << (16u * got);
         got++;
       }
     }

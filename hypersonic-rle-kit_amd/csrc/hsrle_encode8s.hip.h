@@ -71,11 +71,8 @@ __global__ __launch_bounds__(64) void k_single_pick(const uint8_t *__restrict__ 
     {
       const u32x4 x = lds_ld128(bytes + w * 64u + j * 16u);
       const uint32_t x4 = lds_ld32(bytes + w * 64u + j * 16u + 16u);
-      const uint32_t z0 = zero_bytes(x.x ^ alignbyte(x.y, x.x, 1)), z1 = zero_bytes(x.y ^ alignbyte(x.z, x.y, 1));
-      const uint32_t z2 = zero_bytes(x.z ^ alignbyte(x.w, x.z, 1)), z3 = zero_bytes(x.w ^ alignbyte(x4, x.w, 1));
-      const uint32_t b0 = (((z0 >> 7) * 0x00204081u) >> 21) & 0xFu, b1 = (((z1 >> 7) * 0x00204081u) >> 21) & 0xFu;
-      const uint32_t b2 = (((z2 >> 7) * 0x00204081u) >> 21) & 0xFu, b3 = (((z3 >> 7) * 0x00204081u) >> 21) & 0xFu;
-      e64 |= (uint64_t)(b0 | (b1 << 4) | (b2 << 8) | (b3 << 12)) << (16u * j);
+      const uint32_t zm16 = zero_mask16(x.x ^ alignbyte(x.y, x.x, 1), x.y ^ alignbyte(x.z, x.y, 1), x.z ^ alignbyte(x.w, x.z, 1), x.w ^ alignbyte(x4, x.w, 1));
+      e64 |= (uint64_t)zm16 << (16u * j);
     }
     const uint32_t base = w * 64u;
     const uint32_t valid = (n - 1u > base) ? n - 1u - base : 0u;        // positions base + i with base + i + 1 < n
@@ -416,10 +413,8 @@ __global__ __launch_bounds__(64) void k_encode8_single_blocks(const uint8_t *__r
       lds_st128(accScratch + lane * 16u, global_window16(in, blockAt, U, p));
       x = lds_ld128(accScratch + lane * 16u);
     }
-    const uint32_t z0 = zero_bytes(x.x ^ sym4), z1 = zero_bytes(x.y ^ sym4), z2 = zero_bytes(x.z ^ sym4), z3 = zero_bytes(x.w ^ sym4);
-    const uint32_t b0 = (((z0 >> 7) * 0x00204081u) >> 21) & 0xFu, b1 = (((z1 >> 7) * 0x00204081u) >> 21) & 0xFu;
-    const uint32_t b2 = (((z2 >> 7) * 0x00204081u) >> 21) & 0xFu, b3 = (((z3 >> 7) * 0x00204081u) >> 21) & 0xFu;
-    return b0 | (b1 << 4) | (b2 << 8) | (b3 << 12);
+    const uint32_t zm16 = zero_mask16(x.x ^ sym4, x.y ^ sym4, x.z ^ sym4, x.w ^ sym4);
+    return zm16;
   };
 
   // ---- stream header: sizes, mode = single, the symbol ----
@@ -509,10 +504,8 @@ __global__ __launch_bounds__(64) void k_encode8_single_blocks(const uint8_t *__r
     {
       const uint32_t at = landedAt + 16u * j;
       const u32x4 x = lds_ld128(hist + (hbase ^ (at & HM)));
-      const uint32_t z0 = zero_bytes(x.x ^ sym4), z1 = zero_bytes(x.y ^ sym4), z2 = zero_bytes(x.z ^ sym4), z3 = zero_bytes(x.w ^ sym4);
-      const uint32_t b0 = (((z0 >> 7) * 0x00204081u) >> 21) & 0xFu, b1 = (((z1 >> 7) * 0x00204081u) >> 21) & 0xFu;
-      const uint32_t b2 = (((z2 >> 7) * 0x00204081u) >> 21) & 0xFu, b3 = (((z3 >> 7) * 0x00204081u) >> 21) & 0xFu;
-      uint32_t bits = b0 | (b1 << 4) | (b2 << 8) | (b3 << 12);
+      const uint32_t zm16 = zero_mask16(x.x ^ sym4, x.y ^ sym4, x.z ^ sym4, x.w ^ sym4);
+      uint32_t bits = zm16;
       const uint32_t left = (n > at) ? n - at : 0u;                     // bytes at or beyond n never match
       if (left < 16u) bits &= (1u << left) - 1u;
       if (j >= landedChunks) bits = 0u;

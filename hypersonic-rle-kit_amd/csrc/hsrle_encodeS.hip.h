@@ -578,11 +578,8 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
           {
             const u32x4 nx = lds_ld128(hist + (hbase ^ ((cb + j * 16u + 16u) & HM)));
             const u32x4 y = funnel16(x, nx, SU);                         // the bytes S further on
-            const uint32_t z0 = zero_bytes(x.x ^ y.x), z1 = zero_bytes(x.y ^ y.y), z2 = zero_bytes(x.z ^ y.z), z3 = zero_bytes(x.w ^ y.w);
-            // 0x80 flags -> 4 bits per dword
-            const uint32_t b0 = (((z0 >> 7) * 0x00204081u) >> 21) & 0xFu, b1 = (((z1 >> 7) * 0x00204081u) >> 21) & 0xFu;
-            const uint32_t b2 = (((z2 >> 7) * 0x00204081u) >> 21) & 0xFu, b3 = (((z3 >> 7) * 0x00204081u) >> 21) & 0xFu;
-            m |= (uint64_t)(b0 | (b1 << 4) | (b2 << 8) | (b3 << 12)) << (16u * j);
+            const uint32_t zm16 = zero_mask16(x.x ^ y.x, x.y ^ y.y, x.z ^ y.z, x.w ^ y.w);
+            m |= (uint64_t)zm16 << (16u * j);
             x = nx;
           }
         }

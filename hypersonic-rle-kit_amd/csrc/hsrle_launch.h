@@ -48,9 +48,6 @@ struct EncodeArgs
   uint32_t *sizes;
   int *residentWorkgroups = nullptr; // query mode, as in DecodeArgs
   uint32_t *ringSel = nullptr;       // 16 bytes of device scratch: the encoders of 1 / 2 byte symbols choose their history ring per input (hsrle_encode8.hip.h)
-  // fused placement (hsrle_encode8.hip.h): the caller offers the container's offset table and payload and one zeroed word per 64 blocks; an
-  // encoder that places its streams itself sets *fused (the caller then skips the size scan and the compaction pass)
-  uint64_t *fuseOffsets = nullptr; uint8_t *fusePayload = nullptr; unsigned long long *fuseTiles = nullptr; bool *fused = nullptr;
 };
 
 // chunks of ONE monolithic stream (hsrle_mono_encode.hip.h): EncodeArgs with nBlocks = chunks, plus the chunk table
@@ -77,13 +74,6 @@ constexpr int kCodecCount = 110;                 // 50 extreme codecs (SURVEY.md
 constexpr int kGreedyBase = 94;                   // + 3 * index(W in 16,24,32,48,64) + {0 1symlut, 1 3symlut, 2 7symlut}: rle{W}_{K}symlut_byte_short_compress_greedy
 constexpr int kShortBase8 = 50;                   // rle8_multi_short, rle8_{1,3,7}symlut_short
 constexpr int kShortBaseW = 54;                   // + 8 * index(W in 16,24,32,48,64) + {0 sym, 1 1symlut_sym, 2 3symlut_sym, 3 7symlut_sym, 4 byte, 5 1symlut_byte, 6 3symlut_byte, 7 7symlut_byte}
-// fused placement of the 8 bit ring encoders (hsrle_encode8.hip.h): measured SLOWER than the size scan + k_compact (8 GiB: 7.9 against 7.1 ms;
-// video-shaped 12.5 against 6.8): workgroups that are done hold their LDS and wave slots while they wait for their predecessors' sizes and
-// copy, which costs the latency-bound encoders more residency than the saved pass is worth.  Kept for A/B builds (-DHSRLE_FUSE_PLACEMENT=1).
-#ifndef HSRLE_FUSE_PLACEMENT
-#define HSRLE_FUSE_PLACEMENT 0
-#endif
-constexpr bool kFusePlacement = HSRLE_FUSE_PLACEMENT != 0;
 constexpr uint32_t kEncodeLdsCap = 20000;       // bytes of dynamic LDS per encode workgroup (0 = no residency cap); tuned on MI355X
 #ifndef HSRLE_DECODE_TILE
 #define HSRLE_DECODE_TILE 128
@@ -137,8 +127,7 @@ inline hipError_t launch_decode_ring(K128 k128, K64 k64, const DecodeArgs &a, hi
   return launch_decode(k128, a, st);
 }
 
-// THREADS: 64 = one wave per 64 blocks; 128 = an encoder wave and a loader wave per 64 blocks (hsrle_encode8.hip.h)
-template <int THREADS = 64, typename KERNEL>
+template <typename KERNEL>
 inline hipError_t launch_encode(KERNEL k, const EncodeArgs &a, hipStream_t st, int capResidency = 1)
 {
   const uint32_t grid = (a.nBlocks + 63u) / 64u;
@@ -148,21 +137,9 @@ inline hipError_t launch_encode(KERNEL k, const EncodeArgs &a, hipStream_t st, i
   static const uint32_t ldsCap = [] { const char *e = getenv("HSRLE_ENCODE_LDS_CAP"); return e ? (uint32_t)atoi(e) : kEncodeLdsCap; }();
   static const uint32_t lds8 = [] { const char *e = getenv("HSRLE_ENCODE8_LDS"); return e ? (uint32_t)atoi(e) : 0u; }();   // experiment knob
   if (a.residentWorkgroups != nullptr)
-  {
-    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(a.residentWorkgroups, k, THREADS, capResidency ? ldsCap : lds8);
-    *a.residentWorkgroups *= THREADS / 64;                            // the caller asks for waves
-    return e;
-  }
-  if constexpr (kernel_arity(KERNEL{}) == 17)   // the 8 bit ring encoders: MONO mode + fused placement
-  {
-    const bool fuse = kFusePlacement && a.fuseOffsets != nullptr && a.fused != nullptr;
-    if (fuse) *a.fused = true;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(THREADS), capResidency ? ldsCap : lds8, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, (const uint64_t *)nullptr,
-                       (const uint64_t *)nullptr, (const uint64_t *)nullptr, 0u, (uint64_t *)nullptr, 0u, (const uint32_t *)nullptr,
-                       fuse ? a.fuseOffsets : (uint64_t *)nullptr, fuse ? a.fusePayload : (uint8_t *)nullptr, fuse ? a.fuseTiles : (unsigned long long *)nullptr);
-  }
-  else if constexpr (kernel_arity(KERNEL{}) == 14)   // kernels with a MONO mode (hsrle_encodeS.hip.h): block mode = no chunk table
-    hipLaunchKernelGGL(k, dim3(grid), dim3(THREADS), capResidency ? ldsCap : lds8, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, (const uint64_t *)nullptr,
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(a.residentWorkgroups, k, 64, capResidency ? ldsCap : lds8);
+  if constexpr (kernel_arity(KERNEL{}) == 14)   // kernels with a MONO mode (hsrle_encode8.hip.h): block mode = no chunk table
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64), capResidency ? ldsCap : lds8, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, (const uint64_t *)nullptr,
                        (const uint64_t *)nullptr, (const uint64_t *)nullptr, 0u, (uint64_t *)nullptr, 0u, (const uint32_t *)nullptr);
   else
     hipLaunchKernelGGL(k, dim3(grid), dim3(64), capResidency ? ldsCap : lds8, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes);
@@ -171,38 +148,25 @@ inline hipError_t launch_encode(KERNEL k, const EncodeArgs &a, hipStream_t st, i
 
 // the encoders of 1 / 2 byte symbols: probe a sample of the input, then both instantiations -- the one that was not chosen returns at once.
 // HSRLE_ENC_RING=128 / 256 in the environment forces one (tests, A/B).  Without scratch (a.ringSel == nullptr): the 256-byte ring.
-template <int S, int THREADS = 64, typename K256, typename K128>
+template <int S, typename K256, typename K128>
 inline hipError_t launch_encode_ring(K256 k256, K128 k128, const EncodeArgs &a, hipStream_t st)
 {
   static const int forced = [] { const char *e = getenv("HSRLE_ENC_RING"); return e ? atoi(e) : 0; }();
   // (below ~131 072 blocks the device is not full with 9 waves per CU either: more waves bring nothing, and the probe + the second launch
   //  are ~25 us of a call that short)
   if (a.residentWorkgroups != nullptr || forced == 256 || (forced == 0 && (a.ringSel == nullptr || a.nBlocks < 131072u)))
-    return launch_encode<THREADS>(k256, a, st, 0);
+    return launch_encode(k256, a, st, 0);
   if (forced == 128)
-    return launch_encode<THREADS>(k128, a, st, 0);
+    return launch_encode(k128, a, st, 0);
   if (hipMemsetAsync(a.ringSel, 0, 16, st) != hipSuccess) return hipErrorUnknown;
   const uint32_t samples = a.nBlocks < 256u ? a.nBlocks : 256u;
   hipLaunchKernelGGL((k_ring_probe<S>), dim3(samples), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.ringSel);
   hipLaunchKernelGGL((k_ring_decide<S>), dim3(1), dim3(64), 0, st, a.ringSel);
   const uint32_t grid = (a.nBlocks + 63u) / 64u;
-  if constexpr (kernel_arity(K256{}) == 17)
-  {
-    const bool fuse = kFusePlacement && a.fuseOffsets != nullptr && a.fused != nullptr;
-    if (fuse) *a.fused = true;
-    uint64_t *const fo = fuse ? a.fuseOffsets : (uint64_t *)nullptr; uint8_t *const fp = fuse ? a.fusePayload : (uint8_t *)nullptr; unsigned long long *const ft = fuse ? a.fuseTiles : (unsigned long long *)nullptr;
-    hipLaunchKernelGGL(k256, dim3(grid), dim3(THREADS), 0, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, (const uint64_t *)nullptr, (const uint64_t *)nullptr, (const uint64_t *)nullptr, 0u,
-                       (uint64_t *)nullptr, 0u, (const uint32_t *)a.ringSel, fo, fp, ft);
-    hipLaunchKernelGGL(k128, dim3(grid), dim3(THREADS), 0, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, (const uint64_t *)nullptr, (const uint64_t *)nullptr, (const uint64_t *)nullptr, 0u,
-                       (uint64_t *)nullptr, 0u, (const uint32_t *)a.ringSel, fo, fp, ft);
-  }
-  else
-  {
-    hipLaunchKernelGGL(k256, dim3(grid), dim3(THREADS), 0, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, (const uint64_t *)nullptr, (const uint64_t *)nullptr, (const uint64_t *)nullptr, 0u,
-                       (uint64_t *)nullptr, 0u, (const uint32_t *)a.ringSel);
-    hipLaunchKernelGGL(k128, dim3(grid), dim3(THREADS), 0, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, (const uint64_t *)nullptr, (const uint64_t *)nullptr, (const uint64_t *)nullptr, 0u,
-                       (uint64_t *)nullptr, 0u, (const uint32_t *)a.ringSel);
-  }
+  hipLaunchKernelGGL(k256, dim3(grid), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, (const uint64_t *)nullptr, (const uint64_t *)nullptr, (const uint64_t *)nullptr, 0u,
+                     (uint64_t *)nullptr, 0u, (const uint32_t *)a.ringSel);
+  hipLaunchKernelGGL(k128, dim3(grid), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, (const uint64_t *)nullptr, (const uint64_t *)nullptr, (const uint64_t *)nullptr, 0u,
+                     (uint64_t *)nullptr, 0u, (const uint32_t *)a.ringSel);
   return hipGetLastError();
 }
 
@@ -226,14 +190,10 @@ inline hipError_t launch_wave_encode(KERNEL k, const WaveEncodeArgs &a, hipStrea
   return hipGetLastError();
 }
 
-template <int THREADS = 64, typename KERNEL>
+template <typename KERNEL>
 inline hipError_t launch_mono_encode(KERNEL k, const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st)
 {
-  if constexpr (kernel_arity(KERNEL{}) == 17)
-    hipLaunchKernelGGL(k, dim3((a.nBlocks + 63u) / 64u), dim3(THREADS), 0, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, m.starts, m.syms, m.slotOff, m.steps, m.listOut, m.dry, (const uint32_t *)nullptr,
-                       (uint64_t *)nullptr, (uint8_t *)nullptr, (unsigned long long *)nullptr);
-  else
-    hipLaunchKernelGGL(k, dim3((a.nBlocks + 63u) / 64u), dim3(THREADS), 0, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, m.starts, m.syms, m.slotOff, m.steps, m.listOut, m.dry, (const uint32_t *)nullptr);
+  hipLaunchKernelGGL(k, dim3((a.nBlocks + 63u) / 64u), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, m.starts, m.syms, m.slotOff, m.steps, m.listOut, m.dry, (const uint32_t *)nullptr);
   return hipGetLastError();
 }
 

@@ -442,11 +442,8 @@ __global__ __launch_bounds__(64) void k_rle8m_stats_wave(const uint8_t *__restri
       {
         const u32x4 x = lds_ld128(bytes + w * 64u + j * 16u);
         const uint32_t x4 = lds_ld32(bytes + w * 64u + j * 16u + 16u);
-        const uint32_t z0 = zero_bytes(x.x ^ alignbyte(x.y, x.x, 1)), z1 = zero_bytes(x.y ^ alignbyte(x.z, x.y, 1));
-        const uint32_t z2 = zero_bytes(x.z ^ alignbyte(x.w, x.z, 1)), z3 = zero_bytes(x.w ^ alignbyte(x4, x.w, 1));
-        const uint32_t b0 = (((z0 >> 7) * 0x00204081u) >> 21) & 0xFu, b1 = (((z1 >> 7) * 0x00204081u) >> 21) & 0xFu;
-        const uint32_t b2 = (((z2 >> 7) * 0x00204081u) >> 21) & 0xFu, b3 = (((z3 >> 7) * 0x00204081u) >> 21) & 0xFu;
-        e64 |= (uint64_t)(b0 | (b1 << 4) | (b2 << 8) | (b3 << 12)) << (16u * j);
+        const uint32_t zm16 = zero_mask16(x.x ^ alignbyte(x.y, x.x, 1), x.y ^ alignbyte(x.z, x.y, 1), x.z ^ alignbyte(x.w, x.z, 1), x.w ^ alignbyte(x4, x.w, 1));
+        e64 |= (uint64_t)zm16 << (16u * j);
       }
       const uint32_t base = w * 64u;
       const uint64_t left = (uint64_t)n - 1u - a;                         // positions a + i with a + i + 1 < n: i < left

@@ -26,17 +26,17 @@ static hipError_t dec_short0(const DecodeArgs &a, hipStream_t st) { return launc
 static hipError_t dec_short1(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<SHORT1, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, k_decode_blocks<SHORT1, 1, 0, kDecodeTile, 64, kDecodeStep>, a, st); }
 static hipError_t dec_short3(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<SHORT3, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, k_decode_blocks<SHORT3, 1, 0, kDecodeTile, 64, kDecodeStep>, a, st); }
 static hipError_t dec_short7(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<SHORT7, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, k_decode_blocks<SHORT7, 1, 0, kDecodeTile, 64, kDecodeStep>, a, st); }
-static hipError_t enc_short0(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1, 128>(k_encode8_blocks<SHORT0, false, 256>, k_encode8_blocks<SHORT0, false, 128>, a, st); }
-static hipError_t enc_short1(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1, 128>(k_encode8_blocks<SHORT1, false, 256>, k_encode8_blocks<SHORT1, false, 128>, a, st); }
-static hipError_t enc_short3(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1, 128>(k_encode8_blocks<SHORT3, false, 256>, k_encode8_blocks<SHORT3, false, 128>, a, st); }
-static hipError_t enc_short7(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1, 128>(k_encode8_blocks<SHORT7, false, 256>, k_encode8_blocks<SHORT7, false, 128>, a, st); }
+static hipError_t enc_short0(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<SHORT0, false, 256>, k_encode8_blocks<SHORT0, false, 128>, a, st); }
+static hipError_t enc_short1(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<SHORT1, false, 256>, k_encode8_blocks<SHORT1, false, 128>, a, st); }
+static hipError_t enc_short3(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<SHORT3, false, 256>, k_encode8_blocks<SHORT3, false, 128>, a, st); }
+static hipError_t enc_short7(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<SHORT7, false, 256>, k_encode8_blocks<SHORT7, false, 128>, a, st); }
 
 static hipError_t dec_short_single(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<SHORT_SINGLE, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, k_decode_blocks<SHORT_SINGLE, 1, 0, kDecodeTile, 64, kDecodeStep>, a, st); }
 
-static hipError_t enc_plain(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1, 128>(k_encode8_blocks<PLAIN, false, 256>, k_encode8_blocks<PLAIN, false, 128>, a, st); }
-static hipError_t enc_packed(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1, 128>(k_encode8_blocks<PACKED, false, 256>, k_encode8_blocks<PACKED, false, 128>, a, st); }
-static hipError_t enc_lut3(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1, 128>(k_encode8_blocks<LUT3, false, 256>, k_encode8_blocks<LUT3, false, 128>, a, st); }
-static hipError_t enc_lut7(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1, 128>(k_encode8_blocks<LUT7, false, 256>, k_encode8_blocks<LUT7, false, 128>, a, st); }
+static hipError_t enc_plain(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<PLAIN, false, 256>, k_encode8_blocks<PLAIN, false, 128>, a, st); }
+static hipError_t enc_packed(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<PACKED, false, 256>, k_encode8_blocks<PACKED, false, 128>, a, st); }
+static hipError_t enc_lut3(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<LUT3, false, 256>, k_encode8_blocks<LUT3, false, 128>, a, st); }
+static hipError_t enc_lut7(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<LUT7, false, 256>, k_encode8_blocks<LUT7, false, 128>, a, st); }
 // Single: symbol pick by one wave per block, then the ring encoder (hsrle_encode8s.hip.h).  Blocks above kSinglePickMaxBlock (the one-lane
 // drop-in path spans the whole input with one block) and HSRLE_SINGLE_V1=1 (A/B runs) use the first-generation kernel.
 template <int MODE>   // 0 rle8_single, 1 rle8_packed_single, 2 rle8_single_short
@@ -83,14 +83,14 @@ static hipError_t sub_short3(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hi
 static hipError_t sub_short7(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_sub_or_wave<SHORT7, 1, 0>(a, SB, 0u, rec, st); }
 static hipError_t sub_short_single(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_sub_or_wave<SHORT_SINGLE, 1, 0>(a, SB, 0u, rec, st); }
 
-static hipError_t menc_plain(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode<128>(k_encode8_blocks<PLAIN, true>, a, m, st); }
-static hipError_t menc_packed(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode<128>(k_encode8_blocks<PACKED, true>, a, m, st); }
-static hipError_t menc_short0(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode<128>(k_encode8_blocks<SHORT0, true>, a, m, st); }
-static hipError_t menc_lut3(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode<128>(k_encode8_blocks<LUT3, true>, a, m, st); }
-static hipError_t menc_lut7(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode<128>(k_encode8_blocks<LUT7, true>, a, m, st); }
-static hipError_t menc_short1(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode<128>(k_encode8_blocks<SHORT1, true>, a, m, st); }
-static hipError_t menc_short3(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode<128>(k_encode8_blocks<SHORT3, true>, a, m, st); }
-static hipError_t menc_short7(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode<128>(k_encode8_blocks<SHORT7, true>, a, m, st); }
+static hipError_t menc_plain(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode(k_encode8_blocks<PLAIN, true>, a, m, st); }
+static hipError_t menc_packed(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode(k_encode8_blocks<PACKED, true>, a, m, st); }
+static hipError_t menc_short0(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode(k_encode8_blocks<SHORT0, true>, a, m, st); }
+static hipError_t menc_lut3(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode(k_encode8_blocks<LUT3, true>, a, m, st); }
+static hipError_t menc_lut7(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode(k_encode8_blocks<LUT7, true>, a, m, st); }
+static hipError_t menc_short1(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode(k_encode8_blocks<SHORT1, true>, a, m, st); }
+static hipError_t menc_short3(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode(k_encode8_blocks<SHORT3, true>, a, m, st); }
+static hipError_t menc_short7(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode(k_encode8_blocks<SHORT7, true>, a, m, st); }
 
 static hipError_t wenc_plain(const WaveEncodeArgs &a, hipStream_t st) { return launch_wave_encode(k_encode8_wave<PLAIN>, a, st); }
 static hipError_t wenc_packed(const WaveEncodeArgs &a, hipStream_t st) { return launch_wave_encode(k_encode8_wave<PACKED>, a, st); }
@@ -121,12 +121,3 @@ void register_w8(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBloc
 }
 
 } // namespace hsrle
-
-#ifdef HSRLE_E8_STATS
-extern "C" void hsrle_debug_e8stats(unsigned long long *out, int reset)
-{
-  (void)hipDeviceSynchronize();
-  if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(hsrle::g_e8stats), sizeof(unsigned long long) * 32);
-  if (reset) { unsigned long long z[32] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(hsrle::g_e8stats), z, sizeof(z)); }
-}
-#endif
