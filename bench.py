@@ -15,7 +15,8 @@ The JSON line also carries
   roofline      HBM roofline of the decode kernel: algorithmic bytes (compressed + uncompressed) / average kernel
                 duration measured with HIP events on the launch stream, against the 8 TB/s peak
   cpu_baseline  the same decode on the host CPU, one thread, on a bounded sample of the same workload: the compiled reference
-                (oracle/_ref, kind "reference") when it is present, else the oracle's restatement (kind "port")
+                (oracle/_ref, kind "reference") when it is present, else the oracle's restatement (kind "port"); encode.cpu_baseline is
+                the encode direction of the same sample (BASELINE metric: "decode + encode GiB/s ... vs CPU")
   bit_exact     block streams of a sample equal the CPU codec's streams and the full decode equals the input
 """
 import argparse
@@ -32,20 +33,32 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
 
-def measured_traffic(codec, size, block):
-    """HBM bytes per decode launch from the committed rocprofv3 PMC passes of this workload (profiles/r02_traffic.json; None for any other
-    workload).  FETCH_SIZE tallies every L2 -> fabric read request at 64 bytes whether it asks for 64 or 128 (calibrated with
-    tools/ubench/fetch_calib.hip on a buffer of known size, profiles/r02_fetch_calibration.txt), so the read side is known between two
-    bounds: every chunk at least once (the container) and 128 bytes per counted request.  Returns (upper bound, detail)."""
-    try:
-        t = json.load(open(os.path.join(REPO, "profiles", "r02_traffic.json")))
-        if t["codec"] == codec and t["size"] == size and t["block"] == block:
-            return int(t["traffic_upper_bound_bytes"]), {"fetch_size_raw": t["fetch_size_raw_bytes"], "fabric_read_requests": t["fabric_read_requests"],
-                                                          "fetch_bounds": [t["fetch_lower_bound_bytes"], t["fetch_upper_bound_bytes"]], "write_size": t["write_bytes"],
-                                                          "traffic_bounds": [t["traffic_lower_bound_bytes"], t["traffic_upper_bound_bytes"]], "source": "profiles/r02_traffic.json"}
-    except Exception:
-        pass
-    return None, None
+def measured_traffic(codec, size, block, build_id):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this workload AND THIS BUILD (profiles/r*_traffic.json, written by
+    tools/traffic.sh, stamped with the library's build id; a file of another build or workload is refused: traffic = null).  FETCH_SIZE
+    tallies every L2 -> fabric read request at 64 bytes whether it asks for 64 or 128 (calibrated with tools/ubench/fetch_calib.hip on a
+    buffer of known size, profiles/r02_fetch_calibration.txt), so the read side is known between two bounds: every chunk at least once
+    (the container) and 128 bytes per counted request.  Returns (decode upper bound, decode detail, encode upper bound)."""
+    import glob
+
+    stale = None
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            t = json.load(open(path))
+            if not (t["codec"] == codec and t["size"] == size and t["block"] == block):
+                continue
+            if t.get("library_build_id") != build_id:
+                stale = stale or os.path.basename(path)
+                continue
+            detail = {"fetch_size_raw": t["fetch_size_raw_bytes"], "fabric_read_requests": t["fabric_read_requests"],
+                      "fetch_bounds": [t["fetch_lower_bound_bytes"], t["fetch_upper_bound_bytes"]], "write_size": t["write_bytes"],
+                      "traffic_bounds": [t["traffic_lower_bound_bytes"], t["traffic_upper_bound_bytes"]], "launches": t.get("launches"),
+                      "library_build_id": build_id, "source": "profiles/" + os.path.basename(path)}
+            enc = t.get("encode", {}).get("traffic_bounds")
+            return int(t["traffic_upper_bound_bytes"]), detail, (int(enc[1]) if enc else None)
+        except Exception:
+            continue
+    return None, ({"refused": f"profiles/{stale} was measured on another build of the library (this one: {build_id}); rerun tools/traffic.sh"} if stale else None), None
 
 
 def cpu_baseline(container_prefix, n_blocks, block_size, codec_key, expect):
@@ -113,6 +126,57 @@ def cpu_baseline(container_prefix, n_blocks, block_size, codec_key, expect):
             if tb is not None and same:
                 res["all_cores"] = {"value": round(usize / 2**30 / tb, 2), "unit": "GiB/s", "cores": nthreads, "note": "best of %d runs, one block range per POSIX thread" % runs}
     return res
+
+
+def cpu_encode_baseline(sample, block_size, codec_key, gpu_payload_prefix, gpu_offsets):
+    """Encode the sample (the first bytes of the same input) block by block on the host, single thread: the compiled reference (kind
+    "reference") when it is present, else the oracle's restatement ("port").  The streams must be the GPU's."""
+    import numpy as np
+    from hsrle_testlib import CODEC_BY_KEY, REF_SO, Oracle
+
+    codec = CODEC_BY_KEY[codec_key]
+    n = sample.size
+    nb = (n + block_size - 1) // block_size
+    src = np.zeros(n + 64, dtype=np.uint8)                                   # guard pad behind the sample (SURVEY.md 8c; irrelevant for 8 bit symbols)
+    src[:n] = sample
+    if os.path.exists(REF_SO):
+        kind = "reference"
+        lib = ctypes.CDLL(REF_SO)
+        lib.rle_compress_bounds.restype = ctypes.c_uint32
+        stride = (lib.rle_compress_bounds(block_size) + 15) & ~15
+        fn = ctypes.cast(getattr(lib, codec.cname), ctypes.c_void_p)
+        lib.hsrle_ref_encode_blocks.restype = ctypes.c_uint64
+        lib.hsrle_ref_encode_blocks.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+        slots = np.zeros(nb * stride + 64, dtype=np.uint8)
+        sizes = np.zeros(nb, dtype=np.uint32)
+        run = lambda: lib.hsrle_ref_encode_blocks(fn, src.ctypes.data, n, block_size, slots.ctypes.data, stride, sizes.ctypes.data)
+    else:
+        kind = "port"
+        ora = Oracle()
+        stride = (block_size + 193 + 15) & ~15
+        slots = np.zeros(nb * stride + 64, dtype=np.uint8)
+        sizes = np.zeros(nb, dtype=np.uint32)
+        ora.lib.hso_compress_blocks.restype = ctypes.c_uint32
+        ora.lib.hso_compress_blocks.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+        run = lambda: ora.lib.hso_compress_blocks(codec.family, codec.S, codec.aligned, src.ctypes.data, n, block_size, slots.ctypes.data, stride, sizes.ctypes.data)
+    assert run() == nb  # warm-up run, discarded
+    best, total, reps = None, 0.0, 0
+    t_end = time.time() + 10.0
+    while reps < 3 or (time.time() < t_end and reps < 20):
+        t0 = time.perf_counter()
+        got = run()
+        dt = time.perf_counter() - t0
+        assert got == nb
+        total += dt
+        reps += 1
+        best = dt if best is None else min(best, dt)
+    same = bool((np.diff(gpu_offsets.astype(np.int64)) == sizes.astype(np.int64)).all())
+    for i in list(range(0, nb, max(1, nb // 4096))) + [nb - 1]:              # every block's size, a few thousand blocks' bytes
+        if not same:
+            break
+        same = slots[i * stride : i * stride + int(sizes[i])].tobytes() == gpu_payload_prefix[int(gpu_offsets[i]) : int(gpu_offsets[i + 1])]
+    return {"value": round(n / 2**30 / (total / reps), 3), "best": round(n / 2**30 / best, 3), "unit": "GiB/s", "cores": 1, "kind": kind,
+            "sample": f"encode of the first {n >> 20} MiB ({nb} blocks) of the same buffer, block by block, {reps} runs, mean", "streams_match_gpu": same}
 
 
 def side_measurements(hsrle, torch, src, dev):
@@ -389,22 +453,22 @@ def main():
     if distributed:
         from hsrle import dist as hd
 
+        use_c = os.environ.get("HSRLE_DIST_C") == "1"                      # the library's own communicator (hsrle_gather_container_rccl) instead of torch's
+        if use_c:
+            hd.c_comm()                                                    # (communicator creation is setup, not gather time)
         barrier()
         g0 = time.perf_counter()
-        full = hd.gather_container(container, size * world, root=0)
-        barrier()
-        gather_ms = (time.perf_counter() - g0) * 1e3
+        full = hd.gather_container_c(container, size * world, root=0) if use_c else hd.gather_container(container, size * world, root=0)
+        torch.cuda.synchronize()
+        t = torch.tensor([(time.perf_counter() - g0) * 1e3], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                           # the slowest rank's time from the common start to its own completion
+        gather_ms = float(t.item())
         del full
+        if use_c:
+            hd.destroy_c_comms()
 
     if rank == 0:
-        traffic, traffic_detail = measured_traffic(args.codec, size, args.block)
-        enc_traffic = None
-        try:
-            tj = json.load(open(os.path.join(REPO, "profiles", "r02_traffic.json")))
-            if traffic is not None:
-                enc_traffic = int(tj["encode"]["traffic_bounds"][1])
-        except Exception:
-            pass
+        traffic, traffic_detail, enc_traffic = measured_traffic(args.codec, size, args.block, hsrle.build_id())
         total_units = size * world
         alg_bytes = size + info.totalSize
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
@@ -428,7 +492,7 @@ def main():
             "encode": {"value": round(size / 2**30 / (enc_ms * 1e-3), 2), "unit": "GiB/s", "ms": round(enc_ms, 4), "note": "same buffer, encode kernel + size scan + compaction",
                        "roofline": {"bound": "hbm", "achieved": round(alg_bytes / (enc_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": round(alg_bytes / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": enc_traffic, "algorithmic_bytes": int(alg_bytes),
-                                    "note": "algorithmic bytes = input + container per encode; traffic = upper bound of the PMC passes over both kernels (profiles/r02_traffic.json), about 2x the algorithmic bytes: staging slots are written with partial lines and compacted in a second pass"}},
+                                    "note": "algorithmic bytes = input + container per encode; traffic = upper bound of the PMC passes over both kernels (same profiles/ file as roofline.traffic_detail.source), about 2x the algorithmic bytes: staging slots are written with partial lines and compacted in a second pass"}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_detail": traffic_detail, "kernel": kernel_name(args.codec), "waves_per_cu": hsrle.kernel_waves_per_cu(args.codec, True), "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes": int(alg_bytes),
@@ -438,12 +502,16 @@ def main():
             line["gather_ms"] = round(gather_ms, 3)
         if extras:
             line["extras"] = extras
-        if not args.no_cpu and world == 1:
+        if not args.no_cpu:
+            # rank 0's shard, on rank 0's host cores, whatever the world size (the other ranks are through their timed region)
             nb = min(info.blockCount, (1 << 30) // args.block)
             prefix_end = p0 + int(container[64 + 8 * nb : 64 + 8 * nb + 8].view(torch.int64).item()) + 64
             prefix = container[: min(prefix_end, container.numel())].cpu().numpy().tobytes()
-            expect = src[: nb * args.block].cpu().numpy().tobytes()
-            line["cpu_baseline"] = cpu_baseline(prefix, nb, args.block, args.codec, expect)
+            sample = src[: nb * args.block].cpu().numpy()
+            line["cpu_baseline"] = cpu_baseline(prefix, nb, args.block, args.codec, sample.tobytes())
+            import numpy as np
+
+            line["encode"]["cpu_baseline"] = cpu_encode_baseline(sample, args.block, args.codec, prefix[p0:], np.frombuffer(prefix, dtype=np.uint64, count=nb + 1, offset=64))
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(line) + "\n").encode())
 

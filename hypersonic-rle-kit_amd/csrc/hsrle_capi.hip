@@ -9,7 +9,11 @@
 #include "hsrle_launch.h"
 #include "hsrle_index.hip.h"
 #include "hsrle_mono_encode.hip.h"
+#ifdef HSRLE_EXPERIMENTS
 #include "hsrle_encode8w.hip.h"
+#else
+namespace hsrle { constexpr uint64_t kTicketBytes = 256; }   // (scratch behind the staging slots: the ring choice of the 1 / 2 byte encoders lives there)
+#endif
 #include "hsrle_rle8m.hip.h"
 
 #include <stdlib.h>
@@ -75,7 +79,7 @@ static inline uint32_t slot_stride(uint32_t B) { return (bounds32(B) + 15u) & ~1
 static inline uint64_t block_count(uint64_t U, uint32_t B) { return (U + B - 1) / B; }
 static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
-static uint32_t env_u32(const char *name, uint32_t dflt) { const char *e = getenv(name); return (e && *e) ? (uint32_t)strtoul(e, nullptr, 10) : dflt; }
+static uint32_t env_u32(const char *name, uint32_t dflt) { return knob_u32(name, dflt); }   // (developer knobs: -DHSRLE_EXPERIMENTS builds only, hsrle_launch.h)
 static uint32_t pow2_floor(uint64_t v) { uint32_t r = 1; while ((uint64_t)r * 2u <= v && r < 0x80000000u) r *= 2u; return r; }
 
 static bool valid_block_size(uint32_t B) { return B >= HSRLE_MIN_BLOCK_SIZE && B <= HSRLE_MAX_BLOCK_SIZE && (B % 128u) == 0; }
@@ -522,8 +526,9 @@ static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, ui
   // (every block of the 8 GiB buffer against the reference manifest), but OFF by default: at 4 KiB per wave the kernel is bound by the
   // latency chain of one block, not by traffic -- 8 GiB: 13.5 ms against 7.4 ms of the lane-per-block kernel + compaction (input load + masks
   // 2.1 ms, run list 0.7, decisions 2.1, packets 2.6, look-back 1.4 .. 5.9 ms).
-  static const bool waveEncode = env_u32("HSRLE_ENCODE_WAVE", 0) != 0u;
   hipStream_t aux = w.nChunks > 1 ? aux_stream() : nullptr;
+#ifdef HSRLE_EXPERIMENTS
+  static const bool waveEncode = env_u32("HSRLE_ENCODE_WAVE", 0) != 0u;
   if (waveEncode && g_wenc[codec] && B <= kWaveEncodeMaxBlock)
   {
     // (the slot area of the lane-per-block path is not needed: the tile words and the ticket counters live at its start)
@@ -534,7 +539,9 @@ static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, ui
     else if (hipMemsetAsync(ticket, 0, kTicketBytes + 8ull * nBlocks, st) != hipSuccess || g_wenc[codec](wa, st) != hipSuccess)
       rc = HSRLE_ERR_DEVICE;
   }
-  else if (w.nChunks > 1 && aux == nullptr)
+  else
+#endif
+  if (w.nChunks > 1 && aux == nullptr)
     rc = HSRLE_ERR_DEVICE;
   else if (w.nChunks <= 1)
   {
@@ -1242,7 +1249,7 @@ static int rle8m_decode_async(const void *dStream, uint64_t streamSize, uint32_t
   if (dStatus && hipMemsetAsync(dStatus, 0, 4, st) != hipSuccess)
     return HSRLE_ERR_DEVICE;
   // few, large sections: one wave per section (one lane per section needs ~1e5 sections to fill the GPU)
-  static const int forced = getenv("HSRLE_RLE8M_DECODE") ? atoi(getenv("HSRLE_RLE8M_DECODE")) : 0;   // 1 = lane, 2 = wave kernel (A/B runs)
+  static const int forced = (int)knob_u32("HSRLE_RLE8M_DECODE", 0);   // 1 = lane, 2 = wave kernel (A/B runs)
   // ... and sections of 4 KiB and more decode faster that way whatever their number (1 GiB, 4 KiB sections: 1034 against 717 GiB/s on
   // video-shaped bytes, 618 against 629 on bytes that do not compress; 1 KiB sections: 841 / 501 against 737 / 617)
   const bool wave = forced ? forced == 2 : (sections < kRle8mWaveBelow || uncompressedSize / sections >= 4096u);
@@ -1305,8 +1312,8 @@ static int rle8m_encode_async(const void *dIn, uint32_t n, uint32_t sections, vo
   const uint32_t grid = (sections + 63u) / 64u;
   // the statistics are over the whole input: one lane per 4 KiB piece, whatever the section count
   const uint32_t pieces = (n / 4096u > sections) ? n / 4096u : sections;
-  static const uint32_t g_rle8mStatsWaves = getenv("HSRLE_RLE8M_STATS_WAVES") ? (uint32_t)atoi(getenv("HSRLE_RLE8M_STATS_WAVES")) : 32768u;   // (1 GiB run-distributed / video-shaped: 1 024 waves 7.5 / 6.2 ms per encode, 8 192: 3.96 / 4.17, 32 768: 3.75 / 3.98; the byte-walking kernel: 4.03 / 4.60)
-  static const int statsV1 = getenv("HSRLE_RLE8M_STATS") ? atoi(getenv("HSRLE_RLE8M_STATS")) : 0;   // 1 = the byte-walking kernel (A/B runs)
+  static const uint32_t g_rle8mStatsWaves = knob_u32("HSRLE_RLE8M_STATS_WAVES", 32768u);   // (1 GiB run-distributed / video-shaped: 1 024 waves 7.5 / 6.2 ms per encode, 8 192: 3.96 / 4.17, 32 768: 3.75 / 3.98; the byte-walking kernel: 4.03 / 4.60)
+  static const int statsV1 = (int)knob_u32("HSRLE_RLE8M_STATS", 0);   // 1 = the byte-walking kernel (A/B runs)
   if (statsV1 == 1)
     hipLaunchKernelGGL(k_rle8m_stats, dim3((pieces + 63u) / 64u), dim3(64), 0, st, (const uint8_t *)dIn, n, pieces, t);
   else
@@ -1317,7 +1324,7 @@ static int rle8m_encode_async(const void *dIn, uint32_t n, uint32_t sections, vo
     hipLaunchKernelGGL(k_rle8m_stats_wave, dim3(grid), dim3(64), 0, st, (const uint8_t *)dIn, n, t);
   }
   hipLaunchKernelGGL(k_rle8m_info, dim3(1), dim3(256), 0, st, t, sections, (uint8_t *)dOut);
-  static const int forced = getenv("HSRLE_RLE8M_ENCODE") ? atoi(getenv("HSRLE_RLE8M_ENCODE")) : 0;   // 1 = lane, 2 = wave kernel (A/B runs)
+  static const int forced = (int)knob_u32("HSRLE_RLE8M_ENCODE", 0);   // 1 = lane, 2 = wave kernel (A/B runs)
   if (forced ? forced == 2 : sections < kRle8mWaveBelow)
     hipLaunchKernelGGL(k_rle8m_encode_wave, dim3(sections), dim3(64), 0, st, (const uint8_t *)dIn, n, sections, (const Rle8mTables *)t, ws + p.w.offSlots, p.slotStride, sizes);
   else
@@ -1435,6 +1442,13 @@ int hsrle_kernel_waves_per_cu(int codec, int decode)
   else { EncodeArgs a{}; a.residentWorkgroups = &n; if (g_enc[codec](a, nullptr) != hipSuccess) return 0; }
   return n;
 }
+
+int hsrle_experiments_enabled(void) { return kExperiments ? 1 : 0; }
+
+#ifndef HSRLE_BUILD_ID
+#define HSRLE_BUILD_ID "unknown"
+#endif
+const char *hsrle_build_id(void) { return HSRLE_BUILD_ID; }
 
 int hsrle_device_count(void)
 {
@@ -1641,7 +1655,7 @@ int hsrle_decompress_dev(const void *dContainer, uint64_t containerSize, void *d
   // (opt-in: measured on the 88 MB frame it is the slower of the two -- 427 us against 189 us split: the packet hops of ONE lane per
   //  wave are a latency chain of ~1 us per packet that the other 63 lanes wait for, while the split decode's record walk runs 64 such
   //  chains per wave)
-  static const int waveMode = [] { const char *e = getenv("HSRLE_WAVE_DECODE"); return e ? atoi(e) : 0; }();
+  static const int waveMode = kExperiments ? (int)knob_u32("HSRLE_WAVE_DECODE", 0) : 0;
   const bool wave = waveMode != 0 && info.blockCount < kWaveDecodeBelow && info.blockSize <= 16384u && info.codec < (uint32_t)kCodecCount;
   const uint64_t recBytes = (!wave && info.blockCount < 131072u) ? hsrle_decompress_split_workspace_size(&info, info.blockCount, 0) : 0;
   uint8_t *scratch = (uint8_t *)scratch_alloc(256 + recBytes, (hipStream_t)stream);

@@ -20,6 +20,8 @@
 
 namespace hsrle {
 
+#ifdef HSRLE_EXPERIMENTS
+
 constexpr uint32_t kWaveDecodeDescriptors = 256;     // per batch (32 bytes each)
 constexpr uint32_t kWaveDecodeMaxBlock = 16384;      // larger blocks: the block kernel (with the split decode, hsrle_index.hip.h)
 
@@ -226,12 +228,18 @@ inline hipError_t launch_decode_wave(const DecodeArgs &a, uint32_t allowSingle, 
   return hipGetLastError();
 }
 
+#endif   // HSRLE_EXPERIMENTS
+
 // what the codec tables hold as their "sub-block" entry: SB == 0 selects the wave-per-block decoder (rec is not used), else the
 // record walk of the split decode (hsrle_index.hip.h)
 template <int FAM, int S, int AL>
 inline hipError_t launch_sub_or_wave(const DecodeArgs &a, uint32_t SB, uint32_t allowSingle, uint32_t *rec, hipStream_t st)
 {
+#ifdef HSRLE_EXPERIMENTS
   if (SB == 0u) return launch_decode_wave<FAM, S, AL>(a, allowSingle, st);
+#else
+  if (SB == 0u) return hipErrorNotSupported;                        // the wave-per-block decoder is measured slower than the split decode: not in the shipped build
+#endif
   return launch_container_records<FAM, S, AL>(a, SB, allowSingle, rec, st);
 }
 

@@ -9,6 +9,16 @@
 
 namespace hsrle {
 
+// Developer knobs (A/B runs, forcing a kernel variant in the parity suite) exist only in -DHSRLE_EXPERIMENTS builds (tools/build_variant.sh
+// exp -DHSRLE_EXPERIMENTS): the shipped library reads no environment variable in any launch path and holds one kernel per codec and case.
+#ifdef HSRLE_EXPERIMENTS
+inline uint32_t knob_u32(const char *name, uint32_t dflt) { const char *e = getenv(name); return (e && *e) ? (uint32_t)strtoul(e, nullptr, 10) : dflt; }
+constexpr bool kExperiments = true;
+#else
+constexpr uint32_t knob_u32(const char *, uint32_t dflt) { return dflt; }
+constexpr bool kExperiments = false;
+#endif
+
 struct DecodeArgs
 {
   const uint8_t *payload;
@@ -120,7 +130,7 @@ inline hipError_t launch_decode(KERNEL k, const DecodeArgs &a, hipStream_t st)
 template <int PER_MILLE = 250, typename K128, typename K64>
 inline hipError_t launch_decode_ring(K128 k128, K64 k64, const DecodeArgs &a, hipStream_t st)
 {
-  static const int forced = [] { const char *e = getenv("HSRLE_DEC_RING"); return e ? atoi(e) : 0; }();
+  static const int forced = (int)knob_u32("HSRLE_DEC_RING", 0);
   const uint64_t payloadBytes = (uint64_t)(a.payloadEnd - a.payload);
   const bool small = forced ? forced == 64 : (a.entries == nullptr && a.residentWorkgroups == nullptr && payloadBytes * 1000u < a.U * (uint64_t)PER_MILLE);
   if (small && a.entries == nullptr) return launch_decode(k64, a, st);
@@ -134,8 +144,8 @@ inline hipError_t launch_encode(KERNEL k, const EncodeArgs &a, hipStream_t st, i
   // The encoder keeps one 128-byte line per lane open on the read side and one on the write side.  With the full 32 waves per CU
   // those open lines (32 CUs x 32 waves x 64 lanes x 2 x 128 B = 16 MiB per XCD) thrash the 4 MiB L2 and every line is fetched /
   // written several times (measured: 6.8x read, 5.9x write amplification).  A dynamic LDS reservation caps the residency.
-  static const uint32_t ldsCap = [] { const char *e = getenv("HSRLE_ENCODE_LDS_CAP"); return e ? (uint32_t)atoi(e) : kEncodeLdsCap; }();
-  static const uint32_t lds8 = [] { const char *e = getenv("HSRLE_ENCODE8_LDS"); return e ? (uint32_t)atoi(e) : 0u; }();   // experiment knob
+  static const uint32_t ldsCap = knob_u32("HSRLE_ENCODE_LDS_CAP", kEncodeLdsCap);
+  static const uint32_t lds8 = knob_u32("HSRLE_ENCODE8_LDS", 0u);
   if (a.residentWorkgroups != nullptr)
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(a.residentWorkgroups, k, 64, capResidency ? ldsCap : lds8);
   if constexpr (kernel_arity(KERNEL{}) == 14)   // kernels with a MONO mode (hsrle_encode8.hip.h): block mode = no chunk table
@@ -151,7 +161,7 @@ inline hipError_t launch_encode(KERNEL k, const EncodeArgs &a, hipStream_t st, i
 template <int S, typename K256, typename K128>
 inline hipError_t launch_encode_ring(K256 k256, K128 k128, const EncodeArgs &a, hipStream_t st)
 {
-  static const int forced = [] { const char *e = getenv("HSRLE_ENC_RING"); return e ? atoi(e) : 0; }();
+  static const int forced = (int)knob_u32("HSRLE_ENC_RING", 0);
   // (below ~131 072 blocks the device is not full with 9 waves per CU either: more waves bring nothing, and the probe + the second launch
   //  are ~25 us of a call that short)
   if (a.residentWorkgroups != nullptr || forced == 256 || (forced == 0 && (a.ringSel == nullptr || a.nBlocks < 131072u)))
@@ -170,6 +180,7 @@ inline hipError_t launch_encode_ring(K256 k256, K128 k128, const EncodeArgs &a, 
   return hipGetLastError();
 }
 
+#ifdef HSRLE_EXPERIMENTS
 template <typename KERNEL>
 inline hipError_t launch_wave_encode(KERNEL k, const WaveEncodeArgs &a, hipStream_t st)
 {
@@ -189,6 +200,8 @@ inline hipError_t launch_wave_encode(KERNEL k, const WaveEncodeArgs &a, hipStrea
   hipLaunchKernelGGL(k, dim3(grid), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.offsets, a.payload, a.tiles, a.ticket);
   return hipGetLastError();
 }
+
+#endif
 
 template <typename KERNEL>
 inline hipError_t launch_mono_encode(KERNEL k, const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st)

@@ -78,6 +78,18 @@ Header make_header(uint32_t codec, uint64_t U, uint32_t B, uint32_t nBlocks, uin
   return h;
 }
 
+// the same consistency rules as the decode path's check_info (hsrle_capi.hip): a header that passes describes a container whose offset
+// table and payload lie inside `size` bytes
+int check_header(const Header &h, uint64_t size)
+{
+  if (memcmp(h.magic, "HSRLEKIT", 8) != 0 || h.version != 1) return HSRLE_ERR_FORMAT;
+  if (h.blockSize < HSRLE_MIN_BLOCK_SIZE || h.blockSize > HSRLE_MAX_BLOCK_SIZE || (h.blockSize % 128u) != 0 || h.uncompressedSize == 0) return HSRLE_ERR_FORMAT;
+  if ((uint64_t)h.blockCount != (h.uncompressedSize + h.blockSize - 1) / h.blockSize) return HSRLE_ERR_FORMAT;
+  const uint64_t payloadStart = HSRLE_CONTAINER_HEADER_SIZE + 8ull * ((uint64_t)h.blockCount + 1ull);
+  if (h.totalSize != payloadStart + h.payloadSize + HSRLE_CONTAINER_TAIL_PAD || h.totalSize > size) return HSRLE_ERR_FORMAT;
+  return HSRLE_OK;
+}
+
 // table[i] += delta for i in [0, n); optionally table[n] = last
 __global__ void k_rebase_offsets(uint64_t *table, uint64_t n, uint64_t delta, int writeLast, uint64_t last)
 {
@@ -149,39 +161,52 @@ int hsrle_gather_container_rccl(void *pComm, int root, const void *dLocal, uint6
   int world = 0, rank = 0;
   if (g_rccl.commCount(comm, &world) != ncclSuccess || g_rccl.commUserRank(comm, &rank) != ncclSuccess || root < 0 || root >= world) return HSRLE_ERR_ARGUMENT;
 
-  // this rank's (codec, blockSize, blockCount, payloadSize); a rank without blocks says blockCount 0
-  uint64_t mine[4] = { ~0ull, 0, 0, 0 };
+  // this rank's (codec, blockSize, blockCount, payloadSize, what is wrong with its container, the room it offers as root); a rank without
+  // blocks says blockCount 0.  NOTHING returns between here and the end of exchange 1 on one rank alone: every rank must reach the
+  // all-gather, and every rank then draws the SAME verdict from the gathered words before any point-to-point transfer is posted -- a rank
+  // that bailed out on its own (bad local header, root without room) used to leave its peers' streams waiting for ever
+  constexpr int kWords = 6;
+  uint64_t mine[kWords] = { ~0ull, 0, 0, 0, 0, (rank == root && dOut != nullptr) ? outCapacity : 0ull };
   if (dLocal != nullptr && localSize >= HSRLE_CONTAINER_HEADER_SIZE)
   {
     Header h;
-    if (hipMemcpyAsync(&h, dLocal, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return HSRLE_ERR_DEVICE;
-    if (memcmp(h.magic, "HSRLEKIT", 8) != 0 || h.totalSize > localSize) return HSRLE_ERR_FORMAT;
-    mine[0] = h.codec; mine[1] = h.blockSize; mine[2] = h.blockCount; mine[3] = h.payloadSize;
+    if (hipMemcpyAsync(&h, dLocal, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) mine[4] = (uint64_t)HSRLE_ERR_DEVICE;
+    else if (check_header(h, localSize) != HSRLE_OK) mine[4] = (uint64_t)HSRLE_ERR_FORMAT;
+    else { mine[0] = h.codec; mine[1] = h.blockSize; mine[2] = h.blockCount; mine[3] = h.payloadSize; }
   }
+  else if (dLocal != nullptr)
+    mine[4] = (uint64_t)HSRLE_ERR_FORMAT;
 
   // exchange 1
   uint64_t *dInfo = nullptr;
-  if (hipMallocAsync((void **)&dInfo, 32ull * (uint64_t)(world + 1), st) != hipSuccess) return HSRLE_ERR_DEVICE;
-  std::vector<uint64_t> all(4 * (size_t)world);
-  bool ok = hipMemcpyAsync(dInfo, mine, 32, hipMemcpyHostToDevice, st) == hipSuccess && g_rccl.allGather(dInfo, dInfo + 4, 4, ncclUint64, comm, st) == ncclSuccess &&
-            hipMemcpyAsync(all.data(), dInfo + 4, 32ull * (uint64_t)world, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
-  (void)hipFreeAsync(dInfo, st);
-  if (!ok) return HSRLE_ERR_DEVICE;
+  const bool haveInfo = hipMallocAsync((void **)&dInfo, 8ull * kWords * (uint64_t)(world + 1), st) == hipSuccess;
+  if (!haveInfo) { dInfo = nullptr; }
+  std::vector<uint64_t> all(kWords * (size_t)world);
+  bool ok = haveInfo && hipMemcpyAsync(dInfo, mine, 8 * kWords, hipMemcpyHostToDevice, st) == hipSuccess &&
+            g_rccl.allGather(dInfo, dInfo + kWords, kWords, ncclUint64, comm, st) == ncclSuccess &&
+            hipMemcpyAsync(all.data(), dInfo + kWords, 8ull * kWords * (uint64_t)world, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+  if (dInfo) (void)hipFreeAsync(dInfo, st);
+  if (!ok) return HSRLE_ERR_DEVICE;            // (a local allocation / collective failure: nothing a peer could be told about)
 
+  // the verdict: the same on every rank
   uint64_t codec = ~0ull, blockSize = 0, nBlocks = 0, payload = 0;
+  int verdict = HSRLE_OK;
   for (int r = 0; r < world; r++)
   {
-    const uint64_t *v = &all[4 * (size_t)r];
+    const uint64_t *v = &all[kWords * (size_t)r];
+    if (v[4] != 0 && verdict == HSRLE_OK) verdict = (int)v[4];
     if (v[2] == 0) continue;
     if (codec == ~0ull) { codec = v[0]; blockSize = v[1]; }
-    else if (codec != v[0] || blockSize != v[1]) return HSRLE_ERR_FORMAT;     // the ranks do not agree on codec / block size
+    else if ((codec != v[0] || blockSize != v[1]) && verdict == HSRLE_OK) verdict = HSRLE_ERR_FORMAT;     // the ranks do not agree on codec / block size
     nBlocks += v[2]; payload += v[3];
   }
-  if (codec == ~0ull || nBlocks > 0xFFFFFFF0ull) return HSRLE_ERR_FORMAT;
+  if (verdict == HSRLE_OK && (codec == ~0ull || nBlocks > 0xFFFFFFF0ull)) verdict = HSRLE_ERR_FORMAT;
+  if (verdict != HSRLE_OK) return verdict;
   const Header out = make_header((uint32_t)codec, totalUncompressedSize, (uint32_t)blockSize, (uint32_t)nBlocks, payload);
   if (pTotalSize) *pTotalSize = out.totalSize;
+  if (all[kWords * (size_t)root + 5] < out.totalSize) return HSRLE_ERR_CAPACITY;       // the root's room (0 without an output buffer): known to every rank
 
-  const uint64_t myCount = all[4 * (size_t)rank + 2], myPayload = all[4 * (size_t)rank + 3];
+  const uint64_t myCount = all[kWords * (size_t)rank + 2], myPayload = all[kWords * (size_t)rank + 3];
   const uint8_t *local = (const uint8_t *)dLocal;
   if (rank != root)
   {
@@ -192,7 +217,6 @@ int hsrle_gather_container_rccl(void *pComm, int root, const void *dLocal, uint6
     return (g_rccl.groupEnd() == ncclSuccess && ok) ? HSRLE_OK : HSRLE_ERR_DEVICE;
   }
 
-  if (!dOut || outCapacity < out.totalSize) return HSRLE_ERR_CAPACITY;
   uint8_t *o = (uint8_t *)dOut;
   uint64_t *table = (uint64_t *)(o + HSRLE_CONTAINER_HEADER_SIZE);
   uint8_t *pay = o + HSRLE_CONTAINER_HEADER_SIZE + 8ull * (nBlocks + 1ull);
@@ -205,7 +229,7 @@ int hsrle_gather_container_rccl(void *pComm, int root, const void *dLocal, uint6
   ok = true;
   for (int r = 0; r < world && ok; r++)
   {
-    const uint64_t c = all[4 * (size_t)r + 2], p = all[4 * (size_t)r + 3];
+    const uint64_t c = all[kWords * (size_t)r + 2], p = all[kWords * (size_t)r + 3];
     if (c != 0 && r != root)
       ok = p2p(false, table + blk, 8ull * c, r, comm, st) && p2p(false, pay + at, p, r, comm, st);
     blk += c; at += p;
@@ -215,7 +239,7 @@ int hsrle_gather_container_rccl(void *pComm, int root, const void *dLocal, uint6
   blk = 0; at = 0;
   for (int r = 0; r < world; r++)
   {
-    const uint64_t c = all[4 * (size_t)r + 2], p = all[4 * (size_t)r + 3];
+    const uint64_t c = all[kWords * (size_t)r + 2], p = all[kWords * (size_t)r + 3];
     if (c != 0)
     {
       if (r == root)
@@ -230,7 +254,8 @@ int hsrle_gather_container_rccl(void *pComm, int root, const void *dLocal, uint6
     blk += c; at += p;
   }
   hipLaunchKernelGGL(k_rebase_offsets, dim3(1), dim3(64), 0, st, table, nBlocks, 0ull, 1, payload);
-  return hipGetLastError() == hipSuccess ? HSRLE_OK : HSRLE_ERR_DEVICE;
+  // (`out` lives on this stack frame: the header copy above must have read it before we return)
+  return (hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess) ? HSRLE_OK : HSRLE_ERR_DEVICE;
 }
 
 int hsrle_scatter_container_rccl(void *pComm, int root, const void *dContainer, uint64_t containerSize, void *dLocal, uint64_t localCapacity, uint64_t *pLocalSize, void *stream)
@@ -242,44 +267,65 @@ int hsrle_scatter_container_rccl(void *pComm, int root, const void *dContainer, 
   int world = 0, rank = 0;
   if (g_rccl.commCount(comm, &world) != ncclSuccess || g_rccl.commUserRank(comm, &rank) != ncclSuccess || root < 0 || root >= world) return HSRLE_ERR_ARGUMENT;
 
-  // the root tells every rank the container's shape and the payload range of its blocks: meta = codec, blockSize, blockCount, U, then
-  // the payload offset of every rank's first block and of the block behind the last rank's last one (world + 1 values)
-  const size_t metaCount = 4 + (size_t)world + 1;
+  // the root tells every rank the container's shape and the payload range of its blocks: meta = codec, blockSize, blockCount, U, the root's
+  // verdict on the container, then the payload offset of every rank's first block and of the block behind the last rank's last one
+  // (world + 1 values).  As in the gather, no rank returns on its own between here and the go / no-go exchange below.
+  const size_t metaCount = 5 + (size_t)world + 1;
   std::vector<uint64_t> meta(metaCount, 0);
   const uint8_t *src = (const uint8_t *)dContainer;
   if (rank == root)
   {
     Header h;
-    if (!dContainer || containerSize < HSRLE_CONTAINER_HEADER_SIZE) return HSRLE_ERR_ARGUMENT;
-    if (hipMemcpyAsync(&h, dContainer, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return HSRLE_ERR_DEVICE;
-    if (memcmp(h.magic, "HSRLEKIT", 8) != 0 || h.totalSize > containerSize) return HSRLE_ERR_FORMAT;
-    meta[0] = h.codec; meta[1] = h.blockSize; meta[2] = h.blockCount; meta[3] = h.uncompressedSize;
-    for (int r = 0; r <= world; r++)
+    int bad = HSRLE_OK;
+    if (!dContainer || containerSize < HSRLE_CONTAINER_HEADER_SIZE) bad = HSRLE_ERR_ARGUMENT;
+    else if (hipMemcpyAsync(&h, dContainer, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) bad = HSRLE_ERR_DEVICE;
+    else bad = check_header(h, containerSize);
+    if (bad == HSRLE_OK)
     {
-      uint64_t first, count;
-      shard_blocks(h.blockCount, world, r < world ? r : world - 1, &first, &count);
-      const uint64_t idx = r < world ? first : h.blockCount;
-      if (hipMemcpyAsync(&meta[4 + (size_t)r], src + HSRLE_CONTAINER_HEADER_SIZE + 8ull * idx, 8, hipMemcpyDeviceToHost, st) != hipSuccess) return HSRLE_ERR_DEVICE;
+      meta[0] = h.codec; meta[1] = h.blockSize; meta[2] = h.blockCount; meta[3] = h.uncompressedSize;
+      for (int r = 0; r <= world && bad == HSRLE_OK; r++)
+      {
+        uint64_t first, count;
+        shard_blocks(h.blockCount, world, r < world ? r : world - 1, &first, &count);
+        const uint64_t idx = r < world ? first : h.blockCount;
+        if (hipMemcpyAsync(&meta[5 + (size_t)r], src + HSRLE_CONTAINER_HEADER_SIZE + 8ull * idx, 8, hipMemcpyDeviceToHost, st) != hipSuccess) bad = HSRLE_ERR_DEVICE;
+      }
+      if (bad == HSRLE_OK && hipStreamSynchronize(st) != hipSuccess) bad = HSRLE_ERR_DEVICE;
+      // the table entries the shards are cut at: ascending and inside the payload (p1 - p0 below must not wrap)
+      for (int r = 0; r <= world && bad == HSRLE_OK; r++)
+        if (meta[5 + (size_t)r] > h.payloadSize || (r > 0 && meta[5 + (size_t)r] < meta[5 + (size_t)r - 1])) bad = HSRLE_ERR_FORMAT;
     }
-    if (hipStreamSynchronize(st) != hipSuccess) return HSRLE_ERR_DEVICE;
+    meta[4] = (uint64_t)bad;
   }
   uint64_t *dMeta = nullptr;
-  if (hipMallocAsync((void **)&dMeta, 8ull * metaCount, st) != hipSuccess) return HSRLE_ERR_DEVICE;
+  if (hipMallocAsync((void **)&dMeta, 8ull * (metaCount + (size_t)world + 1), st) != hipSuccess) return HSRLE_ERR_DEVICE;
   bool ok = (rank != root || hipMemcpyAsync(dMeta, meta.data(), 8ull * metaCount, hipMemcpyHostToDevice, st) == hipSuccess) &&
             g_rccl.broadcast(dMeta, dMeta, metaCount, ncclUint64, root, comm, st) == ncclSuccess &&
             hipMemcpyAsync(meta.data(), dMeta, 8ull * metaCount, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
-  (void)hipFreeAsync(dMeta, st);
-  if (!ok) return HSRLE_ERR_DEVICE;
+  if (!ok) { (void)hipFreeAsync(dMeta, st); return HSRLE_ERR_DEVICE; }
+  if (meta[4] != 0) { (void)hipFreeAsync(dMeta, st); return (int)meta[4]; }       // the root's verdict, the same on every rank
 
   const uint64_t nBlocks = meta[2], U = meta[3], B = meta[1];
   uint64_t first, count;
   shard_blocks(nBlocks, world, rank, &first, &count);
-  const uint64_t p0 = meta[4 + (size_t)rank], p1 = meta[4 + (size_t)rank + 1];
+  const uint64_t p0 = meta[5 + (size_t)rank], p1 = meta[5 + (size_t)rank + 1];
   const uint64_t lo = first * B, hi = ((first + count) * B < U) ? (first + count) * B : U;
   const Header mineH = make_header((uint32_t)meta[0], hi > lo ? hi - lo : 0, (uint32_t)B, (uint32_t)count, p1 - p0);
   if (pLocalSize) *pLocalSize = count ? mineH.totalSize : 0;
   uint8_t *dst = (uint8_t *)dLocal;
-  if (count != 0 && (!dLocal || localCapacity < mineH.totalSize)) return HSRLE_ERR_CAPACITY;
+  // go / no-go: has every rank the room for its part?  (all-gather of one word; a rank that returned HSRLE_ERR_CAPACITY on its own left
+  // the root's send to it waiting for ever)
+  {
+    const uint64_t go = (count == 0 || (dLocal != nullptr && localCapacity >= mineH.totalSize)) ? 1ull : 0ull;
+    std::vector<uint64_t> gos((size_t)world, 0);
+    uint64_t *dGo = dMeta + metaCount;
+    ok = hipMemcpyAsync(dGo, &go, 8, hipMemcpyHostToDevice, st) == hipSuccess && g_rccl.allGather(dGo, dGo + 1, 1, ncclUint64, comm, st) == ncclSuccess &&
+         hipMemcpyAsync(gos.data(), dGo + 1, 8ull * (uint64_t)world, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    (void)hipFreeAsync(dMeta, st);
+    if (!ok) return HSRLE_ERR_DEVICE;
+    for (int r = 0; r < world; r++)
+      if (gos[(size_t)r] == 0) return HSRLE_ERR_CAPACITY;
+  }
 
   if (g_rccl.groupStart() != ncclSuccess) return HSRLE_ERR_DEVICE;
   ok = true;
@@ -291,7 +337,7 @@ int hsrle_scatter_container_rccl(void *pComm, int root, const void *dContainer, 
       uint64_t f, c;
       shard_blocks(nBlocks, world, r, &f, &c);
       if (c == 0 || r == root) continue;
-      ok = p2p(true, table + 8ull * f, 8ull * (c + 1ull), r, comm, st) && p2p(true, pay + meta[4 + (size_t)r], meta[4 + (size_t)r + 1] - meta[4 + (size_t)r], r, comm, st);
+      ok = p2p(true, table + 8ull * f, 8ull * (c + 1ull), r, comm, st) && p2p(true, pay + meta[5 + (size_t)r], meta[5 + (size_t)r + 1] - meta[5 + (size_t)r], r, comm, st);
     }
   }
   else if (count != 0)

@@ -17,7 +17,7 @@ static hipError_t dec_byte_packed(const DecodeArgs &a, hipStream_t st) { return 
 template <int FAM, int AL>
 static hipError_t enc_any(const EncodeArgs &a, hipStream_t st)
 {
-  static const bool v1 = [] { const char *e = getenv("HSRLE_ENCODE128_V1"); return e && atoi(e) != 0; }();
+  static const bool v1 = knob_u32("HSRLE_ENCODE128_V1", 0u) != 0u;
   if (v1 || a.B > 65536u) return launch_encode(k_encode_blocks<FAM, 16, AL>, a, st);   // (the one-block drop-in path spans the whole input with one block: one lane either way)
   return launch_encode(k_encode128_blocks<FAM == PACKED, AL>, a, st, 0);
 }

@@ -4,7 +4,9 @@
 #include "hsrle_decode.hip.h"
 #include "hsrle_encode.hip.h"
 #include "hsrle_encode8.hip.h"
-#include "hsrle_encode8w.hip.h"
+#ifdef HSRLE_EXPERIMENTS
+#include "hsrle_encode8w.hip.h"        // one wave per block: bit-exact, measured slower
+#endif
 #include "hsrle_encode8s.hip.h"
 #include "hsrle_encode_greedy.hip.h"
 #include "hsrle_index.hip.h"
@@ -42,7 +44,7 @@ static hipError_t enc_lut7(const EncodeArgs &a, hipStream_t st) { return launch_
 template <int MODE>   // 0 rle8_single, 1 rle8_packed_single, 2 rle8_single_short
 static hipError_t enc_single_any(const EncodeArgs &a, hipStream_t st)
 {
-  static const bool v1 = [] { const char *e = getenv("HSRLE_SINGLE_V1"); return e && atoi(e) != 0; }();
+  static const bool v1 = knob_u32("HSRLE_SINGLE_V1", 0u) != 0u;
   if (v1 || a.B > kSinglePickMaxBlock)
   {
     if constexpr (MODE == 2) return launch_encode(k_encode_single_short_blocks<SHORT_SINGLE>, a, st, 0);
@@ -92,12 +94,18 @@ static hipError_t menc_short1(const EncodeArgs &a, const MonoEncodeArgs &m, hipS
 static hipError_t menc_short3(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode(k_encode8_blocks<SHORT3, true>, a, m, st); }
 static hipError_t menc_short7(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode(k_encode8_blocks<SHORT7, true>, a, m, st); }
 
+#ifdef HSRLE_EXPERIMENTS
 static hipError_t wenc_plain(const WaveEncodeArgs &a, hipStream_t st) { return launch_wave_encode(k_encode8_wave<PLAIN>, a, st); }
 static hipError_t wenc_packed(const WaveEncodeArgs &a, hipStream_t st) { return launch_wave_encode(k_encode8_wave<PACKED>, a, st); }
+#endif
 
 void register_w8(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub, MonoEncodeLaunch *menc, WaveEncodeLaunch *wenc)
 {
+#ifdef HSRLE_EXPERIMENTS
   wenc[0] = wenc_plain; wenc[1] = wenc_packed;
+#else
+  (void)wenc;
+#endif
   menc[0] = menc_plain; menc[1] = menc_packed; menc[kShortBase8 + 0] = menc_short0;
   menc[2] = menc_lut3; menc[3] = menc_lut7; menc[kShortBase8 + 1] = menc_short1; menc[kShortBase8 + 2] = menc_short3; menc[kShortBase8 + 3] = menc_short7;
   sub[0] = sub_plain; sub[1] = sub_packed; sub[2] = sub_lut3; sub[3] = sub_lut7; sub[4] = sub_plain_any; sub[5] = sub_packed_any;

@@ -69,6 +69,8 @@ def _lib():
     L.hsrle_status_string.argtypes = [ci]
     L.hsrle_version.restype = ctypes.c_char_p
     L.hsrle_device_count.restype = ci
+    L.hsrle_experiments_enabled.restype = ci
+    L.hsrle_build_id.restype = ctypes.c_char_p
     L.hsrle_suggest_block_size.restype = u32
     L.hsrle_suggest_block_size.argtypes = [u64]
     L.hsrle_kernel_waves_per_cu.restype = ci
@@ -154,6 +156,16 @@ def codec_id(name_or_id):
 def suggest_block_size(n):
     """Block size that gives a buffer of n bytes enough blocks to fill the GPU (hsrle_suggest_block_size)."""
     return int(_lib().hsrle_suggest_block_size(n))
+
+
+def build_id():
+    """The library's build id: a hash of its sources and build flags (Makefile); profiles/*_traffic.json is stamped with it."""
+    return _lib().hsrle_build_id().decode()
+
+
+def experiments_enabled():
+    """True for -DHSRLE_EXPERIMENTS builds (developer knobs / kernels measured slower); the shipped library returns False."""
+    return bool(_lib().hsrle_experiments_enabled())
 
 
 def kernel_waves_per_cu(codec, decode=True):

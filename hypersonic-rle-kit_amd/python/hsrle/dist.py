@@ -203,7 +203,8 @@ def scatter_container(container, root=0, device=None, group=None):
 # ----------------------------------------------------------------------------------------------------------------------
 # the same two operations through the library's C ABI (include/hsrle.h section 4: hsrle_gather_container_rccl /
 # hsrle_scatter_container_rccl over a communicator the library creates with ncclCommInitRank).  torch.distributed only carries the
-# 128-byte unique id to the ranks.  Opt-in (HSRLE_DIST_C=1 in bench.py): the torch path above is the one the CPU tests (gloo) cover.
+# 128-byte unique id to the ranks.  bench.py takes this path for its gather step with HSRLE_DIST_C=1; the torch path above is the one the
+# CPU tests (gloo) cover.
 
 _C_COMMS = {}
 
@@ -226,14 +227,30 @@ def c_comm(group=None):
             raise hsrle.HsrleError(rc, "hsrle_rccl_unique_id")
     dev = torch.device("cuda", torch.cuda.current_device())
     t = torch.tensor(list(ident), dtype=torch.uint8, device=dev if dist.get_backend(group) == "nccl" else "cpu")
-    dist.broadcast(t, 0, group=group)
+    dist.broadcast(t, dist.get_global_rank(group, 0) if group is not None else 0, group=group)   # (src is a GLOBAL rank: the group's first member)
     ident = (ctypes.c_uint8 * 128)(*t.cpu().tolist())
     comm = ctypes.c_void_p()
     rc = L.hsrle_rccl_comm_create(ident, world, rank, ctypes.byref(comm))
     if rc != 0:
         raise hsrle.HsrleError(rc, "hsrle_rccl_comm_create")
     _C_COMMS[key] = comm
+    if len(_C_COMMS) == 1:
+        import atexit
+
+        atexit.register(destroy_c_comms)
     return comm
+
+
+def destroy_c_comms():
+    """hsrle_rccl_comm_destroy for every communicator c_comm() made (call before destroy_process_group; also runs at exit)."""
+    import hsrle
+
+    while _C_COMMS:
+        _, comm = _C_COMMS.popitem()
+        try:
+            hsrle.lib().hsrle_rccl_comm_destroy(comm)
+        except Exception:
+            pass
 
 
 def gather_container_c(local_container, total_uncompressed_size, root=0, group=None):

@@ -366,6 +366,14 @@ int hsrle_synth_dev_async(int kind, int symbolBytes, uint64_t seed, void *dOut, 
 
 /* library / device introspection */
 int hsrle_device_count(void);
+
+/* 1 if the library was built with -DHSRLE_EXPERIMENTS (developer builds: environment knobs that force kernel variants, kernels that were
+ * measured slower than the shipped ones), 0 for the shipped build: no environment variable is read in any launch path. */
+int hsrle_experiments_enabled(void);
+
+/* A hash of the library's sources and build flags (set by the Makefile; "unknown" for other build recipes): measurement files that
+ * describe one build of the kernels (profiles/r03_traffic.json) carry it, and bench.py refuses a file of another build. */
+const char *hsrle_build_id(void);
 /* Workgroups (= wavefronts: every kernel here runs one wave per workgroup) of the codec's decode (decode != 0) or encode kernel
  * that are resident on one CU at a time, as the HIP runtime computes it from the kernel's LDS and register use; 0 on error.
  * The kernels are latency bound, so this is the first number to look at when a build got slower. */

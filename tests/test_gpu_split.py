@@ -112,6 +112,8 @@ def test_config3_frame_split_decode(hs, oracle):
 def test_wave_decode_every_codec(hs, codec):
     """One wave per block (hsrle_decompress_wave_dev_async, csrc/hsrle_decode_wave.hip.h): every grammar, block sizes 128 .. 16 KiB, blocks with
     more packets than a descriptor batch holds, a range of blocks, the bytes behind the output untouched."""
+    if not hs.experiments_enabled():
+        pytest.skip("the wave-per-block decoder is not part of the shipped build (measured slower than the split decode: DESIGN.md 8)")
     import torch
 
     rng = random.Random(31 + CODECS.index(codec))

@@ -32,7 +32,8 @@ def test_rollup_helper_matches_the_c_definition(oracle):
 
 
 @pytest.mark.skipif(big_manifest() is None, reason="big manifests not minted")
-@pytest.mark.parametrize("name,prefix", [("config2_1GiB", 64 << 20), ("headline_8GiB", 32 << 20), ("config4_shard5", 16 << 20), ("config3_video", None)])
+@pytest.mark.parametrize("name,prefix", [("config2_1GiB", 64 << 20), ("headline_8GiB", 32 << 20), ("config4_shard5", 16 << 20), ("config3_video", None)] +
+                         [(k, 8 << 20) for k in sorted((big_manifest() or {"cases": {}})["cases"]) if k.startswith("config5_")])   # every width x {Packed, 3LUT} (+ Single), seed 5
 def test_oracle_block_streams_hash_like_the_reference(oracle, name, prefix):
     e = big_manifest()["cases"][name]
     codec = CODEC_BY_KEY[e["codec"]]
