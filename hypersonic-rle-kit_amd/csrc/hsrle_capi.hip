@@ -18,6 +18,7 @@ namespace hsrle { constexpr uint64_t kTicketBytes = 256; }   // (scratch behind 
 
 #include <stdlib.h>
 
+#include <atomic>
 #include <mutex>
 #include <string.h>
 
@@ -342,6 +343,8 @@ struct DeviceState
   void *ws = nullptr;    // rle8m drop-in: compression workspace
   uint64_t wsSize = 0;
   hipStream_t aux = nullptr;   // second stream of the chunked compression
+  hipMemPool_t pool = nullptr; // the library's OWN stream-ordered pool on this device (scratch_alloc): the application's default pool is never touched
+  bool poolTried = false;
   void *monoIn = nullptr, *monoOut = nullptr, *monoAux = nullptr, *monoWs = nullptr; // staging of the drop-in (host pointer) path
   uint64_t monoInSize = 0, monoOutSize = 0, monoWsSize = 0;
 };
@@ -355,14 +358,6 @@ static bool device_ok()
   std::call_once(g_deviceOnce, [] {
     int n = 0;
     g_deviceCount = (hipGetDeviceCount(&n) == hipSuccess && n > 0) ? n : 0;
-    // stream-ordered allocations are kept by the pool instead of going back to the driver at every synchronisation (the workspace of
-    // an 8 GiB compression is 9 GB: allocating it anew for every call would cost more than the call)
-    for (int d = 0; d < g_deviceCount; d++)
-    {
-      hipMemPool_t pool;
-      uint64_t keep = ~0ull;
-      if (hipDeviceGetDefaultMemPool(&pool, d) == hipSuccess) (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-    }
   });
   return g_deviceCount > 0;
 }
@@ -374,11 +369,44 @@ static DeviceState &this_device()
   return g_devs[d];
 }
 
-// scratch for the duration of one call on `st`: stream-ordered, so concurrent calls on other streams (or threads) never share it
+// Scratch for the duration of one call on `st`: stream-ordered, so concurrent calls on other streams (or threads) never share it.  It
+// comes from a pool the LIBRARY owns (one per device, created on first use): freed scratch stays in that pool up to the retention set
+// with hsrle_scratch_retention() (default 2 GiB: the small per-call scratch of decode / info calls is never given back and re-mapped;
+// the 9 GB workspace of an 8 GiB compression without a caller's workspace is) and hsrle_trim() hands all of it back.  Round 2 raised the
+// release threshold of the device's DEFAULT pool instead, which kept gigabytes away from the host application's own allocator.
+static std::atomic<uint64_t> g_scratchRetention{ 2ull << 30 };
+static hipMemPool_t device_pool()
+{
+  DeviceState &D = this_device();
+  std::lock_guard<std::mutex> lock(D.mu);
+  if (!D.poolTried)
+  {
+    D.poolTried = true;
+    int d = 0;
+    hipMemPoolProps props = {};
+    props.allocType = hipMemAllocationTypePinned;
+    props.handleTypes = hipMemHandleTypeNone;
+    props.location.type = hipMemLocationTypeDevice;
+    props.location.id = (hipGetDevice(&d) == hipSuccess) ? d : 0;
+    hipMemPool_t pool = nullptr;
+    if (hipMemPoolCreate(&pool, &props) == hipSuccess)
+    {
+      uint64_t keep = g_scratchRetention.load();
+      (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+      D.pool = pool;
+    }
+    else
+      (void)hipGetLastError();
+  }
+  return D.pool;
+}
 static void *scratch_alloc(uint64_t bytes, hipStream_t st)
 {
   void *p = nullptr;
-  if (hipMallocAsync(&p, bytes, st) == hipSuccess) return p;
+  hipMemPool_t pool = device_pool();
+  if (pool != nullptr && hipMallocFromPoolAsync(&p, bytes, pool, st) == hipSuccess) return p;
+  (void)hipGetLastError();
+  if (hipMallocAsync(&p, bytes, st) == hipSuccess) return p;           // (no pool of our own on this runtime: the default pool, untouched)
   (void)hipGetLastError();
   return nullptr;
 }
@@ -754,7 +782,9 @@ struct MonoPlan
 };
 
 
-static uint32_t g_monoTune[3] = { env_u32("HSRLE_MONO_BLOCK", 0), env_u32("HSRLE_MONO_REGION", 0), env_u32("HSRLE_MONO_LOOKBACK", 0) };
+// (atomics: hsrle_mono_tuning() is a TEST knob and process-global -- a call that changes it between another thread's *_workspace_size() and
+//  *_mono_dev() can make that workspace too small, which that call reports as HSRLE_ERR_CAPACITY; include/hsrle.h says so)
+static std::atomic<uint32_t> g_monoTune[3] = { { env_u32("HSRLE_MONO_BLOCK", 0) }, { env_u32("HSRLE_MONO_REGION", 0) }, { env_u32("HSRLE_MONO_LOOKBACK", 0) } };
 
 static MonoPlan plan_mono(int codec, uint32_t U, uint32_t C, uint32_t p0)
 {
@@ -1441,6 +1471,24 @@ int hsrle_kernel_waves_per_cu(int codec, int decode)
   if (decode) { DecodeArgs a{}; a.residentWorkgroups = &n; if (g_dec[codec](a, nullptr) != hipSuccess) return 0; }
   else { EncodeArgs a{}; a.residentWorkgroups = &n; if (g_enc[codec](a, nullptr) != hipSuccess) return 0; }
   return n;
+}
+
+int hsrle_scratch_retention(uint64_t bytes)
+{
+  if (!device_ok()) return HSRLE_ERR_DEVICE;
+  g_scratchRetention.store(bytes);
+  hipMemPool_t pool = device_pool();
+  if (pool == nullptr) return HSRLE_ERR_UNSUPPORTED;
+  uint64_t keep = bytes;
+  return hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) == hipSuccess ? HSRLE_OK : HSRLE_ERR_DEVICE;
+}
+
+int hsrle_trim(void)
+{
+  if (!device_ok()) return HSRLE_ERR_DEVICE;
+  hipMemPool_t pool = device_pool();
+  if (pool == nullptr) return HSRLE_OK;
+  return hipMemPoolTrimTo(pool, 0) == hipSuccess ? HSRLE_OK : HSRLE_ERR_DEVICE;
 }
 
 int hsrle_experiments_enabled(void) { return kExperiments ? 1 : 0; }

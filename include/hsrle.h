@@ -209,7 +209,10 @@ void hsrle_mono_encode_stats(uint32_t stats[4]);
 int hsrle_decompress_mono_dev(int codec, const void *dStream, uint32_t streamSize, void *dOut, uint64_t outCapacity, void *dWorkspace, uint64_t workspaceSize,
                               uint32_t *pUncompressedSize, uint32_t *pStats, void *stream);
 /* tuning / test knob of the monolithic decode: output bytes per decode lane (multiple of 128), stream bytes per index lane, look-back
- * bytes of the entry guess; 0 = the library's choice.  Any values give the same output: the index is proven, not assumed. */
+ * bytes of the entry guess; 0 = the library's choice.  Any values give the same output: the index is proven, not assumed.
+ * PROCESS-GLOBAL and meant for tests: the one exception to "no library-owned state" -- a thread that changes it between another thread's
+ * hsrle_*_mono_workspace_size() and its hsrle_*_mono_dev() can leave that call with too small a workspace (it then returns
+ * HSRLE_ERR_CAPACITY, it never writes out of bounds). */
 void hsrle_mono_tuning(uint32_t blockSize, uint32_t regionSize, uint32_t lookBack);
 
 /* ---------------------------------------------------------------------------------------------------------- */
@@ -369,6 +372,14 @@ int hsrle_device_count(void);
 
 /* 1 if the library was built with -DHSRLE_EXPERIMENTS (developer builds: environment knobs that force kernel variants, kernels that were
  * measured slower than the shipped ones), 0 for the shipped build: no environment variable is read in any launch path. */
+/* Memory the library keeps: calls that are given no workspace (hsrle_compress_dev, hsrle_decompress_dev, the host-pointer functions)
+ * take their scratch stream-ordered from a memory pool the LIBRARY owns on the calling thread's device -- never from the device's default
+ * pool, whose settings belong to the application.  Freed scratch stays in that pool up to the retention (default 2 GiB; UINT64_MAX keeps
+ * everything, 0 returns everything at the next synchronisation); hsrle_trim() returns what the pool holds to the driver now.  Calls that
+ * are handed their workspace (the *_async forms) allocate nothing. */
+int hsrle_scratch_retention(uint64_t bytes);
+int hsrle_trim(void);
+
 int hsrle_experiments_enabled(void);
 
 /* A hash of the library's sources and build flags (set by the Makefile; "unknown" for other build recipes): measurement files that
