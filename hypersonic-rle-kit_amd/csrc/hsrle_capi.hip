@@ -71,7 +71,7 @@ static void init_tables()
     register_w32(g_dec, g_enc, g_idx, g_sub, g_menc);
     register_w48(g_dec, g_enc, g_idx, g_sub, g_menc);
     register_w64(g_dec, g_enc, g_idx, g_sub, g_menc);
-    register_w128(g_dec, g_enc, g_idx, g_sub);
+    register_w128(g_dec, g_enc, g_idx, g_sub, g_menc);
   });
 }
 
@@ -968,17 +968,20 @@ static int mono_decode_dev(const MonoHeader &mh, const uint8_t *dStream, uint8_t
 // monolithic stream encode by many lanes (hsrle_mono_encode.hip.h): cut behind long runs, block kernels in MONO mode, compaction
 
 // the run length every state of the codec's encoder stores (SURVEY.md A.2 LONG / the Short family's SMINL); 0 = the codec is not cut
-// (move-to-front list, Single, 128 bit).  *pS / *pAligned: symbol bytes and sym-alignment of the codec.
+// (the Greedy encoders, rle8_single_short).  *pS / *pAligned: symbol bytes and sym-alignment of the codec.
 static uint32_t mono_cut_long(int codec, int *pS = nullptr, int *pAligned = nullptr, int *pListK = nullptr)
 {
   int S = 1, al = 0, K = 0;
   uint32_t longc = 0;
   static const int shortK[4] = { 0, 1, 3, 7 };
-  if (codec == HSRLE_RLE8_MULTI) longc = 6u;                    // rle8_extreme_cpu.h:974: count >= 6 whatever the range
+  if (codec == 4) longc = 8u;                                   // 8 bit Single: runs of THE symbol with count >= LONG (rle8_extreme_cpu.h:10-11, :21-23)
+  else if (codec == 5) longc = 10u;
+  else if (codec == HSRLE_RLE8_MULTI) longc = 6u;               // rle8_extreme_cpu.h:974: count >= 6 whatever the range
   else if (codec == HSRLE_RLE8_PACKED_MULTI) longc = 11u;       // :978 (body) and :122 (tail)
   else if (codec == 2 || codec == 3) { longc = 11u; K = codec == 2 ? 3 : 7; }   // rle8 3 / 7 symbol LUT: rleX_Xsl.h:132 with S = 1
   else if (codec == HSRLE_RLE8_MULTI_SHORT) longc = 13u;        // rleX_Xsl_short.h: always stored from S + 12 on (0-symbol codec)
   else if (codec > kShortBase8 && codec < kShortBase8 + 4) { longc = 12u; K = shortK[codec - kShortBase8]; }   // ... from S + 11 on with a list
+  else if (codec >= 46 && codec < 50) { S = 16; al = codec < 48 ? 1 : 0; longc = (codec == 47) ? 26u : 27u; }   // 128 bit (rle128_extreme_cpu.h:10-11; sym-aligned Packed: the hybrid of A.5 q10)
   else
   {
     static const int widths[5] = { 2, 3, 4, 6, 8 };
@@ -1015,6 +1018,7 @@ struct MonoEncPlan
   uint32_t G, pieces;
   uint64_t offCutPos, offCutSym, offFlags, offIdx, offStarts, offSyms, offSlotOff, offSizes, offOffsets, offL1, offL2, offL3, offCtrl, offSlots, total;
   uint64_t offGuess, offListOut, offRoll1, offRoll2;   // codecs with a move-to-front list: 8 words per chunk / per 64 / per 4096 chunks
+  uint64_t offPick;                                    // 8 bit Single: the symbol pick's sums (k_single_pick_mono)
 };
 
 static MonoEncPlan plan_mono_encode(uint32_t U, bool lists = true)
@@ -1042,6 +1046,7 @@ static MonoEncPlan plan_mono_encode(uint32_t U, bool lists = true)
   m.offL2 = at; at += align_up(8ull * (t2 + 1), 256);
   m.offL3 = at; at += align_up(8ull * (t3 + 1), 256);
   m.offCtrl = at; at += 256;
+  m.offPick = at; at += 4096;
   m.offGuess = m.offListOut = m.offRoll1 = m.offRoll2 = at;
   if (lists)
   {
@@ -1063,7 +1068,8 @@ static int mono_encode_dev(int codec, const uint8_t *dIn, uint32_t U, uint8_t *d
   const uint32_t longc = mono_cut_long(codec, &S, &aligned, &listK);
   if (!g_menc[codec] || longc == 0u)
     return HSRLE_ERR_UNSUPPORTED;
-  const uint32_t hs = codec_header_size(codec);
+  const bool single = codec == 4 || codec == 5;
+  const uint32_t hs = codec_header_size(codec) + (single ? 1u : 0u);   // (Single: the symbol byte follows the header)
   uint64_t *cutPos = (uint64_t *)(ws + m.offCutPos), *idx = (uint64_t *)(ws + m.offIdx), *starts = (uint64_t *)(ws + m.offStarts), *slotOff = (uint64_t *)(ws + m.offSlotOff);
   uint64_t *offsets = (uint64_t *)(ws + m.offOffsets);
   uint64_t *cutSym = (uint64_t *)(ws + m.offCutSym), *syms = (uint64_t *)(ws + m.offSyms);
@@ -1073,17 +1079,28 @@ static int mono_encode_dev(int codec, const uint8_t *dIn, uint32_t U, uint8_t *d
 
   if (hipMemsetAsync(ctrl, 0, 64, st) != hipSuccess)
     return HSRLE_ERR_DEVICE;
+  if (single)
+  {
+    // the stream's ONE symbol first (rle8_extreme_cpu.c:53-153 over the whole input): sums per piece, then the estimator's end game and the argmax -> ctrl[8]
+    uint32_t *table = (uint32_t *)(ws + m.offPick);
+    const uint32_t pp = (U + kPickPiece - 1u) / kPickPiece;
+    if (hipMemsetAsync(table, 0, 2064, st) != hipSuccess || hipMemsetAsync(table + 514, 0xFF, 8, st) != hipSuccess)
+      return HSRLE_ERR_DEVICE;
+    hipLaunchKernelGGL(k_single_pick_mono, dim3(pp), dim3(64), 0, st, dIn, U, pp, table);
+    hipLaunchKernelGGL(k_single_pick_final, dim3(1), dim3(64), 0, st, dIn, U, table, ctrl + 8);
+  }
   const dim3 cgrid((m.pieces + 63u) / 64u);
 #define HSRLE_CUTS(SS) \
   if (aligned) hipLaunchKernelGGL((k_mono_cutsS<SS, 1>), cgrid, dim3(64), 0, st, dIn, (uint64_t)U, m.G, m.pieces, longc, cutPos, cutSym, flags); \
   else hipLaunchKernelGGL((k_mono_cutsS<SS, 0>), cgrid, dim3(64), 0, st, dIn, (uint64_t)U, m.G, m.pieces, longc, cutPos, cutSym, flags)
   switch (S)
   {
-  case 1: hipLaunchKernelGGL(k_mono_cuts8, cgrid, dim3(64), 0, st, dIn, (uint64_t)U, m.G, m.pieces, longc, cutPos, cutSym, flags); break;
+  case 1: hipLaunchKernelGGL(k_mono_cuts8, cgrid, dim3(64), 0, st, dIn, (uint64_t)U, m.G, m.pieces, longc, cutPos, cutSym, flags, single ? (const uint32_t *)(ctrl + 8) : (const uint32_t *)nullptr); break;
   case 2: HSRLE_CUTS(2); break;
   case 3: HSRLE_CUTS(3); break;
   case 4: HSRLE_CUTS(4); break;
   case 6: HSRLE_CUTS(6); break;
+  case 16: HSRLE_CUTS(16); break;
   default: HSRLE_CUTS(8); break;
   }
 #undef HSRLE_CUTS
@@ -1092,9 +1109,11 @@ static int mono_encode_dev(int codec, const uint8_t *dIn, uint32_t U, uint8_t *d
   hipLaunchKernelGGL(k_mono_scatter, dim3((m.pieces + 255u) / 256u), dim3(256), 0, st, (const uint64_t *)cutPos, (const uint64_t *)cutSym, (const uint32_t *)flags, (const uint64_t *)idx,
                      m.pieces, (uint64_t)U, starts, syms, slotOff, ctrl);
   hipLaunchKernelGGL(k_mono_longest, dim3((m.pieces + 1u + 255u) / 256u), dim3(256), 0, st, (const uint64_t *)starts, ctrl);
-  uint32_t head[2] = { 0, 0 };
-  if (hipMemcpyAsync(head, ctrl, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+  uint32_t head[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+  if (hipMemcpyAsync(head, ctrl, 40, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
     return HSRLE_ERR_DEVICE;
+  if (single && head[9] != 0u)
+    return HSRLE_ERR_UNSUPPORTED;                                        // (a run of more than 16 MiB: the pick gave up -- callers fall back to one lane)
   const uint32_t chunks = head[0], longest = head[1];
   if (chunks == 0u || chunks > m.pieces + 1u)
     return HSRLE_ERR_DEVICE;
@@ -1102,6 +1121,7 @@ static int mono_encode_dev(int codec, const uint8_t *dIn, uint32_t U, uint8_t *d
 
   EncodeArgs ea{ dIn, (uint64_t)U, 0u, chunks, ws + m.offSlots, 0u, sizes };
   MonoEncodeArgs ma{ starts, syms, slotOff, 2u * (longest / 64u) + 64u };
+  ma.pick = ctrl + 8;
   if (listK == 0)
   {
     if (g_menc[codec](ea, ma, st) != hipSuccess)

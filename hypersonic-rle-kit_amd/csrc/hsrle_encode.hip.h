@@ -471,6 +471,133 @@ __device__ __forceinline__ uint32_t encode_block_128(const uint8_t *d, uint32_t 
   return s.at;
 }
 
+// One CHUNK of a monolithic 128 bit stream (hsrle_mono_encode.hip.h: the input is cut behind runs of >= LONG bytes, which every state of
+// the encoder stores).  d = the chunk's first byte, nChunk its length, nTrue the bytes from there to the END OF THE INPUT (the loops'
+// bounds look at the true end: A.5 q4).  The first chunk starts as the stream does (the first 16 bytes match themselves); every other one
+// starts where the encoder stands behind a stored run: at the pair search, lastRLE = the chunk's start, lastSymbol = the boundary run's
+// symbol (16 bytes at lastSymAt).  A chunk that is not the last ends with its boundary run's packet: no terminator.  No stream header.
+template <int FAM, int AL>
+__device__ __forceinline__ uint32_t encode_chunk_128(const uint8_t *d, uint32_t nChunk, uint32_t nTrue32, bool first, const uint8_t *lastSymAt, Sink &s)
+{
+  using TR = Traits<FAM, 16, AL>;
+  using RW = RunWriter<FAM, 16, AL>;
+
+  const int32_t n = (int32_t)nTrue32, stopAt = (int32_t)nChunk;
+  const bool finalChunk = nChunk == nTrue32;
+  int32_t i = 0, lastRLE = 0, count = 0;
+  u32x4 symbol = (first && n >= 16) ? ld128(d) : u32x4{ 0, 0, 0, 0 };
+  u32x4 last = first ? u32x4{ 0, 0, 0, 0 } : ld128(lastSymAt);
+  bool skipExtend = !first;
+
+  auto judge = [&](bool final) -> bool {
+    const uint32_t range = (uint32_t)(i - lastRLE - count + 1);
+    const bool same = TR::kPacked ? sym_eq(symbol, last) : false;
+    const int k = RW::decide(same, (uint32_t)count, range);
+    if (k)
+    {
+      if (TR::kPacked) last = symbol;
+      RW::put_run(s, symbol, same, (uint32_t)count, range, k == 2);
+      s.putn(d + lastRLE, (uint32_t)(i - count - lastRLE));
+      if (!final) lastRLE = i;
+    }
+    return k != 0;
+  };
+
+  while (i < n)
+  {
+    bool restart = true;
+
+    while (restart)
+    {
+      restart = false;
+
+      if (!skipExtend)
+      {
+        while (i < n - 16)
+        {
+          const u32x4 x = ld128(d + i);
+          const uint32_t z0 = x.x ^ symbol.x, z1 = x.y ^ symbol.y, z2 = x.z ^ symbol.z, z3 = x.w ^ symbol.w;
+
+          if ((z0 | z1 | z2 | z3) == 0)
+          {
+            count += 16;
+            i += 16;
+          }
+          else
+          {
+            if constexpr (!TR::kAligned)
+            {
+              int32_t off;
+              if (z0) off = (int32_t)(__builtin_ctz(z0) >> 3);
+              else if (z1) off = 4 + (int32_t)(__builtin_ctz(z1) >> 3);
+              else if (z2) off = 8 + (int32_t)(__builtin_ctz(z2) >> 3);
+              else off = 12 + (int32_t)(__builtin_ctz(z3) >> 3);
+              i += off;
+              count += off;
+            }
+            break;
+          }
+        }
+
+        const bool stored = judge(false);
+        if (!finalChunk && i >= stopAt)
+          return stored && i == stopAt ? s.at : 0u;                     // the boundary run's packet ends the chunk (anything else: the cut was wrong)
+      }
+      skipExtend = false;
+
+      while (i < n - 32)
+      {
+        const u32x4 a = ld128(d + i), b = ld128(d + i + 16);
+        const uint32_t z0 = a.x ^ b.x, z1 = a.y ^ b.y, z2 = a.z ^ b.z, z3 = a.w ^ b.w;
+
+        if ((z0 | z1 | z2 | z3) == 0)
+        {
+          symbol = a;
+          i += 32;
+          count = 32;
+          restart = true;
+          break;
+        }
+        else if (z3 >> 24)
+        {
+          i += 16;
+        }
+        else
+        {
+          int32_t hb; // highest mismatching byte
+          if (z3) hb = 12 + ((31 - (int32_t)__builtin_clz(z3)) >> 3);
+          else if (z2) hb = 8 + ((31 - (int32_t)__builtin_clz(z2)) >> 3);
+          else if (z1) hb = 4 + ((31 - (int32_t)__builtin_clz(z1)) >> 3);
+          else hb = (31 - (int32_t)__builtin_clz(z0)) >> 3;
+          i += hb + 1;
+        }
+      }
+    }
+
+    // scalar step; bytes >= n never match
+    symbol = (i + 16 <= n) ? ld128(d + i) : u32x4{ 0, 0, 0, 0 };
+
+    if (i + 32 <= n && sym_eq(symbol, ld128(d + i + 16)))
+    {
+      count = 32;
+      i += 32;
+    }
+    else
+    {
+      count = 0;
+      i += 1;
+    }
+  }
+
+  if (!finalChunk)
+    return 0u;                                                          // (a chunk in front of the last one ends above)
+  if (judge(true))
+    RW::put_term_end(s, true);
+  else
+    RW::put_term_literals(s, d + lastRLE, (uint32_t)(i - lastRLE));
+  return s.at;
+}
+
 // 3 / 7 symbol LUT (rleX_Xsl.h:114-264 process_symbol)
 template <int FAM, int S, int AL>
 __device__ __forceinline__ uint32_t encode_block_lut(const uint8_t *d, uint32_t n, Sink &s)
@@ -868,6 +995,190 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const uint8_t *__restrict_
     size = encode_block_multi<FAM, S, AL>(d, n, s);
 
   sizes[b] = size;
+}
+
+// One CHUNK of a monolithic 8 bit Single stream (hsrle_mono_encode.hip.h).  Behind ANY stored run the scanner's state is its position alone
+// (lastRLE = i, wasted = 0, count = 0, then the search: rle8_extreme_cpu.h:1140-1312), and a run of >= LONG bytes of the symbol is stored whatever
+// the state and found from its first byte whatever the scanner's phase -- so the input is cut behind those, and a chunk is the block loop
+// started at its first byte (which is not the symbol: the loop's first trip falls through to the search).  `end` is the TRUE end - 16; the
+// scalar tail and the terminator belong to the last chunk.  No stream header; a chunk in front of the last ends with its boundary run's packet.
+template <bool PACKEDSINGLE>
+__device__ inline uint32_t encode_chunk_single(const uint8_t *d, uint32_t nChunk, uint32_t nTrue32, uint32_t sym, Sink &s)
+{
+  constexpr int32_t SHORT = PACKEDSINGLE ? 2 : 4;
+  constexpr int32_t MEDIUM = 6;
+  constexpr int32_t LONG = PACKEDSINGLE ? 10 : 8;
+  const uint32_t bs = sym * 0x01010101u;
+  const int32_t n = (int32_t)nTrue32, stopAt = (int32_t)nChunk;
+  const bool finalChunk = nChunk == nTrue32;
+  const int32_t end = n - 16;
+  int32_t i = 0, count = 0, lastRLE = 0, wasted = 0, firstW = 0;
+
+  auto put_count = [&](int32_t cnt) {
+    const uint32_t c = (uint32_t)(cnt - SHORT + 1);
+    if (c <= 255u) s.put8(c); else { s.put8(0); s.put32(c); }
+  };
+  auto emit_short = [&](int32_t range) {
+    put_count(count);
+    s.put8((uint32_t)range);
+    s.putn(d + lastRLE, (uint32_t)(i - count - lastRLE));
+    lastRLE = i;
+  };
+  auto emit_long = [&](int32_t range) {
+    put_count(count);
+    s.put8(0);
+    s.put32((uint32_t)range);
+    s.putn(d + lastRLE, (uint32_t)(i - count - lastRLE));
+    lastRLE = i;
+  };
+
+  while (i < end)
+  {
+    const Cmp16 c(d + i, bs);
+
+    if (c.all())
+    {
+      count += 16;
+      i += 15;
+    }
+    else
+    {
+      if (c.any() || count > 1)
+      {
+        const int32_t z = (int32_t)c.leading();
+        count += z;
+        i += z;
+
+        const int32_t range = i - lastRLE - count + 1;
+        bool stored = false;
+
+        if (count >= SHORT)
+        {
+          if (range <= 255)
+          {
+            emit_short(range);
+            wasted = 0;
+            stored = true;
+          }
+          else if (count >= LONG || (PACKEDSINGLE && (count - SHORT + 1 <= 255 && count >= MEDIUM)))
+          {
+            emit_long(range);
+            wasted = 0;
+            stored = true;
+          }
+          else
+          {
+            wasted++;
+
+            if (wasted == 1 || i - firstW > 255)
+            {
+              firstW = i - count;
+              wasted = 1;
+            }
+            else if (wasted > 2)
+            {
+              // back-track to the first skipped run and force a long packet (rle8_extreme_cpu.h:1244-1285)
+              i = firstW;
+              wasted = 0;
+              count = 0;
+
+              while (i < end && d[i] == sym)
+              {
+                count++;
+                i++;
+              }
+
+              s.put8((uint32_t)(count - SHORT + 1) & 0xFFu);
+              s.put8(0);
+              s.put32((uint32_t)(i - lastRLE - count + 1));
+              s.putn(d + lastRLE, (uint32_t)(i - count - lastRLE));
+              lastRLE = i;
+            }
+          }
+        }
+        if (!finalChunk && i >= stopAt)
+          return (stored && i == stopAt) ? s.at : 0u;                   // the boundary run's packet ends the chunk (anything else: the cut was wrong)
+      }
+
+      count = 0;
+
+      while (i < end)
+      {
+        const Cmp16 b(d + i, bs);
+
+        if (!b.any() || (!b.lastByte() && b.pop() < (uint32_t)SHORT))
+          i += 16;
+        else
+        {
+          i += (int32_t)b.first();
+          count = 1;
+          break;
+        }
+      }
+    }
+
+    i++;
+  }
+  if (!finalChunk)
+    return 0u;
+
+  for (; i < n; i++)
+  {
+    if (d[i] == sym)
+      count++;
+    else
+    {
+      const int32_t range = i - lastRLE - count + 1;
+      if (range <= 255 && count >= SHORT) emit_short(range);
+      else if (count >= LONG) emit_long(range);
+      count = 0;
+    }
+  }
+
+  {
+    const int32_t range = i - lastRLE - count + 1;
+
+    if (range <= 255 && count >= SHORT)
+    {
+      emit_short(range);
+      s.put8(0); s.put32(0); s.put8(0); s.put32(0);
+    }
+    else if (count >= LONG)
+    {
+      emit_long(range);
+      s.put8(0); s.put32(0); s.put8(0); s.put32(0);
+    }
+    else
+    {
+      s.put8(0); s.put32(0); s.put8(0); s.put32((uint32_t)(range + count));
+      s.putn(d + lastRLE, (uint32_t)(i - lastRLE));
+    }
+  }
+  return s.at;
+}
+
+// chunks of ONE monolithic 8 bit Single stream, one lane per chunk (pick[0]: the stream's symbol, k_single_pick_final)
+template <bool PACKEDSINGLE>
+__global__ __launch_bounds__(64) void k_encode_single_chunks(const uint8_t *__restrict__ in, uint64_t U, uint32_t chunks, const uint64_t *__restrict__ starts, const uint64_t *__restrict__ slotOff,
+                                                             uint8_t *__restrict__ slots, uint32_t *__restrict__ sizes, const uint32_t *__restrict__ pick)
+{
+  const uint32_t c = blockIdx.x * 64u + threadIdx.x;
+  if (c >= chunks) return;
+  const uint64_t start = starts[c];
+  Sink s{ slots + slotOff[c], 0u, in + U };
+  sizes[c] = encode_chunk_single<PACKEDSINGLE>(in + start, (uint32_t)(starts[c + 1u] - start), (uint32_t)(U - start), pick[0] & 0xFFu, s);
+}
+
+// chunks of ONE monolithic 128 bit stream, one lane per chunk (hsrle_mono_encode.hip.h; syms[c] = where the boundary run in front of chunk c starts)
+template <int FAM, int AL>
+__global__ __launch_bounds__(64) void k_encode128_chunks(const uint8_t *__restrict__ in, uint64_t U, uint32_t chunks, const uint64_t *__restrict__ starts, const uint64_t *__restrict__ syms,
+                                                         const uint64_t *__restrict__ slotOff, uint8_t *__restrict__ slots, uint32_t *__restrict__ sizes)
+{
+  const uint32_t c = blockIdx.x * 64u + threadIdx.x;
+  if (c >= chunks) return;
+  const uint64_t start = starts[c];
+  Sink s{ slots + slotOff[c], 0u, in + U };
+  sizes[c] = encode_chunk_128<FAM, AL>(in + start, (uint32_t)(starts[c + 1u] - start), (uint32_t)(U - start), c == 0u, in + syms[c], s);
 }
 
 } // namespace hsrle

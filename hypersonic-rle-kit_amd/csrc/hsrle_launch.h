@@ -65,6 +65,7 @@ struct MonoEncodeArgs
 {
   const uint64_t *starts; const uint64_t *syms; const uint64_t *slotOff; uint32_t steps;
   uint64_t *listOut = nullptr; uint32_t dry = 0;     // codecs with a move-to-front list: syms / listOut hold 8 words per chunk
+  const uint32_t *pick = nullptr;                    // 8 bit Single: the stream's symbol (device)
 };
 typedef hipError_t (*MonoEncodeLaunch)(const EncodeArgs &, const MonoEncodeArgs &, hipStream_t);
 // wave-per-block encoder (hsrle_encode8w.hip.h): writes offsets and payload of the container directly
@@ -104,7 +105,7 @@ void register_w24(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlo
 void register_w32(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub, MonoEncodeLaunch *menc);
 void register_w48(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub, MonoEncodeLaunch *menc);
 void register_w64(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub, MonoEncodeLaunch *menc);
-void register_w128(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub);
+void register_w128(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub, MonoEncodeLaunch *menc);
 
 template <typename... A>
 constexpr int kernel_arity(void (*)(A...)) { return (int)sizeof...(A); }

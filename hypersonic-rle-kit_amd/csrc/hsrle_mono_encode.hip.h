@@ -24,11 +24,13 @@ constexpr uint64_t MONO_NO_CUT = ~0ull;
 
 // 8 bit symbols.  cutPos[c] = end (exclusive) of the first maximal run of >= LONGC equal bytes with c * G < end <= (c + 1) * G and
 // end < U, cutSym[c] its byte; MONO_NO_CUT if there is none.  Piece 0 additionally starts the stream: the host adds position 0.
+// onlySym != nullptr (the Single codecs): only runs of that byte are cuts.
 __global__ __launch_bounds__(64) void k_mono_cuts8(const uint8_t *__restrict__ in, uint64_t U, uint32_t G, uint32_t pieces, uint32_t LONGC, uint64_t *__restrict__ cutPos,
-                                                   uint64_t *__restrict__ cutSym, uint32_t *__restrict__ flags)
+                                                   uint64_t *__restrict__ cutSym, uint32_t *__restrict__ flags, const uint32_t *__restrict__ onlySym = nullptr)
 {
   const uint32_t c = blockIdx.x * 64u + threadIdx.x;
   if (c >= pieces) return;
+  const uint32_t want = onlySym != nullptr ? (onlySym[0] & 0xFFu) : 0x100u;                // 0x100: any symbol
   const uint64_t x = (uint64_t)c * G;
   const uint64_t hiEnd = (x + G < U) ? x + G : U;
   uint64_t i = (x > LONGC) ? x - LONGC : 0;
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(64) void k_mono_cuts8(const uint8_t *__restrict__ i
         brk &= brk - 1ull;
         const uint64_t at = i + k;
         if (at > stop) break;
-        if (at - st >= LONGC && at > x) { found = at; fsym = sy; hit = true; break; }
+        if (at - st >= LONGC && at > x && (want == 0x100u || sy == want)) { found = at; fsym = sy; hit = true; break; }
         st = at; sy = (uint32_t)(w1 >> (8u * k)) & 0xFFu;
       }
       if (hit) break;
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(64) void k_mono_cuts8(const uint8_t *__restrict__ i
     const uint32_t v = in[i];
     if (v != sy)
     {
-      if (i - st >= LONGC && i > x) { found = i; fsym = sy; break; }
+      if (i - st >= LONGC && i > x && (want == 0x100u || sy == want)) { found = i; fsym = sy; break; }
       st = i; sy = v;
     }
     i++;
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(64) void k_mono_cutsS(const uint8_t *__restrict__ i
   bool usable = false;
   uint64_t zLong = (j == 0) ? ~0ull : j;        // ~0: none yet.  Scan start: unknown history -> as if a long stretch had just ended here
   uint64_t found = MONO_NO_CUT, fsym = 0;
-  const uint64_t symMask = (S >= 8) ? ~0ull : ((1ull << (8 * S)) - 1ull);
+  const uint64_t symMask = (S >= 8) ? ~0ull : ((1ull << (8 * (S & 7))) - 1ull);
   while (j + SU < U)
   {
     const bool m = in[j] == in[j + SU];
@@ -115,6 +117,9 @@ __global__ __launch_bounds__(64) void k_mono_cutsS(const uint8_t *__restrict__ i
       {
         q = j;
         usable = (zLong == ~0ull) || (zLong + SU <= q);                 // clean start: the last long stretch ended >= S positions in front
+        // (16 byte symbols: the first 16 bytes of the stream count as a match of themselves (A.5 q4), a "run" no stretch stands for --
+        //  no cut that close to the start)
+        if (S == 16 && q < 64u) usable = false;
       }
       ones++;
     }
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(64) void k_mono_cutsS(const uint8_t *__restrict__ i
       {
         const uint64_t L = ones;
         const uint64_t e = ALIGNED ? q + SU * ((L + SU) / SU) : q + SU + L;
-        if (usable && e - q >= LONGC && e > x && e <= hiEnd && e <= lastCut) { found = e; fsym = ld64(in + q) & symMask; break; }
+        if (usable && e - q >= LONGC && e > x && e <= hiEnd && e <= lastCut) { found = e; fsym = (S == 16) ? q : (ld64(in + q) & symMask); break; }   // (16 bytes: WHERE the symbol is)
         zLong = j;
       }
       ones = 0;
@@ -325,8 +330,257 @@ __global__ void k_mono_finish(uint8_t *__restrict__ out, uint32_t U, uint32_t he
     st32(out, U);
     st32(out + 4, (uint32_t)total);
     if (headerSize == 9u) out[8] = 0;
+    if (headerSize == 10u) { out[8] = 1; out[9] = (uint8_t)ctrlIn[8]; }  // 8 bit Single: mode 1 and the symbol (k_single_pick_final left it in ctrl[8])
     ctrl[2] = (uint32_t)total; ctrl[3] = (uint32_t)(total >> 32);
   }
 }
+
+// ---- the symbol pick for ONE monolithic stream (hsrle_mono_encode.hip.h: the drop-in rle8_single_compress / rle8_packed_single_compress by many
+//      lanes).  The same closed form as k_single_pick -- a maximal run of L >= 2 equal bytes that ends in front of U - 16 adds L - (L - 1) / 16
+//      to prob[s] and 1 to pcount[s] -- over pieces of P bytes, one wave each; a run belongs to the piece it STARTS in, and the one run that
+//      is still open at the piece's end is followed through the next pieces by the whole wave (1 KiB per trip; a run of more than 16 MiB
+//      makes the call give up: the drop-in function then walks with one lane, as it did for every input before).  All sums are modulo 2^32,
+//      like the reference's counters.  table: u32 prob[256], pcount[256], [512] end of the last safe run, [513] gave up, [514..515] the first
+//      late run as (position << 32 | L - 1) (zeroed / set to ~0 by the host).  k_single_pick_final does what lane 0 of k_single_pick does.
+constexpr uint32_t kPickPiece = 4096u;
+__global__ __launch_bounds__(64) void k_single_pick_mono(const uint8_t *__restrict__ in, uint32_t U, uint32_t pieces, uint32_t *__restrict__ table)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t bytes[kPickPiece + 80];
+  __shared__ uint64_t eqw[kPickPiece / 64u + 1u];
+  __shared__ uint32_t ltab[512];                                         // this piece's sums: one device atomic per symbol and wave, not per run
+  const uint32_t lane = threadIdx.x, P = kPickPiece;
+  const uint32_t piece = blockIdx.x;
+  if (piece >= pieces) return;
+#pragma unroll
+  for (int k = 0; k < 8; k++) ltab[lane * 8u + (uint32_t)k] = 0u;
+  const uint32_t at = piece * P;
+  const uint32_t n = (U - at) < P ? (U - at) : P;
+  const uint32_t words = (n + 63u) / 64u;
+
+  // the piece + the byte behind it
+  for (uint32_t p = lane * 16u; p < P + 16u; p += 1024u)
+  {
+    u32x4 v = u32x4{ 0, 0, 0, 0 };
+    if ((uint64_t)at + p + 16u <= U) v = ld128(in + at + p);
+    else if ((uint64_t)at + p < U)
+    {
+      uint32_t t[4] = { 0, 0, 0, 0 };
+      for (uint32_t k = 0; (uint64_t)at + p + k < U && k < 16u; k++) t[k >> 2] |= (uint32_t)in[at + p + k] << (8u * (k & 3u));
+      v = u32x4{ t[0], t[1], t[2], t[3] };
+    }
+    lds_st128(bytes + p, v);
+  }
+  __syncthreads();
+  // bit i = (d[i] == d[i + 1]) and at + i + 1 < U, for the positions of the piece
+  for (uint32_t w = lane; w < words; w += 64u)
+  {
+    uint64_t e64 = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; j++)
+    {
+      const u32x4 x = lds_ld128(bytes + w * 64u + j * 16u);
+      const uint32_t x4 = lds_ld32(bytes + w * 64u + j * 16u + 16u);
+      e64 |= (uint64_t)zero_mask16(x.x ^ alignbyte(x.y, x.x, 1), x.y ^ alignbyte(x.z, x.y, 1), x.z ^ alignbyte(x.w, x.z, 1), x.w ^ alignbyte(x4, x.w, 1)) << (16u * j);
+    }
+    const uint32_t base = w * 64u;
+    uint32_t valid = (n > base) ? n - base : 0u;                                       // positions of the piece
+    if ((uint64_t)at + n >= U && valid != 0u) valid = (n - 1u > base) ? n - 1u - base : 0u;   // the input's last byte has no successor
+    if (valid < 64u) e64 &= (1ull << valid) - 1ull;
+    eqw[w] = e64;
+  }
+  if (lane == 0u) eqw[words] = 0ull;
+  __syncthreads();
+
+  const int64_t end = (int64_t)U - 16;
+  const uint64_t prevRun = (at > 0u && in[at - 1u] == in[at]) ? 1ull : 0ull;
+  uint32_t lastSafeEnd = 0u;
+  uint64_t firstLate = ~0ull;
+  uint32_t openJ = 0xFFFFFFFFu;                                                        // the run that is open at the piece's end starts here
+  auto account = [&](uint32_t gj, uint32_t L, uint32_t sy) {
+    if ((int64_t)gj + (int64_t)L < end)
+    {
+      atomicAdd(ltab + sy, L - (L - 1u) / 16u);
+      atomicAdd(ltab + 256u + sy, 1u);
+      lastSafeEnd = (gj + L > lastSafeEnd) ? gj + L : lastSafeEnd;
+    }
+    else
+    {
+      const uint64_t key = ((uint64_t)gj << 32) | (uint64_t)(L - 1u);
+      firstLate = key < firstLate ? key : firstLate;
+    }
+  };
+  for (uint32_t w = lane; w < words; w += 64u)
+  {
+    const uint64_t m = eqw[w];
+    const uint64_t prevBit = (w > 0u) ? eqw[w - 1u] >> 63 : prevRun;
+    uint64_t starts = m & ~((m << 1) | prevBit);
+    while (starts != 0ull)
+    {
+      const uint32_t p = (uint32_t)__builtin_ctzll(starts);
+      starts &= starts - 1ull;
+      const uint32_t j = w * 64u + p;
+      uint32_t ones;
+      const uint64_t t = ~(m >> p);
+      if (p == 0u) ones = (m == ~0ull) ? 64u : (uint32_t)__builtin_ctzll(~m);
+      else ones = (uint32_t)__builtin_ctzll(t | (1ull << 63));
+      if (ones == 64u - p)
+      {
+        uint32_t w2 = w + 1u;
+        for (;;)
+        {
+          const uint64_t mm = eqw[w2];                                   // eqw[words] = 0 ends every run
+          if (mm == ~0ull) { ones += 64u; w2++; continue; }
+          ones += (uint32_t)__builtin_ctzll(~mm);
+          break;
+        }
+      }
+      if (j + ones >= n && (uint64_t)at + n < U) openJ = j;              // its last byte is the first of the next piece: followed below
+      else account(at + j, ones + 1u, bytes[j]);
+    }
+  }
+  // the open run (at most one per piece), by the whole wave
+  const uint64_t who = __ballot(openJ != 0xFFFFFFFFu);
+  if (who != 0ull)
+  {
+    const uint32_t j = (uint32_t)__shfl((int)openJ, (int)__builtin_ctzll(who), 64);
+    const uint32_t sy = bytes[j];
+    const uint32_t sym4 = sy * 0x01010101u;
+    uint64_t pos = (uint64_t)at + n + 1u;                                // d[at + n] belongs to the run
+    uint32_t ext = 0;
+    bool gaveUp = false;
+    for (uint32_t trip = 0;; trip++)
+    {
+      if (trip >= 16384u) { gaveUp = true; break; }
+      const uint64_t q = pos + (uint64_t)lane * 16u;
+      uint32_t good = 0;                                                 // leading bytes of my 16 that continue the run
+      if (q + 16u <= U)
+      {
+        const u32x4 x = ld128(in + q);
+        const uint32_t m16 = zero_mask16(x.x ^ sym4, x.y ^ sym4, x.z ^ sym4, x.w ^ sym4);
+        good = (m16 == 0xFFFFu) ? 16u : (uint32_t)__builtin_ctz(~m16);
+      }
+      else
+        for (uint32_t k = 0; q + k < U && in[q + k] == sy; k++) good++;
+      const uint64_t broke = __ballot(good < 16u);
+      if (broke != 0ull)
+      {
+        const uint32_t f = (uint32_t)__builtin_ctzll(broke);
+        ext += f * 16u + (uint32_t)__shfl((int)good, (int)f, 64);
+        break;
+      }
+      ext += 1024u;
+      pos += 1024u;
+    }
+    if (gaveUp) { if (lane == 0u) table[513] = 1u; }
+    else if (lane == 0u) account(at + j, (n - j) + 1u + ext, sy);
+  }
+#pragma unroll
+  for (int dd = 32; dd >= 1; dd >>= 1)
+  {
+    const uint32_t a = (uint32_t)__shfl_xor((int)lastSafeEnd, dd, 64);
+    lastSafeEnd = a > lastSafeEnd ? a : lastSafeEnd;
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)firstLate, dd, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(firstLate >> 32), dd, 64);
+    const uint64_t o = ((uint64_t)hi << 32) | lo;
+    firstLate = o < firstLate ? o : firstLate;
+  }
+  if (lane == 0u)
+  {
+    if (lastSafeEnd != 0u) atomicMax(table + 512u, lastSafeEnd);
+    if (firstLate != ~0ull) atomicMin(reinterpret_cast<unsigned long long *>(table + 514u), (unsigned long long)firstLate);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+  {
+    const uint32_t v = ltab[lane * 8u + (uint32_t)k];
+    if (v != 0u) atomicAdd(table + lane * 8u + (uint32_t)k, v);
+  }
+}
+
+// one wave: the scanner's first window, the run that reaches U - 16, the final registration (rle8_extreme_cpu.c:66-139, as k_single_pick's lane 0),
+// then the argmax.  out[0] = the symbol, out[1] = 1 if the pick gave up
+__global__ __launch_bounds__(64) void k_single_pick_final(const uint8_t *__restrict__ in, uint32_t U, uint32_t *__restrict__ table, uint32_t *__restrict__ out)
+{
+  const uint32_t lane = threadIdx.x;
+  const int64_t end = (int64_t)U - 16;
+  if (lane == 0u)
+  {
+    const uint32_t d0 = in[0];
+    const uint32_t inv = (~d0) & 0xFFu;
+    uint32_t finSym, finCount;
+    if (end <= 0) { finSym = inv; finCount = 0u; }
+    else
+    {
+      bool any = false;
+      for (uint32_t k = 0; k < 16u; k++) any = any || in[k] == inv;
+      if (any) table[256u + inv] += 1u;                                  // registered with count 0
+      const uint32_t i0 = table[512];                                    // the search behind the last safe run starts here (< end)
+      const uint64_t late = *reinterpret_cast<const uint64_t *>(table + 514u);
+      bool have = false;
+      finSym = 0; finCount = 1u;
+      if (late != ~0ull)
+      {
+        const uint32_t j = (uint32_t)(late >> 32), L = (uint32_t)late + 1u;
+        const uint32_t q = i0 + 15u * ((j - i0) / 15u);                 // the search trip that would find it
+        if ((int64_t)q < end)
+        {
+          have = true;
+          uint32_t i = j + 1u, count = 1u;
+          bool registered = false;
+          while ((int64_t)i < end)
+          {
+            const uint32_t rem = L - (i - j);
+            if (rem >= 16u) { count += 15u; i += 16u; }
+            else
+            {
+              count += rem; i += rem;
+              table[in[j]] += count; table[256u + in[j]] += 1u;
+              registered = true;
+              break;
+            }
+          }
+          if (registered) { finSym = in[i]; finCount = 1u; }
+          else { finSym = in[j]; finCount = count; }
+        }
+      }
+      if (!have)
+      {
+        const uint32_t i = ((int64_t)i0 < end) ? i0 + 15u * (((uint32_t)end - i0 + 14u) / 15u) : i0;   // the search runs off the end
+        finSym = in[i]; finCount = 1u;
+      }
+    }
+    table[finSym] += finCount; table[256u + finSym] += 1u;
+  }
+  __syncthreads();
+  const bool zeroStartsFull = in[0] != 0u;                              // pcount[0] starts as 0xFFFFFFFF unless d[0] == 0 (:61-62)
+  uint64_t bestKey = 0ull;
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+  {
+    const uint32_t s = lane * 4u + (uint32_t)k;
+    const uint32_t prob = table[s];
+    uint32_t pc = table[256u + s];
+    if (s == 0u && zeroStartsFull) pc -= 1u;                            // modulo 2^32, as the reference's counter
+    if (pc > 0u && prob / pc > 2u)
+    {
+      const uint32_t saved = prob - pc * 2u;
+      const uint64_t key = ((uint64_t)saved << 8) | (uint64_t)(255u - s);
+      bestKey = key > bestKey ? key : bestKey;
+    }
+  }
+#pragma unroll
+  for (int dd = 32; dd >= 1; dd >>= 1)
+  {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)bestKey, dd, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(bestKey >> 32), dd, 64);
+    const uint64_t o = ((uint64_t)hi << 32) | lo;
+    bestKey = o > bestKey ? o : bestKey;
+  }
+  if (lane == 0u)
+  {
+    out[0] = (bestKey >> 8) != 0ull ? (255u - (uint32_t)(bestKey & 0xFFull)) : 0u;
+    out[1] = table[513];
+  }
+}
+
 
 } // namespace hsrle

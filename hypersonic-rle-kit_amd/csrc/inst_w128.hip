@@ -36,8 +36,17 @@ static hipError_t sub_sym_packed(const DecodeArgs &a, uint32_t SB, uint32_t *rec
 static hipError_t sub_byte(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_sub_or_wave<PLAIN, 16, 0>(a, SB, 0u, rec, st); }
 static hipError_t sub_byte_packed(const DecodeArgs &a, uint32_t SB, uint32_t *rec, hipStream_t st) { return launch_sub_or_wave<PACKED, 16, 0>(a, SB, 0u, rec, st); }
 
-void register_w128(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub)
+// chunks of one monolithic stream (hsrle_mono_encode.hip.h): the first-generation encoder, one lane per chunk, from its place behind a stored run
+template <int FAM, int AL>
+static hipError_t menc_any(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st)
 {
+  hipLaunchKernelGGL((k_encode128_chunks<FAM, AL>), dim3((a.nBlocks + 63u) / 64u), dim3(64), 0, st, a.in, a.U, a.nBlocks, m.starts, m.syms, m.slotOff, a.slots, a.sizes);
+  return hipGetLastError();
+}
+
+void register_w128(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub, MonoEncodeLaunch *menc)
+{
+  menc[46] = menc_any<PLAIN, 1>; menc[47] = menc_any<PACKED, 1>; menc[48] = menc_any<PLAIN, 0>; menc[49] = menc_any<PACKED, 0>;
   sub[46] = sub_sym; sub[47] = sub_sym_packed; sub[48] = sub_byte; sub[49] = sub_byte_packed;
   idx[46] = idx_sym; idx[47] = idx_sym_packed; idx[48] = idx_byte; idx[49] = idx_byte_packed;
   dec[46] = dec_sym;         enc[46] = enc_sym;

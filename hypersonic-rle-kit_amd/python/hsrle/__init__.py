@@ -215,7 +215,7 @@ def mono_tuning(block=0, region=0, lookback=0):
 
 def mono_compress_dev(codec, src, dst=None, workspace=None, return_chunks=False):
     """ONE monolithic reference stream of the CUDA uint8 tensor `src`, written by many lanes (hsrle_compress_mono_dev; the multi-symbol
-    codecs of 8 .. 64 bit symbols: not Single, 128 bit, Greedy).  Returns the stream tensor."""
+    codecs of every width and the 8 bit Single codecs: not Greedy, not rle8_single_short).  Returns the stream tensor."""
     import torch
 
     _check_u8_cuda(src, "src")

@@ -171,7 +171,9 @@ def test_device_resident_mono_decode_of_synthetic_workloads(hs, oracle, key, kin
 # ---- the encode side: ONE stream written by many lanes (csrc/hsrle_mono_encode.hip.h) ----
 
 # every multi-symbol codec of 8 .. 64 bit symbols: plain, Packed, LUT and the Short family (not Single, 128 bit, Greedy)
-MONO_ENC_KEYS = [c.key for c in CODECS if "single" not in c.key and "greedy" not in c.key and not c.key.startswith("rle128")]
+# many-lane monolithic encode: every codec but the Greedy encoders and rle8_single_short (round 3: + 8 bit Single -- global symbol pick, cuts behind
+# long runs of the symbol -- and the 128 bit codecs)
+MONO_ENC_KEYS = [c.key for c in CODECS if "greedy" not in c.key and c.key != "rle8_single_short"]
 MONO_LIST_KEYS = [k for k in MONO_ENC_KEYS if "symlut" in k]
 
 
@@ -212,6 +214,11 @@ def test_mono_encode_is_the_reference_stream(hs, oracle, key):
     cases += [_run_mix(5, 60000, [1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 40]), _run_mix(6, 60000, [11, 12, 13, 30, 64, 65, 300]),
               bytes(200000), bytes(rng.randrange(256) for _ in range(100000)), b"\x05" * 70 + bytes(range(256)) * 100 + b"\x06" * 40,
               _run_mix(7, 30000, [12, 13]) + b"\x09" * 20, _run_mix(8, 30000, [12, 13]) + b"\x09" * 20 + b"abc", _run_mix(9, 5000, [20]) + bytes(50)]
+    if "single" in key:
+        # the pick: a run that reaches the end / U - 16, runs across many 4 KiB pieces, two symbols with nearly equal gains, nothing to pick
+        cases += [b"ab" * 3000 + b"\x07" * 9000 + b"xy" * 10 + b"\x07" * 17, b"\x07" * 5000 + b"q" + b"\x09" * 5000 + b"r" * 3, bytes(range(256)) * 40,
+                  b"z" * 33 + b"\x01" * 20000 + b"\x02" * 20001 + b"k", _run_mix(15, 300000, [2, 3, 4, 5, 8, 9, 10, 11, 40, 5000]), b"\x00" * 100 + b"\xff" * 15,
+                  _run_mix(16, 70000, [4, 8, 10]) + b"\x07" * 40, bytes([7]) * 12289, bytes([7]) * 4096 + b"x" + bytes([7]) * 4097]
     if codec.S > 1:
         cases += [_wide_run_mix(20 + k, n, codec.S) for k, n in enumerate((300, 5000, 60000, 60000, 150000))]
         cases += [_wide_run_mix(30, 40000, 1), bytes(range(7)) * 9000]
