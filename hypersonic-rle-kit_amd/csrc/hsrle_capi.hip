@@ -1086,7 +1086,7 @@ static int mono_encode_dev(int codec, const uint8_t *dIn, uint32_t U, uint8_t *d
     const uint32_t pp = (U + kPickPiece - 1u) / kPickPiece;
     if (hipMemsetAsync(table, 0, 2064, st) != hipSuccess || hipMemsetAsync(table + 514, 0xFF, 8, st) != hipSuccess)
       return HSRLE_ERR_DEVICE;
-    hipLaunchKernelGGL(k_single_pick_mono, dim3(pp), dim3(64), 0, st, dIn, U, pp, table);
+    hipLaunchKernelGGL(k_single_pick_mono, dim3(pp < 4096u ? pp : 4096u), dim3(64), 0, st, dIn, U, pp, table);
     hipLaunchKernelGGL(k_single_pick_final, dim3(1), dim3(64), 0, st, dIn, U, table, ctrl + 8);
   }
   const dim3 cgrid((m.pieces + 63u) / 64u);

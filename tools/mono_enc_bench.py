@@ -17,6 +17,8 @@ gib = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 n = int(gib * (1 << 30))
 ora = Oracle()
 L = hsrle.lib()
+if os.environ.get("MONO_G"):
+    hsrle.mono_tuning(0, int(os.environ["MONO_G"]), 0)                  # piece size of the cut finder (test knob)
 for key in keys:
     codec = CODEC_BY_KEY[key]
     for kind in (0, 1):
