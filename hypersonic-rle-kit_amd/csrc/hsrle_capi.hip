@@ -1019,6 +1019,7 @@ struct MonoEncPlan
   uint64_t offCutPos, offCutSym, offFlags, offIdx, offStarts, offSyms, offSlotOff, offSizes, offOffsets, offL1, offL2, offL3, offCtrl, offSlots, total;
   uint64_t offGuess, offListOut, offRoll1, offRoll2;   // codecs with a move-to-front list: 8 words per chunk / per 64 / per 4096 chunks
   uint64_t offPick;                                    // 8 bit Single: the symbol pick's sums (k_single_pick_mono)
+  uint64_t offJobs; uint32_t jobCap;                   // 8 bit Single: literal stretches noted by the chunk encoders for k_copy_jobs
 };
 
 static MonoEncPlan plan_mono_encode(uint32_t U, bool lists = true)
@@ -1047,6 +1048,8 @@ static MonoEncPlan plan_mono_encode(uint32_t U, bool lists = true)
   m.offL3 = at; at += align_up(8ull * (t3 + 1), 256);
   m.offCtrl = at; at += 256;
   m.offPick = at; at += 4096;
+  m.jobCap = U / 1024u + 16u;                                            // (every stretch of >= kCopyJobMin bytes there can be)
+  m.offJobs = at; at += align_up(24ull * m.jobCap, 256);
   m.offGuess = m.offListOut = m.offRoll1 = m.offRoll2 = at;
   if (lists)
   {
@@ -1122,6 +1125,7 @@ static int mono_encode_dev(int codec, const uint8_t *dIn, uint32_t U, uint8_t *d
   EncodeArgs ea{ dIn, (uint64_t)U, 0u, chunks, ws + m.offSlots, 0u, sizes };
   MonoEncodeArgs ma{ starts, syms, slotOff, 2u * (longest / 64u) + 64u };
   ma.pick = ctrl + 8;
+  if (single) { ma.jobs = (uint64_t *)(ws + m.offJobs); ma.jobCount = ctrl + 12; ma.jobCap = m.jobCap; }   // (ctrl[12] was zeroed with the rest)
   if (listK == 0)
   {
     if (g_menc[codec](ea, ma, st) != hipSuccess)

@@ -1002,9 +1002,37 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const uint8_t *__restrict_
 // the state and found from its first byte whatever the scanner's phase -- so the input is cut behind those, and a chunk is the block loop
 // started at its first byte (which is not the symbol: the loop's first trip falls through to the search).  `end` is the TRUE end - 16; the
 // scalar tail and the terminator belong to the last chunk.  No stream header; a chunk in front of the last ends with its boundary run's packet.
-template <bool PACKEDSINGLE>
-__device__ inline uint32_t encode_chunk_single(const uint8_t *d, uint32_t nChunk, uint32_t nTrue32, uint32_t sym, Sink &s)
+// Long literal stretches are not copied by the chunk's one lane (a Single stream of data its symbol is rare in is 99.8 % literals: 19 KB per
+// chunk on the run-distributed buffer, 43 GiB/s): the lane NOTES them -- source, destination, length, appended to a list with one atomic --
+// and k_copy_jobs copies them with whole waves afterwards.  (The list is sized for every possible stretch of >= kCopyJobMin bytes; a lane
+// that finds it full copies itself.)
+constexpr uint32_t kCopyJobMin = 1024u;
+struct CopyJobs
 {
+  uint64_t *list;            // 3 words per job: source offset in the input, destination offset in the staging area, bytes
+  uint32_t *count;
+  uint32_t cap;
+  uint64_t srcBase, dstBase; // offsets of the chunk's first input byte / of its staging slot
+};
+
+template <bool PACKEDSINGLE>
+__device__ inline uint32_t encode_chunk_single(const uint8_t *d, uint32_t nChunk, uint32_t nTrue32, uint32_t sym, Sink &s, const CopyJobs &jobs)
+{
+  auto put_literals = [&](int32_t from, uint32_t len) {
+    if (len >= kCopyJobMin && jobs.list != nullptr)
+    {
+      const uint32_t k = atomicAdd(jobs.count, 1u);
+      if (k < jobs.cap)
+      {
+        jobs.list[3ull * k] = jobs.srcBase + (uint64_t)(uint32_t)from;
+        jobs.list[3ull * k + 1] = jobs.dstBase + s.at;
+        jobs.list[3ull * k + 2] = len;
+        s.at += len;
+        return;
+      }
+    }
+    s.putn(d + from, len);
+  };
   constexpr int32_t SHORT = PACKEDSINGLE ? 2 : 4;
   constexpr int32_t MEDIUM = 6;
   constexpr int32_t LONG = PACKEDSINGLE ? 10 : 8;
@@ -1021,14 +1049,14 @@ __device__ inline uint32_t encode_chunk_single(const uint8_t *d, uint32_t nChunk
   auto emit_short = [&](int32_t range) {
     put_count(count);
     s.put8((uint32_t)range);
-    s.putn(d + lastRLE, (uint32_t)(i - count - lastRLE));
+    put_literals(lastRLE, (uint32_t)(i - count - lastRLE));
     lastRLE = i;
   };
   auto emit_long = [&](int32_t range) {
     put_count(count);
     s.put8(0);
     s.put32((uint32_t)range);
-    s.putn(d + lastRLE, (uint32_t)(i - count - lastRLE));
+    put_literals(lastRLE, (uint32_t)(i - count - lastRLE));
     lastRLE = i;
   };
 
@@ -1091,7 +1119,7 @@ __device__ inline uint32_t encode_chunk_single(const uint8_t *d, uint32_t nChunk
               s.put8((uint32_t)(count - SHORT + 1) & 0xFFu);
               s.put8(0);
               s.put32((uint32_t)(i - lastRLE - count + 1));
-              s.putn(d + lastRLE, (uint32_t)(i - count - lastRLE));
+              put_literals(lastRLE, (uint32_t)(i - count - lastRLE));
               lastRLE = i;
             }
           }
@@ -1102,12 +1130,25 @@ __device__ inline uint32_t encode_chunk_single(const uint8_t *d, uint32_t nChunk
 
       count = 0;
 
+      bool streak = false;                                              // the last window was skipped: try four at a time
       while (i < end)
       {
+        // four windows per trip while all four are skipped (far from the symbol's runs the loop is one dependent load per window otherwise:
+        // the longest chunk's lane sets the kernel's time)
+        if (streak && i + 48 < end)
+        {
+          const Cmp16 b0(d + i, bs), b1(d + i + 16, bs), b2(d + i + 32, bs), b3(d + i + 48, bs);
+          const bool s0 = !b0.any() || (!b0.lastByte() && b0.pop() < (uint32_t)SHORT), s1 = !b1.any() || (!b1.lastByte() && b1.pop() < (uint32_t)SHORT);
+          const bool s2 = !b2.any() || (!b2.lastByte() && b2.pop() < (uint32_t)SHORT), s3 = !b3.any() || (!b3.lastByte() && b3.pop() < (uint32_t)SHORT);
+          if (s0 && s1 && s2 && s3) { i += 64; continue; }
+        }
         const Cmp16 b(d + i, bs);
 
         if (!b.any() || (!b.lastByte() && b.pop() < (uint32_t)SHORT))
+        {
           i += 16;
+          streak = true;
+        }
         else
         {
           i += (int32_t)b.first();
@@ -1151,7 +1192,7 @@ __device__ inline uint32_t encode_chunk_single(const uint8_t *d, uint32_t nChunk
     else
     {
       s.put8(0); s.put32(0); s.put8(0); s.put32((uint32_t)(range + count));
-      s.putn(d + lastRLE, (uint32_t)(i - lastRLE));
+      put_literals(lastRLE, (uint32_t)(i - lastRLE));
     }
   }
   return s.at;
@@ -1160,13 +1201,44 @@ __device__ inline uint32_t encode_chunk_single(const uint8_t *d, uint32_t nChunk
 // chunks of ONE monolithic 8 bit Single stream, one lane per chunk (pick[0]: the stream's symbol, k_single_pick_final)
 template <bool PACKEDSINGLE>
 __global__ __launch_bounds__(64) void k_encode_single_chunks(const uint8_t *__restrict__ in, uint64_t U, uint32_t chunks, const uint64_t *__restrict__ starts, const uint64_t *__restrict__ slotOff,
-                                                             uint8_t *__restrict__ slots, uint32_t *__restrict__ sizes, const uint32_t *__restrict__ pick)
+                                                             uint8_t *__restrict__ slots, uint32_t *__restrict__ sizes, const uint32_t *__restrict__ pick,
+                                                             uint64_t *__restrict__ jobList, uint32_t *__restrict__ jobCount, uint32_t jobCap)
 {
   const uint32_t c = blockIdx.x * 64u + threadIdx.x;
   if (c >= chunks) return;
   const uint64_t start = starts[c];
   Sink s{ slots + slotOff[c], 0u, in + U };
-  sizes[c] = encode_chunk_single<PACKEDSINGLE>(in + start, (uint32_t)(starts[c + 1u] - start), (uint32_t)(U - start), pick[0] & 0xFFu, s);
+  const CopyJobs jobs{ jobList, jobCount, jobCap, start, slotOff[c] };
+  sizes[c] = encode_chunk_single<PACKEDSINGLE>(in + start, (uint32_t)(starts[c + 1u] - start), (uint32_t)(U - start), pick[0] & 0xFFu, s, jobs);
+}
+
+// the noted literal stretches of the chunk encoders: persistent waves, one job at a time, destination-aligned 16-byte stores
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void k_copy_jobs(const uint8_t *__restrict__ in, uint8_t *__restrict__ slots, const uint64_t *__restrict__ jobList, const uint32_t *__restrict__ jobCount,
+                                                   uint32_t jobCap)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t n = jobCount[0] < jobCap ? jobCount[0] : jobCap;
+  for (uint32_t j = blockIdx.x * 4u + (threadIdx.x >> 6); j < n; j += gridDim.x * 4u)
+  {
+    const uint8_t *src = in + jobList[3ull * j];
+    uint8_t *dst = slots + jobList[3ull * j + 1];
+    const uint64_t size = jobList[3ull * j + 2];
+    uint64_t head = (16u - ((uintptr_t)dst & 15u)) & 15u;
+    if (head > size) head = size;
+    if (lane < head) dst[lane] = src[lane];
+    const uint64_t body = (size - head) & ~15ull;
+    for (uint64_t k = (uint64_t)lane * 16u; k < body; k += 4096u)
+    {
+      u32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) if (k + 1024u * u < body) v[u] = ld128(src + head + k + 1024u * u);
+#pragma unroll
+      for (int u = 0; u < 4; u++) if (k + 1024u * u < body) st128(dst + head + k + 1024u * u, v[u]);
+    }
+    const uint64_t tail = size - head - body;
+    if (lane < tail) dst[head + body + lane] = src[head + body + lane];
+  }
 }
 
 // chunks of ONE monolithic 128 bit stream, one lane per chunk (hsrle_mono_encode.hip.h; syms[c] = where the boundary run in front of chunk c starts)

@@ -66,6 +66,7 @@ struct MonoEncodeArgs
   const uint64_t *starts; const uint64_t *syms; const uint64_t *slotOff; uint32_t steps;
   uint64_t *listOut = nullptr; uint32_t dry = 0;     // codecs with a move-to-front list: syms / listOut hold 8 words per chunk
   const uint32_t *pick = nullptr;                    // 8 bit Single: the stream's symbol (device)
+  uint64_t *jobs = nullptr; uint32_t *jobCount = nullptr; uint32_t jobCap = 0;   // 8 bit Single: literal stretches noted for k_copy_jobs
 };
 typedef hipError_t (*MonoEncodeLaunch)(const EncodeArgs &, const MonoEncodeArgs &, hipStream_t);
 // wave-per-block encoder (hsrle_encode8w.hip.h): writes offsets and payload of the container directly

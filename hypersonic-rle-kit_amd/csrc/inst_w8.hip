@@ -94,7 +94,10 @@ static hipError_t menc_lut7(const EncodeArgs &a, const MonoEncodeArgs &m, hipStr
 template <bool PACKEDSINGLE>
 static hipError_t menc_single_any(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st)
 {
-  hipLaunchKernelGGL((k_encode_single_chunks<PACKEDSINGLE>), dim3((a.nBlocks + 63u) / 64u), dim3(64), 0, st, a.in, a.U, a.nBlocks, m.starts, m.slotOff, a.slots, a.sizes, m.pick);
+  hipLaunchKernelGGL((k_encode_single_chunks<PACKEDSINGLE>), dim3((a.nBlocks + 63u) / 64u), dim3(64), 0, st, a.in, a.U, a.nBlocks, m.starts, m.slotOff, a.slots, a.sizes, m.pick,
+                     m.jobs, m.jobCount, m.jobCap);
+  if (m.jobs != nullptr)
+    hipLaunchKernelGGL((k_copy_jobs<0>), dim3(2048), dim3(256), 0, st, a.in, a.slots, (const uint64_t *)m.jobs, (const uint32_t *)m.jobCount, m.jobCap);
   return hipGetLastError();
 }
 static hipError_t menc_short1(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode(k_encode8_blocks<SHORT1, true>, a, m, st); }
