@@ -441,9 +441,17 @@ static uint32_t encode_chunk_blocks()
   return v;
 }
 
+// Split encode (hsrle_mono_encode.hip.h): containers with too few blocks for one lane each are encoded chunk by chunk -- the blocks cut behind
+// runs every encoder state stores, like a monolithic stream, with the block starts as forced cuts.  kSplitPieces pieces (= cut finder lanes) per block.
+constexpr uint32_t kSplitEncodeBelow = 131072u;   // blocks: from here on one lane per block fills the device
+constexpr uint32_t kSplitPieces = 4u;
+static bool split_encode_applies(int codec, uint64_t nBlocks, uint32_t B);
+
 struct Workspace
 {
   uint64_t nBlocks, chunk, nChunks, t1, t2, t3;
+  // split encode: cut finder results per piece, chunk table, sizes / offsets per chunk, lists (8 words per chunk), staging slots
+  uint64_t spCutPos, spCutSym, spFlags, spIdx, spStarts, spSyms, spSlotOff, spSizes, spChunkOff, spFirst, spCtrl, spGuess, spListOut, spSlots, spL1, spL2, spL3, spPieces, spMaxChunks;
   uint64_t offSlots, offSizes, offL1, offL2, offL3, total;
 };
 
@@ -464,6 +472,31 @@ static Workspace plan_workspace(uint64_t U, uint32_t B)
   w.offL1 = at; at += align_up((w.t1 + 1) * 8ull, 256);
   w.offL2 = at; at += align_up((w.t2 + 1) * 8ull, 256);
   w.offL3 = at; at += align_up((w.t3 + 1) * 8ull, 256);
+  // (split encode regions: sized for every codec, used by small containers only)
+  w.spPieces = w.nBlocks * kSplitPieces; w.spMaxChunks = w.spPieces + w.nBlocks;
+  w.spCutPos = w.spCutSym = w.spFlags = w.spIdx = w.spStarts = w.spSyms = w.spSlotOff = w.spSizes = w.spChunkOff = w.spFirst = w.spCtrl = w.spGuess = w.spListOut = w.spSlots = w.spL1 = w.spL2 = w.spL3 = 0;
+  if (w.nBlocks < kSplitEncodeBelow && B >= 1024u && B <= (1u << 20))
+  {
+    const uint64_t np = w.spPieces, nc = w.spMaxChunks;
+    const uint64_t s1 = (nc + 2 + kScanTile - 1) / kScanTile, s2 = (s1 + kScanTile - 1) / kScanTile, s3 = (s2 + kScanTile - 1) / kScanTile;
+    w.spCutPos = at; at += align_up(8ull * np, 256);
+    w.spCutSym = at; at += align_up(8ull * np, 256);
+    w.spFlags = at; at += align_up(4ull * np, 256);
+    w.spIdx = at; at += align_up(8ull * (np + 1), 256);
+    w.spStarts = at; at += align_up(8ull * (nc + 2), 256);
+    w.spSyms = at; at += align_up(8ull * (nc + 1), 256);
+    w.spSlotOff = at; at += align_up(8ull * (nc + 1), 256);
+    w.spSizes = at; at += align_up(4ull * (nc + 1), 256);
+    w.spChunkOff = at; at += align_up(8ull * (nc + 2), 256);
+    w.spFirst = at; at += align_up(4ull * (w.nBlocks + 2), 256);
+    w.spCtrl = at; at += 256;
+    w.spGuess = at; at += align_up(64ull * (nc + 1), 256);
+    w.spListOut = at; at += align_up(64ull * (nc + 1), 256);
+    w.spL1 = at; at += align_up(8ull * (s1 + 1), 256);
+    w.spL2 = at; at += align_up(8ull * (s2 + 1), 256);
+    w.spL3 = at; at += align_up(8ull * (s3 + 1), 256);
+    w.spSlots = at; at += align_up(U + (U >> 7) + 256ull * (nc + 2) + 4096ull, 256);
+  }
   w.total = at;
   return w;
 }
@@ -508,6 +541,8 @@ static hipStream_t aux_stream()
   if (!D.aux && hipStreamCreateWithFlags(&D.aux, hipStreamNonBlocking) != hipSuccess) D.aux = nullptr;
   return D.aux;
 }
+
+static int compress_split(int codec, const uint8_t *dIn, uint64_t U, uint32_t B, uint32_t nBlocks, uint8_t *ws, const Workspace &w, uint64_t *offsets, uint8_t *payload, hipStream_t st);
 
 static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, uint64_t cap, uint32_t B, void *dWs, uint64_t wsSize, hipStream_t st)
 {
@@ -569,7 +604,9 @@ static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, ui
   }
   else
 #endif
-  if (w.nChunks > 1 && aux == nullptr)
+  if (w.nChunks <= 1 && w.spSlots != 0 && split_encode_applies(codec, w.nBlocks, B))
+    rc = compress_split(codec, (const uint8_t *)dIn, U, B, nBlocks, ws, w, offsets, payload, st);
+  else if (w.nChunks > 1 && aux == nullptr)
     rc = HSRLE_ERR_DEVICE;
   else if (w.nChunks <= 1)
   {
@@ -1008,6 +1045,88 @@ static uint32_t mono_cut_long(int codec, int *pS = nullptr, int *pAligned = null
   if (pAligned) *pAligned = al;
   if (pListK) *pListK = K;
   return longc;
+}
+
+static bool split_encode_applies(int codec, uint64_t nBlocks, uint32_t B)
+{
+  // the codecs whose ring encoders have the chunk mode (not Single, not 128 bit: their chunk encoders are the per-lane ones of the monolithic path)
+  if (nBlocks >= kSplitEncodeBelow || B < 1024u || B > (1u << 20) || (B % (kSplitPieces * 128u)) != 0u || codec == 4 || codec == 5 || (codec >= 46 && codec < 50)) return false;
+  init_tables();
+  return mono_cut_long(codec) != 0u && g_menc[codec] != nullptr;
+}
+
+// Split encode of a container (no host synchronisation: graph capturable like the plain path): cuts inside the blocks -> chunk table (block
+// starts are forced cuts) -> the ring encoders' chunk mode with B given (headers at block starts, the block's end as the end of the input) ->
+// for the list codecs: every chunk from the default list, then the proof and kSplitPieces repair rounds (a chunk's list is wrong only if
+// a chunk in front of it IN ITS BLOCK stored a symbol the default list does not lead with; a round makes one more chunk per block right) ->
+// size scan over the chunks, placement, offset table + compressedLength fields.
+static int compress_split(int codec, const uint8_t *dIn, uint64_t U, uint32_t B, uint32_t nBlocks, uint8_t *ws, const Workspace &w, uint64_t *offsets, uint8_t *payload, hipStream_t st)
+{
+  int S = 1, aligned = 0, listK = 0;
+  const uint32_t longc = mono_cut_long(codec, &S, &aligned, &listK);
+  const uint32_t G = B / kSplitPieces, pieces = (uint32_t)w.spPieces, maxChunks = (uint32_t)w.spMaxChunks;
+  uint64_t *cutPos = (uint64_t *)(ws + w.spCutPos), *cutSym = (uint64_t *)(ws + w.spCutSym), *idx = (uint64_t *)(ws + w.spIdx), *starts = (uint64_t *)(ws + w.spStarts);
+  uint64_t *syms = (uint64_t *)(ws + w.spSyms), *slotOff = (uint64_t *)(ws + w.spSlotOff), *chunkOff = (uint64_t *)(ws + w.spChunkOff);
+  uint64_t *guess = (uint64_t *)(ws + w.spGuess), *listOut = (uint64_t *)(ws + w.spListOut);
+  uint32_t *flags = (uint32_t *)(ws + w.spFlags), *sizes = (uint32_t *)(ws + w.spSizes), *firstChunk = (uint32_t *)(ws + w.spFirst), *ctrl = (uint32_t *)(ws + w.spCtrl);
+  Workspace sw{};
+  sw.offL1 = w.spL1; sw.offL2 = w.spL2; sw.offL3 = w.spL3;
+  if (hipMemsetAsync(ctrl, 0, 64, st) != hipSuccess || hipMemsetAsync(sizes, 0, 4ull * (maxChunks + 1ull), st) != hipSuccess)
+    return HSRLE_ERR_DEVICE;
+  const dim3 cgrid((pieces + 63u) / 64u);
+#define HSRLE_CUTS(SS) \
+  if (aligned) hipLaunchKernelGGL((k_mono_cutsS<SS, 1>), cgrid, dim3(64), 0, st, dIn, U, G, pieces, longc, cutPos, cutSym, flags, B); \
+  else hipLaunchKernelGGL((k_mono_cutsS<SS, 0>), cgrid, dim3(64), 0, st, dIn, U, G, pieces, longc, cutPos, cutSym, flags, B)
+  switch (S)
+  {
+  case 1: hipLaunchKernelGGL(k_mono_cuts8, cgrid, dim3(64), 0, st, dIn, U, G, pieces, longc, cutPos, cutSym, flags, (const uint32_t *)nullptr, B); break;
+  case 2: HSRLE_CUTS(2); break;
+  case 3: HSRLE_CUTS(3); break;
+  case 4: HSRLE_CUTS(4); break;
+  case 6: HSRLE_CUTS(6); break;
+  default: HSRLE_CUTS(8); break;
+  }
+#undef HSRLE_CUTS
+  if (scan_sizes(flags, pieces, idx, ws, sw, st) != hipSuccess)
+    return HSRLE_ERR_DEVICE;
+  if (listK != 0)
+    hipLaunchKernelGGL(k_mono_list_default, dim3((maxChunks + 255u) / 256u), dim3(256), 0, st, maxChunks, (uint32_t)listK, (uint32_t)S, guess);
+  hipLaunchKernelGGL(k_split_scatter, dim3((pieces + 255u) / 256u), dim3(256), 0, st, (const uint64_t *)cutPos, (const uint64_t *)cutSym, (const uint32_t *)flags, (const uint64_t *)idx, pieces,
+                     kSplitPieces, nBlocks, U, B, starts, listK ? guess : syms, slotOff, firstChunk, ctrl, (uint32_t)listK);
+
+  EncodeArgs ea{ dIn, U, B, maxChunks, ws + w.spSlots, 0u, sizes };
+  ea.ringSel = ctrl;                                                     // chunk mode with B: ctrl[0] = the number of chunks
+  MonoEncodeArgs ma{ starts, listK ? guess : syms, slotOff, 2u * (B / 64u) + 64u };
+  ma.listOut = listK ? listOut : nullptr;
+  if (g_menc[codec](ea, ma, st) != hipSuccess)
+    return HSRLE_ERR_DEVICE;
+  if (listK != 0)
+  {
+    // What every chunk does to a list is known from the first pass: the lists in front of all chunks at once, then the chunks whose list is
+    // not the default one again (run-distributed rle64_3symlut_byte: every chunk).  Then the proof, with repair: a re-encoded chunk may store
+    // other runs than it did from the default list and leave another list behind; after the pass above the first two chunks of every block are
+    // final, every verify round makes one more so, and a block has at most kSplitPieces + 1 chunks.  The rounds tell the encoder which
+    // counter says whether they have anything to do (an empty round is two launches that return at once).
+    const uint32_t base = ma.steps;
+    hipLaunchKernelGGL(k_split_list_guess, dim3((maxChunks + 255u) / 256u), dim3(256), 0, st, guess, (const uint64_t *)listOut, (const uint64_t *)starts, (const uint32_t *)ctrl, B, (uint32_t)listK, (uint32_t)S,
+                       ctrl + 8);
+    ma.steps = base | (1u << 16);
+    if (g_menc[codec](ea, ma, st) != hipSuccess)
+      return HSRLE_ERR_DEVICE;
+    for (uint32_t round = 0; round + 1u < kSplitPieces; round++)
+    {
+      hipLaunchKernelGGL(k_split_list_verify, dim3((maxChunks + 255u) / 256u), dim3(256), 0, st, guess, (const uint64_t *)listOut, (const uint64_t *)starts, (const uint32_t *)ctrl, B, (uint32_t)listK,
+                         (uint32_t)S, ctrl + 9 + round);
+      ma.steps = base | ((2u + round) << 16);
+      if (g_menc[codec](ea, ma, st) != hipSuccess)                       // (chunks whose list was right are switched off: word 7 of their guess)
+        return HSRLE_ERR_DEVICE;
+    }
+  }
+  if (scan_sizes(sizes, maxChunks, chunkOff, ws, sw, st) != hipSuccess)
+    return HSRLE_ERR_DEVICE;
+  hipLaunchKernelGGL(k_compact_var, dim3((maxChunks + 3u) / 4u), dim3(256), 0, st, (const uint8_t *)(ws + w.spSlots), (const uint64_t *)slotOff, (const uint64_t *)chunkOff, payload, maxChunks);
+  hipLaunchKernelGGL(k_split_finish, dim3((nBlocks + 255u) / 256u), dim3(256), 0, st, (const uint32_t *)firstChunk, (const uint64_t *)chunkOff, nBlocks, offsets, payload);
+  return hipGetLastError() == hipSuccess ? HSRLE_OK : HSRLE_ERR_DEVICE;
 }
 
 constexpr uint32_t kMonoListRounds = 64u;     // repair rounds of the guessed move-to-front lists before the caller falls back to one lane

@@ -44,7 +44,13 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
                                                        const uint64_t *__restrict__ monoSlotOff, uint32_t monoSteps, uint64_t *__restrict__ monoListOut, uint32_t monoDry,
                                                        const uint32_t *__restrict__ ringSel)
 {
-  if (ringSel != nullptr && ringSel[0] != (uint32_t)RING) return;
+  if (!MONO && ringSel != nullptr && ringSel[0] != (uint32_t)RING) return;
+  // MONO with B != 0: the chunks are pieces of the BLOCKS of a container, not of one stream (hsrle_mono_encode.hip.h, "split encode": small
+  // containers have too few blocks for one lane each).  Block starts are chunk starts; a block's first chunk writes the block's stream
+  // header, its last one the terminator; the rules' "end of the input" is the end of the chunk's block.  ringSel[0] then holds the
+  // number of chunks (the grid is sized for the most there can be).  Repair rounds of the list codecs (monoSteps >> 16 = r != 0) have nothing
+  // to do when ringSel[7 + r] == 0 (what the guess / verify kernel in front of them counted): every workgroup returns at once.
+  if constexpr (MONO) { if (B != 0u && ringSel != nullptr && (monoSteps >> 16) != 0u && ringSel[7u + (monoSteps >> 16)] == 0u) return; }
   using TR = Traits<FAM, 1, 0>;
   // Codecs with a move-to-front list: the list in front of a chunk is NOT known from the boundary run; the host hands every chunk a list
   // (monoSyms[8 * c + k]: entry k; [8 * c + 7]: encode this chunk?), gets the list behind it back (monoListOut[8 * c + k]; [.. + 7]: mtfDepth) and repeats the chunks whose
@@ -76,6 +82,7 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
   const uint32_t wgFirst = xcd_tile(blockIdx.x, gridDim.x) * 64u;    // XCD-aware tile order (hsrle_common.hip.h)
   const uint32_t b = wgFirst + lane;
   bool active = b < nBlocks;
+  if constexpr (MONO) { if (B != 0u && ringSel != nullptr) active = b < ringSel[0]; }
   if constexpr (MONO && Traits<FAM, 1, 0>::kMtf) { if (active) active = monoSyms[8ull * b + 7] != 0ull; }   // the host's repair rounds switch most chunks off
 
   // ring byte x of row r lives at hist[(r * H) ^ hsw(r) ^ (x & HM)]: chunks XOR-swizzled by the row index (bank spread without pad)
@@ -92,6 +99,11 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
       blockAt = monoStarts[b];
       n = (uint32_t)(monoStarts[b + 1] - blockAt);
       nTrueV = (uint32_t)(U - blockAt);
+      if (B != 0u)
+      {
+        const uint64_t blockEnd = (blockAt / B + 1ull) * B;
+        if (blockEnd < U) nTrueV = (uint32_t)(blockEnd - blockAt);
+      }
     }
     else
     {
@@ -287,9 +299,10 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
   };
 
   // ---- stream header ----
-  if (active && !MONO)
+  const bool blockFirst = MONO && B != 0u && active && (blockAt % B) == 0ull;     // split encode: this chunk opens its block's stream
+  if (active && (!MONO || blockFirst))
   {
-    h32(n);
+    h32(MONO ? nTrue : n);                                              // (the block's length; its compressed length is patched in at placement)
     h32(0);
     if constexpr (!TR::kLut && !TR::kShort) hb(0); // mode = multi
     hflush();
@@ -537,7 +550,7 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
   land();
   wave_sync();
 
-  uint32_t stepsLeft = MONO ? monoSteps : 2u * (B / (uint32_t)Q) + 64u;  // bounded: every step scans a window or lands input
+  uint32_t stepsLeft = MONO ? ((B != 0u) ? (monoSteps & 0xFFFFu) : monoSteps) : 2u * (B / (uint32_t)Q) + 64u;  // bounded: every step scans a window or lands input
 
   while (__ballot(!finished) != 0ull)
   {

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
                                                        const uint64_t *__restrict__ monoSlotOff, uint32_t monoSteps, uint64_t *__restrict__ monoListOut, uint32_t monoDry,
                                                        const uint32_t *__restrict__ ringSel)
 {
-  if (ringSel != nullptr && ringSel[0] != (uint32_t)RING) return;          // (S = 2: the host launches both rings, k_ring_decide chose: hsrle_encode8.hip.h)
+  if (!MONO && ringSel != nullptr && ringSel[0] != (uint32_t)RING) return;          // (S = 2: the host launches both rings, k_ring_decide chose: hsrle_encode8.hip.h)
   // (codecs with a move-to-front list: monoSyms[8 * c + k] = entry k of the list in front of chunk c, monoListOut likewise the list behind it;
   //  monoDry: no stores, only the list -- see k_encode8_blocks)
   [[maybe_unused]] const bool dry = MONO && monoDry != 0u;
@@ -73,8 +73,10 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
 
   const uint32_t lane = threadIdx.x;
   const uint32_t wgFirst = xcd_tile(blockIdx.x, gridDim.x) * 64u;    // XCD-aware tile order (hsrle_common.hip.h)
+  if constexpr (MONO) { if (B != 0u && ringSel != nullptr && (monoSteps >> 16) != 0u && ringSel[7u + (monoSteps >> 16)] == 0u) return; }   // an empty repair round (see k_encode8_blocks)
   const uint32_t b = wgFirst + lane;
   bool active = b < nBlocks;
+  if constexpr (MONO) { if (B != 0u && ringSel != nullptr) active = b < ringSel[0]; }     // split encode (see k_encode8_blocks): chunks of a container's blocks, their number on the device
   if constexpr (MONO && Traits<FAM, S, AL>::kMtf) { if (active) active = monoSyms[8ull * b + 7] != 0ull; }   // repair rounds switch most chunks off
 
   // ring byte x of row r lives at hist[(r * H) ^ hsw(r) ^ (x & HM)]: chunks XOR-swizzled by the row index (bank spread without pad)
@@ -91,6 +93,11 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
       blockAt = monoStarts[b];
       n = (uint32_t)(monoStarts[b + 1] - blockAt);
       nTrueV = (uint32_t)(U - blockAt);
+      if (B != 0u)
+      {
+        const uint64_t blockEnd = (blockAt / B + 1ull) * B;
+        if (blockEnd < U) nTrueV = (uint32_t)(blockEnd - blockAt);
+      }
     }
     else
     {
@@ -301,9 +308,10 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
   };
 
   // ---- stream header ----
-  if (active && !MONO)
+  const bool blockFirst = MONO && B != 0u && active && (blockAt % B) == 0ull;     // split encode: this chunk opens its block's stream
+  if (active && (!MONO || blockFirst))
   {
-    h32(n);
+    h32(MONO ? nTrue : n);                                              // (the block's length; its compressed length is patched in at placement)
     h32(0);
     hflush();
   }
@@ -549,7 +557,7 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
   land();
   wave_sync();
 
-  uint32_t stepsLeft = MONO ? monoSteps : 2u * (B / (uint32_t)Q) + 64u;  // bounded: every step scans a window or lands input
+  uint32_t stepsLeft = MONO ? ((B != 0u) ? (monoSteps & 0xFFFFu) : monoSteps) : 2u * (B / (uint32_t)Q) + 64u;  // bounded: every step scans a window or lands input
 
   while (__ballot(!finished) != 0ull)
   {

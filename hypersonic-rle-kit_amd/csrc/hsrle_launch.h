@@ -208,7 +208,8 @@ inline hipError_t launch_wave_encode(KERNEL k, const WaveEncodeArgs &a, hipStrea
 template <typename KERNEL>
 inline hipError_t launch_mono_encode(KERNEL k, const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st)
 {
-  hipLaunchKernelGGL(k, dim3((a.nBlocks + 63u) / 64u), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, m.starts, m.syms, m.slotOff, m.steps, m.listOut, m.dry, (const uint32_t *)nullptr);
+  // (a.B != 0: chunks of a container's blocks -- a.ringSel[0] is then the number of chunks: hsrle_encode8.hip.h)
+  hipLaunchKernelGGL(k, dim3((a.nBlocks + 63u) / 64u), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, m.starts, m.syms, m.slotOff, m.steps, m.listOut, m.dry, (const uint32_t *)a.ringSel);
   return hipGetLastError();
 }
 

@@ -26,14 +26,20 @@ constexpr uint64_t MONO_NO_CUT = ~0ull;
 // end < U, cutSym[c] its byte; MONO_NO_CUT if there is none.  Piece 0 additionally starts the stream: the host adds position 0.
 // onlySym != nullptr (the Single codecs): only runs of that byte are cuts.
 __global__ __launch_bounds__(64) void k_mono_cuts8(const uint8_t *__restrict__ in, uint64_t U, uint32_t G, uint32_t pieces, uint32_t LONGC, uint64_t *__restrict__ cutPos,
-                                                   uint64_t *__restrict__ cutSym, uint32_t *__restrict__ flags, const uint32_t *__restrict__ onlySym = nullptr)
+                                                   uint64_t *__restrict__ cutSym, uint32_t *__restrict__ flags, const uint32_t *__restrict__ onlySym = nullptr,
+                                                   uint32_t blockB = 0)
 {
+  // blockB != 0 ("split encode" of a container, G divides blockB): every block is a stream of its own -- the scan does not look in front of
+  // the piece's block, and "the end of the input" is the end of that block
   const uint32_t c = blockIdx.x * 64u + threadIdx.x;
   if (c >= pieces) return;
   const uint32_t want = onlySym != nullptr ? (onlySym[0] & 0xFFu) : 0x100u;                // 0x100: any symbol
   const uint64_t x = (uint64_t)c * G;
+  if (x >= U) { cutPos[c] = MONO_NO_CUT; cutSym[c] = 0; flags[c] = 0u; return; }   // (split encode: a piece behind the last, short block)
+  const uint64_t lo = blockB ? (x / blockB) * blockB : 0ull;
+  if (blockB) { const uint64_t be = lo + blockB; if (be < U) U = be; }
   const uint64_t hiEnd = (x + G < U) ? x + G : U;
-  uint64_t i = (x > LONGC) ? x - LONGC : 0;
+  uint64_t i = (x > lo + LONGC) ? x - LONGC : lo;
   uint64_t st = i;
   uint32_t sy = in[i];
   uint64_t found = MONO_NO_CUT;
@@ -90,52 +96,76 @@ __global__ __launch_bounds__(64) void k_mono_cuts8(const uint8_t *__restrict__ i
 // cutSym[c] = that symbol (low S bytes).  Stretches that begin in front of the lane's look-back are not used.
 template <int S, int ALIGNED>
 __global__ __launch_bounds__(64) void k_mono_cutsS(const uint8_t *__restrict__ in, uint64_t U, uint32_t G, uint32_t pieces, uint32_t LONGC, uint64_t *__restrict__ cutPos,
-                                                   uint64_t *__restrict__ cutSym, uint32_t *__restrict__ flags)
+                                                   uint64_t *__restrict__ cutSym, uint32_t *__restrict__ flags, uint32_t blockB = 0)
 {
   const uint32_t c = blockIdx.x * 64u + threadIdx.x;
   if (c >= pieces) return;
   constexpr uint64_t SU = (uint64_t)S;
   const uint64_t x = (uint64_t)c * G;
+  if (x >= U) { cutPos[c] = MONO_NO_CUT; cutSym[c] = 0; flags[c] = 0u; return; }
+  const uint64_t lo = blockB ? (x / blockB) * blockB : 0ull;              // split encode: the piece's block is the whole world (see k_mono_cuts8)
+  if (blockB) { const uint64_t be = lo + blockB; if (be < U) U = be; }
   const uint64_t hiEnd = (x + G < U) ? x + G : U;
   const uint64_t lastCut = (U > 64u + 4u * SU) ? U - 64u - 4u * SU : 0u;     // no cut near the end of the input (its rules look at the end)
   const uint64_t back = (uint64_t)LONGC + 4u * SU + 16u;
-  uint64_t j = (x > back) ? x - back : 0;
+  uint64_t j = (x > lo + back) ? x - back : lo;
   // state of the scan over the match bits: length of the current stretch of set bits and its start; whether that stretch is usable (its
   // start was seen and is clean); position of the zero bit that ended the last stretch of >= S set bits
-  uint64_t ones = (j == 0) ? 0 : SU;            // (a stretch that is open where the scan begins counts as long and is not usable)
+  uint64_t ones = (j == lo) ? 0 : SU;           // (a stretch that is open where the scan begins counts as long and is not usable)
   uint64_t q = j;
   bool usable = false;
-  uint64_t zLong = (j == 0) ? ~0ull : j;        // ~0: none yet.  Scan start: unknown history -> as if a long stretch had just ended here
+  uint64_t zLong = (j == lo) ? ~0ull : j;       // ~0: none yet.  Scan start: unknown history -> as if a long stretch had just ended here
   uint64_t found = MONO_NO_CUT, fsym = 0;
   const uint64_t symMask = (S >= 8) ? ~0ull : ((1ull << (8 * (S & 7))) - 1ull);
-  while (j + SU < U)
+  // 16 positions per trip: their match bits from two 16-byte loads (zero_mask16: the run detectors' movemask), then the stretches of
+  // set / clear bits with ctz -- a trip per position (two byte loads each) was 117 us of the 88 MB frame's 420 us
+  auto stretch_begins = [&](uint64_t at) {
+    q = at;
+    usable = (zLong == ~0ull) || (zLong + SU <= q);                     // clean start: the last long stretch ended >= S positions in front
+    // (16 byte symbols: the first 16 bytes of the stream count as a match of themselves (A.5 q4), a "run" no stretch stands for --
+    //  no cut that close to the start)
+    if (S == 16 && q < lo + 64u) usable = false;
+  };
+  bool done = false;
+  while (!done && j + SU < U)
   {
-    const bool m = in[j] == in[j + SU];
-    if (m)
+    uint32_t m16, have = 16u;                                             // bit k: d[j + k] == d[j + k + S]; `have` of them are positions in front of U - S
+    if (j + 16u + SU <= U)
     {
-      if (ones == 0)
-      {
-        q = j;
-        usable = (zLong == ~0ull) || (zLong + SU <= q);                 // clean start: the last long stretch ended >= S positions in front
-        // (16 byte symbols: the first 16 bytes of the stream count as a match of themselves (A.5 q4), a "run" no stretch stands for --
-        //  no cut that close to the start)
-        if (S == 16 && q < 64u) usable = false;
-      }
-      ones++;
+      const u32x4 a = ld128(in + j), b = ld128(in + j + SU);
+      m16 = zero_mask16(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w);
     }
     else
     {
-      if (ones >= SU)
-      {
-        const uint64_t L = ones;
-        const uint64_t e = ALIGNED ? q + SU * ((L + SU) / SU) : q + SU + L;
-        if (usable && e - q >= LONGC && e > x && e <= hiEnd && e <= lastCut) { found = e; fsym = (S == 16) ? q : (ld64(in + q) & symMask); break; }   // (16 bytes: WHERE the symbol is)
-        zLong = j;
-      }
-      ones = 0;
-      if (j > hiEnd) break;                                              // every later stretch ends behind this piece
+      m16 = 0u; have = (uint32_t)(U - SU - j);
+      for (uint32_t k = 0; k < have; k++) m16 |= (in[j + k] == in[j + k + SU]) ? (1u << k) : 0u;
     }
-    j++;
+    uint32_t pos = 0;
+    while (pos < have)
+    {
+      const uint32_t rest = m16 >> pos;
+      if (rest & 1u)
+      {
+        const uint32_t t = umin((uint32_t)__builtin_ctz(~rest), have - pos);    // set bits from pos on
+        if (ones == 0) stretch_begins(j + pos);
+        ones += t; pos += t;
+      }
+      else
+      {
+        // the stretch (if any) ended in front of position j + pos
+        if (ones >= SU)
+        {
+          const uint64_t L = ones;
+          const uint64_t e = ALIGNED ? q + SU * ((L + SU) / SU) : q + SU + L;
+          if (usable && e - q >= LONGC && e > x && e <= hiEnd && e <= lastCut) { found = e; fsym = (S == 16) ? q : (ld64(in + q) & symMask); done = true; break; }   // (16 bytes: WHERE the symbol is)
+          zLong = j + pos;
+        }
+        ones = 0;
+        if (j + pos > hiEnd) { done = true; break; }                     // every later stretch ends behind this piece
+        pos += umin(rest ? (uint32_t)__builtin_ctz(rest) : 32u, have - pos);     // clear bits from pos on
+      }
+    }
+    j += have;
   }
   cutPos[c] = found;
   cutSym[c] = fsym;
@@ -333,6 +363,90 @@ __global__ void k_mono_finish(uint8_t *__restrict__ out, uint32_t U, uint32_t he
     if (headerSize == 10u) { out[8] = 1; out[9] = (uint8_t)ctrlIn[8]; }  // 8 bit Single: mode 1 and the symbol (k_single_pick_final left it in ctrl[8])
     ctrl[2] = (uint32_t)total; ctrl[3] = (uint32_t)(total >> 32);
   }
+}
+
+// ---- split encode: the chunk table of a CONTAINER (blocks of B bytes, pieces of G = B / ppb bytes).  Chunk starts = the block starts and the
+//      cuts; idx = exclusive scan of the pieces' cut flags.  Piece p's cut opens chunk idx[p] + p / ppb + 1 (every block start up to and including
+//      p's block comes first), block b opens chunk idx[b * ppb] + b.  ctrl[0] = the number of chunks.
+__global__ __launch_bounds__(256) void k_split_scatter(const uint64_t *__restrict__ cutPos, const uint64_t *__restrict__ cutSym, const uint32_t *__restrict__ flags,
+                                                       const uint64_t *__restrict__ idx, uint32_t pieces, uint32_t ppb, uint32_t nBlocks, uint64_t U, uint32_t B,
+                                                       uint64_t *__restrict__ starts, uint64_t *__restrict__ syms, uint64_t *__restrict__ slotOff, uint32_t *__restrict__ firstChunk,
+                                                       uint32_t *__restrict__ ctrl, uint32_t listWords)
+{
+  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  auto slot_of = [](uint64_t at, uint64_t k) -> uint64_t { return (at + (at >> 7) + 256ull * k + 15ull) & ~15ull; };
+  if (p == 0u)
+  {
+    const uint64_t total = idx[pieces] + nBlocks;
+    starts[total] = U;
+    firstChunk[nBlocks] = (uint32_t)total;
+    ctrl[0] = (uint32_t)total;
+  }
+  if (p >= pieces) return;
+  const uint32_t b = p / ppb;
+  if (p % ppb == 0u)
+  {
+    const uint64_t k = idx[p] + b, at = (uint64_t)b * B;
+    starts[k] = at; slotOff[k] = slot_of(at, k); firstChunk[b] = (uint32_t)k;
+    if (listWords == 0u) syms[k] = 0ull;                                 // (codecs with a list: syms is the guess array, filled by k_mono_list_default)
+  }
+  if (flags[p] != 0u)
+  {
+    const uint64_t k = idx[p] + b + 1ull;
+    starts[k] = cutPos[p]; slotOff[k] = slot_of(cutPos[p], k);
+    if (listWords == 0u) syms[k] = cutSym[p];
+  }
+}
+
+// split encode, list codecs: after the pass from the default lists every chunk knows what it does to a list (its d leading symbols, listOut);
+// the list in front of chunk c = those of the chunks in front of it IN ITS BLOCK composed over the default list (at most ppb of them)
+__global__ __launch_bounds__(256) void k_split_list_guess(uint64_t *__restrict__ guess, const uint64_t *__restrict__ listOut, const uint64_t *__restrict__ starts, const uint32_t *__restrict__ ctrl,
+                                                          uint32_t B, uint32_t K, uint32_t S, uint32_t *__restrict__ todo)
+{
+  const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+  if (c >= ctrl[0]) return;
+  MonoListAcc a; a.n = 0;
+#pragma unroll
+  for (int k = 0; k < 7; k++) a.e[k] = 0;
+  for (uint32_t i = c; a.n < K && (starts[i] % B) != 0ull; i--) a.add(listOut + 8ull * (i - 1u), K);      // (chunk i does not open its block: chunk i - 1 is in it)
+  for (uint32_t k = 0; k < K && a.n < K; k++) a.add_one(mono_default_entry(k, S), K);
+  bool changed = false;
+#pragma unroll
+  for (int k = 0; k < 7; k++)
+    if ((uint32_t)k < K && guess[8ull * c + k] != a.e[k]) { changed = true; guess[8ull * c + k] = a.e[k]; }
+  guess[8ull * c + 7] = changed ? 1ull : 0ull;
+  if (changed) atomicAdd(todo, 1u);
+}
+
+// the proof for the list codecs, block aware: chunk c's list against the list chunk c - 1 ended with -- or the default list if c opens a block
+__global__ __launch_bounds__(256) void k_split_list_verify(uint64_t *__restrict__ guess, const uint64_t *__restrict__ listOut, const uint64_t *__restrict__ starts, const uint32_t *__restrict__ ctrl,
+                                                           uint32_t B, uint32_t K, uint32_t S, uint32_t *__restrict__ bad)
+{
+  const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+  if (c >= ctrl[0]) return;
+  const bool opens = (starts[c] % B) == 0ull;
+  bool wrong = false;
+#pragma unroll
+  for (int k = 0; k < 7; k++)
+    if ((uint32_t)k < K)
+    {
+      const uint64_t want = opens ? mono_default_entry((uint32_t)k, S) : listOut[8ull * (c - 1u) + k];
+      if (guess[8ull * c + k] != want) { wrong = true; guess[8ull * c + k] = want; }
+    }
+  guess[8ull * c + 7] = wrong ? 1ull : 0ull;
+  if (wrong) atomicAdd(bad, 1u);
+}
+
+// after the placement of the chunks: the container's offset table and every block stream's compressedLength field
+__global__ __launch_bounds__(256) void k_split_finish(const uint32_t *__restrict__ firstChunk, const uint64_t *__restrict__ chunkOff, uint32_t nBlocks, uint64_t *__restrict__ offsets,
+                                                      uint8_t *__restrict__ payload)
+{
+  const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+  if (b >= nBlocks) return;
+  const uint64_t off = chunkOff[firstChunk[b]], next = chunkOff[firstChunk[b + 1u]];
+  offsets[b] = off;
+  st32(payload + off + 4, (uint32_t)(next - off));
+  if (b + 1u == nBlocks) offsets[nBlocks] = next;
 }
 
 // ---- the symbol pick for ONE monolithic stream (hsrle_mono_encode.hip.h: the drop-in rle8_single_compress / rle8_packed_single_compress by many
