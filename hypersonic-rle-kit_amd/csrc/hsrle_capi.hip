@@ -774,7 +774,7 @@ static int decompress_wave_async(const void *dContainer, const hsrle_container_i
     return HSRLE_ERR_ARGUMENT;
   if (info->codec >= (uint32_t)kCodecCount || !valid_block_size(info->blockSize) || info->blockCount != block_count(info->uncompressedSize, info->blockSize))
     return HSRLE_ERR_FORMAT;
-  if (info->blockSize > 16384u)
+  if (info->blockSize > 16384u || !kExperiments)                        // (the wave-per-block decoder is not part of the shipped build: measured slower than the split decode)
     return HSRLE_ERR_UNSUPPORTED;
   if ((uint64_t)first + count > info->blockCount)
     return HSRLE_ERR_ARGUMENT;

@@ -47,7 +47,7 @@ def main():
         ok = int(status.item()) == 0 and torch.equal(out, src)
         print(f"  sub-block {sub:5d} (-> {eff:5d}): {ms * 1e3:8.1f} us  {args.size / 2**30 / (ms * 1e-3):8.1f} GiB/s  {(args.size + info.totalSize) / (ms * 1e-3) / 1e12:6.3f} TB/s algorithmic  exact {ok}", flush=True)
     # one wave per block (hsrle_decompress_wave_dev_async)
-    if args.block <= 16384:
+    if args.block <= 16384 and hsrle.experiments_enabled():
         run = lambda: hsrle.decompress_wave_async(container, info, out, status)
         out.zero_()
         for _ in range(3):
