@@ -58,7 +58,30 @@ for name, kind in (("runs", hsrle.SYNTH_RUNS), ("noise", None)):
     backc = hd.scatter_container_c(fullc, fullc.numel(), root=0)
     torch.cuda.synchronize()
     assert torch.equal(backc, full), "C-ABI scatter(gather(x)) != x"
-    del src, container, full, back, out, dst, fullc, backc
+    # error paths of the C ABI (round 3: every rank draws its verdict from exchanged words BEFORE any point-to-point transfer is posted, so
+    # an error is an error code on every rank, never a hang): root without room, shard without room, a header that lies
+    import ctypes
+    L = hsrle.lib(); comm = hd.c_comm(); stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.hsrle_gather_container_rccl.restype = ctypes.c_int
+    L.hsrle_gather_container_rccl.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p]
+    L.hsrle_scatter_container_rccl.restype = ctypes.c_int
+    L.hsrle_scatter_container_rccl.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p]
+    small = torch.empty(1024, dtype=torch.uint8, device=dev); total = ctypes.c_uint64(0)
+    rc = L.hsrle_gather_container_rccl(comm, 0, ctypes.c_void_p(container.data_ptr()), container.numel(), size, ctypes.c_void_p(small.data_ptr()), small.numel(), ctypes.byref(total), stream)
+    assert rc == 2 and total.value == full.numel(), ("gather into a root without room", rc)            # HSRLE_ERR_CAPACITY, and the size it needs
+    rc = L.hsrle_gather_container_rccl(comm, 0, ctypes.c_void_p(container.data_ptr()), container.numel(), size, None, 0, ctypes.byref(total), stream)
+    assert rc == 2, ("gather without an output buffer", rc)
+    rc = L.hsrle_scatter_container_rccl(comm, 0, ctypes.c_void_p(full.data_ptr()), full.numel(), ctypes.c_void_p(small.data_ptr()), small.numel(), ctypes.byref(total), stream)
+    assert rc == 2, ("scatter into a shard without room", rc)
+    bad = full.clone(); bad[40:48] = 0xFF                                  # totalSize: the header no longer describes the container
+    big = torch.empty(full.numel() + 4096, dtype=torch.uint8, device=dev)
+    rc = L.hsrle_scatter_container_rccl(comm, 0, ctypes.c_void_p(bad.data_ptr()), bad.numel(), ctypes.c_void_p(big.data_ptr()), big.numel(), ctypes.byref(total), stream)
+    assert rc == 3, ("scatter of a container whose header lies", rc)                                   # HSRLE_ERR_FORMAT
+    rc = L.hsrle_gather_container_rccl(comm, 0, ctypes.c_void_p(bad.data_ptr()), bad.numel(), size, ctypes.c_void_p(big.data_ptr()), big.numel(), ctypes.byref(total), stream)
+    assert rc == 3, ("gather of a local container whose header lies", rc)
+    res["c_error_paths_" + name] = "ok"
+    del src, container, full, back, out, dst, fullc, backc, bad, big, small
+hd.destroy_c_comms()
 dist.destroy_process_group()
 print("RESULT " + json.dumps(res))
 """
