@@ -444,7 +444,7 @@ static uint32_t encode_chunk_blocks()
 // Split encode (hsrle_mono_encode.hip.h): containers with too few blocks for one lane each are encoded chunk by chunk -- the blocks cut behind
 // runs every encoder state stores, like a monolithic stream, with the block starts as forced cuts.  kSplitPieces pieces (= cut finder lanes) per block.
 constexpr uint32_t kSplitEncodeBelow = 131072u;   // blocks: from here on one lane per block fills the device
-constexpr uint32_t kSplitPieces = 4u;
+constexpr uint32_t kSplitPieces = 4u, kSplitPiecesMax = 8u;             // (the workspace is planned for the larger number: split_pieces())
 static bool split_encode_applies(int codec, uint64_t nBlocks, uint32_t B);
 
 struct Workspace
@@ -473,7 +473,7 @@ static Workspace plan_workspace(uint64_t U, uint32_t B)
   w.offL2 = at; at += align_up((w.t2 + 1) * 8ull, 256);
   w.offL3 = at; at += align_up((w.t3 + 1) * 8ull, 256);
   // (split encode regions: sized for every codec, used by small containers only)
-  w.spPieces = w.nBlocks * kSplitPieces; w.spMaxChunks = w.spPieces + w.nBlocks;
+  w.spPieces = w.nBlocks * kSplitPiecesMax; w.spMaxChunks = w.spPieces + w.nBlocks;
   w.spCutPos = w.spCutSym = w.spFlags = w.spIdx = w.spStarts = w.spSyms = w.spSlotOff = w.spSizes = w.spChunkOff = w.spFirst = w.spCtrl = w.spGuess = w.spListOut = w.spSlots = w.spL1 = w.spL2 = w.spL3 = 0;
   if (w.nBlocks < kSplitEncodeBelow && B >= 1024u && B <= (1u << 20))
   {
@@ -488,8 +488,8 @@ static Workspace plan_workspace(uint64_t U, uint32_t B)
     w.spSlotOff = at; at += align_up(8ull * (nc + 1), 256);
     w.spSizes = at; at += align_up(4ull * (nc + 1), 256);
     w.spChunkOff = at; at += align_up(8ull * (nc + 2), 256);
+    w.spCtrl = at; at += 256;                                            // (the table of first chunks follows the control words directly: the ring encoders find it at ctrl + 64)
     w.spFirst = at; at += align_up(4ull * (w.nBlocks + 2), 256);
-    w.spCtrl = at; at += 256;
     w.spGuess = at; at += align_up(64ull * (nc + 1), 256);
     w.spListOut = at; at += align_up(64ull * (nc + 1), 256);
     w.spL1 = at; at += align_up(8ull * (s1 + 1), 256);
@@ -1047,6 +1047,16 @@ static uint32_t mono_cut_long(int codec, int *pS = nullptr, int *pAligned = null
   return longc;
 }
 
+// pieces per block (= cut finder lanes; a block has at most pieces + 1 chunks).  8 pieces were measured for the list codecs that settle their
+// lists inside the encode kernel (88 MB frame / 64 MiB runs, us: rle64_3symlut_byte 4: 310 / 378, 8: 341 / 485; rle32_7symlut_sym 4: 411 / 355,
+// 8: 409 / 328; rle16_3symlut_byte 4: 434 / 315, 8: 497 / 327): the kernel's time follows its total trips, not the trips per wave, so
+// shorter chunks buy nothing.  The workspace is planned for kSplitPiecesMax so that experiment builds can try (HSRLE_SPLIT_PIECES).
+static uint32_t split_pieces(uint32_t B)
+{
+  const uint32_t k = knob_u32("HSRLE_SPLIT_PIECES", kSplitPieces);
+  return (k == kSplitPiecesMax && B % (kSplitPiecesMax * 128u) == 0u) ? k : kSplitPieces;
+}
+
 static bool split_encode_applies(int codec, uint64_t nBlocks, uint32_t B)
 {
   // the codecs whose ring encoders have the chunk mode (not Single, not 128 bit: their chunk encoders are the per-lane ones of the monolithic path)
@@ -1064,7 +1074,8 @@ static int compress_split(int codec, const uint8_t *dIn, uint64_t U, uint32_t B,
 {
   int S = 1, aligned = 0, listK = 0;
   const uint32_t longc = mono_cut_long(codec, &S, &aligned, &listK);
-  const uint32_t G = B / kSplitPieces, pieces = (uint32_t)w.spPieces, maxChunks = (uint32_t)w.spMaxChunks;
+  const uint32_t ppb = split_pieces(B);
+  const uint32_t G = B / ppb, pieces = nBlocks * ppb, maxChunks = pieces + nBlocks;
   uint64_t *cutPos = (uint64_t *)(ws + w.spCutPos), *cutSym = (uint64_t *)(ws + w.spCutSym), *idx = (uint64_t *)(ws + w.spIdx), *starts = (uint64_t *)(ws + w.spStarts);
   uint64_t *syms = (uint64_t *)(ws + w.spSyms), *slotOff = (uint64_t *)(ws + w.spSlotOff), *chunkOff = (uint64_t *)(ws + w.spChunkOff);
   uint64_t *guess = (uint64_t *)(ws + w.spGuess), *listOut = (uint64_t *)(ws + w.spListOut);
@@ -1091,18 +1102,21 @@ static int compress_split(int codec, const uint8_t *dIn, uint64_t U, uint32_t B,
     return HSRLE_ERR_DEVICE;
   if (listK != 0)
     hipLaunchKernelGGL(k_mono_list_default, dim3((maxChunks + 255u) / 256u), dim3(256), 0, st, maxChunks, (uint32_t)listK, (uint32_t)S, guess);
+  // list codecs of 2 .. 8 byte symbols settle their lists INSIDE the encode kernel: a wave takes the chunks of kSplitGroup whole blocks (k_encodeS_blocks)
+  const uint32_t kSplitGroup = 64u / (ppb + 1u);                         // blocks per wave: x (ppb + 1) chunks at most <= a wave's 64 lanes
+  const bool inKernelLists = listK != 0 && S > 1;
   hipLaunchKernelGGL(k_split_scatter, dim3((pieces + 255u) / 256u), dim3(256), 0, st, (const uint64_t *)cutPos, (const uint64_t *)cutSym, (const uint32_t *)flags, (const uint64_t *)idx, pieces,
-                     kSplitPieces, nBlocks, U, B, starts, listK ? guess : syms, slotOff, firstChunk, ctrl, (uint32_t)listK);
+                     ppb, nBlocks, U, B, starts, listK ? guess : syms, slotOff, firstChunk, ctrl, (uint32_t)listK, inKernelLists ? kSplitGroup : 0u);
 
-  EncodeArgs ea{ dIn, U, B, maxChunks, ws + w.spSlots, 0u, sizes };
-  ea.ringSel = ctrl;                                                     // chunk mode with B: ctrl[0] = the number of chunks
+  EncodeArgs ea{ dIn, U, B, inKernelLists ? ((nBlocks + kSplitGroup - 1u) / kSplitGroup) * 64u : maxChunks, ws + w.spSlots, 0u, sizes };
+  ea.ringSel = ctrl;                                                     // chunk mode with B: ctrl[0] = the number of chunks, [1] = blocks per wave (0: chunks in a row), [2] = blocks
   MonoEncodeArgs ma{ starts, listK ? guess : syms, slotOff, 2u * (B / 64u) + 64u };
   ma.listOut = listK ? listOut : nullptr;
   if (g_menc[codec](ea, ma, st) != hipSuccess)
     return HSRLE_ERR_DEVICE;
-  if (listK != 0)
+  if (listK != 0 && !inKernelLists)
   {
-    // What every chunk does to a list is known from the first pass: the lists in front of all chunks at once, then the chunks whose list is
+    // (8 bit symbols: between launches.)  What every chunk does to a list is known from the first pass: the lists in front of all chunks at once, then the chunks whose list is
     // not the default one again (run-distributed rle64_3symlut_byte: every chunk).  Then the proof, with repair: a re-encoded chunk may store
     // other runs than it did from the default list and leave another list behind; after the pass above the first two chunks of every block are
     // final, every verify round makes one more so, and a block has at most kSplitPieces + 1 chunks.  The rounds tell the encoder which
@@ -1113,7 +1127,7 @@ static int compress_split(int codec, const uint8_t *dIn, uint64_t U, uint32_t B,
     ma.steps = base | (1u << 16);
     if (g_menc[codec](ea, ma, st) != hipSuccess)
       return HSRLE_ERR_DEVICE;
-    for (uint32_t round = 0; round + 1u < kSplitPieces; round++)
+    for (uint32_t round = 0; round + 1u < ppb; round++)
     {
       hipLaunchKernelGGL(k_split_list_verify, dim3((maxChunks + 255u) / 256u), dim3(256), 0, st, guess, (const uint64_t *)listOut, (const uint64_t *)starts, (const uint32_t *)ctrl, B, (uint32_t)listK,
                          (uint32_t)S, ctrl + 9 + round);

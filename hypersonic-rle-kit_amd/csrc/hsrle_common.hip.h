@@ -248,4 +248,43 @@ struct LaneRing
   }
 };
 
+// ---- move-to-front lists as transformers (hsrle_mono_encode.hip.h: what a chunk does to the list in front of it is "these d symbols, most
+//      recent first, now lead"): lists are 8 words per chunk, entry k in word k, word 7 = d (results) / "encode me" (guesses) ----
+__device__ __forceinline__ uint64_t mono_default_entry(uint32_t k, uint32_t S)
+{
+  // 0x00, 0x7F, 0xFF, 0x01, 0x7E, 0x80, 0xFE in every symbol byte (rleX_Xsl.h: the initial list)
+  const uint64_t b = (0xFE807E01FF7F00ull >> (8u * k)) & 0xFFull;
+  const uint64_t all = b * 0x0101010101010101ull;
+  return (S >= 8u) ? all : (all & ((1ull << (8u * S)) - 1ull));
+}
+
+// newest-first accumulation of at most K distinct symbols
+struct MonoListAcc
+{
+  uint64_t e[7];
+  uint32_t n;
+  __device__ __forceinline__ void add_one(uint64_t v, uint32_t K)
+  {
+    bool have = false;
+#pragma unroll
+    for (int k = 0; k < 7; k++) have = have || ((uint32_t)k < n && e[k] == v);
+    if (!have && n < K)
+    {
+#pragma unroll
+      for (int k = 0; k < 7; k++) if ((uint32_t)k == n) e[k] = v;
+      n++;
+    }
+  }
+  __device__ __forceinline__ void add(const uint64_t *__restrict__ t, uint32_t K)
+  {
+    const uint32_t d = (uint32_t)t[7];
+#pragma unroll
+    for (int j = 0; j < 7; j++)
+      if ((uint32_t)j < d && n < K) add_one(t[j], K);
+  }
+};
+
+// a word another lane of this wave may have rewritten since this lane last read its line: past the L1
+__device__ __forceinline__ uint64_t ld_fresh64(const uint64_t *p) { return __hip_atomic_load(const_cast<uint64_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 } // namespace hsrle

@@ -74,10 +74,35 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
   const uint32_t lane = threadIdx.x;
   const uint32_t wgFirst = xcd_tile(blockIdx.x, gridDim.x) * 64u;    // XCD-aware tile order (hsrle_common.hip.h)
   if constexpr (MONO) { if (B != 0u && ringSel != nullptr && (monoSteps >> 16) != 0u && ringSel[7u + (monoSteps >> 16)] == 0u) return; }   // an empty repair round (see k_encode8_blocks)
-  const uint32_t b = wgFirst + lane;
+  // Split encode of a list codec with the lists settled IN the kernel (ringSel[1] = grp != 0): a wave takes the chunks of grp whole blocks
+  // (their chunks are consecutive: lane = chunk - first chunk of the wave's first block; ringSel + 64 = first chunk of every block, ringSel[2] = blocks;
+  // the host chooses grp so that grp blocks never have more than 64 chunks), so every chunk
+  // a chunk's list depends on sits in the same wave -- after a pass the lanes compose the lists from what the chunks in front of them left
+  // (as k_split_list_guess does between launches) and the chunks whose list changed go round again: no proof launches that find nothing
+  // (4 x 21 us of the 88 MB frame's 332).  All other modes make one round.
+  [[maybe_unused]] const uint32_t grp = (MONO && B != 0u && ringSel != nullptr) ? ringSel[1] : 0u;
+  for (uint32_t listRound = 0;; listRound++)
+  {
+  uint32_t b = wgFirst + lane;
   bool active = b < nBlocks;
-  if constexpr (MONO) { if (B != 0u && ringSel != nullptr) active = b < ringSel[0]; }     // split encode (see k_encode8_blocks): chunks of a container's blocks, their number on the device
-  if constexpr (MONO && Traits<FAM, S, AL>::kMtf) { if (active) active = monoSyms[8ull * b + 7] != 0ull; }   // repair rounds switch most chunks off
+  [[maybe_unused]] uint32_t blockFirstChunk = 0;
+  [[maybe_unused]] bool mine = false;
+  if constexpr (MONO)
+  {
+    if (grp != 0u)
+    {
+      const uint32_t *const first = ringSel + 64;
+      const uint32_t blk0 = blockIdx.x * grp, blk1 = umin(blk0 + grp, ringSel[2]);
+      active = false;
+      if (blk0 < blk1)
+      {
+        const uint32_t c0 = first[blk0];
+        if (lane < first[blk1] - c0) { b = c0 + lane; active = true; mine = true; blockFirstChunk = first[(uint32_t)(monoStarts[b] / B)]; }
+      }
+    }
+    else if (B != 0u && ringSel != nullptr) active = b < ringSel[0];   // split encode (see k_encode8_blocks): chunks of a container's blocks, their number on the device
+  }
+  if constexpr (MONO && Traits<FAM, S, AL>::kMtf) { if (active) active = ld_fresh64(monoSyms + 8ull * b + 7) != 0ull; }   // repair rounds switch most chunks off
 
   // ring byte x of row r lives at hist[(r * H) ^ hsw(r) ^ (x & HM)]: chunks XOR-swizzled by the row index (bank spread without pad)
   auto hsw_of = [](uint32_t r) -> uint32_t { return (r & 7u) << 4; };
@@ -140,7 +165,7 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
     if (active)
     {
 #pragma unroll
-      for (int k = 0; k < K; k++) { const uint64_t v = monoSyms[8ull * b + k]; lut0[k] = (uint32_t)v; lut1[k] = (uint32_t)(v >> 32); }
+      for (int k = 0; k < K; k++) { const uint64_t v = ld_fresh64(monoSyms + 8ull * b + k); lut0[k] = (uint32_t)v; lut1[k] = (uint32_t)(v >> 32); }
     }
   }
 
@@ -155,6 +180,7 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
   // the stream; the bytes behind it (< 16) are fetched into the accumulator.  Literals between two stored runs are NOT noted: with
   // the noting code inlined into handle_run the encoders lost 4 - 7 % on every input (same-box A/B), whatever the threshold.
   uint32_t pendSrc = 0, pendDst = 0, pendBytes = 0, pend2Src = 0, pend2Dst = 0, pend2Bytes = 0;
+  [[maybe_unused]] bool tailNoted = false;   // MONO: the stream's last bytes are part of a noted stretch (no store of the last partial chunk)
   auto store_bytes = [&](uint8_t *p, u32x4 w, uint32_t lo, uint32_t hi) __attribute__((always_inline)) {
     const uint64_t w0 = (uint64_t)w.x | ((uint64_t)w.y << 32), w1 = (uint64_t)w.z | ((uint64_t)w.w << 32);
     if (!dry)
@@ -227,19 +253,35 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
       }
       oacc = w;
     }
-    else if (mayNote && len >= kNotedLiteralMin && (pendBytes == 0u || pend2Bytes == 0u))
+    else if (mayNote && (MONO || len >= kNotedLiteralMin) && (pendBytes == 0u || pend2Bytes == 0u))
     {
       // what the accumulator holds goes out now; the stretch is noted up to the last 16-byte boundary of the stream it reaches; the
       // bytes behind that boundary come into the accumulator (through LDS: see below)
       if (c != 0u) store_bytes(dst, oacc, 0u, c);
-      const uint32_t tail = (opos + len) & 15u, noted = len - tail;
-      if (!dry)
+      if constexpr (MONO)
       {
-        if (pendBytes == 0u) { pendSrc = at; pendDst = opos; pendBytes = noted; }
-        else { pend2Src = at; pend2Dst = opos; pend2Bytes = noted; }
+        // Chunk encoders: whatever has left the ring is noted, whole -- these are the last bytes of the stream (only finish_literals may
+        // note), so the accumulator is not needed again and the lane neither loads nor waits.  Fetching a 112 .. 255 byte tail in the
+        // lane's own code cost a drained memory pipeline per 16 bytes with one lane active: 12 us per block end, 83 % of the split
+        // encode kernel of the 88 MB frame (rle64_3symlut_byte, 200 us).
+        if (!dry)
+        {
+          if (pendBytes == 0u) { pendSrc = at; pendDst = opos; pendBytes = len; }
+          else { pend2Src = at; pend2Dst = opos; pend2Bytes = len; }
+        }
+        tailNoted = true;
       }
-      lds_st128(accScratch + lane * 16u, tail != 0u ? global_window16(in, blockAt, U, at + noted) : zero4);
-      oacc = lds_ld128(accScratch + lane * 16u);
+      else
+      {
+        const uint32_t tail = (opos + len) & 15u, noted = len - tail;
+        if (!dry)
+        {
+          if (pendBytes == 0u) { pendSrc = at; pendDst = opos; pendBytes = noted; }
+          else { pend2Src = at; pend2Dst = opos; pend2Bytes = noted; }
+        }
+        lds_st128(accScratch + lane * 16u, tail != 0u ? global_window16(in, blockAt, U, at + noted) : zero4);
+        oacc = lds_ld128(accScratch + lane * 16u);
+      }
     }
     else
     {
@@ -640,7 +682,7 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
         // end of input: the literal terminator unless the stream ended with a run
         if (!ended && n == nTrue) { finish_literals(); ended = true; }
         // the last partial chunk, then the stream size (header field compressedLength and the size table)
-        if ((opos & 15u) != 0u && !dry)
+        if ((opos & 15u) != 0u && !dry && !(MONO && tailNoted))
           st128(slot + (opos & ~15u), oacc);
         if constexpr (!MONO) st32(slot + 4, opos);
         if (!dry) sizes[b] = opos;
@@ -659,6 +701,40 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
     wave_sync();
   }
   coop_flush(true);
+  if constexpr (MONO && Traits<FAM, S, AL>::kMtf)
+  {
+    if (grp == 0u) break;
+    // the lists in front of this wave's chunks from what the chunks left behind (all of a block's chunks are here: no other wave writes
+    // what is read below); a chunk whose list comes out different is switched on for the next round
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    wave_sync();
+    bool changed = false;
+    if (mine)
+    {
+      MonoListAcc a; a.n = 0;
+#pragma unroll
+      for (int k = 0; k < 7; k++) a.e[k] = 0;
+      for (uint32_t i = b; i > blockFirstChunk && a.n < (uint32_t)K; i--)
+      {
+        uint64_t t[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) t[k] = ld_fresh64(monoListOut + 8ull * (i - 1u) + k);
+        a.add(t, (uint32_t)K);
+      }
+      for (uint32_t k = 0; k < (uint32_t)K && a.n < (uint32_t)K; k++) a.add_one(mono_default_entry(k, (uint32_t)S), (uint32_t)K);
+      uint64_t *const g = const_cast<uint64_t *>(monoSyms) + 8ull * b;
+#pragma unroll
+      for (int k = 0; k < 7; k++)
+        if (k < K && ld_fresh64(g + k) != a.e[k]) { changed = true; g[k] = a.e[k]; }
+      g[7] = changed ? 1ull : 0ull;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (__ballot(changed) == 0ull || listRound >= 64u) break;           // (a block's chunks settle one per round at worst)
+    wave_sync();
+  }
+  else
+    break;
+  }
 }
 
 } // namespace hsrle

@@ -227,39 +227,7 @@ __global__ __launch_bounds__(256) void k_mono_longest(const uint64_t *__restrict
 //      right list and go through 3 again.)
 // Lists are 8 words per chunk: entry k (the symbol, S bytes, zero-extended) in word k, word 7 = d (results) / "encode me" (guesses).
 
-__device__ __forceinline__ uint64_t mono_default_entry(uint32_t k, uint32_t S)
-{
-  // 0x00, 0x7F, 0xFF, 0x01, 0x7E, 0x80, 0xFE in every symbol byte (rleX_Xsl.h: the initial list)
-  const uint64_t b = (0xFE807E01FF7F00ull >> (8u * k)) & 0xFFull;
-  const uint64_t all = b * 0x0101010101010101ull;
-  return (S >= 8u) ? all : (all & ((1ull << (8u * S)) - 1ull));
-}
-
-// newest-first accumulation of at most K distinct symbols
-struct MonoListAcc
-{
-  uint64_t e[7];
-  uint32_t n;
-  __device__ __forceinline__ void add_one(uint64_t v, uint32_t K)
-  {
-    bool have = false;
-#pragma unroll
-    for (int k = 0; k < 7; k++) have = have || ((uint32_t)k < n && e[k] == v);
-    if (!have && n < K)
-    {
-#pragma unroll
-      for (int k = 0; k < 7; k++) if ((uint32_t)k == n) e[k] = v;
-      n++;
-    }
-  }
-  __device__ __forceinline__ void add(const uint64_t *__restrict__ t, uint32_t K)
-  {
-    const uint32_t d = (uint32_t)t[7];
-#pragma unroll
-    for (int j = 0; j < 7; j++)
-      if ((uint32_t)j < d && n < K) add_one(t[j], K);
-  }
-};
+// (mono_default_entry, MonoListAcc: hsrle_common.hip.h -- the ring encoders compose lists in their split mode too)
 
 // roll-ups: out[t] = the transformers src[64 t .. 64 t + 63] composed (one lane each)
 __global__ __launch_bounds__(64) void k_mono_list_tiles(const uint64_t *__restrict__ src, uint32_t count, uint32_t K, uint64_t *__restrict__ out)
@@ -371,7 +339,7 @@ __global__ void k_mono_finish(uint8_t *__restrict__ out, uint32_t U, uint32_t he
 __global__ __launch_bounds__(256) void k_split_scatter(const uint64_t *__restrict__ cutPos, const uint64_t *__restrict__ cutSym, const uint32_t *__restrict__ flags,
                                                        const uint64_t *__restrict__ idx, uint32_t pieces, uint32_t ppb, uint32_t nBlocks, uint64_t U, uint32_t B,
                                                        uint64_t *__restrict__ starts, uint64_t *__restrict__ syms, uint64_t *__restrict__ slotOff, uint32_t *__restrict__ firstChunk,
-                                                       uint32_t *__restrict__ ctrl, uint32_t listWords)
+                                                       uint32_t *__restrict__ ctrl, uint32_t listWords, uint32_t blocksPerWave)
 {
   const uint32_t p = blockIdx.x * 256u + threadIdx.x;
   auto slot_of = [](uint64_t at, uint64_t k) -> uint64_t { return (at + (at >> 7) + 256ull * k + 15ull) & ~15ull; };
@@ -381,6 +349,8 @@ __global__ __launch_bounds__(256) void k_split_scatter(const uint64_t *__restric
     starts[total] = U;
     firstChunk[nBlocks] = (uint32_t)total;
     ctrl[0] = (uint32_t)total;
+    ctrl[1] = blocksPerWave;                                             // != 0: the encoder takes whole blocks per wave and settles the lists itself
+    ctrl[2] = nBlocks;
   }
   if (p >= pieces) return;
   const uint32_t b = p / ppb;
