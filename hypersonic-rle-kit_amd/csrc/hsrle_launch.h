@@ -139,6 +139,13 @@ inline hipError_t launch_decode_ring(K128 k128, K64 k64, const DecodeArgs &a, hi
   return launch_decode(k128, a, st);
 }
 
+// rle8_multi / rle8_packed_multi: which containers the run list encoder takes (hsrle_encode8r.hip.h; force: 1 always, 2 never -- experiment builds)
+inline bool run_list_applies(uint64_t nBlocks, uint32_t B, uint64_t U, uint32_t force = 0u)
+{
+  if (B < 1024u || B > 4096u || U < 1024u || force == 2u) return false;
+  return force == 1u || nBlocks < 131072u;
+}
+
 template <typename KERNEL>
 inline hipError_t launch_encode(KERNEL k, const EncodeArgs &a, hipStream_t st, int capResidency = 1)
 {

@@ -4,6 +4,7 @@
 #include "hsrle_decode.hip.h"
 #include "hsrle_encode.hip.h"
 #include "hsrle_encode8.hip.h"
+#include "hsrle_encode8r.hip.h"
 #ifdef HSRLE_EXPERIMENTS
 #include "hsrle_encode8w.hip.h"        // one wave per block: bit-exact, measured slower
 #endif
@@ -35,8 +36,23 @@ static hipError_t enc_short7(const EncodeArgs &a, hipStream_t st) { return launc
 
 static hipError_t dec_short_single(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<SHORT_SINGLE, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, k_decode_blocks<SHORT_SINGLE, 1, 0, kDecodeTile, 64, kDecodeStep>, a, st); }
 
-static hipError_t enc_plain(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<PLAIN, false, 256>, k_encode8_blocks<PLAIN, false, 128>, a, st); }
-static hipError_t enc_packed(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<PACKED, false, 256>, k_encode8_blocks<PACKED, false, 128>, a, st); }
+// rle8_multi / rle8_packed_multi: the ring encoder (one lane per block) for containers that fill the device with it, the run list encoder
+// (hsrle_encode8r.hip.h: the whole wave per block) for smaller ones of 1 .. 4 KiB blocks.  Experiment builds: HSRLE_RUNLIST=1 / 2 = always / never.
+template <int FAM>
+static hipError_t enc_multi8(const EncodeArgs &a, hipStream_t st)
+{
+  static const uint32_t force = knob_u32("HSRLE_RUNLIST", 0u);
+  if (run_list_applies(a.nBlocks, a.B, a.U, force) && a.residentWorkgroups == nullptr)
+  {
+    const uint32_t want = (a.nBlocks + 2303u) / 2304u;                   // (9 waves per CU resident: all of a small container's waves at once)
+    const uint32_t bpw = knob_u32("HSRLE_RL_BPW", want > 64u ? 64u : want);
+    hipLaunchKernelGGL((k_encode8_runlist<FAM>), dim3((a.nBlocks + bpw - 1u) / bpw), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, bpw);
+    return hipGetLastError();
+  }
+  return launch_encode_ring<1>(k_encode8_blocks<FAM, false, 256>, k_encode8_blocks<FAM, false, 128>, a, st);
+}
+static hipError_t enc_plain(const EncodeArgs &a, hipStream_t st) { return enc_multi8<PLAIN>(a, st); }
+static hipError_t enc_packed(const EncodeArgs &a, hipStream_t st) { return enc_multi8<PACKED>(a, st); }
 static hipError_t enc_lut3(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<LUT3, false, 256>, k_encode8_blocks<LUT3, false, 128>, a, st); }
 static hipError_t enc_lut7(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<LUT7, false, 256>, k_encode8_blocks<LUT7, false, 128>, a, st); }
 // Single: symbol pick by one wave per block, then the ring encoder (hsrle_encode8s.hip.h).  Blocks above kSinglePickMaxBlock (the one-lane

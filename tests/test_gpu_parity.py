@@ -448,9 +448,11 @@ def test_compress_and_decompress_are_graph_capturable(hs):
         assert int(status[0].item()) == 0 and torch.equal(out, src), f"replay {rep}: decode differs from the input"
 
 
-def test_wave_per_block_encoder_is_bit_exact_too(hs):
-    """(-DHSRLE_EXPERIMENTS builds only: the shipped library holds one encoder per codec.)  HSRLE_ENCODE_WAVE=1 selects the one-wave-per-block encoder of rle8_multi / rle8_packed_multi (csrc/hsrle_encode8w.hip.h; off by default,
-    it is slower).  Same bar: every block stream == the oracle's, for small ragged blocks and for a 64 MiB buffer of 4 KiB blocks."""
+@pytest.mark.parametrize("knob", ["HSRLE_ENCODE_WAVE", "HSRLE_RUNLIST"])
+def test_wave_per_block_encoder_is_bit_exact_too(hs, knob):
+    """(-DHSRLE_EXPERIMENTS builds only: the shipped library holds one encoder per codec.)  HSRLE_ENCODE_WAVE=1 selects the one-wave-per-block encoder of rle8_multi / rle8_packed_multi (csrc/hsrle_encode8w.hip.h),
+    HSRLE_RUNLIST=1 their run list encoder for blocks of 1 .. 4 KiB (csrc/hsrle_encode8r.hip.h); both off by default, they are slower.
+    Same bar: every block stream == the oracle's, for small ragged blocks and for a 64 MiB buffer of 4 KiB blocks."""
     import subprocess
     import sys
 
@@ -465,7 +467,7 @@ ora = Oracle(); rng = random.Random(5)
 data = b"".join(mixed_runs(rng, 3000) + fuzz_sections(rng) + single_symbol_mix(rng, 700) + bytes(rng.randrange(256) for _ in range(rng.choice([0, 5, 700]))) for _ in range(60))
 for key in ("rle8_multi", "rle8_packed_multi"):
     codec = CODEC_BY_KEY[key]
-    for block in (128, 384, 1024, 4096):
+    for block in (128, 384, 1024, 1536, 2048, 3072, 4096):
         src = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
         container, info = hsrle.compress(key, src, block_size=block)
         _, streams = hsrle.split_container(container.cpu().numpy().tobytes())
@@ -478,7 +480,7 @@ for key in ("rle8_multi", "rle8_packed_multi"):
         assert streams == ora.compress_blocks(codec, src.cpu().numpy(), 4096), (key, kind)
 print("WAVE_OK")
 """ % (os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hypersonic-rle-kit_amd", "python"), os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HSRLE_ENCODE_WAVE="1"), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{knob: "1"}), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "WAVE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
