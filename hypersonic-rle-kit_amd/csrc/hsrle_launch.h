@@ -147,6 +147,15 @@ inline bool run_list_applies(uint64_t nBlocks, uint32_t B, uint64_t U, uint32_t 
 }
 
 template <typename KERNEL>
+inline hipError_t launch_run_list(KERNEL k, const EncodeArgs &a, hipStream_t st)
+{
+  const uint32_t want = (a.nBlocks + 2303u) / 2304u;                     // (9 waves per CU resident: all of a small container's waves at once)
+  const uint32_t bpw = knob_u32("HSRLE_RL_BPW", want > 64u ? 64u : want);
+  hipLaunchKernelGGL(k, dim3((a.nBlocks + bpw - 1u) / bpw), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, bpw);
+  return hipGetLastError();
+}
+
+template <typename KERNEL>
 inline hipError_t launch_encode(KERNEL k, const EncodeArgs &a, hipStream_t st, int capResidency = 1)
 {
   const uint32_t grid = (a.nBlocks + 63u) / 64u;

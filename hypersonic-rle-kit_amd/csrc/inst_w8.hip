@@ -43,12 +43,7 @@ static hipError_t enc_multi8(const EncodeArgs &a, hipStream_t st)
 {
   static const uint32_t force = knob_u32("HSRLE_RUNLIST", 0u);
   if (run_list_applies(a.nBlocks, a.B, a.U, force) && a.residentWorkgroups == nullptr)
-  {
-    const uint32_t want = (a.nBlocks + 2303u) / 2304u;                   // (9 waves per CU resident: all of a small container's waves at once)
-    const uint32_t bpw = knob_u32("HSRLE_RL_BPW", want > 64u ? 64u : want);
-    hipLaunchKernelGGL((k_encode8_runlist<FAM>), dim3((a.nBlocks + bpw - 1u) / bpw), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, bpw);
-    return hipGetLastError();
-  }
+    return launch_run_list(k_encode8_runlist<FAM>, a, st);
   return launch_encode_ring<1>(k_encode8_blocks<FAM, false, 256>, k_encode8_blocks<FAM, false, 128>, a, st);
 }
 static hipError_t enc_plain(const EncodeArgs &a, hipStream_t st) { return enc_multi8<PLAIN>(a, st); }
