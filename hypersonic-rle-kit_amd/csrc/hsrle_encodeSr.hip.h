@@ -50,18 +50,18 @@ __global__ __launch_bounds__(64) void k_encodeS_runlist(const uint8_t *__restric
   const uint32_t wgLast = umin(wgFirst + bpw, nBlocks);
   if (wgFirst >= nBlocks) return;
 
-  auto block_len = [&](uint32_t b) -> uint32_t {
+  auto block_len = [&](uint32_t b) __attribute__((always_inline)) -> uint32_t {
     const uint64_t at = (uint64_t)b * B;
     return (uint32_t)((U - at) < (uint64_t)B ? (U - at) : (uint64_t)B);
   };
-  auto load16 = [&](uint64_t g) -> u32x4 {
+  auto load16 = [&](uint64_t g) __attribute__((always_inline)) -> u32x4 {
     if (g + 16u <= U) return ld128(in + g);
     uint32_t t[4] = { 0, 0, 0, 0 };
     for (uint32_t k = 0; k < 16u && g + k < U; k++) t[k >> 2] |= (uint32_t)in[g + k] << (8u * (k & 3u));
     return u32x4{ t[0], t[1], t[2], t[3] };
   };
   struct Win { u32x4 a, b, c, d; };
-  auto load_block = [&](uint32_t b) -> Win {
+  auto load_block = [&](uint32_t b) __attribute__((always_inline)) -> Win {
     Win w; w.a = w.b = w.c = w.d = u32x4{ 0, 0, 0, 0 };
     const uint32_t n = block_len(b);
     if (lane * 64u < n)
@@ -73,20 +73,20 @@ __global__ __launch_bounds__(64) void k_encodeS_runlist(const uint8_t *__restric
   };
 
   // ---- building a block's stream in the output tile (as in k_encode8_runlist) ----
-  auto load16p = [&](const uint8_t *p) -> u32x4 { return load16((uint64_t)(p - in)); };
-  auto tile_dwords = [&](uint32_t q, u32x4 v, uint32_t nd) {
+  auto load16p = [&](const uint8_t *p) __attribute__((always_inline)) -> u32x4 { return load16((uint64_t)(p - in)); };
+  auto tile_dwords = [&](uint32_t q, u32x4 v, uint32_t nd) __attribute__((always_inline)) {
     uint32_t *const o = (uint32_t *)(otile + q);
     if (nd > 0u) o[0] = v.x;
     if (nd > 1u) o[1] = v.y;
     if (nd > 2u) o[2] = v.z;
     if (nd > 3u) o[3] = v.w;
   };
-  auto tile_bytes = [&](uint32_t q, uint32_t w, uint32_t nb) {
+  auto tile_bytes = [&](uint32_t q, uint32_t w, uint32_t nb) __attribute__((always_inline)) {
     if (nb > 0u) otile[q] = (uint8_t)w;
     if (nb > 1u) otile[q + 1u] = (uint8_t)(w >> 8);
     if (nb > 2u) otile[q + 2u] = (uint8_t)(w >> 16);
   };
-  auto lane_copy = [&](const uint8_t *src, uint32_t d, uint32_t len) {
+  auto lane_copy = [&](const uint8_t *src, uint32_t d, uint32_t len) __attribute__((always_inline)) {
     uint32_t h = (4u - (d & 3u)) & 3u;
     if (h > len) h = len;
     const uint32_t rem = len - h, full = rem >> 4, r = rem & 15u;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(64) void k_encodeS_runlist(const uint8_t *__restric
     tile_dwords(qt, vt, nd);
     tile_bytes(qt + 4u * nd, nd == 0u ? vt.x : (nd == 1u ? vt.y : (nd == 2u ? vt.z : vt.w)), r & 3u);
   };
-  auto wave_copy = [&](const uint8_t *src, uint32_t d, uint32_t len) {
+  auto wave_copy = [&](const uint8_t *src, uint32_t d, uint32_t len) __attribute__((always_inline)) {
     uint32_t h = (4u - (d & 3u)) & 3u;
     if (h > len) h = len;
     const uint32_t rem = len - h, full = rem >> 4, r = rem & 15u;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64) void k_encodeS_runlist(const uint8_t *__restric
       }
     }
   };
-  auto tile_hdr = [&](uint32_t q, uint64_t w0, uint64_t w1, uint64_t w2, uint32_t n) {    // n (<= 18) header bytes, any alignment
+  auto tile_hdr = [&](uint32_t q, uint64_t w0, uint64_t w1, uint64_t w2, uint32_t n) __attribute__((always_inline)) {    // n (<= 18) header bytes, any alignment
 #pragma unroll
     for (uint32_t i = 0; i < 18u; i++)
       if (i < n) otile[q + i] = (uint8_t)((i < 8u ? w0 >> (8u * i) : (i < 16u ? w1 >> (8u * (i - 8u)) : w2 >> (8u * (i - 16u)))) & 0xFFull);
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(64) void k_encodeS_runlist(const uint8_t *__restric
     __device__ __forceinline__ void b32(uint32_t v) { push((uint64_t)v, 4u); }
   };
   // field sizes shared by the walk (lengths) and the emission (bytes): rleX_Xsl.h:116-195, rleX_extreme_cpu_encode.h:165-313
-  auto lut_fields = [&](uint32_t count, uint32_t gap, uint32_t &c, uint32_t &c7, uint32_t &range, uint32_t &r7) {
+  auto lut_fields = [&](uint32_t count, uint32_t gap, uint32_t &c, uint32_t &c7, uint32_t &range, uint32_t &r7) __attribute__((always_inline)) {
     constexpr uint32_t MAXC = 127u, MAXR = (1u << TR::RB) - 1u;
     range = gap + 2u;
     c = TR::kAligned ? (count / SU - 3u / SU + 2u) : (count - 3u + 2u);
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(64) void k_encodeS_runlist(const uint8_t *__restric
   };
 
   // ---- phases B and C for the blocks [b0, b1) whose candidates are in the list ----
-  auto flush = [&](uint32_t b0, uint32_t b1) {
+  auto flush = [&](uint32_t b0, uint32_t b1) __attribute__((always_inline)) {
     wave_sync();
     // B: one lane per block
     const uint32_t myBlock = b0 + lane;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(64) void k_encodeS_runlist(const uint8_t *__restric
     {
       bool on, lng, tail; uint32_t off, hn, d, gap, head; uint64_t w0, w1, w2; const uint8_t *src; u32x4 v0, v1, v2, v3;
     };
-    auto stage1 = [&](Stage &st, uint32_t j, uint32_t cb, bool live) {
+    auto stage1 = [&](Stage &st, uint32_t j, uint32_t cb, bool live) __attribute__((always_inline)) {
       const uint32_t b = b0 + j;
       const uint64_t blockAt = (uint64_t)b * B;
       const uint32_t c1 = bOff[j + 1u], c = cb + lane;
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(64) void k_encodeS_runlist(const uint8_t *__restric
       st.head = ld32(a);
       st.v0 = ld128(q); st.v1 = ld128(q + 16u); st.v2 = ld128(q + 32u); st.v3 = ld128(q + 48u);
     };
-    auto stage2 = [&](Stage &st, uint32_t j, uint32_t cb) {
+    auto stage2 = [&](Stage &st, uint32_t j, uint32_t cb) __attribute__((always_inline)) {
       const uint32_t b = b0 + j;
       const uint64_t blockAt = (uint64_t)b * B;
       const bool fast = blockAt + (uint64_t)B + 80ull <= U;
@@ -366,7 +366,8 @@ __global__ __launch_bounds__(64) void k_encodeS_runlist(const uint8_t *__restric
             if (full > 1u) tile_dwords(q + 16u, st.v1, 4u);
             if (full > 2u) tile_dwords(q + 32u, st.v2, 4u);
             if (full > 3u) tile_dwords(q + 48u, st.v3, 4u);
-            const u32x4 vt = full == 0u ? st.v0 : (full == 1u ? st.v1 : (full == 2u ? st.v2 : st.v3));
+            u32x4 vt = st.v3;                                               // (not a ?: chain of the members: that is an indexed access and puts the set in scratch memory)
+            if (full == 0u) vt = st.v0; else if (full == 1u) vt = st.v1; else if (full == 2u) vt = st.v2;
             const uint32_t nd = r >> 2, qt = q + 16u * full;
             tile_dwords(qt, vt, nd);
             tile_bytes(qt + 4u * nd, nd == 0u ? vt.x : (nd == 1u ? vt.y : (nd == 2u ? vt.z : vt.w)), r & 3u);
@@ -394,18 +395,26 @@ __global__ __launch_bounds__(64) void k_encodeS_runlist(const uint8_t *__restric
       }
     };
     {
+      // (two register sets in turn: a copy of the set that is being loaded would wait for its loads)
       uint32_t j = 0, cb = bOff[0];
+      auto advance = [&]() __attribute__((always_inline)) -> bool {
+        if (cb + 64u <= bOff[j + 1u]) cb += 64u; else { j++; cb = bOff[j]; }
+        return b0 + j < b1;
+      };
       bool have = b0 < b1;
-      Stage cur, nxt;
-      stage1(nxt, 0u, cb, have);
+      Stage sa, sb;
+      stage1(sa, 0u, cb, have);
       while (have)
       {
-        cur = nxt;
-        const uint32_t cj = j, ccb = cb;
-        if (cb + 64u <= bOff[j + 1u]) cb += 64u; else { j++; cb = bOff[j]; }
-        have = b0 + j < b1;
-        stage1(nxt, have ? j : 0u, have ? cb : 0u, have);
-        stage2(cur, cj, ccb);
+        const uint32_t ja = j, cba = cb;
+        const bool haveB = advance();
+        stage1(sb, haveB ? j : 0u, haveB ? cb : 0u, haveB);
+        stage2(sa, ja, cba);
+        if (!haveB) break;
+        const uint32_t jb = j, cbb = cb;
+        have = advance();
+        stage1(sa, have ? j : 0u, have ? cb : 0u, have);
+        stage2(sb, jb, cbb);
       }
     }
   };
