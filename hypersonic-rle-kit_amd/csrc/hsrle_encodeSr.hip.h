@@ -23,7 +23,9 @@
 
 namespace hsrle {
 
-constexpr uint32_t kRunListCapS = 832u;         // candidates per wave and batch (>= 4096 / (4 + 1): any one block of 4 byte symbols fits)
+// candidates per wave and batch: any one 4 KiB block fits (a candidate takes S + 1 positions at least: 819 / 585 / 455), and no more than
+// that -- LDS is waves (S = 8: 14.7 KB, 10 waves per CU)
+constexpr uint32_t run_list_cap(int S) { return S == 8 ? 512u : (S == 6 ? 640u : 832u); }
 
 template <int FAM, int S, int AL>
 __global__ __launch_bounds__(64) void k_encodeS_runlist(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t nBlocks,
@@ -34,7 +36,7 @@ __global__ __launch_bounds__(64) void k_encodeS_runlist(const uint8_t *__restric
   using TR = Traits<FAM, S, AL>;
   constexpr uint32_t SU = (uint32_t)S;
   constexpr int K = TR::K;
-  constexpr uint32_t CAP = kRunListCapS;
+  constexpr uint32_t CAP = run_list_cap(S);
   constexpr uint64_t SYMMASK = (S == 8) ? ~0ull : ((1ull << (8 * (S & 7))) - 1ull);
 
   __shared__ uint32_t cand[CAP];              // A: stretch start | first clear position << 16;  B: run start p | run end e << 16

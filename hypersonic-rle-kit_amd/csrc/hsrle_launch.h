@@ -146,10 +146,12 @@ inline bool run_list_applies(uint64_t nBlocks, uint32_t B, uint64_t U, uint32_t 
   return force == 1u || nBlocks < 131072u;
 }
 
+// blocks per wave: all of a small container's waves resident at once (wavesPerCu: what the kernel's LDS allows -- 8 bit 9, 4 / 6 / 8 byte symbols 8 / 9 / 10)
 template <typename KERNEL>
-inline hipError_t launch_run_list(KERNEL k, const EncodeArgs &a, hipStream_t st)
+inline hipError_t launch_run_list(KERNEL k, const EncodeArgs &a, hipStream_t st, uint32_t wavesPerCu = 9u)
 {
-  const uint32_t want = (a.nBlocks + 2303u) / 2304u;                     // (9 waves per CU resident: all of a small container's waves at once)
+  const uint32_t resident = 256u * wavesPerCu;
+  const uint32_t want = (a.nBlocks + resident - 1u) / resident;
   const uint32_t bpw = knob_u32("HSRLE_RL_BPW", want > 64u ? 64u : want);
   hipLaunchKernelGGL(k, dim3((a.nBlocks + bpw - 1u) / bpw), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, bpw);
   return hipGetLastError();

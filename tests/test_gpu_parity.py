@@ -8,6 +8,8 @@ import ctypes
 import random
 import struct
 
+import numpy as np
+
 import pytest
 
 from hsrle_testlib import CODECS, CODEC_BY_KEY, FUZZ_LENGTHS, Oracle, fuzz_sections, mixed_runs, single_symbol_mix
@@ -66,6 +68,30 @@ def test_blocks_bit_exact_and_roundtrip(hs, oracle, codec):
             assert s == expect, f"{codec.key} block {i} (size {block_size}) differs from the oracle"
         out = hs.decompress(container)
         assert out.cpu().numpy().tobytes() == data
+
+
+@pytest.mark.parametrize("codec", CODECS, ids=lambda c: c.key)
+def test_small_containers_of_1_to_4_kib_blocks_bit_exact(hs, oracle, codec):
+    """Containers of fewer than 131 072 blocks of 1 .. 4 KiB: rle8_multi / rle8_packed_multi and the plain / Packed / LUT codecs of 4, 6, 8 byte
+    symbols go through the run list encoders (csrc/hsrle_encode8r.hip.h, hsrle_encodeSr.hip.h), the others through the split encode or the
+    ring encoders.  Whatever the path: every block stream == the oracle's, ragged last block included; decode == input."""
+    rng = random.Random(4242 + CODECS.index(codec))
+    parts = _inputs(777 + CODECS.index(codec), 60)
+    # (stretches that meet within S bytes, symbols that come back, a long tail of literals, a run up to the very end)
+    for S in (1, 4, 6, 8):
+        sym = bytes(rng.randrange(256) for _ in range(S))
+        parts.append((sym * 40)[: 37 * S + 3] + bytes([rng.randrange(256)]) + (sym * 40)[: 9 * S + 1] + bytes(rng.randrange(256) for _ in range(300)) + sym * 30)
+    data = b"".join(parts)
+    for block_size, cut in ((1024, 0), (1536, 1), (3072, 700), (4096, 4095)):
+        d = data[: len(data) - cut] if cut else data
+        src = _to_dev(d)
+        container, info = hs.compress(codec.key, src, block_size=block_size)
+        cinfo, streams = hs.split_container(container.cpu().numpy().tobytes())
+        expect = oracle.compress_blocks(codec, np.frombuffer(d, dtype=np.uint8), block_size)
+        assert len(streams) == len(expect)
+        for i, (a, b) in enumerate(zip(streams, expect)):
+            assert a == b, f"{codec.key} block {i} (size {block_size}) differs from the oracle"
+        assert hs.decompress(container).cpu().numpy().tobytes() == d
 
 
 @pytest.mark.parametrize("codec", CODECS, ids=lambda c: c.key)
