@@ -47,9 +47,11 @@ template <int FAM>
 __global__ __launch_bounds__(64) void k_encode8_runlist(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t nBlocks,
                                                         uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes, uint32_t bpw)
 {
-  static_assert(FAM == PLAIN || FAM == PACKED, "rle8_multi / rle8_packed_multi");
-  constexpr bool PK = FAM == PACKED;
-  constexpr uint32_t T = PK ? 3u : 6u;                                   // the shortest run any state stores
+  static_assert(FAM == PLAIN || FAM == PACKED || FAM == LUT3 || FAM == LUT7, "rle8_multi / rle8_packed_multi / rle8_3symlut / rle8_7symlut");
+  using TR = Traits<FAM, 1, 0>;
+  constexpr bool PK = FAM == PACKED, LT = TR::kLut;
+  constexpr int K = TR::K;
+  constexpr uint32_t T = (FAM == PLAIN) ? 6u : 3u;                       // the shortest run any state stores
   constexpr uint32_t CAP = kRunListCap;
   constexpr uint32_t kStored = 1u, kSame = 2u, kLong = 4u;
 
@@ -160,7 +162,9 @@ __global__ __launch_bounds__(64) void k_encode8_runlist(const uint8_t *__restric
     // B: one lane per block
     const uint32_t myBlock = b0 + lane;
     const bool walker = myBlock < b1;
-    uint32_t n = 0, lastRLE = 0, lastSym = 0, opos = 9u;               // (behind the stream header: size, compressed size, mode byte 0 = multi)
+    uint32_t n = 0, lastRLE = 0, lastSym = 0, opos = TR::kHeaderSize;     // (behind the stream header: size, compressed size, and the mode byte 0 = multi of the codecs without a list)
+    [[maybe_unused]] uint64_t lutw = 0;                                   // LUT: the move-to-front list, entry k in byte k (rleX_Xsl.h: starts as 00 7F FF 01 7E 80 FE)
+    if constexpr (LT) lutw = 0x00FE807E01FF7F00ull & ((1ull << (8 * K)) - 1ull);
     if (walker)
     {
       n = block_len(myBlock);
@@ -171,7 +175,29 @@ __global__ __launch_bounds__(64) void k_encode8_runlist(const uint8_t *__restric
         [[maybe_unused]] const uint32_t sym = csym[c];
         const uint32_t e = st + count, gap = st - lastRLE, rng = gap + 1u;
         uint32_t flags = 0, hl = 0;
-        if constexpr (PK)
+        if constexpr (LT)
+        {
+          // rleX_Xsl.h:116-195 (k_encode8_blocks handle_run)
+          constexpr uint32_t MAXC = 127u, MAXR = (1u << TR::RB) - 1u;
+          const uint32_t range = gap + 2u, cst = count - 1u;
+          uint32_t m = (uint32_t)K;
+#pragma unroll
+          for (int q = K - 1; q >= 0; q--)
+            if (((lutw >> (8 * q)) & 0xFFull) == (uint64_t)sym) m = (uint32_t)q;
+          uint32_t pen = (range <= 0xFFFFFu) ? (range <= MAXR ? 0u : 2u) : 4u;   // 0xFFFFF vs 0xFFFF in the writer: A.5 q3
+          pen += (cst <= 0xFFFFFu) ? (cst <= MAXC ? 0u : 2u) : 4u;
+          pen += (m == (uint32_t)K) ? 1u : 0u;
+          if (count >= 11u || count >= 3u + pen)
+          {
+            const uint32_t limit = (m == (uint32_t)K) ? (uint32_t)K - 1u : m;
+            const uint64_t keepHi = lutw & ~((1ull << (8u * (limit + 1u))) - 1ull);
+            const uint64_t low = lutw & ((1ull << (8u * limit)) - 1ull);
+            lutw = keepHi | (low << 8) | (uint64_t)sym;
+            flags = kStored | (m << 1);
+            hl = 2u + (m == (uint32_t)K ? 1u : 0u) + (cst > MAXC ? (cst <= 0xFFFFu ? 2u : 4u) : 0u) + (range > MAXR ? (range <= 0xFFFFu ? 2u : 4u) : 0u);
+          }
+        }
+        else if constexpr (PK)
         {
           // body / tail split of the canonical AVX2 encoder (k_encode8_blocks handle_run)
           const int32_t kk = (int32_t)(count - 1u) / 32;
@@ -196,13 +222,13 @@ __global__ __launch_bounds__(64) void k_encode8_runlist(const uint8_t *__restric
           flags = kStored | (rng <= 255u ? 0u : kLong);                   // rle8_extreme_cpu.h:974: count >= 6 is all it takes
           hl = 1u + ((count - 5u) <= 255u ? 1u : 5u) + (rng <= 255u ? 1u : 5u);
         }
-        info[c] = opos | (gap << 14) | (flags << 27);
+        info[c] = opos | (gap << 14) | (flags << 27);                     // (flags: stored | same << 1 | long range << 2, or stored | list index << 1)
         if (flags != 0u) { opos += hl + gap; lastRLE = e; }
       }
     }
     const bool ended = walker && lastRLE >= n;                            // a stored run reached the end: the end terminator, no literals
     const uint32_t termOff = opos;
-    constexpr uint32_t termLen = PK ? 9u : 11u;
+    const uint32_t termLen = LT ? (ended ? 6u : 8u) : (PK ? 9u : 11u);
     const uint32_t kLit = (!walker || ended) ? 0u : n - lastRLE;
     const uint32_t size = termOff + termLen + kLit;
     const uint32_t endedI = ended ? 1u : 0u;
@@ -227,6 +253,7 @@ __global__ __launch_bounds__(64) void k_encode8_runlist(const uint8_t *__restric
       const uint32_t jTerm = (uint32_t)__builtin_amdgcn_readlane((int)termOff, (int)j), jLit = (uint32_t)__builtin_amdgcn_readlane((int)kLit, (int)j);
       const uint32_t jLast = (uint32_t)__builtin_amdgcn_readlane((int)lastRLE, (int)j);
       const bool jEnded = __builtin_amdgcn_readlane((int)endedI, (int)j) != 0;
+      const uint32_t jTermLen = (uint32_t)__builtin_amdgcn_readlane((int)termLen, (int)j);
       if (live && c < c1)
       {
         const uint32_t iv = info[c], flags = iv >> 27;
@@ -235,7 +262,24 @@ __global__ __launch_bounds__(64) void k_encode8_runlist(const uint8_t *__restric
           const uint32_t cv = cand[c], st = cv & 0xFFFFu, count = cv >> 16, sym = csym[c];
           const uint32_t off = iv & 0x3FFFu, rng = ((iv >> 14) & 0x1FFFu) + 1u;
           uint64_t lo, hi = 0; uint32_t hn;
-          if constexpr (PK)
+          if constexpr (LT)
+          {
+            // u16 (list index | count field | range field) [symbol] [count u16 / u32] [range u16 / u32]
+            constexpr uint32_t MAXC = 127u, MAXR = (1u << TR::RB) - 1u;
+            const uint32_t m = flags >> 1, range = rng + 1u, cst = count - 1u;     // (rng = gap + 1 here)
+            const uint32_t c7 = (cst <= MAXC) ? cst : (cst <= 0xFFFFu ? 1u : 0u), r7 = (range <= MAXR) ? range : (range <= 0xFFFFu ? 1u : 0u);
+            lo = (uint64_t)(((m << (K == 3 ? 14 : 13)) | (c7 << TR::RB) | r7) & 0xFFFFu);
+            hn = 2u;
+            if (m == (uint32_t)K) { lo |= (uint64_t)sym << 16; hn = 3u; }
+            if (cst != c7) { lo |= (uint64_t)cst << (8u * hn); hn += (cst <= 0xFFFFu) ? 2u : 4u; }      // hn <= 3: fits the low word
+            if (range != r7)
+            {
+              lo |= (uint64_t)range << (8u * hn);                          // hn <= 7
+              if (hn > 4u) hi = (uint64_t)range >> (64u - 8u * hn);
+              hn += (range <= 0xFFFFu) ? 2u : 4u;
+            }
+          }
+          else if constexpr (PK)
           {
             // count byte (| same bit) [count u32] [symbol] range byte / u32
             const uint32_t cc = count - 2u, sm = (flags & kSame) ? 0x80u : 0u;
@@ -270,7 +314,13 @@ __global__ __launch_bounds__(64) void k_encode8_runlist(const uint8_t *__restric
       else if (live && c == c1)
       {
         // the block's last item: terminator + the literals behind the last stored run
-        if constexpr (PK)
+        if constexpr (LT)
+        {
+          // end: u16 (1 << RB) | 1, u16 0, u16 0;  literals: u16 1 << RB, u16 0, u32 literals + 2
+          if (jEnded) { s.lo = (uint64_t)((1u << TR::RB) | 1u); s.hi = 0; }
+          else { s.lo = (uint64_t)(1u << TR::RB) | ((uint64_t)(jLit + 2u) << 32); s.hi = 0; }
+        }
+        else if constexpr (PK)
         {
           // 0x80, u32 0, then u32 1 (end) or u32 ((literals + 1) << 1 | 1)
           const uint32_t v = jEnded ? 1u : (((jLit + 1u) << 1) | 1u);
@@ -282,9 +332,9 @@ __global__ __launch_bounds__(64) void k_encode8_runlist(const uint8_t *__restric
           const uint32_t v = jEnded ? 0u : jLit + 1u;
           s.lo = (uint64_t)v << 56; s.hi = (uint64_t)(v >> 8);
         }
-        s.on = true; s.tail = true; s.off = jTerm; s.hn = termLen; s.gap = jLit;
+        s.on = true; s.tail = true; s.off = jTerm; s.hn = jTermLen; s.gap = jLit;
         s.src = in + blockAt + jLast;
-        s.d = jTerm + termLen;
+        s.d = jTerm + jTermLen;
       }
       s.lng = s.on && s.gap > 64u;
       // the loads may run up to 67 bytes past the literals: not in the last blocks of the input (those copy in stage 2)
@@ -305,7 +355,7 @@ __global__ __launch_bounds__(64) void k_encode8_runlist(const uint8_t *__restric
       if (s.on)
       {
         tile_hdr(s.off, s.lo, s.hi, s.hn);
-        if (s.tail) { ((uint32_t *)otile)[0] = (uint32_t)__builtin_amdgcn_readlane((int)n, (int)j); ((uint32_t *)otile)[1] = jSize; otile[8] = 0; }
+        if (s.tail) { ((uint32_t *)otile)[0] = (uint32_t)__builtin_amdgcn_readlane((int)n, (int)j); ((uint32_t *)otile)[1] = jSize; if constexpr (TR::kHeaderSize == 9u) otile[8] = 0; }
         if (!s.lng && s.gap != 0u)
         {
           if (fast)

@@ -1,5 +1,5 @@
 // hsrle_encodeSr.hip.h -- the run list encoder (hsrle_encode8r.hip.h: the whole wave per block, one lane per block only for the emit
-// decisions) for the codecs of 4, 6 and 8 byte symbols: plain, Packed, 3 / 7 symbol LUT; sym- and byte-aligned.
+// decisions) for the codecs of 2, 3, 4, 6 and 8 byte symbols: plain, Packed, 3 / 7 symbol LUT; sym- and byte-aligned.
 //
 // Replaces: src/rleX_extreme_cpu_encode.h:14-609 (32 / 64 bit), src/rle48_extreme_cpu_encode.h, src/rleX_Xsl_multibyte_encoder.h:18-370 +
 //           src/rleX_Xsl.h:114-264 (LUT) -- the same streams as k_encodeS_blocks (hsrle_encodeS.hip.h), whose handle_run is restated here
@@ -20,19 +20,20 @@
 
 #include "hsrle_common.hip.h"
 #include "hsrle_decode.hip.h" // wave_sync
+#include <type_traits>
 
 namespace hsrle {
 
 // candidates per wave and batch: any one 4 KiB block fits (a candidate takes S + 1 positions at least: 819 / 585 / 455), and no more than
-// that -- LDS is waves (S = 8: 14.7 KB, 10 waves per CU)
-constexpr uint32_t run_list_cap(int S) { return S == 8 ? 512u : (S == 6 ? 640u : 832u); }
+// that -- LDS is waves (S = 8: 14.7 KB, 10 waves per CU; S = 2: 21.6 KB, 7)
+constexpr uint32_t run_list_cap(int S) { return S == 8 ? 512u : (S == 6 ? 640u : (S == 4 ? 832u : (S == 3 ? 1024u : 1408u))); }
 
 template <int FAM, int S, int AL>
 __global__ __launch_bounds__(64) void k_encodeS_runlist(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t nBlocks,
                                                         uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes, uint32_t bpw)
 {
   static_assert(FAM == PLAIN || FAM == PACKED || FAM == LUT3 || FAM == LUT7, "plain, Packed, LUT");
-  static_assert(S == 4 || S == 6 || S == 8, "4 / 6 / 8 byte symbols");
+  static_assert(S == 2 || S == 3 || S == 4 || S == 6 || S == 8, "2 .. 8 byte symbols");
   using TR = Traits<FAM, S, AL>;
   constexpr uint32_t SU = (uint32_t)S;
   constexpr int K = TR::K;
@@ -40,11 +41,12 @@ __global__ __launch_bounds__(64) void k_encodeS_runlist(const uint8_t *__restric
   constexpr uint64_t SYMMASK = (S == 8) ? ~0ull : ((1ull << (8 * (S & 7))) - 1ull);
 
   __shared__ uint32_t cand[CAP];              // A: stretch start | first clear position << 16;  B: run start p | run end e << 16
-  __shared__ __attribute__((aligned(16))) uint32_t info[1024];   // stream offset of the packet | gap << 14 | stored << 27 | LUT index or same << 28
-  __shared__ uint64_t csym[CAP];              // A: the S bytes at the stretch start;  B: the run's symbol
+  constexpr uint32_t INFO = CAP > 1024u ? CAP : 1024u;
+  __shared__ __attribute__((aligned(16))) uint32_t info[INFO];   // stream offset of the packet | gap << 14 | stored << 27 | LUT index or same << 28
+  using sym_t = typename std::conditional<(S <= 4), uint32_t, uint64_t>::type;
+  __shared__ sym_t csym[CAP];                 // A: the S bytes at the stretch start;  B: the run's symbol
   __shared__ __attribute__((aligned(16))) uint8_t otile[4352];   // the stream of the block under phase C (>= the slot of a 4 KiB block)
   __shared__ uint32_t bOff[65];               // first candidate of the batch's blocks
-  static_assert(CAP <= 1024u, "info[] holds a batch and, in phase A, the 4 KiB input tile");
   uint8_t *const tile = (uint8_t *)info;      // the block under phase A (symbol lookups): phase A never touches info[]
 
   const uint32_t lane = threadIdx.x;
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(64) void k_encodeS_runlist(const uint8_t *__restric
           {
             iv = opos | (gap << 14) | (1u << 27) | (tag << 28);
             cand[c] = p | (e << 16);
-            csym[c] = sym;
+            csym[c] = (sym_t)sym;
             opos += hl + gap;
             lastRLE = e;
           }
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(64) void k_encodeS_runlist(const uint8_t *__restric
       const uint32_t *const tw = (const uint32_t *)(tile + (s & ~3u));
       const uint32_t r = s & 3u, d0 = tw[0], d1 = tw[1], d2 = ((s & ~3u) + 12u <= 4096u) ? tw[2] : 0u;
       const uint32_t lo = r ? alignbyte(d1, d0, r) : d0, hi = r ? alignbyte(d2, d1, r) : d1;
-      csym[used + rank] = ((uint64_t)lo | ((uint64_t)hi << 32)) & SYMMASK;
+      csym[used + rank] = (sym_t)(((uint64_t)lo | ((uint64_t)hi << 32)) & SYMMASK);
       rank++;
     }
     wave_sync();

@@ -36,7 +36,7 @@ static hipError_t enc_short7(const EncodeArgs &a, hipStream_t st) { return launc
 
 static hipError_t dec_short_single(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<SHORT_SINGLE, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, k_decode_blocks<SHORT_SINGLE, 1, 0, kDecodeTile, 64, kDecodeStep>, a, st); }
 
-// rle8_multi / rle8_packed_multi: the ring encoder (one lane per block) for containers that fill the device with it, the run list encoder
+// rle8_multi / rle8_packed_multi / rle8_3symlut / rle8_7symlut: the ring encoder (one lane per block) for containers that fill the device with it, the run list encoder
 // (hsrle_encode8r.hip.h: the whole wave per block) for smaller ones of 1 .. 4 KiB blocks.  Experiment builds: HSRLE_RUNLIST=1 / 2 = always / never.
 template <int FAM>
 static hipError_t enc_multi8(const EncodeArgs &a, hipStream_t st)
@@ -48,8 +48,8 @@ static hipError_t enc_multi8(const EncodeArgs &a, hipStream_t st)
 }
 static hipError_t enc_plain(const EncodeArgs &a, hipStream_t st) { return enc_multi8<PLAIN>(a, st); }
 static hipError_t enc_packed(const EncodeArgs &a, hipStream_t st) { return enc_multi8<PACKED>(a, st); }
-static hipError_t enc_lut3(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<LUT3, false, 256>, k_encode8_blocks<LUT3, false, 128>, a, st); }
-static hipError_t enc_lut7(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<LUT7, false, 256>, k_encode8_blocks<LUT7, false, 128>, a, st); }
+static hipError_t enc_lut3(const EncodeArgs &a, hipStream_t st) { return enc_multi8<LUT3>(a, st); }
+static hipError_t enc_lut7(const EncodeArgs &a, hipStream_t st) { return enc_multi8<LUT7>(a, st); }
 // Single: symbol pick by one wave per block, then the ring encoder (hsrle_encode8s.hip.h).  Blocks above kSinglePickMaxBlock (the one-lane
 // drop-in path spans the whole input with one block) and HSRLE_SINGLE_V1=1 (A/B runs) use the first-generation kernel.
 template <int MODE>   // 0 rle8_single, 1 rle8_packed_single, 2 rle8_single_short
