@@ -432,7 +432,7 @@ __global__ __launch_bounds__(64) void k_encode8_runlist(const uint8_t *__restric
     if (b + 2u < wgLast) nx2 = load_block(b + 2u);                       // two blocks ahead: the loads of a block fly for two blocks' phase A
     const uint32_t n = block_len(b);
     const uint32_t myAt = lane * 64u;
-    lds_st128(tile + myAt, w.a); lds_st128(tile + myAt + 16u, w.b); lds_st128(tile + myAt + 32u, w.c); lds_st128(tile + myAt + 48u, w.d);
+    lds_st128(tile + myAt, w.a); lds_st128(tile + myAt + 16u, w.b); lds_st128(tile + myAt + 32u, w.c); lds_st128(tile + myAt + 48u, w.d);   // (for the symbol lookups)
 
     // equality with the successor byte: bit i = d[myAt + i] == d[myAt + i + 1], only where both lie in the block
     const uint32_t nxt = (uint32_t)__shfl_down((int)w.a.x, 1, 64);       // (lane 63's successor lies outside the block: masked below)
@@ -476,6 +476,10 @@ __global__ __launch_bounds__(64) void k_encode8_runlist(const uint8_t *__restric
       if (lane == 0u) bOff[b - batchFirst] = used;
       flush(batchFirst, b);
       batchFirst = b; used = 0u;
+      // the tile lives in info[], which the flush has just used: this block's bytes once more (kept in registers across the flush they
+      // cost the kernel a wave per SIMD)
+      const Win again = load_block(b);
+      lds_st128(tile + myAt, again.a); lds_st128(tile + myAt + 16u, again.b); lds_st128(tile + myAt + 32u, again.c); lds_st128(tile + myAt + 48u, again.d);
     }
     if (lane == 0u) bOff[b - batchFirst] = used;
 

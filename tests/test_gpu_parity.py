@@ -94,6 +94,24 @@ def test_small_containers_of_1_to_4_kib_blocks_bit_exact(hs, oracle, codec):
         assert hs.decompress(container).cpu().numpy().tobytes() == d
 
 
+@pytest.mark.parametrize("key", ["rle8_multi", "rle8_packed_multi", "rle8_3symlut", "rle8_7symlut", "rle16_sym_packed", "rle16_7symlut_byte", "rle24_byte", "rle24_3symlut_sym",
+                                 "rle32_sym", "rle32_7symlut_byte", "rle48_byte_packed", "rle48_3symlut_sym", "rle64_sym_packed", "rle64_3symlut_byte", "rle64_7symlut_sym"])
+def test_run_list_batches_that_overflow_the_candidate_list(hs, oracle, key):
+    """The 88 MB video-shaped frame (21 600 blocks of 4 KiB, BASELINE config 3) gives every wave of the run list encoders more blocks than its
+    candidate list holds: the batch is flushed in the middle of the wave's blocks (and the input tile, which shares LDS with the batch's packet
+    table, filled again).  All 21 600 streams == the oracle's."""
+    import torch
+
+    codec = CODEC_BY_KEY[key]
+    src = hs.synth(SYNTH_VIDEO_KIND, codec.S, 2, 88473600, device="cuda")
+    container, info = hs.compress(key, src, block_size=4096)
+    cinfo, streams = hs.split_container(container.cpu().numpy().tobytes())
+    expect = oracle.compress_blocks(codec, src.cpu().numpy(), 4096)
+    bad = [i for i, (a, b) in enumerate(zip(streams, expect)) if a != b]
+    assert len(streams) == len(expect) == 21600 and not bad, f"{key}: {len(bad)} block streams differ from the oracle, first {bad[:5]}"
+    assert torch.equal(hs.decompress(container), src)
+
+
 @pytest.mark.parametrize("codec", CODECS, ids=lambda c: c.key)
 def test_dropin_monolithic(hs, oracle, codec):
     """rle.h-named entry points (host pointers, one stream): stream == oracle; decode of oracle stream == input; error returns."""
