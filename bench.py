@@ -500,6 +500,7 @@ def main():
         }
         if gather_ms is not None:
             line["gather_ms"] = round(gather_ms, 3)
+        line["library_build_id"] = hsrle.build_id()
         if extras:
             line["extras"] = extras
         if not args.no_cpu:

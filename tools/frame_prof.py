@@ -1,4 +1,4 @@
-import sys, os; R=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0,R+'/hypersonic-rle-kit_amd/python'); sys.path.insert(0,R+'/tests')
+import sys, os; R=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,R+'/hypersonic-rle-kit_amd/python'); sys.path.insert(0,R+'/tests')
 import torch, hsrle
 from hsrle_testlib import CODEC_BY_KEY
 key=sys.argv[1] if len(sys.argv)>1 else "rle64_3symlut_byte"; S=CODEC_BY_KEY[key].S
