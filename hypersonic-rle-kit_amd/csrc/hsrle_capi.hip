@@ -1060,8 +1060,8 @@ static uint32_t split_pieces(uint32_t B)
 static bool split_encode_applies(int codec, uint64_t nBlocks, uint32_t B)
 {
   // the codecs whose ring encoders have the chunk mode (not Single, not 128 bit: their chunk encoders are the per-lane ones of the monolithic path)
-  // rle8_multi / rle8_packed_multi / rle8_{3,7}symlut (ids 0 .. 3) and the plain / Packed / LUT codecs of 2 .. 8 byte symbols (ids 6 .. 45): the run list encoders take these whole
-  if ((codec <= 3 || (codec >= 6 && codec <= 45)) && run_list_applies(nBlocks, B, 1024u, knob_u32("HSRLE_RUNLIST", 0u))) return false;
+  // rle8_multi / rle8_packed_multi / rle8_{3,7}symlut (ids 0 .. 3), the plain / Packed / LUT codecs of 2 .. 8 byte symbols (ids 6 .. 45) and their Short family (ids 50 .. 93): the run list encoders take these whole
+  if ((codec <= 3 || (codec >= 6 && codec <= 45) || (codec >= kShortBase8 && codec < kGreedyBase)) && run_list_applies(nBlocks, B, 1024u, knob_u32("HSRLE_RUNLIST", 0u))) return false;
   if (nBlocks >= kSplitEncodeBelow || B < 1024u || B > (1u << 20) || (B % (kSplitPieces * 128u)) != 0u || codec == 4 || codec == 5 || (codec >= 46 && codec < 50)) return false;
   init_tables();
   return mono_cut_long(codec) != 0u && g_menc[codec] != nullptr;

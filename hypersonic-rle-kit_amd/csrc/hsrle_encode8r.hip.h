@@ -47,12 +47,12 @@ template <int FAM>
 __global__ __launch_bounds__(64) void k_encode8_runlist(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t nBlocks,
                                                         uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes, uint32_t bpw)
 {
-  static_assert(FAM == PLAIN || FAM == PACKED || FAM == LUT3 || FAM == LUT7, "rle8_multi / rle8_packed_multi / rle8_3symlut / rle8_7symlut");
+  static_assert(FAM == PLAIN || FAM == PACKED || FAM == LUT3 || FAM == LUT7 || (FAM >= SHORT0 && FAM <= SHORT7), "rle8_multi / rle8_packed_multi / rle8_{3,7}symlut / their Short family");
   using TR = Traits<FAM, 1, 0>;
-  constexpr bool PK = FAM == PACKED, LT = TR::kLut;
+  constexpr bool PK = FAM == PACKED, LT = TR::kLut, SH = TR::kShort;
   constexpr int K = TR::K;
-  constexpr uint32_t T = (FAM == PLAIN) ? 6u : 3u;                       // the shortest run any state stores
-  constexpr uint32_t CAP = kRunListCap;
+  constexpr uint32_t T = SH ? TR::SMINS : ((FAM == PLAIN) ? 6u : 3u);    // the shortest run any state stores (Short with a list: 2)
+  constexpr uint32_t CAP = (T == 2u) ? 2112u : kRunListCap;             // (runs of two bytes: up to 2048 candidates in a 4 KiB block)
   constexpr uint32_t kStored = 1u, kSame = 2u, kLong = 4u;
 
   __shared__ uint32_t cand[CAP];              // start | count << 16
@@ -150,9 +150,9 @@ __global__ __launch_bounds__(64) void k_encode8_runlist(const uint8_t *__restric
       }
     }
   };
-  auto tile_hdr = [&](uint32_t q, uint64_t lo, uint64_t hi, uint32_t n) __attribute__((always_inline)) {    // n (<= 11) header bytes, any alignment
+  auto tile_hdr = [&](uint32_t q, uint64_t lo, uint64_t hi, uint32_t n) __attribute__((always_inline)) {    // n (<= 12) header bytes, any alignment
 #pragma unroll
-    for (uint32_t i = 0; i < 11u; i++)
+    for (uint32_t i = 0; i < 12u; i++)
       if (i < n) otile[q + i] = (uint8_t)((i < 8u ? lo >> (8u * i) : hi >> (8u * (i - 8u))) & 0xFFull);
   };
 
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(64) void k_encode8_runlist(const uint8_t *__restric
     const bool walker = myBlock < b1;
     uint32_t n = 0, lastRLE = 0, lastSym = 0, opos = TR::kHeaderSize;     // (behind the stream header: size, compressed size, and the mode byte 0 = multi of the codecs without a list)
     [[maybe_unused]] uint64_t lutw = 0;                                   // LUT: the move-to-front list, entry k in byte k (rleX_Xsl.h: starts as 00 7F FF 01 7E 80 FE)
-    if constexpr (LT) lutw = 0x00FE807E01FF7F00ull & ((1ull << (8 * K)) - 1ull);
+    if constexpr (TR::kMtf) lutw = 0x00FE807E01FF7F00ull & ((1ull << (8 * K)) - 1ull);
     if (walker)
     {
       n = block_len(myBlock);
@@ -175,7 +175,42 @@ __global__ __launch_bounds__(64) void k_encode8_runlist(const uint8_t *__restric
         [[maybe_unused]] const uint32_t sym = csym[c];
         const uint32_t e = st + count, gap = st - lastRLE, rng = gap + 1u;
         uint32_t flags = 0, hl = 0;
-        if constexpr (LT)
+        if constexpr (SH)
+        {
+          // rleX_Xsl_short.h:152-357 (k_encode8_blocks handle_run)
+          const uint32_t range = gap + 2u;
+          [[maybe_unused]] uint32_t m = (uint32_t)K;
+          if constexpr (K > 0)
+          {
+#pragma unroll
+            for (int q = K - 1; q >= 0; q--)
+              if (((lutw >> (8 * q)) & 0xFFull) == (uint64_t)sym) m = (uint32_t)q;
+          }
+          const int32_t sc = (int32_t)count - (int32_t)TR::SMINS + 2;
+          const bool pack1 = gap <= TR::SMAXPR && (uint32_t)(sc - 2) <= TR::SMAXPC;
+          uint32_t pen = (K > 0 && m == (uint32_t)K) ? 1u : 0u;
+          if (!pack1)
+          {
+            pen += 2u;
+            if (!(sc <= (int32_t)TR::SMAXTC && range <= TR::SMAXTR))
+              pen += ((range <= 0xFFFFFu) ? (range <= TR::SMAXTR ? 0u : 2u) : 4u) + ((sc <= 0xFFFFF) ? (sc <= (int32_t)TR::SMAXTC ? 0u : 2u) : 4u);
+          }
+          if (count >= TR::SMINL || count >= TR::SMINS + pen)
+          {
+            if constexpr (K > 0)
+            {
+              const uint32_t limit = (m == (uint32_t)K) ? (uint32_t)K - 1u : m;
+              const uint64_t keepHi = lutw & ~((1ull << (8u * (limit + 1u))) - 1ull);
+              const uint64_t low = lutw & ((1ull << (8u * limit)) - 1ull);
+              lutw = keepHi | (low << 8) | (uint64_t)sym;
+            }
+            const uint32_t scu = (uint32_t)sc;
+            flags = kStored | (m << 1);
+            hl = pack1 ? 1u : 3u + (scu > TR::SMAXTC ? (scu <= 0xFFFFu ? 2u : 4u) : 0u) + (range > TR::SMAXTR ? (range <= 0xFFFFu ? 2u : 4u) : 0u);
+            if (K == 0 || m == (uint32_t)K) hl += 1u;
+          }
+        }
+        else if constexpr (LT)
         {
           // rleX_Xsl.h:116-195 (k_encode8_blocks handle_run)
           constexpr uint32_t MAXC = 127u, MAXR = (1u << TR::RB) - 1u;
@@ -228,7 +263,7 @@ __global__ __launch_bounds__(64) void k_encode8_runlist(const uint8_t *__restric
     }
     const bool ended = walker && lastRLE >= n;                            // a stored run reached the end: the end terminator, no literals
     const uint32_t termOff = opos;
-    const uint32_t termLen = LT ? (ended ? 6u : 8u) : (PK ? 9u : 11u);
+    const uint32_t termLen = SH ? (ended ? 7u : 9u) + (K == 0 ? 1u : 0u) : (LT ? (ended ? 6u : 8u) : (PK ? 9u : 11u));
     const uint32_t kLit = (!walker || ended) ? 0u : n - lastRLE;
     const uint32_t size = termOff + termLen + kLit;
     const uint32_t endedI = ended ? 1u : 0u;
@@ -262,7 +297,35 @@ __global__ __launch_bounds__(64) void k_encode8_runlist(const uint8_t *__restric
           const uint32_t cv = cand[c], st = cv & 0xFFFFu, count = cv >> 16, sym = csym[c];
           const uint32_t off = iv & 0x3FFFu, rng = ((iv >> 14) & 0x1FFFu) + 1u;
           uint64_t lo, hi = 0; uint32_t hn;
-          if constexpr (LT)
+          if constexpr (SH)
+          {
+            // one byte (list index | count | range), or three (list index | all ones, count, range) + the values that do not fit; then the symbol unless the list has it
+            const uint32_t m = flags >> 1, gapv = rng - 1u, range = rng + 1u;                      // (rng = gap + 1 here)
+            const int32_t sc = (int32_t)count - (int32_t)TR::SMINS + 2;
+            const bool pack1 = gapv <= TR::SMAXPR && (uint32_t)(sc - 2) <= TR::SMAXPC;
+            const uint32_t scu = (uint32_t)sc, mi = (K > 0) ? m << (TR::SCB + TR::SRBP) : 0u;
+            if (pack1) { lo = (uint64_t)((mi | ((uint32_t)(sc - 2) << TR::SRBP) | gapv) & 0xFFu); hn = 1u; }
+            else
+            {
+              const uint32_t scx = (scu <= TR::SMAXTC) ? scu : (scu <= 0xFFFFu ? 1u : 0u), rx = (range <= TR::SMAXTR) ? range : (range <= 0xFFFFu ? 1u : 0u);
+              const uint32_t b0 = (mi | (TR::SCINV << TR::SRBP) | ((scx << (TR::SRB - 8u)) >> 8)) & 0xFFu, b1 = ((scx << (TR::SRB - 8u)) | (rx >> 8)) & 0xFFu, b2 = rx & 0xFFu;
+              lo = (uint64_t)(b0 | (b1 << 8) | (b2 << 16));
+              hn = 3u;
+              if (scx != scu) { lo |= (uint64_t)scu << 24; hn += (scu <= 0xFFFFu) ? 2u : 4u; }                 // hn <= 7
+              if (rx != range)
+              {
+                lo |= (uint64_t)range << (8u * hn);
+                if (hn > 4u) hi = (uint64_t)range >> (64u - 8u * hn);
+                hn += (range <= 0xFFFFu) ? 2u : 4u;                                                           // hn <= 11
+              }
+            }
+            if (K == 0 || m == (uint32_t)K)
+            {
+              if (hn < 8u) lo |= (uint64_t)sym << (8u * hn); else hi |= (uint64_t)sym << (8u * (hn - 8u));
+              hn += 1u;
+            }
+          }
+          else if constexpr (LT)
           {
             // u16 (list index | count field | range field) [symbol] [count u16 / u32] [range u16 / u32]
             constexpr uint32_t MAXC = 127u, MAXR = (1u << TR::RB) - 1u;
@@ -314,7 +377,14 @@ __global__ __launch_bounds__(64) void k_encode8_runlist(const uint8_t *__restric
       else if (live && c == c1)
       {
         // the block's last item: terminator + the literals behind the last stored run
-        if constexpr (LT)
+        if constexpr (SH)
+        {
+          // rleX_Xsl_short.h:470-523: all-ones count byte, STB, then 1, u16 0, u16 0 (end) or 0, u16 0, u32 literals + 2; one more zero byte in the codec without a list
+          const uint32_t b0 = (TR::SCINV << TR::SRBP) & 0xFFu;
+          if (jEnded) { s.lo = (uint64_t)(b0 | (TR::STB << 8) | (1u << 16)); s.hi = 0; }
+          else { s.lo = (uint64_t)(b0 | (TR::STB << 8)) | ((uint64_t)(jLit + 2u) << 40); s.hi = (uint64_t)(jLit + 2u) >> 24; }
+        }
+        else if constexpr (LT)
         {
           // end: u16 (1 << RB) | 1, u16 0, u16 0;  literals: u16 1 << RB, u16 0, u32 literals + 2
           if (jEnded) { s.lo = (uint64_t)((1u << TR::RB) | 1u); s.hi = 0; }
@@ -450,7 +520,8 @@ __global__ __launch_bounds__(64) void k_encode8_runlist(const uint8_t *__restric
     uint64_t pe = (uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(e64 >> 32), 1, 64) << 32;     // only the top bits of the lane below are needed
     if (lane == 0u) pe = 0ull;
     const uint64_t h1 = (e64 << 1) | (pe >> 63);
-    uint64_t longEnough = h1 & ((e64 << 2) | (pe >> 62));                // T = 3: two match bits in front
+    uint64_t longEnough = h1;                                            // T - 1 match bits in front
+    if constexpr (T >= 3u) longEnough &= (e64 << 2) | (pe >> 62);
     if constexpr (T == 6u) longEnough &= ((e64 << 3) | (pe >> 61)) & ((e64 << 4) | (pe >> 60)) & ((e64 << 5) | (pe >> 59));
     const uint64_t ustarts = e64 & ~h1;                                  // a stretch of match bits begins: the run's first byte
     const uint64_t fends = ~e64 & longEnough & wmask;                    // the last byte of a run of at least T bytes

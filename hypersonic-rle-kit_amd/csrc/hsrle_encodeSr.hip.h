@@ -32,7 +32,7 @@ template <int FAM, int S, int AL>
 __global__ __launch_bounds__(64) void k_encodeS_runlist(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t nBlocks,
                                                         uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes, uint32_t bpw)
 {
-  static_assert(FAM == PLAIN || FAM == PACKED || FAM == LUT3 || FAM == LUT7, "plain, Packed, LUT");
+  static_assert(FAM == PLAIN || FAM == PACKED || FAM == LUT3 || FAM == LUT7 || (FAM >= SHORT0 && FAM <= SHORT7), "plain, Packed, LUT, Short");
   static_assert(S == 2 || S == 3 || S == 4 || S == 6 || S == 8, "2 .. 8 byte symbols");
   using TR = Traits<FAM, S, AL>;
   constexpr uint32_t SU = (uint32_t)S;
@@ -132,9 +132,9 @@ __global__ __launch_bounds__(64) void k_encodeS_runlist(const uint8_t *__restric
       }
     }
   };
-  auto tile_hdr = [&](uint32_t q, uint64_t w0, uint64_t w1, uint64_t w2, uint32_t n) __attribute__((always_inline)) {    // n (<= 18) header bytes, any alignment
+  auto tile_hdr = [&](uint32_t q, uint64_t w0, uint64_t w1, uint64_t w2, uint32_t n) __attribute__((always_inline)) {    // n (<= 20) header bytes, any alignment
 #pragma unroll
-    for (uint32_t i = 0; i < 18u; i++)
+    for (uint32_t i = 0; i < 20u; i++)
       if (i < n) otile[q + i] = (uint8_t)((i < 8u ? w0 >> (8u * i) : (i < 16u ? w1 >> (8u * (i - 8u)) : w2 >> (8u * (i - 16u)))) & 0xFFull);
   };
   // a header under construction: up to 24 bytes, little endian
@@ -161,6 +161,19 @@ __global__ __launch_bounds__(64) void k_encodeS_runlist(const uint8_t *__restric
     r7 = (range <= MAXR) ? range : (range <= 0xFFFFu ? 1u : 0u);
   };
 
+  // Short family (rleX_Xsl_short.h:152-357): stored count, the one-byte form, the three-byte form's field values
+  struct ShortF { int32_t sc; bool pack1; uint32_t scx, rx, range; };
+  auto short_fields = [&](uint32_t count, uint32_t gap) __attribute__((always_inline)) -> ShortF {
+    ShortF f;
+    f.range = gap + 2u;
+    f.sc = TR::kAligned ? (int32_t)(count / SU) - (int32_t)(TR::SMINS / SU) + 2 : (int32_t)count - (int32_t)TR::SMINS + 2;
+    f.pack1 = gap <= TR::SMAXPR && (uint32_t)(f.sc - 2) <= TR::SMAXPC;
+    const uint32_t scu = (uint32_t)f.sc;
+    f.scx = (scu <= TR::SMAXTC) ? scu : (scu <= 0xFFFFu ? 1u : 0u);
+    f.rx = (f.range <= TR::SMAXTR) ? f.range : (f.range <= 0xFFFFu ? 1u : 0u);
+    return f;
+  };
+
   // ---- phases B and C for the blocks [b0, b1) whose candidates are in the list ----
   auto flush = [&](uint32_t b0, uint32_t b1) __attribute__((always_inline)) {
     wave_sync();
@@ -170,7 +183,7 @@ __global__ __launch_bounds__(64) void k_encodeS_runlist(const uint8_t *__restric
     uint32_t n = 0, lastRLE = 0, from = 0, opos = 8u;                     // (behind the stream header: size, compressed size)
     [[maybe_unused]] uint64_t la = 0;                                     // Packed: the last stored symbol (starts as zeros)
     [[maybe_unused]] uint64_t lut[K ? K : 1];
-    if constexpr (TR::kLut)
+    if constexpr (TR::kMtf)
     {
       constexpr uint32_t init[7] = { 0x00u, 0x7Fu, 0xFFu, 0x01u, 0x7Eu, 0x80u, 0xFEu };
 #pragma unroll
@@ -199,7 +212,41 @@ __global__ __launch_bounds__(64) void k_encodeS_runlist(const uint8_t *__restric
           if (rot != 0u) sym = ((sym >> (8u * rot)) | (sym << (8u * (SU - rot)))) & SYMMASK;
           const uint32_t count = e - p, gap = p - lastRLE;
           bool stored; uint32_t hl, tag = 0;
-          if constexpr (TR::kLut)
+          if constexpr (TR::kShort)
+          {
+            const ShortF f = short_fields(count, gap);
+            [[maybe_unused]] uint32_t m = (uint32_t)K;
+            if constexpr (K > 0)
+            {
+#pragma unroll
+              for (int k = K - 1; k >= 0; k--)
+                if (lut[k] == sym) m = (uint32_t)k;
+            }
+            uint32_t pen = (K > 0 && m == (uint32_t)K) ? SU : 0u;
+            const uint32_t scu = (uint32_t)f.sc;
+            if (!f.pack1)
+            {
+              pen += 2u;
+              if (!(f.sc <= (int32_t)TR::SMAXTC && f.range <= TR::SMAXTR))
+                pen += ((f.range <= 0xFFFFFu) ? (f.range <= TR::SMAXTR ? 0u : 2u) : 4u) + ((f.sc <= 0xFFFFF) ? (f.sc <= (int32_t)TR::SMAXTC ? 0u : 2u) : 4u);
+            }
+            stored = count >= TR::SMINL || count >= TR::SMINS + pen;
+            if constexpr (K > 0)
+            {
+              if (stored)
+              {
+                const uint32_t limit = (m == (uint32_t)K) ? (uint32_t)K - 1u : m;
+#pragma unroll
+                for (int k = K - 1; k >= 1; k--)
+                  if ((uint32_t)k <= limit) lut[k] = lut[k - 1];
+                lut[0] = sym;
+              }
+            }
+            hl = f.pack1 ? 1u : 3u + (f.scx != scu ? (scu <= 0xFFFFu ? 2u : 4u) : 0u) + (f.rx != f.range ? (f.range <= 0xFFFFu ? 2u : 4u) : 0u);
+            if (K == 0 || m == (uint32_t)K) hl += SU;
+            tag = m;
+          }
+          else if constexpr (TR::kLut)
           {
             uint32_t cc, c7, range, r7;
             lut_fields(count, gap, cc, c7, range, r7);
@@ -252,8 +299,9 @@ __global__ __launch_bounds__(64) void k_encodeS_runlist(const uint8_t *__restric
     }
     const bool ended = walker && lastRLE >= n;                            // a stored run reached the end: the end terminator, no literals
     const uint32_t termOff = opos;
-    // terminators: LUT 2 + 2 + (2 | 4); plain S + 1 + 4 + 1 + 4; Packed 1 + 4 + (4 | 1 + 4)
-    const uint32_t termLen = TR::kLut ? (ended ? 6u : 8u) : ((TR::kPacked ? 5u : SU + 5u) + (TR::kRange7 ? 4u : 5u));
+    // terminators: Short 3 + 2 + (2 | 4) + (one zero byte | a zero symbol, 0-symbol codecs only); LUT 2 + 2 + (2 | 4); plain S + 1 + 4 + 1 + 4; Packed 1 + 4 + (4 | 1 + 4)
+    const uint32_t termLen = TR::kShort ? (ended ? 7u + (K == 0 ? 1u : 0u) : 9u + (K == 0 ? SU : 0u))
+                                        : (TR::kLut ? (ended ? 6u : 8u) : ((TR::kPacked ? 5u : SU + 5u) + (TR::kRange7 ? 4u : 5u)));
     const uint32_t kLit = (!walker || ended) ? 0u : n - lastRLE;
     const uint32_t size = termOff + termLen + kLit;
     const uint32_t endedI = ended ? 1u : 0u;
@@ -283,7 +331,24 @@ __global__ __launch_bounds__(64) void k_encodeS_runlist(const uint8_t *__restric
           const uint64_t sym = csym[c];
           const uint32_t off = iv & 0x3FFFu, gap = (iv >> 14) & 0x1FFFu, tag = iv >> 28;
           Hdr h;
-          if constexpr (TR::kLut)
+          if constexpr (TR::kShort)
+          {
+            const ShortF f = short_fields(count, gap);
+            const uint32_t scu = (uint32_t)f.sc;
+            const uint32_t mi = (K > 0) ? tag << (TR::SCB + TR::SRBP) : 0u;
+            if (f.pack1)
+              h.b8(mi | ((uint32_t)(f.sc - 2) << TR::SRBP) | gap);
+            else
+            {
+              h.b8(mi | (TR::SCINV << TR::SRBP) | ((f.scx << (TR::SRB - 8u)) >> 8));
+              h.b8((f.scx << (TR::SRB - 8u)) | (f.rx >> 8));
+              h.b8(f.rx);
+              if (f.scx != scu) { if (scu <= 0xFFFFu) h.b16(scu); else h.b32(scu); }
+              if (f.rx != f.range) { if (f.range <= 0xFFFFu) h.b16(f.range); else h.b32(f.range); }
+            }
+            if (K == 0 || tag == (uint32_t)K) h.push(sym, SU);
+          }
+          else if constexpr (TR::kLut)
           {
             uint32_t cc, c7, range, r7;
             lut_fields(count, gap, cc, c7, range, r7);
@@ -320,7 +385,15 @@ __global__ __launch_bounds__(64) void k_encodeS_runlist(const uint8_t *__restric
       {
         // the block's last item: terminator + the literals behind the last stored run
         Hdr h;
-        if constexpr (TR::kLut)
+        if constexpr (TR::kShort)
+        {
+          // rleX_Xsl_short.h:470-523: the three-byte form with count field 0 / 1, then u16 0 + u16 0 + ONE zero byte (end) or u16 0 + u32 literals + 2 +
+          // a whole zero symbol (literals) -- the zero byte / symbol only in the codecs without a list
+          h.b8(TR::SCINV << TR::SRBP); h.b8(TR::STB);
+          if (jEnded) { h.b8(1); h.b16(0); h.b16(0); if (K == 0) h.b8(0); }
+          else { h.b8(0); h.b16(0); h.b32(jLit + 2u); if (K == 0) h.push(0ull, SU); }
+        }
+        else if constexpr (TR::kLut)
         {
           // rleX_Xsl_multibyte_encoder.h:329-370: end (1 << RB) | 1, 0, 0 (u16 each); literals 1 << RB, 0 (u16), literals + 2 (u32)
           if (jEnded) { h.b16((1u << TR::RB) | 1u); h.b16(0); h.b16(0); }

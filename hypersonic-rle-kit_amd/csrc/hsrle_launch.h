@@ -1,9 +1,11 @@
 // hsrle_launch.h -- host-side launch table: codec id -> kernel launcher.  The kernels are instantiated per symbol
 // width in inst_w*.hip (one translation unit per width so the library builds in parallel).
 #pragma once
+#include <atomic>
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include "hsrle_ring_probe.hip.h"
 
@@ -146,11 +148,42 @@ inline bool run_list_applies(uint64_t nBlocks, uint32_t B, uint64_t U, uint32_t 
   return force == 1u || nBlocks < 131072u;
 }
 
-// blocks per wave: all of a small container's waves resident at once (wavesPerCu: what the kernel's LDS allows -- 8 bit 9, 4 / 6 / 8 byte symbols 8 / 9 / 10)
-template <typename KERNEL>
-inline hipError_t launch_run_list(KERNEL k, const EncodeArgs &a, hipStream_t st, uint32_t wavesPerCu = 9u)
+// blocks per wave: all of a small container's waves resident at once.  How many waves of a kernel a CU holds is asked once per kernel
+// (LDS and registers decide: 7 .. 10 for the run list encoders) and remembered in a small table; racing first calls write the same value.
+inline uint32_t run_list_waves_per_cu(const void *kernel)
 {
-  const uint32_t resident = 256u * wavesPerCu;
+  struct Entry { std::atomic<const void *> k; std::atomic<int> v; };
+  static Entry table[256];
+  for (auto &e : table)
+  {
+    const void *have = e.k.load(std::memory_order_acquire);
+    if (have == kernel) { const int v = e.v.load(std::memory_order_relaxed); if (v > 0) return (uint32_t)v; break; }
+    if (have == nullptr) break;
+  }
+  // (not hipOccupancyMaxActiveBlocksPerMultiprocessor: it divides the LDS without the 1 280-byte allocation granule and says 11 or 12 where the
+  //  hardware holds 10 -- and a grid just above what is resident leaves a tail of waves that run alone: 88 MB frame 215 us instead of 161)
+  int n = 8;
+  hipFuncAttributes fa;
+  if (hipFuncGetAttributes(&fa, kernel) == hipSuccess)
+  {
+    const uint32_t lds = (((uint32_t)fa.sharedSizeBytes + 1279u) / 1280u) * 1280u, regs = (((uint32_t)fa.numRegs + 7u) / 8u) * 8u;
+    const uint32_t byLds = lds ? 163840u / lds : 32u, byRegs = regs ? 4u * (512u / regs > 8u ? 8u : 512u / regs) : 32u;
+    n = (int)(byLds < byRegs ? byLds : byRegs);
+    if (n < 1) n = 1;
+    if (knob_u32("HSRLE_RL_DEBUG", 0u)) fprintf(stderr, "run list kernel %p: lds %zu regs %d -> %d waves per CU\n", kernel, (size_t)fa.sharedSizeBytes, fa.numRegs, n);
+  }
+  for (auto &e : table)
+  {
+    const void *expected = nullptr;
+    if (e.k.load(std::memory_order_acquire) == kernel || e.k.compare_exchange_strong(expected, kernel)) { e.v.store(n, std::memory_order_relaxed); break; }
+  }
+  return (uint32_t)n;
+}
+
+template <typename KERNEL>
+inline hipError_t launch_run_list(KERNEL k, const EncodeArgs &a, hipStream_t st)
+{
+  const uint32_t resident = 256u * run_list_waves_per_cu((const void *)k);
   const uint32_t want = (a.nBlocks + resident - 1u) / resident;
   const uint32_t bpw = knob_u32("HSRLE_RL_BPW", want > 64u ? 64u : want);
   hipLaunchKernelGGL(k, dim3((a.nBlocks + bpw - 1u) / bpw), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, bpw);

@@ -29,10 +29,6 @@ static hipError_t dec_short0(const DecodeArgs &a, hipStream_t st) { return launc
 static hipError_t dec_short1(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<SHORT1, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, k_decode_blocks<SHORT1, 1, 0, kDecodeTile, 64, kDecodeStep>, a, st); }
 static hipError_t dec_short3(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<SHORT3, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, k_decode_blocks<SHORT3, 1, 0, kDecodeTile, 64, kDecodeStep>, a, st); }
 static hipError_t dec_short7(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<SHORT7, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, k_decode_blocks<SHORT7, 1, 0, kDecodeTile, 64, kDecodeStep>, a, st); }
-static hipError_t enc_short0(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<SHORT0, false, 256>, k_encode8_blocks<SHORT0, false, 128>, a, st); }
-static hipError_t enc_short1(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<SHORT1, false, 256>, k_encode8_blocks<SHORT1, false, 128>, a, st); }
-static hipError_t enc_short3(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<SHORT3, false, 256>, k_encode8_blocks<SHORT3, false, 128>, a, st); }
-static hipError_t enc_short7(const EncodeArgs &a, hipStream_t st) { return launch_encode_ring<1>(k_encode8_blocks<SHORT7, false, 256>, k_encode8_blocks<SHORT7, false, 128>, a, st); }
 
 static hipError_t dec_short_single(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<SHORT_SINGLE, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, k_decode_blocks<SHORT_SINGLE, 1, 0, kDecodeTile, 64, kDecodeStep>, a, st); }
 
@@ -47,6 +43,10 @@ static hipError_t enc_multi8(const EncodeArgs &a, hipStream_t st)
   return launch_encode_ring<1>(k_encode8_blocks<FAM, false, 256>, k_encode8_blocks<FAM, false, 128>, a, st);
 }
 static hipError_t enc_plain(const EncodeArgs &a, hipStream_t st) { return enc_multi8<PLAIN>(a, st); }
+static hipError_t enc_short0(const EncodeArgs &a, hipStream_t st) { return enc_multi8<SHORT0>(a, st); }
+static hipError_t enc_short1(const EncodeArgs &a, hipStream_t st) { return enc_multi8<SHORT1>(a, st); }
+static hipError_t enc_short3(const EncodeArgs &a, hipStream_t st) { return enc_multi8<SHORT3>(a, st); }
+static hipError_t enc_short7(const EncodeArgs &a, hipStream_t st) { return enc_multi8<SHORT7>(a, st); }
 static hipError_t enc_packed(const EncodeArgs &a, hipStream_t st) { return enc_multi8<PACKED>(a, st); }
 static hipError_t enc_lut3(const EncodeArgs &a, hipStream_t st) { return enc_multi8<LUT3>(a, st); }
 static hipError_t enc_lut7(const EncodeArgs &a, hipStream_t st) { return enc_multi8<LUT7>(a, st); }

@@ -95,7 +95,8 @@ def test_small_containers_of_1_to_4_kib_blocks_bit_exact(hs, oracle, codec):
 
 
 @pytest.mark.parametrize("key", ["rle8_multi", "rle8_packed_multi", "rle8_3symlut", "rle8_7symlut", "rle16_sym_packed", "rle16_7symlut_byte", "rle24_byte", "rle24_3symlut_sym",
-                                 "rle32_sym", "rle32_7symlut_byte", "rle48_byte_packed", "rle48_3symlut_sym", "rle64_sym_packed", "rle64_3symlut_byte", "rle64_7symlut_sym"])
+                                 "rle32_sym", "rle32_7symlut_byte", "rle48_byte_packed", "rle48_3symlut_sym", "rle64_sym_packed", "rle64_3symlut_byte", "rle64_7symlut_sym",
+                                 "rle8_multi_short", "rle8_7symlut_short", "rle16_3symlut_byte_short", "rle32_sym_short", "rle64_1symlut_sym_short", "rle64_7symlut_byte_short"])
 def test_run_list_batches_that_overflow_the_candidate_list(hs, oracle, key):
     """The 88 MB video-shaped frame (21 600 blocks of 4 KiB, BASELINE config 3) gives every wave of the run list encoders more blocks than its
     candidate list holds: the batch is flushed in the middle of the wave's blocks (and the input tile, which shares LDS with the batch's packet
