@@ -1057,11 +1057,13 @@ static uint32_t split_pieces(uint32_t B)
   return (k == kSplitPiecesMax && B % (kSplitPiecesMax * 128u) == 0u) ? k : kSplitPieces;
 }
 
+static bool run_list_codec(int codec) { return codec <= 3 || (codec >= 6 && codec <= 45) || (codec >= kShortBase8 && codec < kGreedyBase); }
+
 static bool split_encode_applies(int codec, uint64_t nBlocks, uint32_t B)
 {
   // the codecs whose ring encoders have the chunk mode (not Single, not 128 bit: their chunk encoders are the per-lane ones of the monolithic path)
   // rle8_multi / rle8_packed_multi / rle8_{3,7}symlut (ids 0 .. 3), the plain / Packed / LUT codecs of 2 .. 8 byte symbols (ids 6 .. 45) and their Short family (ids 50 .. 93): the run list encoders take these whole
-  if ((codec <= 3 || (codec >= 6 && codec <= 45) || (codec >= kShortBase8 && codec < kGreedyBase)) && run_list_applies(nBlocks, B, 1024u, knob_u32("HSRLE_RUNLIST", 0u))) return false;
+  if (run_list_codec(codec) && run_list_applies(nBlocks, B, 1024u, knob_u32("HSRLE_RUNLIST", 0u))) return false;
   if (nBlocks >= kSplitEncodeBelow || B < 1024u || B > (1u << 20) || (B % (kSplitPieces * 128u)) != 0u || codec == 4 || codec == 5 || (codec >= 46 && codec < 50)) return false;
   init_tables();
   return mono_cut_long(codec) != 0u && g_menc[codec] != nullptr;
@@ -1651,6 +1653,15 @@ int hsrle_trim(void)
 }
 
 int hsrle_experiments_enabled(void) { return kExperiments ? 1 : 0; }
+
+int hsrle_encode_path(int codec, uint64_t uncompressedSize, uint32_t blockSize)
+{
+  if (codec < 0 || codec >= kCodecCount || uncompressedSize == 0 || !valid_block_size(blockSize)) return -1;
+  const Workspace w = plan_workspace(uncompressedSize, blockSize);
+  if (w.nChunks <= 1 && w.spSlots != 0 && split_encode_applies(codec, w.nBlocks, blockSize)) return HSRLE_PATH_SPLIT;
+  if (w.nChunks <= 1 && run_list_codec(codec) && run_list_applies(w.nBlocks, blockSize, uncompressedSize, knob_u32("HSRLE_RUNLIST", 0u))) return HSRLE_PATH_RUN_LIST;
+  return HSRLE_PATH_RING;
+}
 
 #ifndef HSRLE_BUILD_ID
 #define HSRLE_BUILD_ID "unknown"

@@ -70,6 +70,8 @@ def _lib():
     L.hsrle_version.restype = ctypes.c_char_p
     L.hsrle_device_count.restype = ci
     L.hsrle_experiments_enabled.restype = ci
+    L.hsrle_encode_path.restype = ci
+    L.hsrle_encode_path.argtypes = [ci, ctypes.c_uint64, ctypes.c_uint32]
     L.hsrle_build_id.restype = ctypes.c_char_p
     L.hsrle_suggest_block_size.restype = u32
     L.hsrle_suggest_block_size.argtypes = [u64]
@@ -161,6 +163,19 @@ def suggest_block_size(n):
 def build_id():
     """The library's build id: a hash of its sources and build flags (Makefile); profiles/*_traffic.json is stamped with it."""
     return _lib().hsrle_build_id().decode()
+
+
+PATH_RING, PATH_SPLIT, PATH_RUN_LIST = 0, 1, 2
+
+
+def encode_path(codec, size, block_size):
+    """Which encoder `compress` uses for `size` bytes in blocks of `block_size` (include/hsrle.h: hsrle_encode_path; needs no device): PATH_RING
+    (one lane per block), PATH_SPLIT (small containers, chunks inside the blocks) or PATH_RUN_LIST (small containers, a wave per block)."""
+    cid = codec if isinstance(codec, int) else codec_id(codec)
+    r = int(_lib().hsrle_encode_path(cid, size, block_size))
+    if r < 0:
+        raise ValueError("hsrle_encode_path: bad codec, size or block size")
+    return r
 
 
 def experiments_enabled():

@@ -382,6 +382,17 @@ int hsrle_trim(void);
 
 int hsrle_experiments_enabled(void);
 
+/* Which encoder hsrle_compress_dev[_async] uses for a container of `uncompressedSize` bytes in blocks of `blockSize` (no device needed;
+ * the streams are the reference's whichever it is -- this is for capacity planning and for reading profiles):
+ *   HSRLE_PATH_RING      one lane per block (the ring encoders): containers of >= 131 072 blocks, and whatever the other two do not take
+ *   HSRLE_PATH_SPLIT     small containers, chunks inside the blocks
+ *   HSRLE_PATH_RUN_LIST  small containers of 1 .. 4 KiB blocks, a wave per block
+ * -1: bad codec / block size / size. */
+#define HSRLE_PATH_RING 0
+#define HSRLE_PATH_SPLIT 1
+#define HSRLE_PATH_RUN_LIST 2
+int hsrle_encode_path(int codec, uint64_t uncompressedSize, uint32_t blockSize);
+
 /* A hash of the library's sources and build flags (set by the Makefile; "unknown" for other build recipes): measurement files that
  * describe one build of the kernels (profiles/r03_traffic.json) carry it, and bench.py refuses a file of another build. */
 const char *hsrle_build_id(void);

@@ -75,6 +75,30 @@ def test_pure_host_helpers(lib):
     assert lib.hsrle_container_bound(1 << 20, 4000) == 0  # block size must be a multiple of 128
 
 
+def test_encode_path_selection(lib):
+    """hsrle_encode_path (no device): which encoder a container takes.  Big containers: one lane per block; small ones of 1 .. 4 KiB blocks: the
+    run list encoders for the multi-symbol 8 bit codecs, the 2 .. 8 byte codecs and their Short family, the split encode for the rest that
+    can be cut (Single and 128 bit cannot: they stay with the ring encoders); other block sizes: split encode or ring."""
+    lib.hsrle_encode_path.restype = ctypes.c_int
+    lib.hsrle_encode_path.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_uint32]
+    lib.hsrle_codec_from_name.restype = ctypes.c_int
+    cid = lambda n: lib.hsrle_codec_from_name(n.encode())
+    RING, SPLIT, RUN_LIST = 0, 1, 2
+    frame = 88473600
+    for name in ("rle8_multi", "rle8_packed_multi", "rle8_3symlut", "rle8_7symlut", "rle16_sym", "rle24_7symlut_byte", "rle32_byte_packed", "rle48_3symlut_sym", "rle64_3symlut_byte",
+                 "rle8_multi_short", "rle8_7symlut_short", "rle16_1symlut_sym_short", "rle64_7symlut_byte_short"):
+        assert cid(name) >= 0
+        assert lib.hsrle_encode_path(cid(name), frame, 4096) == RUN_LIST, name
+        assert lib.hsrle_encode_path(cid(name), frame, 1024) == RUN_LIST, name
+        assert lib.hsrle_encode_path(cid(name), 8 << 30, 4096) == RING, name        # 2 097 152 blocks
+        assert lib.hsrle_encode_path(cid(name), frame, 8192) == SPLIT, name         # run list: blocks of 1 .. 4 KiB only
+        assert lib.hsrle_encode_path(cid(name), frame, 512) == RING, name
+    for name in ("rle8_single", "rle8_packed_single", "rle128_sym", "rle128_byte_packed", "rle16_3symlut_byte_short_greedy"):
+        assert lib.hsrle_encode_path(cid(name), frame, 4096) == RING, name
+    assert lib.hsrle_encode_path(cid("rle8_single_short"), frame, 4096) in (RING, SPLIT)
+    assert lib.hsrle_encode_path(-1, frame, 4096) == -1 and lib.hsrle_encode_path(0, frame, 1000) == -1 and lib.hsrle_encode_path(0, 0, 4096) == -1
+
+
 def test_codec_table_matches_tests_table(lib):
     from hsrle_testlib import CODECS
 
