@@ -150,7 +150,7 @@ inline bool run_list_applies(uint64_t nBlocks, uint32_t B, uint64_t U, uint32_t 
 
 // blocks per wave: all of a small container's waves resident at once.  How many waves of a kernel a CU holds is asked once per kernel
 // (LDS and registers decide: 7 .. 10 for the run list encoders) and remembered in a small table; racing first calls write the same value.
-inline uint32_t run_list_waves_per_cu(const void *kernel)
+inline uint32_t run_list_waves_per_cu(const void *kernel, hipStream_t st)
 {
   struct Entry { std::atomic<const void *> k; std::atomic<int> v; };
   static Entry table[256];
@@ -163,6 +163,10 @@ inline uint32_t run_list_waves_per_cu(const void *kernel)
   // (not hipOccupancyMaxActiveBlocksPerMultiprocessor: it divides the LDS without the 1 280-byte allocation granule and says 11 or 12 where the
   //  hardware holds 10 -- and a grid just above what is resident leaves a tail of waves that run alone: 88 MB frame 215 us instead of 161)
   int n = 8;
+  // (a first call that is being captured into a graph asks nothing: the query is not a stream operation, and what may and may not be called
+  //  under capture is the runtime's business -- the default serves, the next eager call fills the table)
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return (uint32_t)n;
   hipFuncAttributes fa;
   if (hipFuncGetAttributes(&fa, kernel) == hipSuccess)
   {
@@ -183,7 +187,7 @@ inline uint32_t run_list_waves_per_cu(const void *kernel)
 template <typename KERNEL>
 inline hipError_t launch_run_list(KERNEL k, const EncodeArgs &a, hipStream_t st)
 {
-  const uint32_t resident = 256u * run_list_waves_per_cu((const void *)k);
+  const uint32_t resident = 256u * run_list_waves_per_cu((const void *)k, st);
   const uint32_t want = (a.nBlocks + resident - 1u) / resident;
   const uint32_t bpw = knob_u32("HSRLE_RL_BPW", want > 64u ? 64u : want);
   hipLaunchKernelGGL(k, dim3((a.nBlocks + bpw - 1u) / bpw), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, bpw);

@@ -458,6 +458,40 @@ def test_reference_cli_runs_on_the_gpu_library(tmp_path):
     assert "FAILED" not in out and "Short" in out
 
 
+def test_first_compress_of_a_process_under_graph_capture():
+    """A process whose FIRST compress call is captured into a graph (no eager warm-up): the run list encoders size their grid from the kernel's
+    residency, a host-side query they skip while the stream is capturing.  The replayed container == an eager one."""
+    import subprocess
+    import sys
+
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+import torch, hsrle
+size, block, key = 24 << 20, 4096, "rle64_3symlut_byte"
+src = hsrle.synth(hsrle.SYNTH_VIDEO, 8, 5, size, device="cuda")
+dst = torch.zeros(hsrle.container_bound(size, block), dtype=torch.uint8, device="cuda")
+ws = torch.empty(hsrle.workspace_size(size, block), dtype=torch.uint8, device="cuda")
+torch.cuda.synchronize()
+side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+g = torch.cuda.CUDAGraph()
+with torch.cuda.stream(side):
+    g.capture_begin()
+    hsrle.compress_async(key, src, dst, block, workspace=ws)
+    g.capture_end()
+torch.cuda.current_stream().wait_stream(side)
+g.replay(); torch.cuda.synchronize()
+info = hsrle.container_info(dst)
+captured = dst[: info.totalSize].clone()
+eager, einfo = hsrle.compress(key, src, block_size=block)
+assert info.totalSize == einfo.totalSize and torch.equal(captured, eager[: einfo.totalSize])
+assert torch.equal(hsrle.decompress(eager), src)
+print("CAPTURE_OK")
+""" % (os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hypersonic-rle-kit_amd", "python"),)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "CAPTURE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_compress_and_decompress_are_graph_capturable(hs):
     """With a caller-provided workspace the async entry points only enqueue kernels on the given stream (no allocation, no
     synchronisation), so they can be captured into a HIP graph and replayed (include/hsrle.h)."""
