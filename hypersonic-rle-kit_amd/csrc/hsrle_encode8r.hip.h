@@ -1,9 +1,11 @@
-// hsrle_encode8r.hip.h -- the 8 bit multi-symbol block encoders (rle8_multi, rle8_packed_multi) as a RUN LIST encoder: the parallel
-// parts of a block's encode are done by the whole wave, only the emit decisions by one lane per block.
+// hsrle_encode8r.hip.h -- the 8 bit multi-symbol block encoders (rle8_multi, rle8_packed_multi, rle8_{3,7}symlut and the Short family:
+// rle8_multi_short, rle8_{1,3,7}symlut_short) as a RUN LIST encoder: the parallel parts of a block's encode are done by the whole wave,
+// only the emit decisions by one lane per block.
 //
-// Replaces: src/rle8_extreme_cpu.h:86-344 (wrapper, scalar tail, final block), :936-1099 (canonical AVX2 body) -- the same streams as
-//           k_encode8_blocks<PLAIN / PACKED> (hsrle_encode8.hip.h), whose header explains the rules; this file only orders the work
-//           differently.
+// Replaces: src/rle8_extreme_cpu.h:86-344 (wrapper, scalar tail, final block), :936-1099 (canonical AVX2 body); src/rleX_Xsl.h:114-264
+//           (process_symbol of the LUT codecs), :269-346, :421-485 (TYPE_SIZE 8); src/rleX_Xsl_short.h:152-357 (process_symbol of the Short
+//           family), :470-523 (its terminators) -- the same streams as k_encode8_blocks (hsrle_encode8.hip.h), whose handle_run is restated
+//           here as a decision (the walk) and a header (the emission); this file only orders the work differently.
 //
 // k_encode8_blocks gives every block to one lane for the whole encode: run detection, the emit decisions, the packet headers and the
 // literal copies all sit in one per-lane state machine, 64 of them in lock step -- ~1 400 VALU instructions per 64-byte step of a wave,

@@ -1,9 +1,10 @@
 // hsrle_encodeSr.hip.h -- the run list encoder (hsrle_encode8r.hip.h: the whole wave per block, one lane per block only for the emit
-// decisions) for the codecs of 2, 3, 4, 6 and 8 byte symbols: plain, Packed, 3 / 7 symbol LUT; sym- and byte-aligned.
+// decisions) for the codecs of 2, 3, 4, 6 and 8 byte symbols: plain, Packed, 3 / 7 symbol LUT and the Short family (0 / 1 / 3 / 7 symbol list);
+// sym- and byte-aligned.
 //
 // Replaces: src/rleX_extreme_cpu_encode.h:14-609 (32 / 64 bit), src/rle48_extreme_cpu_encode.h, src/rleX_Xsl_multibyte_encoder.h:18-370 +
-//           src/rleX_Xsl.h:114-264 (LUT) -- the same streams as k_encodeS_blocks (hsrle_encodeS.hip.h), whose handle_run is restated here
-//           as a decision (walk) and a header (emission).
+//           src/rleX_Xsl.h:114-264 (LUT), src/rleX_Xsl_short.h:152-357 + :470-523 (Short: process_symbol, terminators) -- the same streams as
+//           k_encodeS_blocks (hsrle_encodeS.hip.h), whose handle_run is restated here as a decision (walk) and a header (emission).
 //
 // What differs from the 8 bit version:
 //   A  match bits m[j] = (d[j] == d[j + S]) (false from n - S on); a candidate is a stretch of at least S set bits: (start s, first
@@ -13,7 +14,7 @@
 //      (p - s) mod S bytes (the bytes of a stretch have period S).
 //   B  the walk carries the search position, lastRLE, the Packed codecs' last symbol or the LUT codecs' move-to-front list; it leaves the
 //      run [p, e), its symbol and where its packet goes.
-//   C  headers of up to 18 bytes.
+//   C  headers of up to 19 bytes (Short, three-byte form with both 32 bit fields and an 8 byte symbol).
 // Used for containers of fewer than 131 072 blocks of 1 .. 4 KiB (hsrle_launch.h: run_list_applies); the 88 MB frame of BASELINE config 3
 // (rle64_3symlut_byte) is the case it was built for.
 #pragma once
