@@ -1,4 +1,5 @@
-// hsrle_decode_wave.hip.h -- one WAVE per block: the decoder for containers with too few blocks to fill the chip with one lane each
+// experiments/hsrle_decode_wave.hip.h -- NOT PART OF THE SHIPPED LIBRARY (-DHSRLE_EXPERIMENTS builds only: measured slower than the split
+// decode).  One WAVE per block: the decoder for containers with too few blocks to fill the chip with one lane each
 // (BASELINE config 3: the 88 MB frame in 4 KiB blocks is 21 600 blocks = 338 waves of the block kernel, 1.3 per CU).
 //
 // Replaces, for such containers, the same reference loops as k_decode_blocks (src/rle8_extreme_cpu.h:1546-2434,
@@ -14,13 +15,11 @@
 // incomplete chunk of a batch are carried into the next one.  Nothing outside [0, uncompressedSize) is written.
 #pragma once
 
-#include "hsrle_common.hip.h"
-#include "hsrle_decode.hip.h"
-#include "hsrle_index.hip.h"
+#include "../hsrle_common.hip.h"
+#include "../hsrle_decode.hip.h"
+#include "../hsrle_index.hip.h"
 
 namespace hsrle {
-
-#ifdef HSRLE_EXPERIMENTS
 
 constexpr uint32_t kWaveDecodeDescriptors = 256;     // per batch (32 bytes each)
 constexpr uint32_t kWaveDecodeMaxBlock = 16384;      // larger blocks: the block kernel (with the split decode, hsrle_index.hip.h)
@@ -226,21 +225,6 @@ inline hipError_t launch_decode_wave(const DecodeArgs &a, uint32_t allowSingle, 
   hipLaunchKernelGGL((k_decode_wave_blocks<FAM, S, AL>), dim3(a.blockCount), dim3(64), wave_decode_lds_bytes(a.B), st, a.payload, a.offsets, a.payloadEnd, a.out, a.U, a.B, a.firstBlock,
                      a.blockCount, allowSingle, a.status);
   return hipGetLastError();
-}
-
-#endif   // HSRLE_EXPERIMENTS
-
-// what the codec tables hold as their "sub-block" entry: SB == 0 selects the wave-per-block decoder (rec is not used), else the
-// record walk of the split decode (hsrle_index.hip.h)
-template <int FAM, int S, int AL>
-inline hipError_t launch_sub_or_wave(const DecodeArgs &a, uint32_t SB, uint32_t allowSingle, uint32_t *rec, hipStream_t st)
-{
-#ifdef HSRLE_EXPERIMENTS
-  if (SB == 0u) return launch_decode_wave<FAM, S, AL>(a, allowSingle, st);
-#else
-  if (SB == 0u) return hipErrorNotSupported;                        // the wave-per-block decoder is measured slower than the split decode: not in the shipped build
-#endif
-  return launch_container_records<FAM, S, AL>(a, SB, allowSingle, rec, st);
 }
 
 } // namespace hsrle

@@ -1,3 +1,4 @@
+// experiments/: NOT PART OF THE SHIPPED LIBRARY (-DHSRLE_EXPERIMENTS builds only: bit-exact, measured slower than the lane-per-block encoder)
 // hsrle_encode8w.hip.h -- ONE WAVE PER BLOCK encoder for the two list-free 8 bit multi-symbol codecs (rle8_multi, rle8_packed_multi),
 // blocks of at most 4096 bytes: the position-parallel form of the reference's scan (src/rle8_extreme_cpu.h:936-1099: cmpeq + movemask
 // + ctz over the input, emit rule :974-1001, scalar tail :111-199, final block :203-338).
@@ -19,8 +20,8 @@
 // Blocks are taken in ticket order by resident waves (a block's predecessors are always finished or in flight: no deadlock).
 #pragma once
 
-#include "hsrle_common.hip.h"
-#include "hsrle_decode.hip.h" // funnel16, lds_read16, wave_sync
+#include "../hsrle_common.hip.h"
+#include "../hsrle_decode.hip.h" // funnel16, lds_read16, wave_sync
 
 namespace hsrle {
 

@@ -10,7 +10,7 @@
 #include "hsrle_index.hip.h"
 #include "hsrle_mono_encode.hip.h"
 #ifdef HSRLE_EXPERIMENTS
-#include "hsrle_encode8w.hip.h"
+#include "experiments/hsrle_encode8w.hip.h"
 #else
 namespace hsrle { constexpr uint64_t kTicketBytes = 256; }   // (scratch behind the staging slots: the ring choice of the 1 / 2 byte encoders lives there)
 #endif
@@ -472,10 +472,12 @@ static Workspace plan_workspace(uint64_t U, uint32_t B)
   w.offL1 = at; at += align_up((w.t1 + 1) * 8ull, 256);
   w.offL2 = at; at += align_up((w.t2 + 1) * 8ull, 256);
   w.offL3 = at; at += align_up((w.t3 + 1) * 8ull, 256);
-  // (split encode regions: sized for every codec, used by small containers only)
+  // (split encode regions: sized for every codec, but only where the split path can run -- small containers of blocks above 4 KiB; up to
+  //  4 KiB the run list encoders take every codec that has a chunk mode (split_encode_applies), and reserving the regions there cost
+  //  3x the input for nothing: ADVICE r3.  Experiment builds can send those containers to the split path too, HSRLE_RUNLIST=2.)
   w.spPieces = w.nBlocks * kSplitPiecesMax; w.spMaxChunks = w.spPieces + w.nBlocks;
   w.spCutPos = w.spCutSym = w.spFlags = w.spIdx = w.spStarts = w.spSyms = w.spSlotOff = w.spSizes = w.spChunkOff = w.spFirst = w.spCtrl = w.spGuess = w.spListOut = w.spSlots = w.spL1 = w.spL2 = w.spL3 = 0;
-  if (w.nBlocks < kSplitEncodeBelow && B >= 1024u && B <= (1u << 20))
+  if (w.nBlocks < kSplitEncodeBelow && B >= 1024u && B <= (1u << 20) && (kExperiments || B > 4096u))
   {
     const uint64_t np = w.spPieces, nc = w.spMaxChunks;
     const uint64_t s1 = (nc + 2 + kScanTile - 1) / kScanTile, s2 = (s1 + kScanTile - 1) / kScanTile, s3 = (s2 + kScanTile - 1) / kScanTile;
@@ -766,7 +768,7 @@ static int decompress_split_async(const void *dContainer, const hsrle_container_
   return g_dec[info->codec](da, st) == hipSuccess ? HSRLE_OK : HSRLE_ERR_DEVICE;
 }
 
-// one WAVE per block (hsrle_decode_wave.hip.h): for containers with too few blocks to fill the chip with one lane each
+// one WAVE per block (experiments/hsrle_decode_wave.hip.h): for containers with too few blocks to fill the chip with one lane each
 constexpr uint32_t kWaveDecodeBelow = 65536u;     // blocks: above, one lane per block has the waves it needs
 static int decompress_wave_async(const void *dContainer, const hsrle_container_info_t *info, uint32_t first, uint32_t count, void *dOut, uint64_t cap, uint32_t *dStatus, hipStream_t st)
 {
@@ -1855,11 +1857,13 @@ int hsrle_decompress_split_dev_async(const void *dContainer, const hsrle_contain
   return decompress_split_async(dContainer, info, firstBlock, blockCount, dOut, outCapacity, dStatus, dWorkspace, workspaceSize, subBlockSize, (hipStream_t)stream);
 }
 
+#ifdef HSRLE_EXPERIMENTS   // the wave-per-block decoder exists in experiment builds only (csrc/experiments/hsrle_decode_wave.hip.h)
 int hsrle_decompress_wave_dev_async(const void *dContainer, const hsrle_container_info_t *info, uint32_t firstBlock, uint32_t blockCount, void *dOut, uint64_t outCapacity,
                                     uint32_t *dStatus, void *stream)
 {
   return decompress_wave_async(dContainer, info, firstBlock, blockCount, dOut, outCapacity, dStatus, (hipStream_t)stream);
 }
+#endif
 
 int hsrle_decompress_dev(const void *dContainer, uint64_t containerSize, void *dOut, uint64_t outCapacity, uint64_t *pUncompressedSize, void *stream)
 {
@@ -1869,7 +1873,7 @@ int hsrle_decompress_dev(const void *dContainer, uint64_t containerSize, void *d
 
   // a container with too few blocks to fill the GPU with one lane per block is decoded split (one lane per sub-block):
   // this call owns its scratch, so it can afford the records
-  // ... or, for blocks of up to 16 KiB, by one WAVE per block (hsrle_decode_wave.hip.h): no records, no second kernel
+  // ... or, for blocks of up to 16 KiB, by one WAVE per block (experiments/hsrle_decode_wave.hip.h): no records, no second kernel
   // (opt-in: measured on the 88 MB frame it is the slower of the two -- 427 us against 189 us split: the packet hops of ONE lane per
   //  wave are a latency chain of ~1 us per packet that the other 63 lanes wait for, while the split decode's record walk runs 64 such
   //  chains per wave)

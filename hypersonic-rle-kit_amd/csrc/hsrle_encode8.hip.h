@@ -156,6 +156,17 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
         p[k] = (uint8_t)((k < 8u ? w0 >> (8u * k) : w1 >> (8u * (k - 8u))) & 0xFFull);
   };
 
+  // timing-only diagnostic builds (output is wrong): -DHSRLE_ABLATE_ENC_STORES=1 no chunk store is ever executed; =2 one chunk in four;
+  // =3 every chunk, but each lane only ever writes the first 128 bytes of its slot (the memory side without the open lines)
+#if defined(HSRLE_ABLATE_ENC_STORES) && HSRLE_ABLATE_ENC_STORES == 1
+#define HS_ENC_ST128(p, at, w) { if (U == 0x7FFFFFFFFFFFFFF1ull) st128((p) + (at), w); }
+#elif defined(HSRLE_ABLATE_ENC_STORES) && HSRLE_ABLATE_ENC_STORES == 2
+#define HS_ENC_ST128(p, at, w) { if ((((uint32_t)((p) - slot) + (at)) & 48u) == 48u) st128((p) + (at), w); }
+#elif defined(HSRLE_ABLATE_ENC_STORES) && HSRLE_ABLATE_ENC_STORES == 3
+#define HS_ENC_ST128(p, at, w) { st128(slot + (((uint32_t)((p) - slot) + (at)) & 112u), w); }
+#else
+#define HS_ENC_ST128(p, at, w) st128((p) + (at), w)
+#endif
   // append the low nb (<= 12) bytes of hv
   auto append = [&](u32x4 hv, uint32_t nb) {
     const uint32_t c = opos & 15u;
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
     const u32x4 w = HS_EMERGE(oacc, lowp, c);
     if (c + nb >= 16u)
     {
-      if (!dry) st128(slot + (opos & ~15u), w);
+      if (!dry) HS_ENC_ST128(slot, (opos & ~15u), w);
       oacc = (c == 0u) ? zero4 : funnel16(hv, zero4, 16u - c);          // hv >> (16 - c) bytes
     }
     else
@@ -212,7 +223,7 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
       uint32_t k = 0;
       while (k + 16u <= total)
       {
-        if (!dry) st128(dst + k, w);
+        if (!dry) HS_ENC_ST128(dst, k, w);
         k += 16u;
         if (k < total) w = ring_win(srcp + k);
       }

@@ -8,7 +8,7 @@
 //                     16-byte window of the run counts 15, the first window is compared with ~d[0], what the last registered run is
 //                     depends on the scanner's phase at n - 16) but which, away from the end, registers exactly the maximal runs of
 //                     >= 2 equal bytes: a run of L bytes adds L - (L - 1) / 16 to prob[s] and 1 to pcount[s].  (Closed form checked
-//                     against the oracle on 90 000 inputs: tools/scratch/pick_model.py.)  So: equality bits of the whole block in
+//                     against the oracle on 90 000 inputs: tools/pick_model.py.)  So: equality bits of the whole block in
 //                     LDS, every lane takes the run starts of 64 positions, LDS atomics into a 256-entry table, the one run that
 //                     reaches n - 16 and the final registration by lane 0, argmax by shuffles.  The symbol goes to byte 9 (rle8_single_short:
 //                     byte 8) of the block's staging slot -- where the stream keeps it -- and the encoder picks it up there.

@@ -797,3 +797,24 @@ inline hipError_t launch_container_records(const DecodeArgs &a, uint32_t SB, uin
 }
 
 } // namespace hsrle
+
+#ifdef HSRLE_EXPERIMENTS
+#include "experiments/hsrle_decode_wave.hip.h"   // launch_decode_wave: one wave per block (measured slower than the split decode; experiment builds only)
+#endif
+
+namespace hsrle {
+
+// what the codec tables hold as their "sub-block" entry: the record walk of the split decode; SB == 0 selects the wave-per-block decoder
+// of the experiment builds (rec is not used)
+template <int FAM, int S, int AL>
+inline hipError_t launch_sub_or_wave(const DecodeArgs &a, uint32_t SB, uint32_t allowSingle, uint32_t *rec, hipStream_t st)
+{
+#ifdef HSRLE_EXPERIMENTS
+  if (SB == 0u) return launch_decode_wave<FAM, S, AL>(a, allowSingle, st);
+#else
+  if (SB == 0u) return hipErrorNotSupported;                        // not in the shipped build
+#endif
+  return launch_container_records<FAM, S, AL>(a, SB, allowSingle, rec, st);
+}
+
+} // namespace hsrle

@@ -3,7 +3,6 @@
 #include "hsrle_encode.hip.h"
 #include "hsrle_encode128.hip.h"
 #include "hsrle_index.hip.h"
-#include "hsrle_decode_wave.hip.h"
 #include "hsrle_launch.h"
 
 namespace hsrle {

@@ -6,12 +6,11 @@
 #include "hsrle_encode8.hip.h"
 #include "hsrle_encode8r.hip.h"
 #ifdef HSRLE_EXPERIMENTS
-#include "hsrle_encode8w.hip.h"        // one wave per block: bit-exact, measured slower
+#include "experiments/hsrle_encode8w.hip.h"        // one wave per block: bit-exact, measured slower
 #endif
 #include "hsrle_encode8s.hip.h"
 #include "hsrle_encode_greedy.hip.h"
 #include "hsrle_index.hip.h"
-#include "hsrle_decode_wave.hip.h"
 #include "hsrle_launch.h"
 
 namespace hsrle {

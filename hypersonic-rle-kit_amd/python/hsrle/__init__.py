@@ -124,8 +124,9 @@ def _lib():
     L.hsrle_decompress_split_workspace_size.argtypes = [ctypes.POINTER(ContainerInfo), u32, u32]
     L.hsrle_decompress_split_dev_async.restype = ci
     L.hsrle_decompress_split_dev_async.argtypes = [vp, ctypes.POINTER(ContainerInfo), u32, u32, vp, u64, vp, vp, u64, u32, vp]
-    L.hsrle_decompress_wave_dev_async.restype = ci
-    L.hsrle_decompress_wave_dev_async.argtypes = [vp, ctypes.POINTER(ContainerInfo), u32, u32, vp, u64, vp, vp]
+    if hasattr(L, "hsrle_decompress_wave_dev_async"):                    # experiment builds only
+        L.hsrle_decompress_wave_dev_async.restype = ci
+        L.hsrle_decompress_wave_dev_async.argtypes = [vp, ctypes.POINTER(ContainerInfo), u32, u32, vp, u64, vp, vp]
     L.hsrle_hash_blocks_dev_async.restype = ci
     L.hsrle_hash_blocks_dev_async.argtypes = [vp, ctypes.POINTER(ContainerInfo), u32, u32, vp, vp]
     L.hsrle_synth_dev_async.restype = ci
@@ -401,7 +402,9 @@ def decompress_split_async(container, info, dst, workspace, status=None, sub_blo
 
 
 def decompress_wave_async(container, info, dst, status=None, first_block=0, block_count=None, stream=None):
-    """Wave decode (hsrle_decompress_wave_dev_async): one wave per block, for containers with few blocks."""
+    """Wave decode (hsrle_decompress_wave_dev_async): one wave per block.  Experiment builds only."""
+    if not hasattr(_lib(), "hsrle_decompress_wave_dev_async"):
+        raise HsrleError(ERR_UNSUPPORTED, "hsrle_decompress_wave_dev_async (not in the shipped build)")
     _check_u8_cuda(container, "container")
     _check_u8_cuda(dst, "dst")
     if block_count is None:

@@ -307,16 +307,16 @@ uint64_t hsrle_decompress_split_workspace_size(const hsrle_container_info_t *inf
 int hsrle_decompress_split_dev_async(const void *dContainer, const hsrle_container_info_t *info, uint32_t firstBlock, uint32_t blockCount, void *dOut, uint64_t outCapacity,
                                      uint32_t *dStatus, void *dWorkspace, uint64_t workspaceSize, uint32_t subBlockSize, void *stream);
 
+#ifdef HSRLE_EXPERIMENTS
 /*
- * Wave decode: the other answer to containers with too few blocks -- one WAVE per block (csrc/hsrle_decode_wave.hip.h): the block's
- * stream goes to LDS, one lane hops through its packets leaving a descriptor each, all 64 lanes expand them to whole aligned 16-byte
- * stores.  One kernel, no workspace; block sizes up to 16 KiB (HSRLE_ERR_UNSUPPORTED above).  Measured slower than the split decode
- * on the 88 MB frame (427 against 189 us: one lane's packet hops are a latency chain the other 63 lanes wait for), so
- * hsrle_decompress_dev only uses it with HSRLE_WAVE_DECODE=1 in the environment (containers of fewer than 65 536 blocks).
- * Only enqueues: graph-capturable.
+ * EXPERIMENT BUILDS ONLY (-DHSRLE_EXPERIMENTS; the shipped library does not export this symbol).  Wave decode: one WAVE per block
+ * (csrc/experiments/hsrle_decode_wave.hip.h) -- the block's stream goes to LDS, one lane hops through its packets leaving a descriptor
+ * each, all 64 lanes expand them to whole aligned 16-byte stores.  Block sizes up to 16 KiB.  Measured slower than the split decode on the
+ * 88 MB frame (427 against 189 us), which is why it does not ship.
  */
 int hsrle_decompress_wave_dev_async(const void *dContainer, const hsrle_container_info_t *info, uint32_t firstBlock, uint32_t blockCount, void *dOut, uint64_t outCapacity,
                                     uint32_t *dStatus, void *stream);
+#endif
 
 /*
  * 64 bit hash of every block stream of blocks [firstBlock, firstBlock + blockCount) of a device-resident container into dHashes

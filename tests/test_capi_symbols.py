@@ -12,6 +12,7 @@ HEADER = os.path.join(REPO, "include", "hsrle.h")
 
 def declared_symbols():
     text = open(HEADER).read()
+    text = re.sub(r"#ifdef HSRLE_EXPERIMENTS.*?#endif", "", text, flags=re.S)   # experiment builds only: not part of the shipped library
     names = set(re.findall(r"\b((?:hsrle|rle)[A-Za-z0-9_]*)\s*\(", re.sub(r"/\*.*?\*/", "", text, flags=re.S)))
     # macro-declared drop-in pairs
     pairs = ["rle8_3symlut", "rle8_7symlut", "rle128_sym", "rle128_sym_packed", "rle128_byte", "rle128_byte_packed"]

@@ -1,11 +1,11 @@
 """The closed form of the 8 bit Single symbol pick that k_single_pick (csrc/hsrle_encode8s.hip.h) computes wave-parallel, restated in
-python (tools/scratch/pick_model.py) and checked against the oracle's literal restatement of the reference's estimator
+python (tools/pick_model.py) and checked against the oracle's literal restatement of the reference's estimator
 (src/rle8_extreme_cpu.c:53-153; byte 9 of an rle8_single stream is the picked symbol).  CPU only."""
 import os
 import random
 import sys
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools", "scratch"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
 
 from hsrle_testlib import CODEC_BY_KEY, Oracle
 from pick_model import gen, pick
