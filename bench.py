@@ -61,7 +61,7 @@ def measured_traffic(codec, size, block, build_id):
     return None, ({"refused": f"profiles/{stale} was measured on another build of the library (this one: {build_id}); rerun tools/traffic.sh"} if stale else None), None
 
 
-def cpu_baseline(container_prefix, n_blocks, block_size, codec_key, expect):
+def cpu_baseline(container_prefix, n_blocks, block_size, codec_key, expect, budget_s=12.0, all_cores=True):
     """Decode the first n_blocks of the container on the host (bounded sample), single thread."""
     import numpy as np
     from hsrle_testlib import CODEC_BY_KEY, REF_SO, Oracle
@@ -90,8 +90,8 @@ def cpu_baseline(container_prefix, n_blocks, block_size, codec_key, expect):
 
     assert run() == usize  # warm-up run, discarded (reference protocol: src/main.c:822-887)
     best, total, reps = None, 0.0, 0
-    t_end = time.time() + 12.0
-    while reps < 3 or (time.time() < t_end and reps < 40):
+    t_end = time.time() + budget_s
+    while reps < (3 if budget_s >= 4.0 else 1) or (time.time() < t_end and reps < 40):
         t0 = time.perf_counter()
         got = run()
         dt = time.perf_counter() - t0
@@ -105,7 +105,7 @@ def cpu_baseline(container_prefix, n_blocks, block_size, codec_key, expect):
 
     # context, not the baseline: the same decode spread over all host cores by the shim's pthread loop (one contiguous block range
     # per thread).  SURVEY.md §8d "CPU beside it": 1-thread and N-thread.
-    if kind == "reference" and hasattr(lib, "hsrle_ref_decode_blocks_mt"):
+    if all_cores and kind == "reference" and hasattr(lib, "hsrle_ref_decode_blocks_mt"):
         nthreads = max(1, min(os.cpu_count() or 1, 1024))
         lib.hsrle_ref_decode_blocks_mt.restype = ctypes.c_uint64
         lib.hsrle_ref_decode_blocks_mt.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int]
@@ -128,7 +128,7 @@ def cpu_baseline(container_prefix, n_blocks, block_size, codec_key, expect):
     return res
 
 
-def cpu_encode_baseline(sample, block_size, codec_key, gpu_payload_prefix, gpu_offsets):
+def cpu_encode_baseline(sample, block_size, codec_key, gpu_payload_prefix, gpu_offsets, budget_s=10.0):
     """Encode the sample (the first bytes of the same input) block by block on the host, single thread: the compiled reference (kind
     "reference") when it is present, else the oracle's restatement ("port").  The streams must be the GPU's."""
     import numpy as np
@@ -137,7 +137,7 @@ def cpu_encode_baseline(sample, block_size, codec_key, gpu_payload_prefix, gpu_o
     codec = CODEC_BY_KEY[codec_key]
     n = sample.size
     nb = (n + block_size - 1) // block_size
-    src = np.zeros(n + 64, dtype=np.uint8)                                   # guard pad behind the sample (irrelevant for 8 bit symbols)
+    src = np.zeros(n + 64, dtype=np.uint8)                                   # guard pad behind the sample: bytes that never match
     src[:n] = sample
     if os.path.exists(REF_SO):
         kind = "reference"
@@ -145,11 +145,13 @@ def cpu_encode_baseline(sample, block_size, codec_key, gpu_payload_prefix, gpu_o
         lib.rle_compress_bounds.restype = ctypes.c_uint32
         stride = (lib.rle_compress_bounds(block_size) + 15) & ~15
         fn = ctypes.cast(getattr(lib, codec.cname), ctypes.c_void_p)
-        lib.hsrle_ref_encode_blocks.restype = ctypes.c_uint64
-        lib.hsrle_ref_encode_blocks.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+        # symbols of 2 .. 16 bytes: every block from a guard-padded private copy (the reference over-reads its input; the copy is part of the time)
+        enc = lib.hsrle_ref_encode_blocks_guarded if (codec.S > 1 and hasattr(lib, "hsrle_ref_encode_blocks_guarded")) else lib.hsrle_ref_encode_blocks
+        enc.restype = ctypes.c_uint64
+        enc.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
         slots = np.zeros(nb * stride + 64, dtype=np.uint8)
         sizes = np.zeros(nb, dtype=np.uint32)
-        run = lambda: lib.hsrle_ref_encode_blocks(fn, src.ctypes.data, n, block_size, slots.ctypes.data, stride, sizes.ctypes.data)
+        run = lambda: enc(fn, src.ctypes.data, n, block_size, slots.ctypes.data, stride, sizes.ctypes.data)
     else:
         kind = "port"
         ora = Oracle()
@@ -161,8 +163,8 @@ def cpu_encode_baseline(sample, block_size, codec_key, gpu_payload_prefix, gpu_o
         run = lambda: ora.lib.hso_compress_blocks(codec.family, codec.S, codec.aligned, src.ctypes.data, n, block_size, slots.ctypes.data, stride, sizes.ctypes.data)
     assert run() == nb  # warm-up run, discarded
     best, total, reps = None, 0.0, 0
-    t_end = time.time() + 10.0
-    while reps < 3 or (time.time() < t_end and reps < 20):
+    t_end = time.time() + budget_s
+    while reps < (3 if budget_s >= 4.0 else 1) or (time.time() < t_end and reps < 20):
         t0 = time.perf_counter()
         got = run()
         dt = time.perf_counter() - t0
@@ -250,6 +252,70 @@ def side_measurements(hsrle, torch, src, dev):
     return out
 
 
+def config5_rows(hsrle, torch, dev, with_cpu):
+    """BASELINE config 5 (src/main.c:803-1076 prints this table per codec on the CPU): for every codec that has a reference-minted manifest --
+    8 GiB run-distributed(W, seed 5), every width x {Packed, 3LUT} + the 8 bit Single codecs -- encode and decode throughput, ratio, roofline
+    fraction ((C + U) / t against 8 TB/s), all 2 097 152 block streams against the compiled reference's roll-ups, and the reference CPU codec
+    (one core) on the first 64 MiB of the same buffer beside it.  Not `value`."""
+    import numpy as np
+    from hsrle_testlib import CODEC_BY_KEY, big_manifest, big_case, rollups
+
+    man = big_manifest()
+    rows = []
+    if not man:
+        return rows
+    names = sorted(k for k in man["cases"] if k.startswith("config5_"))
+    dst = ws = out = None
+    for name in names:
+        e = man["cases"][name]
+        codec = CODEC_BY_KEY[e["codec"]]
+        size, block = e["size"], e["block"]
+        src = hsrle.synth(e["kind"], codec.S, e["seed"], size, device=dev)
+        if dst is None:
+            dst = torch.empty(hsrle.container_bound(size, block), dtype=torch.uint8, device=dev)
+            ws = torch.empty(hsrle.workspace_size(size, block), dtype=torch.uint8, device=dev)
+            out = torch.empty(size, dtype=torch.uint8, device=dev)
+        status = torch.zeros(16, dtype=torch.int32, device=dev)
+
+        def timed(fn, warm, reps):
+            for _ in range(warm):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+
+        enc_ms = timed(lambda: hsrle.compress_async(e["codec"], src, dst, block, workspace=ws), 1, 3)
+        info = hsrle.container_info(dst)
+        container = dst[: info.totalSize]
+        dec_ms = timed(lambda: hsrle.decompress_async(container, info, out, status), 2, 5)
+        _, _, want = big_case(e["codec"], e["kind"], e["seed"], size, block)
+        got = rollups(hsrle.hash_blocks(container, info).cpu().numpy())
+        exact = (info.blockCount == e["blocks"] and info.payloadSize == e["payload_size"] and bool((got == want).all())
+                 and int(status[0].item()) == 0 and torch.equal(out, src))
+        alg = size + info.totalSize
+        row = {"codec": e["codec"], "ratio": round(info.totalSize / size, 4), "decode_GiBps": round(size / 2**30 / (dec_ms * 1e-3), 1), "encode_GiBps": round(size / 2**30 / (enc_ms * 1e-3), 1),
+               "decode_frac": round(alg / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "encode_frac": round(alg / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               "bit_exact": bool(exact), "blocks_compared": int(info.blockCount)}
+        if with_cpu:
+            nb = (64 << 20) // block
+            p0 = info.payload_start
+            prefix_end = p0 + int(container[64 + 8 * nb : 64 + 8 * nb + 8].view(torch.int64).item()) + 64
+            prefix = container[: min(prefix_end, container.numel())].cpu().numpy().tobytes()
+            sample = src[: nb * block].cpu().numpy()
+            cd = cpu_baseline(prefix, nb, block, e["codec"], sample.tobytes(), budget_s=0.4, all_cores=False)
+            ce = cpu_encode_baseline(sample, block, e["codec"], prefix[p0:], np.frombuffer(prefix, dtype=np.uint64, count=nb + 1, offset=64), budget_s=0.4)
+            row.update({"cpu_decode_GiBps": cd["value"], "cpu_encode_GiBps": ce["value"], "cpu_kind": cd["kind"], "cpu_cores": 1,
+                        "cpu_streams_match_gpu": bool(ce["streams_match_gpu"] and cd["matches_gpu_input"])})
+        rows.append(row)
+        del src
+    return rows
+
+
 def kernel_name(codec_key):
     """The decode kernel instantiation behind a codec id (hsrle_decode.hip.h: k_decode_blocks<FAM, S, AL, T, R, Q, SGL>)."""
     from hsrle_testlib import CODEC_BY_KEY, FAMILY_NAMES
@@ -311,7 +377,8 @@ def main():
     ap.add_argument("--codec", default="rle8_packed_multi")
     ap.add_argument("--synth", choices=["runs", "video"], default="runs", help="synthetic generator: run-distributed (headline) or video-shaped (BASELINE config 3)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (config 3 frame, monolithic 1 GiB stream)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (config 3 frame, monolithic 1 GiB stream, config 5 rows)")
+    ap.add_argument("--no-config5", action="store_true", help="skip the sixteen 8 GiB codec rows of BASELINE config 5 (extras.config5)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -393,7 +460,11 @@ def main():
     wall = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps
 
+    per_rank_ms = [round(wall / args.steps * 1e3, 4)]
     if distributed:
+        allw = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(allw, torch.tensor([wall], dtype=torch.float64, device=dev))
+        per_rank_ms = [round(float(w.item()) / args.steps * 1e3, 4) for w in allw]
         t = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
@@ -450,6 +521,7 @@ def main():
 
     # ---- the one exchange step of the sharded path: gather the per-rank compressed segments into one stream ----
     gather_ms = None
+    gather_bytes = 0.0
     if distributed:
         from hsrle import dist as hd
 
@@ -463,6 +535,10 @@ def main():
         t = torch.tensor([(time.perf_counter() - g0) * 1e3], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)                           # the slowest rank's time from the common start to its own completion
         gather_ms = float(t.item())
+        # bytes that cross xGMI: every non-root rank's container (its segment travels whole; the root's own stays where it is)
+        t = torch.tensor([float(info.totalSize) if rank != 0 else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        gather_bytes = float(t.item())
         del full
         if use_c:
             hd.destroy_c_comms()
@@ -494,15 +570,24 @@ def main():
                                     "frac": round(alg_bytes / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": enc_traffic, "algorithmic_bytes": int(alg_bytes),
                                     "note": "algorithmic bytes = input + container per encode; traffic = upper bound of the PMC passes over both kernels (same profiles/ file as roofline.traffic_detail.source), about 2x the algorithmic bytes: staging slots are written with partial lines and compacted in a second pass"}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "traffic_detail": traffic_detail, "kernel": kernel_name(args.codec), "waves_per_cu": hsrle.kernel_waves_per_cu(args.codec, True), "kernel_ms": round(kernel_ms, 4),
+                         "traffic": traffic, "traffic_source": "committed PMC passes of this build and this workload (profiles/, tools/traffic.sh): not a measurement of this run", "traffic_detail": traffic_detail, "kernel": kernel_name(args.codec), "waves_per_cu": hsrle.kernel_waves_per_cu(args.codec, True), "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes": int(alg_bytes),
                          "note": "algorithmic bytes = container (compressed) + uncompressed output per launch; traffic = upper bound of the PMC passes in profiles/ (128 B per counted fabric read request + WRITE_SIZE), lower bound in traffic_detail"},
         }
         if gather_ms is not None:
+            # the one exchange step of the sharded path ("aggregate GiB/s with and without the gather"): what the root receives
+            # over xGMI -- every other rank's compressed segment -- against the time from the common start to the slowest rank's completion;
+            # the ceiling for the root's ingress is 7 links x ~153 GB/s.  value_with_gather charges ONE gather to ONE decode step.
             line["gather_ms"] = round(gather_ms, 3)
+            line["gather_bytes"] = int(gather_bytes)
+            line["gather_GBps"] = round(gather_bytes / (gather_ms * 1e-3) / 1e9, 2) if gather_bytes else 0.0
+            line["gather_link_ceiling_GBps"] = 7 * 153
+            line["value_with_gather"] = round(total_units / 2**30 / (wall / args.steps + gather_ms * 1e-3), 2)
+            line["per_rank_ms_per_step"] = per_rank_ms
         line["library_build_id"] = hsrle.build_id()
         if extras:
             line["extras"] = extras
+        run_config5 = extras is not None and not args.no_extras and not args.no_config5 and args.codec == "rle8_packed_multi" and args.synth == "runs" and world == 1
         if not args.no_cpu:
             # rank 0's shard, on rank 0's host cores, whatever the world size (the other ranks are through their timed region)
             nb = min(info.blockCount, (1 << 30) // args.block)
@@ -513,6 +598,18 @@ def main():
             import numpy as np
 
             line["encode"]["cpu_baseline"] = cpu_encode_baseline(sample, args.block, args.codec, prefix[p0:], np.frombuffer(prefix, dtype=np.uint64, count=nb + 1, offset=64))
+        if run_config5:
+            # BASELINE config 5 in the driver-run line: frees the headline buffers first (each row holds its own 8 GiB input, container, workspace, output)
+            del src, dst, ws, out, container
+            torch.cuda.empty_cache()
+            try:
+                t5 = time.time()
+                rows = config5_rows(hsrle, torch, dev, with_cpu=not args.no_cpu)
+                line.setdefault("extras", {})["config5"] = {"workload": "8 GiB run-distributed(W, seed 5), 4 KiB blocks, every codec with a reference-minted manifest", "rows": rows,
+                                                            "all_bit_exact": bool(rows) and all(r["bit_exact"] for r in rows), "seconds": round(time.time() - t5, 1),
+                                                            "cpu_sample": "reference CPU codec, one core, first 64 MiB of the same buffer, block by block" if not args.no_cpu else None}
+            except Exception as ex:  # noqa: BLE001
+                line.setdefault("extras", {})["config5"] = {"error": repr(ex)[:300]}
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(line) + "\n").encode())
 

@@ -45,6 +45,9 @@ int hsrle_ref_has_avx2(void)
  * (rle_decompress_additional_size); blocks are decoded in order so the next block repairs that, and the caller gives the
  * output buffer 256 bytes of slack for the last one. */
 #include <stdint.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
 typedef uint32_t (*hsrle_ref_codec_fn)(const uint8_t *, uint32_t, uint8_t *, uint32_t);
 
 uint64_t hsrle_ref_decode_blocks(hsrle_ref_codec_fn fn, const uint8_t *payload, const uint64_t *offsets, uint64_t nBlocks, uint32_t blockSize,
@@ -74,6 +77,41 @@ uint64_t hsrle_ref_encode_blocks(hsrle_ref_codec_fn fn, const uint8_t *pIn, uint
     pSizes[b] = c;
   }
   return nBlocks;
+}
+
+/* Block by block from a guard-padded private copy of each block (the reference encoders of 2 .. 16 byte symbols read up to
+ * 2 * S - 1 bytes past the end of their input and may match there; the pad is filled so that they never do -- what the manifests were minted
+ * with and what the GPU library implements).  One thread, no hashing: the CPU encode baseline of bench.py for the wide codecs. */
+uint64_t hsrle_ref_encode_blocks_guarded(hsrle_ref_codec_fn fn, const uint8_t *pIn, uint64_t inSize, uint32_t blockSize, uint8_t *pOut, uint32_t stride, uint32_t *pSizes)
+{
+  const uint64_t nBlocks = (inSize + blockSize - 1) / blockSize;
+  uint8_t *tmp = (uint8_t *)malloc((size_t)blockSize + 128);
+  if (!tmp) return 0;
+  uint64_t done = 0;
+  for (uint64_t b = 0; b < nBlocks; b++, done++)
+  {
+    const uint64_t off = b * blockSize;
+    const uint32_t len = (uint32_t)((inSize - off) < blockSize ? (inSize - off) : blockSize);
+    memcpy(tmp, pIn + off, len);
+    for (uint32_t k = len; k < len + 64; k++)
+    {
+      static const int d[7] = { 1, 2, 3, 4, 6, 8, 16 };
+      uint8_t v = 0;
+      for (;;)
+      {
+        int clash = 0;
+        for (int q = 0; q < 7; q++) if (k >= (uint32_t)d[q] && tmp[k - d[q]] == v) clash = 1;
+        if (!clash) break;
+        v++;
+      }
+      tmp[k] = v;
+    }
+    const uint32_t c = fn(tmp, len, pOut + b * stride, stride);
+    if (c == 0) break;
+    pSizes[b] = c;
+  }
+  free(tmp);
+  return done == nBlocks ? nBlocks : 0;
 }
 
 /* The same over `nThreads` POSIX threads (one contiguous block range each): the "all host cores" context figure of bench.py.

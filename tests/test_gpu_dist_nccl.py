@@ -99,3 +99,24 @@ def test_rccl_world_of_one_gather_scatter_and_pieces():
     if os.path.isdir(out):
         with open(os.path.join(out, "rccl_world1.json"), "w") as f:
             json.dump(res, f, indent=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c_abi", [True, False], ids=["c_abi_gather", "torch_gather"])
+def test_bench_distributed_leg_runs_as_a_world_of_one(c_abi):
+    """bench.py's own sharded leg (HSRLE_FORCE_DIST=1: RCCL process group, seeds 100 + rank, the gather of the compressed segments through the
+    library's C ABI or through torch.distributed) on the hardware that is there -- so the code an 8-GPU driver run executes has run before.
+    The line must carry the gather figures (ms, bytes, GB/s, value with the gather), the CPU baseline and a bit-exact verdict."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", HSRLE_FORCE_DIST="1", HSRLE_DIST_C="1" if c_abi else "0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--size-gib", "1", "--no-extras", "--steps", "5", "--warmup", "2"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["bit_exact"] is True and j["scaling"] == "weak"
+    assert j["gather_ms"] > 0 and j["gather_bytes"] == 0 and "gather_GBps" in j and j["value_with_gather"] > 0   # a world of one: nothing crosses a link
+    assert j["value_with_gather"] < j["value"] and len(j["per_rank_ms_per_step"]) == 1
+    assert j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["matches_gpu_input"] and j["encode"]["cpu_baseline"]["streams_match_gpu"]
+    assert j["roofline"]["frac"] > 0 and j["config"]["sharding"] == "blocks x1"
