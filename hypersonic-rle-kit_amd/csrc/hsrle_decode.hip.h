@@ -100,6 +100,26 @@ __device__ __forceinline__ u32x4 lds_read16(const uint8_t *base, uint32_t p)
 
 // 16 bytes of the periodic run pattern starting at pattern phase ph (0 <= ph < S), S in {2,4,8,16}
 __device__ __forceinline__ u32x4 pattern_chunk16(u32x4 pv, uint32_t ph) { return funnel16(pv, pv, ph); }
+// the same with the period known: 2 and 4 byte symbols are one dword rotated (1 instruction instead of the 14 of the general funnel),
+// 8 byte symbols a dword pair
+template <int S>
+__device__ __forceinline__ u32x4 pattern_chunk16_s(u32x4 pv, uint32_t ph)
+{
+  if constexpr (S == 2 || S == 4)
+  {
+    const uint32_t d = alignbyte(pv.x, pv.x, ph);
+    return u32x4{ d, d, d, d };
+  }
+  else if constexpr (S == 8)
+  {
+    const bool sw = (ph & 4u) != 0u;
+    const uint32_t a = sw ? pv.y : pv.x, b = sw ? pv.x : pv.y;
+    const uint32_t lo = alignbyte(b, a, ph & 3u), hi = alignbyte(a, b, ph & 3u);
+    return u32x4{ lo, hi, lo, hi };
+  }
+  else
+    return funnel16(pv, pv, ph);
+}
 
 // S in {3,6}: the three distinct dwords e0 e1 e2 of the pattern stream that starts at phase ph; 16-byte chunk number k of
 // that stream is { e[k%3], e[(k+1)%3], e[(k+2)%3], e[k%3] } (16 bytes ahead == one dword further in the 12-byte period)
@@ -156,6 +176,24 @@ __device__ __forceinline__ uint32_t ex32(uint64_t lo, uint64_t hi, uint32_t pos)
   const uint64_t a = (lo >> (sh & 63u)) | ((hi << 1) << (63u - (sh & 63u)));
   const uint64_t b = hi >> (sh & 63u);
   return (uint32_t)(sh < 64u ? a : b);
+}
+
+// constant-position fields of a 16-byte header window (the common, short packet forms sit at compile-time positions: no second ring read,
+// no variable funnel): the 32 bits at byte P (P <= 12), the S-byte symbol at byte P (P + S <= 16; dwords beyond the symbol zero)
+template <int P>
+__device__ __forceinline__ uint32_t win_u32(u32x4 v)
+{
+  static_assert(P >= 0 && P <= 12, "inside the window");
+  if constexpr ((P & 3) == 0) return v[P >> 2];
+  else return alignbyte(v[(P >> 2) + 1], v[P >> 2], (uint32_t)(P & 3));
+}
+template <int S, int P>
+__device__ __forceinline__ u32x4 win_symbol(u32x4 v)
+{
+  static_assert(S <= 8 && P + S <= 16 && P + (S > 4 ? 8 : 4) <= 16, "the symbol lies inside the window");
+  u32x4 r = u32x4{ win_u32<P>(v), 0, 0, 0 };
+  if constexpr (S > 4) r.y = win_u32<P + 4>(v);
+  return mask_symbol<S>(r);
 }
 
 // The workgroup IS one wavefront (64 threads): LDS instructions of one wave execute in order, so lanes see each other's
@@ -787,6 +825,55 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
           const u32x4 hv = HS_RD16(0);
           const uint64_t lo = (uint64_t)hv.x | ((uint64_t)hv.y << 32), hi = (uint64_t)hv.z | ((uint64_t)hv.w << 32);
 
+          // ---- fast path of the 3 / 7 symbol LUT codecs with 2 and 4 byte symbols: a packet whose count and range are not extended has
+          //      every field at a compile-time position of the first window -- one ring read instead of two (the new symbol) or three,
+          //      no 64 bit shifts, no nested branches.  Everything else (extended fields, the terminators) takes the general parse below;
+          //      same results, field for field.  Same-box A/B, 8 GiB: rle16_3symlut_byte +11 % / +4 % (run data / video-shaped),
+          //      rle32_3symlut_sym +9 % / +13 %, rle16_7symlut_sym +2 % / +12 %.  The same idea for the plain / Packed / Short packets and for
+          //      3, 6, 8 byte symbols was built and measured too: -1 ... -5 % (their general parse has no divergent second read to save,
+          //      and a wave in which ANY lane needs the general parse executes both) -- not shipped ----
+          bool fastDone = false;
+          if constexpr (TR::kLut && (S == 2 || S == 4))
+          {
+            const uint32_t w16 = hv.x & 0xFFFFu;
+            const uint32_t idx = w16 >> (FAM == LUT3 ? 14 : 13);
+            const uint32_t c7 = (w16 >> TR::RB) & 0x7Fu, r7 = w16 & ((1u << TR::RB) - 1u);
+            if (c7 >= 2u && r7 >= 2u)                                       // neither field extended (rleX_Xsl.h:723-748)
+            {
+              const bool isNew = idx == (uint32_t)TR::K;
+              const u32x4 nv = win_symbol<S, 2>(hv);
+              uint32_t tmp[TR::SW];
+#pragma unroll
+              for (int w = 0; w < TR::SW; w++) tmp[w] = nv[w];
+#pragma unroll
+              for (int k = 0; k < TR::K; k++)
+                if (idx == (uint32_t)k)
+                {
+#pragma unroll
+                  for (int w = 0; w < TR::SW; w++) tmp[w] = lut[k][w];
+                }
+              const uint32_t limit = isNew ? (uint32_t)TR::K - 1u : idx;
+#pragma unroll
+              for (int k = TR::K - 1; k >= 1; k--)
+                if ((uint32_t)k <= limit)
+                {
+#pragma unroll
+                  for (int w = 0; w < TR::SW; w++) lut[k][w] = lut[k - 1][w];
+                }
+              u32x4 pv = u32x4{ 0, 0, 0, 0 };
+#pragma unroll
+              for (int w = 0; w < TR::SW; w++) { lut[0][w] = tmp[w]; pv[w] = tmp[w]; }
+              set_sym(pv);
+              cnt = c7; range = r7;
+              used = 2u + (isNew ? (uint32_t)S : 0u);
+              lit = range - 2u;
+              run = TR::kAligned ? (cnt + 3u / (uint32_t)S - 2u) * (uint32_t)S : cnt + 1u;
+              fastDone = true;
+            }
+          }
+
+          if (!fastDone)
+          {
           if constexpr (TR::kShort)
           {
             // Short family header, see the 8 bit loop
@@ -980,6 +1067,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
             lit = (range == 0) ? 0u : range - 1u;
             run = (cnt == 0) ? 0u : (TR::kAligned ? (cnt + TR::SHORT / (uint32_t)S - 1u) * (uint32_t)S : cnt + TR::SHORT - 1u);
           }
+          }
 #undef HS_RD16
         }
 
@@ -1034,7 +1122,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
           const uint32_t ph = (phase + 16u * (uint32_t)S - c) % (uint32_t)S;
           if constexpr (16 % S == 0)
           {
-            const u32x4 v = pattern_chunk16(patv, ph);                    // every chunk of the run holds the same 16 bytes
+            const u32x4 v = pattern_chunk16_s<S>(patv, ph);               // every chunk of the run holds the same 16 bytes
             const u32x4 w = HS_MERGE_LOW(acc, v, c);
             lds_st128(row + (d0 ^ tsw), w);
             for (uint32_t k = 16; k < total; k += 16)
