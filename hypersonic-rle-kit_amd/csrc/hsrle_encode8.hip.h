@@ -27,6 +27,13 @@
 
 namespace hsrle {
 
+#ifdef HSRLE_ENC_STAMPS   // diagnostic build (never shipped): per-phase cycle sums of lane 0 of every wave of k_encode8_blocks
+__device__ unsigned long long g_enc_stamps[8];
+#define HS_ESTAMP(slot) { const unsigned long long tq_ = __builtin_readcyclecounter(); est[slot] += tq_ - et0; et0 = tq_; }
+#else
+#define HS_ESTAMP(slot)
+#endif
+
 // (which ring the encoders of 1 and 2 byte symbols use for an input: hsrle_ring_probe.hip.h)
 // MONO = true: the lanes encode consecutive CHUNKS of ONE monolithic reference stream instead of independent blocks (hsrle_mono_encode.hip.h
 // finds the chunk boundaries).  Chunk c covers the input bytes [monoStarts[c], monoStarts[c + 1]); every boundary is the end of a run
@@ -563,10 +570,16 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
 
   uint32_t stepsLeft = MONO ? ((B != 0u) ? (monoSteps & 0xFFFFu) : monoSteps) : 2u * (B / (uint32_t)Q) + 64u;  // bounded: every step scans a window or lands input
 
+#ifdef HSRLE_ENC_STAMPS
+  unsigned long long est[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, et0 = __builtin_readcyclecounter();
+  uint32_t myTrips = 0, myRuns = 0;
+#endif
   while (__ballot(!finished) != 0ull)
   {
     if (stepsLeft-- == 0u) break;
+    HS_ESTAMP(0)
     issue();
+    HS_ESTAMP(1)
 
     // ---------------- scan what is in the ring ----------------
     // Phase A (uniform): equality mask of up to 64 positions -> bit masks of run starts and run ends.
@@ -594,12 +607,16 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
         const uint32_t validBits = (n - cb > W) ? W : (n - cb - 1u);
         e64 &= (validBits >= 64u) ? ~0ull : ((1ull << validBits) - 1ull);
         const uint64_t wmask = (W >= 64u) ? ~0ull : ((1ull << W) - 1ull);
+        HS_ESTAMP(2)
         const uint64_t prev = (e64 << 1) | (inRun ? 1ull : 0ull);      // "the position before me matched"
         winStarts = e64 & ~prev;
         uint64_t pendingEnds = ~e64 & prev & wmask;                     // bit i: a run ends with position i (exclusive end cb + i + 1)
 
         while (pendingEnds != 0ull)
         {
+#ifdef HSRLE_ENC_STAMPS
+          { const unsigned long long am_ = __ballot(true); if (lane == (uint32_t)__builtin_ctzll(am_)) myTrips++; myRuns++; }
+#endif
           const uint32_t i = (uint32_t)__builtin_ctzll(pendingEnds);
           const uint64_t sBelow = winStarts & ((2ull << i) - 1ull);
           uint32_t st = runStart, sy = sym;
@@ -650,10 +667,19 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
     }
 
     wave_sync();
+    HS_ESTAMP(3)
     land();
     wave_sync();
+    HS_ESTAMP(4)
+#ifdef HSRLE_ENC_STAMPS
+    est[5] += 1;
+#endif
   }
   coop_flush(true);
+#ifdef HSRLE_ENC_STAMPS
+  if (lane == 0u) { for (int q = 0; q < 6; q++) atomicAdd(g_enc_stamps + q, est[q]); atomicAdd(g_enc_stamps + 6, 1ull); }
+  atomicAdd(g_enc_stamps + 7, ((unsigned long long)myTrips << 32) | myRuns);   // wave-level trips of the run-end loop | lane-level run ends
+#endif
 }
 
 } // namespace hsrle

@@ -150,3 +150,12 @@ void register_w8(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBloc
 }
 
 } // namespace hsrle
+
+#ifdef HSRLE_ENC_STAMPS
+extern "C" int hsrle_debug_enc_stamps(unsigned long long *out, int reset)
+{
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hsrle::g_enc_stamps), sizeof(hsrle::g_enc_stamps)) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; if (hipMemcpyToSymbol(HIP_SYMBOL(hsrle::g_enc_stamps), z, sizeof(z)) != hipSuccess) return 1; }
+  return 0;
+}
+#endif
