@@ -1487,7 +1487,10 @@ static Rle8mPlan plan_rle8m(uint32_t n, uint32_t sections)
 static uint32_t rle8m_bounds(uint32_t sections, uint32_t n) { return n + (256 / 8) + 1 + 256 + 4u * (2u + sections - 1u + 1u); }
 
 // the caller has checked device_ok()
-static int rle8m_encode_async(const void *dIn, uint32_t n, uint32_t sections, void *dOut, uint64_t outCapacity, void *dWs, uint64_t wsSize, uint32_t *dStatus, hipStream_t st)
+// maxLen / onlyMax: the four unsectioned encoders share these kernels (rle8_low_entropy[_short]_compress[_only_max_frequency]: runs are cut
+// every 255 or 32 bytes, and either every symbol whose runs average >= 2 carries repeat codes or only the one that saves the most)
+static int rle8m_encode_async(const void *dIn, uint32_t n, uint32_t sections, void *dOut, uint64_t outCapacity, void *dWs, uint64_t wsSize, uint32_t *dStatus, hipStream_t st,
+                              uint32_t maxLen = 255u, uint32_t onlyMax = 0u)
 {
   if (!dIn || !dOut || !dWs || n == 0 || sections == 0)
     return HSRLE_ERR_ARGUMENT;
@@ -1508,20 +1511,20 @@ static int rle8m_encode_async(const void *dIn, uint32_t n, uint32_t sections, vo
   static const uint32_t g_rle8mStatsWaves = knob_u32("HSRLE_RLE8M_STATS_WAVES", 32768u);   // (1 GiB run-distributed / video-shaped: 1 024 waves 7.5 / 6.2 ms per encode, 8 192: 3.96 / 4.17, 32 768: 3.75 / 3.98; the byte-walking kernel: 4.03 / 4.60)
   static const int statsV1 = (int)knob_u32("HSRLE_RLE8M_STATS", 0);   // 1 = the byte-walking kernel (A/B runs)
   if (statsV1 == 1)
-    hipLaunchKernelGGL(k_rle8m_stats, dim3((pieces + 63u) / 64u), dim3(64), 0, st, (const uint8_t *)dIn, n, pieces, t);
+    hipLaunchKernelGGL(k_rle8m_stats, dim3((pieces + 63u) / 64u), dim3(64), 0, st, (const uint8_t *)dIn, n, pieces, t, maxLen);
   else
   {
     const uint32_t waves = (uint32_t)(((uint64_t)n + 4095u) / 4096u);
     uint32_t grid = waves < g_rle8mStatsWaves ? waves : g_rle8mStatsWaves;
     if ((uint64_t)grid * kRle8mStatsPieces < waves) grid = (waves + kRle8mStatsPieces - 1u) / kRle8mStatsPieces;   // (no wave gets more pieces than its packed counters hold)
-    hipLaunchKernelGGL(k_rle8m_stats_wave, dim3(grid), dim3(64), 0, st, (const uint8_t *)dIn, n, t);
+    hipLaunchKernelGGL(k_rle8m_stats_wave, dim3(grid), dim3(64), 0, st, (const uint8_t *)dIn, n, t, maxLen);
   }
-  hipLaunchKernelGGL(k_rle8m_info, dim3(1), dim3(256), 0, st, t, sections, (uint8_t *)dOut);
+  hipLaunchKernelGGL(k_rle8m_info, dim3(1), dim3(256), 0, st, t, sections, (uint8_t *)dOut, onlyMax);
   static const int forced = (int)knob_u32("HSRLE_RLE8M_ENCODE", 0);   // 1 = lane, 2 = wave kernel (A/B runs)
   if (forced ? forced == 2 : sections < kRle8mWaveBelow)
-    hipLaunchKernelGGL(k_rle8m_encode_wave, dim3(sections), dim3(64), 0, st, (const uint8_t *)dIn, n, sections, (const Rle8mTables *)t, ws + p.w.offSlots, p.slotStride, sizes);
+    hipLaunchKernelGGL(k_rle8m_encode_wave, dim3(sections), dim3(64), 0, st, (const uint8_t *)dIn, n, sections, (const Rle8mTables *)t, ws + p.w.offSlots, p.slotStride, sizes, maxLen);
   else
-    hipLaunchKernelGGL(k_rle8m_encode, dim3(grid), dim3(64), 0, st, (const uint8_t *)dIn, n, sections, (const Rle8mTables *)t, ws + p.w.offSlots, p.slotStride, sizes);
+    hipLaunchKernelGGL(k_rle8m_encode, dim3(grid), dim3(64), 0, st, (const uint8_t *)dIn, n, sections, (const Rle8mTables *)t, ws + p.w.offSlots, p.slotStride, sizes, maxLen);
   if (scan_sizes(sizes, sections, offsets, ws, p.w, st) != hipSuccess)
     return HSRLE_ERR_DEVICE;
   hipLaunchKernelGGL(k_rle8m_place, dim3((sections + 3u) / 4u), dim3(256), 0, st, (const uint8_t *)(ws + p.w.offSlots), p.slotStride, (const uint64_t *)offsets, (const Rle8mTables *)t,
@@ -1675,6 +1678,91 @@ int hsrle_device_count(void)
   int n = 0;
   return (hipGetDeviceCount(&n) == hipSuccess) ? n : 0;
 }
+
+// ---- the low-entropy codec in its UNSECTIONED forms (src/rle.h:53-57, :90-93; rle8_low_entropy_cpu.c:6-124, rle8_low_entropy_short_cpu.c:16-124):
+//      [u32 compressedSize][u32 uncompressedSize][info][one stream] -- an rle8m stream of ONE section without its section-count field.  They run
+//      on the rle8m kernels (one section: one wave walks the input / the stream, so these calls are functional, not fast: the sectioned
+//      form is the one the format offers for parallel hardware); the layout is converted while the bytes cross PCIe. ----
+static uint32_t le_bounds(uint32_t n) { return n + (256 / 8) + 1 + 256 + 8u; }
+
+static uint32_t le_mono_compress(const uint8_t *pIn, uint32_t inSize, uint8_t *pOut, uint32_t outSize, uint32_t maxLen, uint32_t onlyMax)
+{
+  // argument checks of the reference (rle8_low_entropy_cpu.c:13-14; the Short form checks against the same bound, rle8_low_entropy_short_cpu.c:23)
+  if (pIn == nullptr || inSize == 0 || pOut == nullptr || outSize < le_bounds(inSize) || !device_ok())
+    return 0;
+  const Rle8mPlan p = plan_rle8m(inSize, 1u);
+  const uint64_t cap = (uint64_t)rle8m_bounds(1u, inSize) + (uint64_t)inSize;            // (a stream is at most twice its input: every byte a flagged symbol with a zero code)
+  DeviceState &D = this_device();
+  std::lock_guard<std::mutex> lock(D.mu);
+  if (!grow(&D.monoIn, &D.monoInSize, (uint64_t)inSize + 64) || !grow(&D.monoOut, &D.monoOutSize, cap + 64) || !grow(&D.ws, &D.wsSize, p.total))
+    return 0;
+  if (!D.monoAux && hipMalloc(&D.monoAux, 256) != hipSuccess)
+    return 0;
+  uint32_t *dStatus = (uint32_t *)((uint8_t *)D.monoAux + 64);
+  if (hipMemcpy(D.monoIn, pIn, inSize, hipMemcpyHostToDevice) != hipSuccess)
+    return 0;
+  if (rle8m_encode_async(D.monoIn, inSize, 1u, D.monoOut, cap, D.ws, D.wsSize, dStatus, nullptr, maxLen, onlyMax) != HSRLE_OK)
+    return 0;
+  uint32_t status = 1, size = 0;
+  if (hipMemcpy(&status, dStatus, 4, hipMemcpyDeviceToHost) != hipSuccess || status != 0)
+    return 0;
+  if (hipMemcpy(&size, D.monoOut, 4, hipMemcpyDeviceToHost) != hipSuccess || size < 12u + 33u)
+    return 0;
+  // (the reference does not look at the room its stream needs, compress_with_info only asks for outSize >= inSize and then writes up to twice
+  //  that: rle8_low_entropy_cpu.c:476.  A stream that does not fit the caller's buffer is a failure here, never a write behind it.)
+  const uint32_t out = size - 4u;
+  if (out > outSize)
+    return 0;
+  memcpy(pOut, &out, 4);
+  memcpy(pOut + 4, &inSize, 4);
+  if (hipMemcpy(pOut + 8, (const uint8_t *)D.monoOut + 12, out - 8u, hipMemcpyDeviceToHost) != hipSuccess)
+    return 0;
+  return out;
+}
+
+static uint32_t le_mono_decompress(const uint8_t *pIn, uint32_t inSize, uint8_t *pOut, uint32_t outSize)
+{
+  // argument + header checks of the reference (rle8_low_entropy_cpu.c:98-107)
+  if (pIn == nullptr || pOut == nullptr || inSize < 8u + 33u || outSize == 0 || !device_ok())
+    return 0;
+  uint32_t expIn, expOut;
+  memcpy(&expIn, pIn, 4); memcpy(&expOut, pIn + 4, 4);
+  if (expOut > outSize || expIn > inSize || expIn < 8u + 33u || expOut == 0 || expIn > 0xFFFFFF00u)
+    return 0;
+  DeviceState &D = this_device();
+  std::lock_guard<std::mutex> lock(D.mu);
+  if (!grow(&D.monoIn, &D.monoInSize, (uint64_t)expIn + 4 + 256) || !grow(&D.monoOut, &D.monoOutSize, (uint64_t)expOut + 64))
+    return 0;
+  if (!D.monoAux && hipMalloc(&D.monoAux, 256) != hipSuccess)
+    return 0;
+  uint32_t *dStatus = (uint32_t *)((uint8_t *)D.monoAux + 64);
+  const uint32_t head[3] = { expIn + 4u, expOut, 1u };                                     // the rle8m header of one section
+  if (hipMemcpy(D.monoIn, head, 12, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy((uint8_t *)D.monoIn + 12, pIn + 8, expIn - 8u, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemset((uint8_t *)D.monoIn + expIn + 4u, 0, 64) != hipSuccess)
+    return 0;
+  if (rle8m_decode_async(D.monoIn, (uint64_t)expIn + 4u, expOut, 1u, D.monoOut, expOut, dStatus, nullptr) != HSRLE_OK)
+    return 0;
+  uint32_t status = 1;
+  if (hipMemcpy(&status, dStatus, 4, hipMemcpyDeviceToHost) != hipSuccess || status != 0)
+    return 0;
+  if (hipMemcpy(pOut, D.monoOut, expOut, hipMemcpyDeviceToHost) != hipSuccess)
+    return 0;
+  return expOut;
+}
+
+uint32_t rle8_low_entropy_compress_bounds(const uint32_t inSize) { return le_bounds(inSize); }
+uint32_t rle8_low_entropy_short_compress_bounds(const uint32_t inSize) { return le_bounds(inSize); }
+uint32_t rle8_low_entropy_decompressed_size(const uint8_t *pIn, const uint32_t inSize)
+{
+  if (pIn == nullptr || inSize < 8u) return 0;                                               // rle8_low_entropy_cpu.c:88-94
+  uint32_t v; memcpy(&v, pIn + 4, 4); return v;
+}
+uint32_t rle8_low_entropy_compress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize) { return le_mono_compress(pIn, inSize, pOut, outSize, 255u, 0u); }
+uint32_t rle8_low_entropy_compress_only_max_frequency(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize) { return le_mono_compress(pIn, inSize, pOut, outSize, 255u, 1u); }
+uint32_t rle8_low_entropy_decompress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize) { return le_mono_decompress(pIn, inSize, pOut, outSize); }
+uint32_t rle8_low_entropy_short_compress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize) { return le_mono_compress(pIn, inSize, pOut, outSize, 32u, 0u); }
+uint32_t rle8_low_entropy_short_compress_only_max_frequency(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize) { return le_mono_compress(pIn, inSize, pOut, outSize, 32u, 1u); }
+uint32_t rle8_low_entropy_short_decompress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize) { return le_mono_decompress(pIn, inSize, pOut, outSize); }
 
 // ---- rle8m: names of the reference's GPU decode path (src/rle.h:464-466) and of its CPU twin (src/rle.h:63) ----
 bool rle8m_opencl_init(const size_t inputDataSize, const size_t outputDataSize, const size_t maxSubsectionCount)

@@ -348,7 +348,7 @@ struct Rle8mTables                          // device scratch shared by the kern
 };
 
 // (`sections` here is any partition of the input into pieces: the statistics are over the whole input)
-__global__ __launch_bounds__(64) void k_rle8m_stats(const uint8_t *__restrict__ d, uint32_t n, uint32_t sections, Rle8mTables *__restrict__ t)
+__global__ __launch_bounds__(64) void k_rle8m_stats(const uint8_t *__restrict__ d, uint32_t n, uint32_t sections, Rle8mTables *__restrict__ t, uint32_t maxLen)
 {
   __shared__ uint32_t prob[256], pcount[256];
   const uint32_t lane = threadIdx.x;
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(64) void k_rle8m_stats(const uint8_t *__restrict__ 
       if (sym != 0xFFFFFFFFu)
       {
         atomicAdd(&prob[sym], len);
-        atomicAdd(&pcount[sym], len / 255u + 1u);
+        atomicAdd(&pcount[sym], len / maxLen + 1u);
         sym = 0xFFFFFFFFu;
       }
       if (i >= (uint32_t)b) break;                                        // a run that starts behind my section is not mine
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(64) void k_rle8m_stats(const uint8_t *__restrict__ 
 // leaves it, through global memory) -- to LDS histograms; one flush of the histograms per wave.  (k_rle8m_stats above walks a byte
 // per lane and trip: 1.87 ms per GiB, as long as the encode kernel; kept for HSRLE_RLE8M_STATS=1 A/B runs.)
 constexpr uint32_t kRle8mStatsPieces = 15;    // 4 KiB pieces per wave at most (15 * 4096 < 65536: the packed LDS counters)
-__global__ __launch_bounds__(64) void k_rle8m_stats_wave(const uint8_t *__restrict__ d, uint32_t n, Rle8mTables *__restrict__ t)
+__global__ __launch_bounds__(64) void k_rle8m_stats_wave(const uint8_t *__restrict__ d, uint32_t n, Rle8mTables *__restrict__ t, uint32_t maxLen)
 {
   constexpr uint32_t P = 4096u;
   __shared__ __attribute__((aligned(16))) uint8_t bytes[P + 16u];
@@ -499,11 +499,11 @@ __global__ __launch_bounds__(64) void k_rle8m_stats_wave(const uint8_t *__restri
         const bool toEnd = (uint64_t)a + base + p + L == (uint64_t)n;     // the run that reaches the end of the input counts once
         // the usual run (< 255 bytes: one count) is ONE LDS atomic into the packed table (pcount << 16 | prob: a wave sees at most
         // kRle8mStatsPieces * 4096 bytes, so neither half overflows); the others go to the global table directly
-        if (L < 255ull) atomicAdd(&pk[sy], (1u << 16) | (uint32_t)L);
+        if (L < (uint64_t)maxLen) atomicAdd(&pk[sy], (1u << 16) | (uint32_t)L);
         else
         {
           atomicAdd(&t->prob[sy], (uint32_t)L);
-          atomicAdd(&t->pcount[sy], toEnd ? 1u : (uint32_t)(L / 255ull) + 1u);
+          atomicAdd(&t->pcount[sy], toEnd ? 1u : (uint32_t)(L / (uint64_t)maxLen) + 1u);
         }
       }
     }
@@ -516,14 +516,26 @@ __global__ __launch_bounds__(64) void k_rle8m_stats_wave(const uint8_t *__restri
   }
 }
 
-__global__ __launch_bounds__(256) void k_rle8m_info(Rle8mTables *__restrict__ t, uint32_t sections, uint8_t *__restrict__ out)
+// onlyMax: the rule of the *_only_max_frequency encoders (rle8_low_entropy_cpu.c:340-439, rle8_low_entropy_short_cpu.c:622-720): ONE symbol
+// carries repeat codes -- the first one with the most bytes saved (prob - 2 * pcount, among the symbols with prob / pcount > 2), if any
+__global__ __launch_bounds__(256) void k_rle8m_info(Rle8mTables *__restrict__ t, uint32_t sections, uint8_t *__restrict__ out, uint32_t onlyMax)
 {
   __shared__ uint32_t pc[256];
   __shared__ uint8_t order[256], flag[256];
+  __shared__ uint64_t saved[256];
   const uint32_t i = threadIdx.x;
   const uint32_t p = t->prob[i], c = t->pcount[i];
   pc[i] = c;
-  flag[i] = (c > 0u && p / c >= 2u) ? 1 : 0;
+  flag[i] = (!onlyMax && c > 0u && p / c >= 2u) ? 1 : 0;
+  saved[i] = (c > 0u && p / c > 2u) ? (uint64_t)p - 2ull * (uint64_t)c : 0ull;   // (size_t arithmetic of uint32 operands in the reference: prob - pcount * 2 with the product taken in 32 bits)
+  __syncthreads();
+  if (onlyMax && i == 0u)
+  {
+    uint64_t best = 0; uint32_t at = 0;
+    for (uint32_t j = 0; j < 256u; j++)
+      if (saved[j] > best) { best = saved[j]; at = j; }
+    if (best > 0ull) flag[at] = 1;
+  }
   __syncthreads();
   uint32_t used = 0, rank = 0, unusedBelow = 0;
   for (uint32_t j = 0; j < 256u; j++)
@@ -561,7 +573,7 @@ __global__ __launch_bounds__(256) void k_rle8m_info(Rle8mTables *__restrict__ t,
 }
 
 __global__ __launch_bounds__(64) void k_rle8m_encode(const uint8_t *__restrict__ d, uint32_t n, uint32_t sections, const Rle8mTables *__restrict__ t,
-                                                      uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes)
+                                                      uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes, uint32_t maxLen)
 {
   __shared__ uint32_t rleBits[8];
   __shared__ __attribute__((aligned(4))) uint8_t order[256];
@@ -608,7 +620,7 @@ __global__ __launch_bounds__(64) void k_rle8m_encode(const uint8_t *__restrict__
       if ((rleBits[b >> 5] >> (b & 31u)) & 1u)
       {
         const uint32_t left = len - i - 1u;
-        range = (i < target) ? 255u : (left < 255u ? left : 255u);        // :497 / :521
+        range = (i < target) ? maxLen : (left < maxLen ? left : maxLen);   // :497 / :521 (maxLen 255; the Short form: 32)
         runSym = b; count = 0; j = 1; scanning = true;
       }
       else
@@ -633,7 +645,7 @@ __global__ __launch_bounds__(64) void k_rle8m_encode(const uint8_t *__restrict__
 // byte, decides whether a token ENDS there (no token starts inside another, so emitting at the end keeps the order) and the count is the
 // distance to the run start modulo 255; run starts come from the ballot of the run breaks, offsets from a wave scan.
 __global__ __launch_bounds__(64) void k_rle8m_encode_wave(const uint8_t *__restrict__ d, uint32_t n, uint32_t sections, const Rle8mTables *__restrict__ t,
-                                                           uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes)
+                                                           uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes, uint32_t maxLen)
 {
   __shared__ uint32_t rleBits[8];
   __shared__ __attribute__((aligned(4))) uint8_t order[256];
@@ -668,7 +680,7 @@ __global__ __launch_bounds__(64) void k_rle8m_encode_wave(const uint8_t *__restr
     const uint32_t runStart = mine ? ip + (63u - (uint32_t)__builtin_clzll(mine)) : carryRunStart;
     const uint32_t rel = pos - runStart;
     const bool nextBreaks = pos + 1u >= len - 1u || nextb != b;           // (the last byte of the section is a break)
-    const bool isEnd = valid && (!fl || pos == len - 1u || nextBreaks || (rel + 1u) % 255u == 0u);
+    const bool isEnd = valid && (!fl || pos == len - 1u || nextBreaks || (rel + 1u) % maxLen == 0u);
     // a token is one byte, or two with a repeat code: the offsets are population counts of the lanes below (no scan needed)
     const uint64_t E = __builtin_amdgcn_ballot_w64(isEnd), E2 = __builtin_amdgcn_ballot_w64(isEnd && fl);
     const uint32_t off = __builtin_amdgcn_mbcnt_hi((uint32_t)(E >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)E, 0u)) +
@@ -677,7 +689,7 @@ __global__ __launch_bounds__(64) void k_rle8m_encode_wave(const uint8_t *__restr
     {
       uint8_t *q = o + op + off;
       q[0] = (uint8_t)b;
-      if (fl) q[1] = order[rel % 255u];
+      if (fl) q[1] = order[rel % maxLen];
     }
     op += (uint32_t)__builtin_popcountll(E) + (uint32_t)__builtin_popcountll(E2);
     carryPrev = (uint32_t)__builtin_amdgcn_readlane((int)b, 63);

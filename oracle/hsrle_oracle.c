@@ -1368,7 +1368,10 @@ uint32_t hso_rle8m_compress_bounds(uint32_t subSections, uint32_t inSize)
 
 typedef struct { uint8_t rle[256]; uint8_t symbolsByProb[256]; uint8_t symbolCount; } le_info_t;
 
-static void le_get_info(const uint8_t *d, uint32_t n, le_info_t *info)
+/* maxLen: 255, or 32 for the Short form (ULTRA_MAX_BLOCK_LENGTH, src/rle8_low_entropy_short_cpu.c:9, :571).  onlyMax: the rule of the
+ * *_only_max_frequency encoders (src/rle8_low_entropy_cpu.c:340-439, src/rle8_low_entropy_short_cpu.c:622-720): one symbol -- the first
+ * with the most bytes saved among those whose runs average more than 2 -- carries repeat codes, if any does. */
+static void le_get_info_ex(const uint8_t *d, uint32_t n, le_info_t *info, uint32_t maxLen, int onlyMax)
 {
   uint32_t prob[256], pcount[256];
   uint8_t consumed[256];
@@ -1389,7 +1392,7 @@ static void le_get_info(const uint8_t *d, uint32_t n, le_info_t *info)
     else
     {
       prob[last] += count;
-      pcount[last] += (count / 255) + 1;
+      pcount[last] += (count / maxLen) + 1;
       count = 1;
       last = d[i];
     }
@@ -1398,8 +1401,24 @@ static void le_get_info(const uint8_t *d, uint32_t n, le_info_t *info)
   prob[last] += count;
   pcount[last]++;
 
-  for (int i = 0; i < 256; i++)
-    info->rle[i] = (pcount[i] > 0) ? ((prob[i] / pcount[i]) >= 2) : 0;
+  if (!onlyMax)
+  {
+    for (int i = 0; i < 256; i++)
+      info->rle[i] = (pcount[i] > 0) ? ((prob[i] / pcount[i]) >= 2) : 0;
+  }
+  else
+  {
+    size_t maxSaved = 0, maxAt = 0;
+    memset(info->rle, 0, sizeof(info->rle));
+    for (size_t i = 0; i < 256; i++)
+      if (pcount[i] > 0 && prob[i] / pcount[i] > 2)
+      {
+        const size_t saved = prob[i] - (pcount[i] * 2);       /* (uint32 arithmetic, as in the reference: :392) */
+        if (saved > maxSaved) { maxSaved = saved; maxAt = i; }
+      }
+    if (maxSaved > 0)
+      info->rle[maxAt] = 1;
+  }
 
   uint32_t remaining = 256;
 
@@ -1426,6 +1445,8 @@ static void le_get_info(const uint8_t *d, uint32_t n, le_info_t *info)
   info->symbolCount = (uint8_t)remaining;
 }
 
+static void le_get_info(const uint8_t *d, uint32_t n, le_info_t *info) { le_get_info_ex(d, n, info, 255, 0); }
+
 static uint32_t le_write_info(const le_info_t *info, uint8_t *out)
 {
   uint32_t index = 0;
@@ -1443,7 +1464,7 @@ static uint32_t le_write_info(const le_info_t *info, uint8_t *out)
   return index + sc;
 }
 
-static uint32_t le_compress_section(const uint8_t *d, uint32_t n, const le_info_t *info, uint8_t *out)
+static uint32_t le_compress_section_ex(const uint8_t *d, uint32_t n, const le_info_t *info, uint8_t *out, uint32_t maxLen)
 {
   uint32_t index = 0;
 
@@ -1456,7 +1477,7 @@ static uint32_t le_compress_section(const uint8_t *d, uint32_t n, const le_info_
     {
       /* :497-511 (range 255) and :521-535 (range min(n - i - 1, 255) in the last 256 bytes) */
       const uint32_t left = n - i - 1, target = (n >= 256) ? n - 256 : 0;
-      const uint32_t range = (i < target) ? 255 : (left < 255 ? left : 255);
+      const uint32_t range = (i < target) ? maxLen : (left < maxLen ? left : maxLen);   /* (Short form: 32, rle8_low_entropy_short_cpu.c:152, :179) */
       uint32_t count = 0, j = 1;
 
       for (; j < range; j++)
@@ -1469,6 +1490,8 @@ static uint32_t le_compress_section(const uint8_t *d, uint32_t n, const le_info_
 
   return index;
 }
+
+static uint32_t le_compress_section(const uint8_t *d, uint32_t n, const le_info_t *info, uint8_t *out) { return le_compress_section_ex(d, n, info, out, 255); }
 
 uint32_t hso_rle8m_compress(uint32_t subSections, const uint8_t *pIn, uint32_t inSize, uint8_t *pOut, uint32_t outSize)
 {
@@ -1555,6 +1578,75 @@ uint32_t hso_rle8m_decompress(const uint8_t *pIn, uint32_t inSize, uint8_t *pOut
   }
 
   return expOut;
+}
+
+/* The UNSECTIONED forms of the same codec: [u32 compressedSize][u32 uncompressedSize][info][one stream].
+ *   rle8_low_entropy_compress / _compress_only_max_frequency / _decompress            src/rle8_low_entropy_cpu.c:6-124
+ *   rle8_low_entropy_short_compress / _only_max_frequency / _short_decompress         src/rle8_low_entropy_short_cpu.c:16-124
+ * variant bit 0: the Short form (runs cut every 32 bytes instead of 255), bit 1: only_max_frequency.  Like the reference, the encoder
+ * does not check the room its stream needs beyond `bounds` (it can take up to twice the input): callers give it 2 * inSize more. */
+uint32_t hso_low_entropy_compress_bounds(uint32_t inSize) { return inSize + (256 / 8) + 1 + 256 + 4 * 2; }
+
+uint32_t hso_low_entropy_compress(int variant, const uint8_t *pIn, uint32_t inSize, uint8_t *pOut, uint32_t outSize)
+{
+  if (pIn == NULL || inSize == 0 || pOut == NULL || outSize < hso_low_entropy_compress_bounds(inSize))
+    return 0;
+
+  const uint32_t maxLen = (variant & 1) ? 32 : 255;
+  le_info_t info;
+  le_get_info_ex(pIn, inSize, &info, maxLen, (variant & 2) != 0);
+
+  uint32_t index = 4;
+  patch32(pOut, index, inSize); index += 4;
+  index += le_write_info(&info, pOut + index);
+  if (outSize - index < inSize) return 0;                      /* compress_with_info: outSize < inSize (:476) -- never true above the bound */
+  index += le_compress_section_ex(pIn, inSize, &info, pOut + index, maxLen);
+  patch32(pOut, 0, index);
+  return index;
+}
+
+/* one decoder for both forms: the count comes out of the code table (src/rle8_low_entropy_cpu.c:96-124, :930-1021; short: :103-124, :454-534) */
+uint32_t hso_low_entropy_decompress(const uint8_t *pIn, uint32_t inSize, uint8_t *pOut, uint32_t outSize)
+{
+  if (pIn == NULL || pOut == NULL || inSize < 8 || outSize == 0)
+    return 0;
+
+  const uint32_t expIn = get32(pIn), expOut = get32(pIn + 4);
+
+  if (expOut > outSize || expIn > inSize)
+    return 0;
+
+  uint64_t index = 8;
+  if (index + 33 > expIn) return 0;
+
+  uint8_t rle[256], symbolToCount[256], listed[256];
+  for (int i = 0; i < 256; i++) rle[i] = (pIn[index + (i >> 3)] >> (i & 7)) & 1;
+  index += 32;
+  uint32_t sc = pIn[index++];
+  if (!sc) sc = 255;
+  if (index + sc > expIn) return 0;
+  memset(listed, 0, 256);
+  for (uint32_t i = 0; i < sc; i++) { symbolToCount[pIn[index + i]] = (uint8_t)i; listed[pIn[index + i]] = 1; }
+  index += sc;
+  uint32_t next = sc;
+  for (int i = 0; i < 256; i++) if (!listed[i]) symbolToCount[i] = (uint8_t)next++;
+
+  uint64_t o = 0;
+  while (index < expIn)
+  {
+    const uint8_t b = pIn[index++];
+    if (o >= expOut) return 0;
+    pOut[o++] = b;
+    if (rle[b])
+    {
+      if (index >= expIn) return 0;
+      const uint32_t count = symbolToCount[pIn[index++]];
+      if (o + count > expOut) return 0;
+      memset(pOut + o, b, count);
+      o += count;
+    }
+  }
+  return (o == expOut) ? expOut : 0;
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -83,6 +83,12 @@ uint32_t hso_rle8m_compress_bounds(uint32_t subSections, uint32_t inSize);
 uint32_t hso_rle8m_compress(uint32_t subSections, const uint8_t *pIn, uint32_t inSize, uint8_t *pOut, uint32_t outSize);
 uint32_t hso_rle8m_decompress(const uint8_t *pIn, uint32_t inSize, uint8_t *pOut, uint32_t outSize);
 
+/* the unsectioned forms of the low-entropy codec (reference: rle8_low_entropy[_short]_compress[_only_max_frequency] /
+ * _decompress, src/rle8_low_entropy_cpu.c:6-124, src/rle8_low_entropy_short_cpu.c:16-124).  variant: bit 0 Short form, bit 1 only_max_frequency */
+uint32_t hso_low_entropy_compress_bounds(uint32_t inSize);
+uint32_t hso_low_entropy_compress(int variant, const uint8_t *pIn, uint32_t inSize, uint8_t *pOut, uint32_t outSize);
+uint32_t hso_low_entropy_decompress(const uint8_t *pIn, uint32_t inSize, uint8_t *pOut, uint32_t outSize);
+
 /* oracle/hsrle_synth.c: bytes [offset, offset + size) of a deterministic synthetic workload (offset multiple of 64 KiB) */
 int hso_synth(int kind, int symbolBytes, uint64_t seed, uint64_t offset, uint8_t *out, uint64_t size);
 

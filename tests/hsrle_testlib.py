@@ -150,6 +150,26 @@ class Oracle:
         got = L.hso_rle8m_decompress(bytes(stream), ctypes.c_uint32(len(stream)), out, ctypes.c_uint32(out_size))
         return out.raw[:out_size] if got == out_size else None
 
+    def low_entropy_compress(self, variant, data):
+        """Unsectioned low-entropy stream (variant: bit 0 Short form, bit 1 only_max_frequency), or None where the stream outgrows the
+        bound (the reference then writes behind its caller's buffer: self.le_overflowed)."""
+        L = self.lib
+        L.hso_low_entropy_compress_bounds.restype = ctypes.c_uint32
+        L.hso_low_entropy_compress.restype = ctypes.c_uint32
+        data = bytes(data)
+        cap = L.hso_low_entropy_compress_bounds(ctypes.c_uint32(len(data)))
+        out = ctypes.create_string_buffer(cap + 2 * len(data) + 64)
+        size = L.hso_low_entropy_compress(ctypes.c_int(variant), data, ctypes.c_uint32(len(data)), out, ctypes.c_uint32(cap))
+        self.le_overflowed = size > cap
+        return out.raw[:size] if 0 < size <= cap else None
+
+    def low_entropy_decompress(self, stream, out_size):
+        L = self.lib
+        L.hso_low_entropy_decompress.restype = ctypes.c_uint32
+        out = ctypes.create_string_buffer(out_size + 64)
+        got = L.hso_low_entropy_decompress(bytes(stream), ctypes.c_uint32(len(stream)), out, ctypes.c_uint32(out_size))
+        return out.raw[:out_size] if got == out_size else None
+
     def compress(self, codec, data):
         data = bytes(data)
         n = len(data)
@@ -222,6 +242,29 @@ class Reference:
         L.rle8m_decompress.restype = ctypes.c_uint32
         out = ctypes.create_string_buffer(out_size + 256)
         got = L.rle8m_decompress(bytes(stream), ctypes.c_uint32(len(stream)), out, ctypes.c_uint32(out_size))
+        return out.raw[:out_size] if got == out_size else None
+
+    LE_NAMES = ("rle8_low_entropy_compress", "rle8_low_entropy_short_compress", "rle8_low_entropy_compress_only_max_frequency", "rle8_low_entropy_short_compress_only_max_frequency")
+
+    def low_entropy_compress(self, variant, data):
+        """variant: bit 0 Short form, bit 1 only_max_frequency (LE_NAMES[variant])"""
+        L = self.lib
+        L.rle8_low_entropy_compress_bounds.restype = ctypes.c_uint32
+        f = getattr(L, self.LE_NAMES[variant])
+        f.restype = ctypes.c_uint32
+        data = bytes(data)
+        cap = L.rle8_low_entropy_compress_bounds(ctypes.c_uint32(len(data)))
+        out = ctypes.create_string_buffer(cap + 2 * len(data) + 64)   # see Oracle.low_entropy_compress
+        size = f(data, ctypes.c_uint32(len(data)), out, ctypes.c_uint32(cap))
+        self.le_overflowed = size > cap
+        return out.raw[:size] if 0 < size <= cap else None
+
+    def low_entropy_decompress(self, short, stream, out_size):
+        f = self.lib.rle8_low_entropy_short_decompress if short else self.lib.rle8_low_entropy_decompress
+        f.restype = ctypes.c_uint32
+        out = ctypes.create_string_buffer(out_size + 512)            # (the reference's vector loops write whole vectors behind the end)
+        src = bytes(stream) + bytes(512)
+        got = f(src, ctypes.c_uint32(len(stream)), out, ctypes.c_uint32(out_size))
         return out.raw[:out_size] if got == out_size else None
 
     def _fn(self, name):

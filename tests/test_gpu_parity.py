@@ -325,6 +325,50 @@ def test_rle8m_fuzz_small_and_ragged_inputs(hs, oracle):
     assert n >= 150
 
 
+LE_NAMES = ("rle8_low_entropy_compress", "rle8_low_entropy_short_compress", "rle8_low_entropy_compress_only_max_frequency", "rle8_low_entropy_short_compress_only_max_frequency")
+
+
+def test_low_entropy_unsectioned_forms_match_the_oracle(hs, oracle):
+    """rle8_low_entropy[_short]_compress[_only_max_frequency] / _decompress behind the reference's names on the GPU -- the
+    four encoders write the oracle's (= the reference's) streams byte for byte, give up (0) exactly where the reference's stream outgrows its
+    bound, and both decoders read the oracle's streams; sizes around the encoders' 256-byte tail rule and runs around 32 / 255 included."""
+    rng = random.Random(812)
+    lib = hs.lib()
+    lib.rle8_low_entropy_compress_bounds.restype = ctypes.c_uint32
+    lib.rle8_low_entropy_decompressed_size.restype = ctypes.c_uint32
+    inputs = [mixed_runs(rng, 200000, alphabet=3), single_symbol_mix(rng, 9000), bytes([5]) * 100000 + mixed_runs(rng, 3000), mixed_runs(rng, 333),
+              bytes(range(256)) * 40 + b"\x00" * 5000, b"\x00" * 70000, b"\x07", b"ab" * 2000 + b"a" * 4000, bytes(rng.randrange(256) for _ in range(5000)),
+              mixed_runs(rng, 1 << 20, alphabet=4)]
+    for it in range(120):
+        length = rng.choice([1, 2, 3, 15, 16, 17, 31, 32, 33, 34, 63, 64, 65, 100, 254, 255, 256, 257, 258, 300, 511, 512, 513, 700, 1000, 3000])
+        alphabet = [rng.randrange(256) for _ in range(rng.choice([1, 2, 3, 5, 17]))]
+        d = bytearray()
+        while len(d) < length:
+            d += bytes([rng.choice(alphabet)]) * rng.choice([1, 1, 2, 3, 7, 30, 31, 32, 33, 34, 64, 253, 254, 255, 256, 257, 600])
+        inputs.append(bytes(d[:length]))
+    n = gave_up = 0
+    for data in inputs:
+        cap = lib.rle8_low_entropy_compress_bounds(ctypes.c_uint32(len(data)))
+        assert cap == len(data) + 32 + 1 + 256 + 8
+        for variant in range(4):
+            want = oracle.low_entropy_compress(variant, data)
+            size, got = hs.call_dropin(LE_NAMES[variant], data, cap)
+            if want is None:
+                assert size == 0, f"{LE_NAMES[variant]} on {len(data)} bytes: the reference's stream outgrows the bound, the GPU call must fail"
+                gave_up += 1
+                continue
+            assert size == len(want) and got == want, f"{LE_NAMES[variant]} on {len(data)} bytes: {'GPU gave up' if size == 0 else 'stream differs'}"
+            assert lib.rle8_low_entropy_decompressed_size(want, ctypes.c_uint32(len(want))) == len(data)
+            name = "rle8_low_entropy_short_decompress" if variant & 1 else "rle8_low_entropy_decompress"
+            size, back = hs.call_dropin(name, want, len(data))
+            assert size == len(data) and back == data, f"{name} on a {len(want)}-byte stream"
+            n += 1
+    assert n >= 400     # (gave_up stays 0 in practice: with ONE section the flags come from the statistics of the very bytes that are encoded, so a stream cannot outgrow the bound by more than the tail quirk)
+    # argument errors of the reference: NULL / empty / short buffers -> 0
+    assert hs.call_dropin("rle8_low_entropy_compress", b"abc", 10)[0] == 0
+    assert hs.call_dropin("rle8_low_entropy_decompress", oracle.low_entropy_compress(0, b"aaaaabbbbb" * 50), 10)[0] == 0
+
+
 def test_partial_block_range(hs):
     import torch
 

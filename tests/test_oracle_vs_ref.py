@@ -60,3 +60,37 @@ def test_rle8m_streams_identical(oracle, reference):
                 assert oracle.rle8m_decompress(r, len(d)) == d and reference.rle8m_decompress(m, len(d)) == d
             n += 1
     assert n > 1000
+
+
+def _le_inputs(seed, count):
+    """Low-entropy shaped inputs: few distinct symbols, runs of every length around 1, 2, 31..33, 254..256 and far beyond, sizes around the
+    256-byte tail rule of the encoders -- plus the generic fuzz inputs."""
+    rng = random.Random(seed)
+    out = []
+    for k in range(count):
+        alphabet = [rng.randrange(256) for _ in range(rng.choice([1, 2, 3, 5, 17, 256]))]
+        target = rng.choice([1, 2, 3, 31, 32, 33, 64, 255, 256, 257, 300, 511, 512, 513, 700, 3000, 20000])
+        d = bytearray()
+        while len(d) < target:
+            sym = rng.choice(alphabet)
+            run = rng.choice([1, 1, 1, 2, 2, 3, 4, 7, 30, 31, 32, 33, 34, 63, 64, 65, 253, 254, 255, 256, 257, 510, 511, 1000])
+            d += bytes([sym]) * run
+        out.append(bytes(d[:target]))
+    return out
+
+
+def test_low_entropy_unsectioned_streams_identical(oracle, reference):
+    """rle8_low_entropy[_short]_compress[_only_max_frequency] / _decompress -- the oracle's restatement against the compiled
+    reference, stream for stream (the four encoders) and both ways through the decoders."""
+    n = 0
+    for d in _le_inputs(8, 300) + list(_inputs(22, 150)):
+        for variant in range(4):
+            r, m = reference.low_entropy_compress(variant, d), oracle.low_entropy_compress(variant, d)
+            assert r == m, f"low entropy variant {variant}: oracle stream differs from the reference (input {len(d)} bytes)"
+            assert reference.le_overflowed == oracle.le_overflowed
+            if r is not None:
+                assert oracle.low_entropy_decompress(r, len(d)) == d
+                assert reference.low_entropy_decompress(variant & 1, m, len(d)) == d
+            n += 1
+    assert n > 1500
+
