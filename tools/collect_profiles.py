@@ -1,5 +1,5 @@
-"""Copy the judged summaries of a final measurement run (tools/scratch/final_measure.sh -> gpurun_out/<dir>) into profiles/ under a round tag:
-  python tools/collect_profiles.py gpurun_out/r3_final r03"""
+"""Copy the judged summaries of a final measurement run (tools/final_measure.sh <tag> -> gpurun_out/<tag>_final) into profiles/ under a round tag:
+  python tools/collect_profiles.py gpurun_out/r04_final r04"""
 import csv, json, shutil, sys, os
 src, tag = sys.argv[1], sys.argv[2]
 P = "profiles"
@@ -28,4 +28,14 @@ with open(f"{P}/{tag}_config3_encode_kernel_stats.txt", "w") as f:
     f.write("%-90s %8s %12s\n" % ("kernel", "calls", "avg us"))
     for r in frows:
         f.write("%-90s %8s %12.1f\n" % (r["Name"][:90], r["Calls"], float(r["AverageNs"]) / 1e3))
+if os.path.exists(src + "/split/s_kernel_stats.csv"):
+    srows = list(csv.DictReader(open(src + "/split/s_kernel_stats.csv")))
+    with open(f"{P}/{tag}_config3_split_kernel_stats.txt", "w") as f:
+        f.write("rocprofv3 --kernel-trace --stats -- python3 tools/split_bench.py   (the 88 MB frame, rle64_3symlut_byte, 4 KiB blocks: plain and split decode; library build %s)\n" % d.get("library_build_id", "?"))
+        f.write("%-90s %8s %12s\n" % ("kernel", "calls", "avg us"))
+        for r in srows:
+            f.write("%-90s %8s %12.1f\n" % (r["Name"][:90], r["Calls"], float(r["AverageNs"]) / 1e3))
+        for l in open(src + "/split.log"):
+            if "us" in l and "GiB/s" in l:
+                f.write(l)
 print("ok")

@@ -63,7 +63,7 @@ def cpu_cols(c, src, cont, info):
     # encoders peek past the block end; "bytes beyond the end never match" is the container's rule)
     same=all(CPU.compress(c, bytes(inp[i*bs:(i+1)*bs]))==bytes(payload[int(offs[i]):int(offs[i+1])]) for i in range(0,nb,max(1,nb//61)))
     return CPU_SAMPLE/te/2**30, CPU_SAMPLE/td/2**30, okd and same
-print('GPU: whole %d MiB buffer, %d B blocks, device resident.  CPU: %s, 1 thread, first %d MiB.'%(size>>20,bs,'compiled reference (oracle/_ref)' if have_ref else "oracle restatement ('port')",CPU_SAMPLE>>20)); print()
+print('GPU: whole %d MiB buffer, %d B blocks, device resident, library build %s.  CPU: %s, 1 thread, first %d MiB.'%(size>>20,bs,hsrle.build_id(),'compiled reference (oracle/_ref)' if have_ref else "oracle restatement ('port')",CPU_SAMPLE>>20)); print()
 print('| codec | data | ratio | GPU encode GiB/s | GPU decode GiB/s | decode % of 8 TB/s (C+U) | CPU encode GiB/s | CPU decode GiB/s | round trip + streams == CPU |'); print('|---|---|---:|---:|---:|---:|---:|---:|---|')
 for kname,kind in kinds:
     cache={}
