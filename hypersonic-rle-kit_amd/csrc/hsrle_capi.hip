@@ -1680,44 +1680,129 @@ int hsrle_device_count(void)
 }
 
 // ---- the low-entropy codec in its UNSECTIONED forms (src/rle.h:53-57, :90-93; rle8_low_entropy_cpu.c:6-124, rle8_low_entropy_short_cpu.c:16-124):
-//      [u32 compressedSize][u32 uncompressedSize][info][one stream] -- an rle8m stream of ONE section without its section-count field.  They run
-//      on the rle8m kernels (one section: one wave walks the input / the stream, so these calls are functional, not fast: the sectioned
-//      form is the one the format offers for parallel hardware); the layout is converted while the bytes cross PCIe. ----
+//      [u32 compressedSize][u32 uncompressedSize][info][one stream].  Many waves on the one stream: the input is cut at run boundaries, the stream
+//      at arbitrary bytes whose symbol / code parity a short backward scan finds (hsrle_rle8m.hip.h, "the UNSECTIONED low-entropy streams"). ----
 static uint32_t le_bounds(uint32_t n) { return n + (256 / 8) + 1 + 256 + 8u; }
+
+// many waves for ONE stream (hsrle_rle8m.hip.h, "the UNSECTIONED low-entropy streams"): pieces of kLePiece input / stream bytes
+constexpr uint32_t kLePiece = 16384u;
+struct LePlan
+{
+  Workspace w;                   // scan levels for the piece sizes
+  uint32_t pieces;
+  uint64_t offTables, offTmpInfo, offCuts, offSizes, offOffsets, offSlots, total;
+};
+static LePlan plan_le(uint64_t bytes, bool withSlots, uint32_t piece = kLePiece)
+{
+  LePlan p;
+  p.pieces = (uint32_t)((bytes + piece - 1u) / piece);
+  if (p.pieces == 0u) p.pieces = 1u;
+  Workspace &w = p.w;
+  w = Workspace{};
+  w.nBlocks = p.pieces; w.chunk = p.pieces; w.nChunks = 1;
+  w.t1 = (w.nBlocks + kScanTile - 1) / kScanTile;
+  w.t2 = (w.t1 + kScanTile - 1) / kScanTile;
+  w.t3 = (w.t2 + kScanTile - 1) / kScanTile;
+  uint64_t at = 0;
+  p.offTables = at; at += align_up(sizeof(Rle8mTables), 256);
+  p.offTmpInfo = at; at += 512;
+  p.offCuts = at; at += align_up(4ull * ((uint64_t)p.pieces + 1ull), 256);
+  p.offSizes = at; at += align_up(4ull * ((uint64_t)p.pieces + 1ull), 256);
+  p.offOffsets = at; at += align_up(8ull * ((uint64_t)p.pieces + 2ull), 256);
+  w.offL1 = at; at += align_up((w.t1 + 1) * 8ull, 256);
+  w.offL2 = at; at += align_up((w.t2 + 1) * 8ull, 256);
+  w.offL3 = at; at += align_up((w.t3 + 1) * 8ull, 256);
+  p.offSlots = at; if (withSlots) at += align_up(2ull * bytes + 64ull, 256);
+  p.total = at;
+  return p;
+}
+
+// dOut: capacity >= le_bounds(n) (a stream that does not fit sets RLE8M_ERR_STREAM in *dStatus: the reference would write behind its
+// caller's buffer there, rle8_low_entropy_cpu.c:476).  Only enqueues.  The stream's size is its first u32.
+static int le_encode_async(const void *dIn, uint32_t n, void *dOut, uint64_t outCapacity, void *dWs, uint64_t wsSize, uint32_t *dStatus, uint32_t maxLen, uint32_t onlyMax, hipStream_t st)
+{
+  if (!dIn || !dOut || !dWs || n == 0)
+    return HSRLE_ERR_ARGUMENT;
+  if (outCapacity < le_bounds(n))
+    return HSRLE_ERR_CAPACITY;
+  const LePlan p = plan_le(n, true);
+  if (wsSize < p.total)
+    return HSRLE_ERR_CAPACITY;
+  uint8_t *ws = (uint8_t *)dWs;
+  Rle8mTables *t = (Rle8mTables *)(ws + p.offTables);
+  uint32_t *cuts = (uint32_t *)(ws + p.offCuts), *sizes = (uint32_t *)(ws + p.offSizes);
+  uint64_t *offsets = (uint64_t *)(ws + p.offOffsets);
+  if (hipMemsetAsync(t, 0, sizeof(Rle8mTables), st) != hipSuccess || (dStatus && hipMemsetAsync(dStatus, 0, 8, st) != hipSuccess))
+    return HSRLE_ERR_DEVICE;
+  {
+    const uint32_t waves = (uint32_t)(((uint64_t)n + 4095u) / 4096u);
+    uint32_t grid = waves < 32768u ? waves : 32768u;
+    if ((uint64_t)grid * kRle8mStatsPieces < waves) grid = (waves + kRle8mStatsPieces - 1u) / kRle8mStatsPieces;
+    hipLaunchKernelGGL(k_rle8m_stats_wave, dim3(grid), dim3(64), 0, st, (const uint8_t *)dIn, n, t, maxLen);
+  }
+  hipLaunchKernelGGL(k_rle8m_info, dim3(1), dim3(256), 0, st, t, 1u, ws + p.offTmpInfo, onlyMax);
+  hipLaunchKernelGGL(k_le_move_info, dim3(1), dim3(64), 0, st, (const uint8_t *)(ws + p.offTmpInfo), (const Rle8mTables *)t, (uint8_t *)dOut);
+  hipLaunchKernelGGL(k_le_cuts, dim3((p.pieces + 63u) / 64u), dim3(64), 0, st, (const uint8_t *)dIn, n, kLePiece, p.pieces, cuts);
+  hipLaunchKernelGGL(k_le_encode_wave, dim3(p.pieces), dim3(64), 0, st, (const uint8_t *)dIn, n, (const uint32_t *)cuts, p.pieces, (const Rle8mTables *)t, ws + p.offSlots, sizes, maxLen);
+  if (scan_sizes(sizes, p.pieces, offsets, ws, p.w, st) != hipSuccess)
+    return HSRLE_ERR_DEVICE;
+  hipLaunchKernelGGL(k_le_place, dim3((p.pieces + 3u) / 4u), dim3(256), 0, st, (const uint8_t *)(ws + p.offSlots), (const uint32_t *)cuts, (const uint64_t *)offsets, (const Rle8mTables *)t,
+                     (uint8_t *)dOut, outCapacity, n, p.pieces, dStatus);
+  return hipGetLastError() == hipSuccess ? HSRLE_OK : HSRLE_ERR_DEVICE;
+}
+
+// dStream: the stream (readable up to streamSize + 64), dataStart = 8 + 33 + listed symbols (the caller has read the header).  dStatus: two
+// words ([0] error bits, [1] "a piece's parity could not be found within kLeCarryLimit bytes").  onePiece: decode with ONE wave (the fallback).
+static int le_decode_async(const void *dStream, uint32_t streamSize, uint32_t dataStart, uint32_t expOut, void *dOut, uint64_t outCapacity, void *dWs, uint64_t wsSize, uint32_t *dStatus,
+                           bool onePiece, hipStream_t st)
+{
+  if (!dStream || !dOut || !dWs || streamSize < dataStart || expOut == 0 || outCapacity < expOut || !dStatus)
+    return HSRLE_ERR_ARGUMENT;
+  const uint32_t body = streamSize - dataStart;
+  const uint32_t G = onePiece ? (((body + 63u) / 64u) * 64u + 64u) : kLePiece;
+  const LePlan p = plan_le(body, false, G);
+  if (wsSize < p.total)
+    return HSRLE_ERR_CAPACITY;
+  uint8_t *ws = (uint8_t *)dWs;
+  uint32_t *carry = (uint32_t *)(ws + p.offCuts), *sizes = (uint32_t *)(ws + p.offSizes);
+  uint64_t *outStart = (uint64_t *)(ws + p.offOffsets);
+  if (hipMemsetAsync(dStatus, 0, 8, st) != hipSuccess)
+    return HSRLE_ERR_DEVICE;
+  hipLaunchKernelGGL(k_le_carry, dim3((p.pieces + 63u) / 64u), dim3(64), 0, st, (const uint8_t *)dStream, (uint64_t)streamSize, G, p.pieces, carry, dStatus);
+  hipLaunchKernelGGL(k_le_decode_wave<true>, dim3(p.pieces), dim3(64), 0, st, (const uint8_t *)dStream, (uint64_t)streamSize, (uint8_t *)dOut, dStatus, expOut, G, p.pieces,
+                     (const uint32_t *)carry, (const uint64_t *)nullptr, sizes);
+  if (scan_sizes(sizes, p.pieces, outStart, ws, p.w, st) != hipSuccess)
+    return HSRLE_ERR_DEVICE;
+  hipLaunchKernelGGL(k_le_decode_wave<false>, dim3(p.pieces), dim3(64), 0, st, (const uint8_t *)dStream, (uint64_t)streamSize, (uint8_t *)dOut, dStatus, expOut, G, p.pieces,
+                     (const uint32_t *)carry, (const uint64_t *)outStart, (uint32_t *)nullptr);
+  return hipGetLastError() == hipSuccess ? HSRLE_OK : HSRLE_ERR_DEVICE;
+}
 
 static uint32_t le_mono_compress(const uint8_t *pIn, uint32_t inSize, uint8_t *pOut, uint32_t outSize, uint32_t maxLen, uint32_t onlyMax)
 {
   // argument checks of the reference (rle8_low_entropy_cpu.c:13-14; the Short form checks against the same bound, rle8_low_entropy_short_cpu.c:23)
   if (pIn == nullptr || inSize == 0 || pOut == nullptr || outSize < le_bounds(inSize) || !device_ok())
     return 0;
-  const Rle8mPlan p = plan_rle8m(inSize, 1u);
-  const uint64_t cap = (uint64_t)rle8m_bounds(1u, inSize) + (uint64_t)inSize;            // (a stream is at most twice its input: every byte a flagged symbol with a zero code)
+  const LePlan p = plan_le(inSize, true);
   DeviceState &D = this_device();
   std::lock_guard<std::mutex> lock(D.mu);
-  if (!grow(&D.monoIn, &D.monoInSize, (uint64_t)inSize + 64) || !grow(&D.monoOut, &D.monoOutSize, cap + 64) || !grow(&D.ws, &D.wsSize, p.total))
+  if (!grow(&D.monoIn, &D.monoInSize, (uint64_t)inSize + 64) || !grow(&D.monoOut, &D.monoOutSize, (uint64_t)outSize + 64) || !grow(&D.ws, &D.wsSize, p.total))
     return 0;
   if (!D.monoAux && hipMalloc(&D.monoAux, 256) != hipSuccess)
     return 0;
   uint32_t *dStatus = (uint32_t *)((uint8_t *)D.monoAux + 64);
   if (hipMemcpy(D.monoIn, pIn, inSize, hipMemcpyHostToDevice) != hipSuccess)
     return 0;
-  if (rle8m_encode_async(D.monoIn, inSize, 1u, D.monoOut, cap, D.ws, D.wsSize, dStatus, nullptr, maxLen, onlyMax) != HSRLE_OK)
+  if (le_encode_async(D.monoIn, inSize, D.monoOut, outSize, D.ws, D.wsSize, dStatus, maxLen, onlyMax, nullptr) != HSRLE_OK)
     return 0;
   uint32_t status = 1, size = 0;
   if (hipMemcpy(&status, dStatus, 4, hipMemcpyDeviceToHost) != hipSuccess || status != 0)
     return 0;
-  if (hipMemcpy(&size, D.monoOut, 4, hipMemcpyDeviceToHost) != hipSuccess || size < 12u + 33u)
+  if (hipMemcpy(&size, D.monoOut, 4, hipMemcpyDeviceToHost) != hipSuccess || size < 8u + 33u || size > outSize)
     return 0;
-  // (the reference does not look at the room its stream needs, compress_with_info only asks for outSize >= inSize and then writes up to twice
-  //  that: rle8_low_entropy_cpu.c:476.  A stream that does not fit the caller's buffer is a failure here, never a write behind it.)
-  const uint32_t out = size - 4u;
-  if (out > outSize)
+  if (hipMemcpy(pOut, D.monoOut, size, hipMemcpyDeviceToHost) != hipSuccess)
     return 0;
-  memcpy(pOut, &out, 4);
-  memcpy(pOut + 4, &inSize, 4);
-  if (hipMemcpy(pOut + 8, (const uint8_t *)D.monoOut + 12, out - 8u, hipMemcpyDeviceToHost) != hipSuccess)
-    return 0;
-  return out;
+  return size;
 }
 
 static uint32_t le_mono_decompress(const uint8_t *pIn, uint32_t inSize, uint8_t *pOut, uint32_t outSize)
@@ -1729,26 +1814,74 @@ static uint32_t le_mono_decompress(const uint8_t *pIn, uint32_t inSize, uint8_t 
   memcpy(&expIn, pIn, 4); memcpy(&expOut, pIn + 4, 4);
   if (expOut > outSize || expIn > inSize || expIn < 8u + 33u || expOut == 0 || expIn > 0xFFFFFF00u)
     return 0;
+  uint32_t listed = pIn[8 + 32];
+  if (listed == 0u) listed = 255u;
+  const uint32_t dataStart = 8u + 33u + listed;
+  if (dataStart > expIn)
+    return 0;
+  const LePlan p = plan_le(expIn - dataStart, false);
+  const LePlan p1 = plan_le(expIn - dataStart, false, expIn + 128u);
   DeviceState &D = this_device();
   std::lock_guard<std::mutex> lock(D.mu);
-  if (!grow(&D.monoIn, &D.monoInSize, (uint64_t)expIn + 4 + 256) || !grow(&D.monoOut, &D.monoOutSize, (uint64_t)expOut + 64))
+  if (!grow(&D.monoIn, &D.monoInSize, (uint64_t)expIn + 256) || !grow(&D.monoOut, &D.monoOutSize, (uint64_t)expOut + 64) || !grow(&D.ws, &D.wsSize, p.total > p1.total ? p.total : p1.total))
     return 0;
   if (!D.monoAux && hipMalloc(&D.monoAux, 256) != hipSuccess)
     return 0;
   uint32_t *dStatus = (uint32_t *)((uint8_t *)D.monoAux + 64);
-  const uint32_t head[3] = { expIn + 4u, expOut, 1u };                                     // the rle8m header of one section
-  if (hipMemcpy(D.monoIn, head, 12, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy((uint8_t *)D.monoIn + 12, pIn + 8, expIn - 8u, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemset((uint8_t *)D.monoIn + expIn + 4u, 0, 64) != hipSuccess)
+  if (hipMemcpy(D.monoIn, pIn, expIn, hipMemcpyHostToDevice) != hipSuccess || hipMemset((uint8_t *)D.monoIn + expIn, 0, 128) != hipSuccess)
     return 0;
-  if (rle8m_decode_async(D.monoIn, (uint64_t)expIn + 4u, expOut, 1u, D.monoOut, expOut, dStatus, nullptr) != HSRLE_OK)
-    return 0;
-  uint32_t status = 1;
-  if (hipMemcpy(&status, dStatus, 4, hipMemcpyDeviceToHost) != hipSuccess || status != 0)
+  uint32_t status[2] = { 1, 0 };
+  for (int attempt = 0; attempt < 2; attempt++)
+  {
+    if (le_decode_async(D.monoIn, expIn, dataStart, expOut, D.monoOut, expOut, D.ws, D.wsSize, dStatus, attempt != 0, nullptr) != HSRLE_OK)
+      return 0;
+    if (hipMemcpy(status, dStatus, 8, hipMemcpyDeviceToHost) != hipSuccess)
+      return 0;
+    if (status[1] == 0u) break;                                          // (status[1]: a degenerate stretch of flagged-valued bytes -- once more with one wave)
+  }
+  if (status[0] != 0u || status[1] != 0u)
     return 0;
   if (hipMemcpy(pOut, D.monoOut, expOut, hipMemcpyDeviceToHost) != hipSuccess)
     return 0;
   return expOut;
 }
+
+// device-resident forms (benchmarks, pipelines that keep the data on the GPU).  variant: bit 0 the Short form, bit 1 only_max_frequency.
+uint64_t hsrle_low_entropy_workspace_size(uint32_t inSize) { return inSize == 0 ? 0 : plan_le(inSize, true).total; }
+int hsrle_low_entropy_compress_dev_async(const void *dIn, uint32_t inSize, int variant, void *dOut, uint64_t outCapacity, void *dWorkspace, uint64_t workspaceSize, uint32_t *dStatus, void *stream)
+{
+  if (!device_ok()) return HSRLE_ERR_DEVICE;
+  if (variant < 0 || variant > 3) return HSRLE_ERR_ARGUMENT;
+  return le_encode_async(dIn, inSize, dOut, outCapacity, dWorkspace, workspaceSize, dStatus, (variant & 1) ? 32u : 255u, (variant & 2) ? 1u : 0u, (hipStream_t)stream);
+}
+// reads the stream's header (synchronises the stream once), decodes, reads the verdict: HSRLE_OK / HSRLE_ERR_FORMAT / ...
+int hsrle_low_entropy_decompress_dev(const void *dStream, uint64_t streamSize, void *dOut, uint64_t outCapacity, void *dWorkspace, uint64_t workspaceSize, uint32_t *pUncompressedSize, void *stream)
+{
+  if (!device_ok()) return HSRLE_ERR_DEVICE;
+  if (!dStream || !dOut || !dWorkspace || streamSize < 8u + 33u || workspaceSize < 256u) return HSRLE_ERR_ARGUMENT;
+  uint8_t head[48];
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemcpyAsync(head, dStream, 48, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return HSRLE_ERR_DEVICE;
+  uint32_t expIn, expOut;
+  memcpy(&expIn, head, 4); memcpy(&expOut, head + 4, 4);
+  uint32_t listed = head[40]; if (listed == 0u) listed = 255u;
+  const uint32_t dataStart = 8u + 33u + listed;
+  if ((uint64_t)expIn > streamSize || dataStart > expIn || expOut == 0u) return HSRLE_ERR_FORMAT;
+  if (outCapacity < expOut) return HSRLE_ERR_CAPACITY;
+  uint32_t *dStatus = (uint32_t *)dWorkspace;                              // the first 256 bytes of the workspace: the status words
+  uint32_t status[2] = { 1, 0 };
+  for (int attempt = 0; attempt < 2; attempt++)
+  {
+    const int rc = le_decode_async(dStream, expIn, dataStart, expOut, dOut, outCapacity, (uint8_t *)dWorkspace + 256, workspaceSize - 256, dStatus, attempt != 0, st);
+    if (rc != HSRLE_OK) return rc;
+    if (hipMemcpyAsync(status, dStatus, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return HSRLE_ERR_DEVICE;
+    if (status[1] == 0u) break;
+  }
+  if (status[0] != 0u || status[1] != 0u) return HSRLE_ERR_FORMAT;
+  if (pUncompressedSize) *pUncompressedSize = expOut;
+  return HSRLE_OK;
+}
+uint64_t hsrle_low_entropy_decompress_workspace_size(uint64_t streamSize) { const uint64_t a = plan_le(streamSize, false).total, b = plan_le(streamSize, false, (uint32_t)(streamSize > 0xFFFFFF00ull ? 0xFFFFFF00ull : streamSize) + 128u).total; return 256u + (a > b ? a : b); }
 
 uint32_t rle8_low_entropy_compress_bounds(const uint32_t inSize) { return le_bounds(inSize); }
 uint32_t rle8_low_entropy_short_compress_bounds(const uint32_t inSize) { return le_bounds(inSize); }

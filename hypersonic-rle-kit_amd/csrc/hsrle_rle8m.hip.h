@@ -499,7 +499,9 @@ __global__ __launch_bounds__(64) void k_rle8m_stats_wave(const uint8_t *__restri
         const bool toEnd = (uint64_t)a + base + p + L == (uint64_t)n;     // the run that reaches the end of the input counts once
         // the usual run (< 255 bytes: one count) is ONE LDS atomic into the packed table (pcount << 16 | prob: a wave sees at most
         // kRle8mStatsPieces * 4096 bytes, so neither half overflows); the others go to the global table directly
-        if (L < (uint64_t)maxLen) atomicAdd(&pk[sy], (1u << 16) | (uint32_t)L);
+        // (round 4: with the Short form's maxLen of 32 a run of 32 .. 254 bytes counts L / 32 + 1 times; it stays in the packed table too --
+        //  both halves grow by at most L -- instead of going to the global one: every zero run of a video-shaped buffer did, 13.6 GiB/s)
+        if (L < 255ull) atomicAdd(&pk[sy], ((toEnd ? 1u : (uint32_t)L / maxLen + 1u) << 16) | (uint32_t)L);
         else
         {
           atomicAdd(&t->prob[sy], (uint32_t)L);
@@ -734,4 +736,326 @@ __global__ __launch_bounds__(256) void k_rle8m_place(const uint8_t *__restrict__
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// The UNSECTIONED low-entropy streams (rle8_low_entropy[_short]_compress[_only_max_frequency] / _decompress,
+// src/rle8_low_entropy_cpu.c:6-124, src/rle8_low_entropy_short_cpu.c:16-124) by many waves (round 4).  The format offers no independent
+// units -- [u32 size][u32 inSize][info][ONE stream] -- but both directions can be cut without changing a byte:
+//   encode  the sequential encoder (compress_with_info, :474-543) stands at every run boundary of the input sooner or later (a run of a
+//           flagged symbol is consumed whole, 255 / 32 bytes per token counted from the run's start; everything else byte by byte).  So the
+//           input is cut at the first run boundary at or behind every G-th byte (k_le_cuts), the pieces are encoded independently by the
+//           wave kernel's grammar -- the end-of-input rule (the last byte is never part of a repeat count, :521) only in the piece that
+//           ends the input -- and the piece streams are the stream, back to back (k_le_place).
+//   decode  which stream bytes are symbols and which are repeat codes follows from the byte VALUES alone: a byte is a code iff the stretch
+//           of flagged-valued bytes right in front of it has odd length (k_rle8m_decode_wave).  A piece may therefore start at any stream
+//           byte once the parity in front of it is known (k_le_carry: a short backward scan); a dry pass of the decoder gives every
+//           piece's output size, a scan the output positions, the second pass writes.
+constexpr uint32_t kLeNone = 0xFFFFFFFFu;
+constexpr uint32_t kLeCarryLimit = 1u << 16;    // flagged-valued stretch in front of a piece longer than this: the caller falls back to one wave
+
+// cuts[k], k >= 1: the first position in [k G, (k + 1) G) whose byte differs from its predecessor (kLeNone: the whole piece continues a run)
+__global__ __launch_bounds__(64) void k_le_cuts(const uint8_t *__restrict__ d, uint32_t n, uint32_t G, uint32_t P, uint32_t *__restrict__ cuts)
+{
+  const uint32_t k = blockIdx.x * 64u + threadIdx.x;
+  if (k >= P) return;
+  if (k == 0u) { cuts[0] = 0u; return; }
+  const uint64_t a = (uint64_t)k * G;
+  const uint64_t e = (a + G < (uint64_t)n) ? a + G : (uint64_t)n;
+  ByteWindow w{ d, n };
+  uint32_t prev = w.get((uint32_t)a - 1u);
+  uint32_t cut = kLeNone;
+  for (uint64_t i = a; i < e; i++)
+  {
+    const uint32_t c = w.get((uint32_t)i);
+    if (c != prev) { cut = (uint32_t)i; break; }
+  }
+  cuts[k] = cut;
+}
+
+// k_rle8m_encode_wave over the pieces of ONE stream: piece k = [cuts[k], next cut that exists) -- both run boundaries, so no token crosses
+// them and the distance to the run start is the sequential encoder's -- into slots + 2 * cuts[k] (a stream is at most twice its input)
+__global__ __launch_bounds__(64) void k_le_encode_wave(const uint8_t *__restrict__ d, uint32_t n, const uint32_t *__restrict__ cuts, uint32_t P, const Rle8mTables *__restrict__ t,
+                                                        uint8_t *__restrict__ slots, uint32_t *__restrict__ sizes, uint32_t maxLen)
+{
+  __shared__ uint32_t rleBits[8];
+  __shared__ __attribute__((aligned(4))) uint8_t order[256];
+  const uint32_t lane = threadIdx.x;
+  if (lane < 8u) rleBits[lane] = t->rleBits[lane];
+  reinterpret_cast<uint32_t *>(order)[lane] = reinterpret_cast<const uint32_t *>(t->order)[lane];
+  __syncthreads();
+
+  const uint32_t k = blockIdx.x;
+  if (k >= P) return;
+  const uint32_t a = cuts[k];
+  if (a == kLeNone) { if (lane == 0u) sizes[k] = 0u; return; }
+  uint32_t b = n;
+  for (uint32_t j = k + 1u; j < P; j++) { const uint32_t c = cuts[j]; if (c != kLeNone) { b = c; break; } }
+  const uint8_t *const p = d + a;
+  const uint32_t len = b - a;
+  const bool tail = b == n;                                               // the piece that ends the input: its last byte is never part of a repeat count
+  uint8_t *const o = slots + 2ull * (uint64_t)a;
+
+  uint32_t op = 0, carryPrev = 0, carryRunStart = 0;
+  uint32_t bNext = (lane < len) ? (uint32_t)p[lane] : 0u;
+  for (uint32_t ip = 0; ip < len; ip += 64u)
+  {
+    const uint32_t pos = ip + lane;
+    const bool valid = pos < len;
+    const uint32_t bb = bNext;
+    bNext = (pos + 64u < len) ? (uint32_t)p[pos + 64u] : 0u;
+    const bool fl = valid && ((rleBits[bb >> 5] >> (bb & 31u)) & 1u);
+    const uint32_t up = (uint32_t)__shfl_up((int)bb, 1), down = (uint32_t)__shfl_down((int)bb, 1), first = (uint32_t)__shfl((int)bNext, 0);
+    const uint32_t prevb = (lane == 0u) ? carryPrev : up;
+    const uint32_t nextb = (lane == 63u) ? first : down;
+    const bool lastOfInput = tail && pos == len - 1u;
+    const bool brk = valid && (pos == 0u || bb != prevb || lastOfInput);
+    const uint64_t B = __builtin_amdgcn_ballot_w64(brk);
+    const uint64_t mine = B & (~0ull >> (63u - lane));
+    const uint32_t runStart = mine ? ip + (63u - (uint32_t)__builtin_clzll(mine)) : carryRunStart;
+    const uint32_t rel = pos - runStart;
+    // the next byte starts a new token: the piece ends here (its successor differs: a cut), the input's last byte stands alone, or the byte differs
+    const bool nextBreaks = pos + 1u >= len || (tail && pos + 1u >= len - 1u) || nextb != bb;
+    const bool isEnd = valid && (!fl || lastOfInput || nextBreaks || (rel + 1u) % maxLen == 0u);
+    const uint64_t E = __builtin_amdgcn_ballot_w64(isEnd), E2 = __builtin_amdgcn_ballot_w64(isEnd && fl);
+    const uint32_t off = __builtin_amdgcn_mbcnt_hi((uint32_t)(E >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)E, 0u)) +
+                         __builtin_amdgcn_mbcnt_hi((uint32_t)(E2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)E2, 0u));
+    if (isEnd)
+    {
+      uint8_t *q = o + op + off;
+      q[0] = (uint8_t)bb;
+      if (fl) q[1] = order[rel % maxLen];
+    }
+    op += (uint32_t)__builtin_popcountll(E) + (uint32_t)__builtin_popcountll(E2);
+    carryPrev = (uint32_t)__builtin_amdgcn_readlane((int)bb, 63);
+    carryRunStart = (uint32_t)__builtin_amdgcn_readlane((int)runStart, 63);
+  }
+  if (lane == 0u) sizes[k] = op;
+}
+
+// piece streams -> the stream behind [u32 size][u32 inSize][info]; one wave per piece.  The info bytes were written by k_rle8m_info for an
+// rle8m header of one section (at byte 12): they move to byte 8 here (infoFrom = 12).
+__global__ __launch_bounds__(256) void k_le_place(const uint8_t *__restrict__ slots, const uint32_t *__restrict__ cuts, const uint64_t *__restrict__ offsets, const Rle8mTables *__restrict__ t,
+                                                  uint8_t *__restrict__ out, uint64_t outCapacity, uint32_t n, uint32_t P, uint32_t *__restrict__ status)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (k >= P) return;
+  const uint32_t H = t->headerSize - 4u;                                  // (the tables count an rle8m header of one section: 4 bytes more)
+  const uint64_t off = offsets[k], total = offsets[P];
+  const uint32_t size = (uint32_t)(offsets[k + 1] - off);
+  if ((uint64_t)H + total > outCapacity || (uint64_t)H + total > 0xFFFFFFFFull)
+  {
+    if (k == 0u && lane == 0u && status) atomicOr(status, RLE8M_ERR_STREAM);
+    return;
+  }
+  if (k == 0u && lane == 0u) { st32(out, (uint32_t)(H + total)); st32(out + 4, n); }
+  if (size == 0u) return;
+  const uint8_t *src = slots + 2ull * (uint64_t)cuts[k];
+  uint8_t *dst = out + H + off;
+  for (uint32_t j = lane * 16u; j + 16u <= size; j += 64u * 16u) st128(dst + j, ld128(src + j));
+  const uint32_t body = size & ~15u;
+  if (lane < size - body) dst[body + lane] = src[body + lane];
+}
+
+// the info bytes of an unsectioned stream: k_rle8m_info writes them at byte 12 of ITS output (an rle8m header of one section); here they go
+// to byte 8 of the real one.  One workgroup.
+__global__ __launch_bounds__(64) void k_le_move_info(const uint8_t *__restrict__ tmpInfo, const Rle8mTables *__restrict__ t, uint8_t *__restrict__ out)
+{
+  const uint32_t len = t->headerSize - 12u;                               // 33 + listed
+  for (uint32_t j = threadIdx.x; j < len; j += 64u) out[8u + j] = tmpInfo[12u + j];
+}
+
+// header of an unsectioned stream -> the decoder's tables (the rle8m routine with the info at byte 8 and one section)
+__device__ __forceinline__ uint32_t le_tables(const uint8_t *__restrict__ s, uint64_t streamBytes, uint32_t lane, uint32_t *rleBits, uint8_t *codeToCount, uint8_t *listed, uint32_t *hdr)
+{
+  const uint32_t expIn = ld32(s);
+  const uint64_t info = 8ull;
+  bool bad = expIn > streamBytes || info + 33u > (uint64_t)expIn;
+  uint32_t listedCount = 0;
+  if (!bad)
+  {
+    listedCount = s[info + 32];
+    if (listedCount == 0u) listedCount = 255u;
+    bad = info + 33u + listedCount > (uint64_t)expIn;
+  }
+  if (!bad)
+  {
+    if (lane < 8u) rleBits[lane] = ld32(s + info + 4u * lane);
+    for (uint32_t k = lane; k < 256u; k += 64u) listed[k] = 0;
+    __syncthreads();
+    for (uint32_t k = lane; k < listedCount; k += 64u)
+    {
+      const uint32_t sym = s[info + 33u + k];
+      codeToCount[sym] = (uint8_t)k;
+      listed[sym] = 1;
+    }
+    __syncthreads();
+    {
+      uint32_t next = listedCount;
+      for (uint32_t c = 0; c < 256u; c += 64u)
+      {
+        const bool unl = !listed[c + lane];
+        const uint64_t m = __builtin_amdgcn_ballot_w64(unl);
+        if (unl) codeToCount[c + lane] = (uint8_t)(next + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)));
+        next += (uint32_t)__builtin_popcountll(m);
+      }
+      if (lane == 0u) hdr[0] = (uint32_t)(info + 33u + listedCount);
+    }
+  }
+  else if (lane == 0u)
+    hdr[0] = 0u;
+  __syncthreads();
+  return hdr[0];
+}
+
+// carry[k]: parity of the stretch of flagged-valued bytes right in front of piece k (piece k starts at dataStart + k G): the piece's
+// first byte is a repeat code iff it is odd.  One lane per piece, a backward scan that ends at the first byte whose value is not flagged
+// (typically within a few bytes); a stretch of kLeCarryLimit bytes sets RLE8M_ERR_HEADER in status[1] and the caller decodes with one wave.
+__global__ __launch_bounds__(64) void k_le_carry(const uint8_t *__restrict__ s, uint64_t streamBytes, uint32_t G, uint32_t Q, uint32_t *__restrict__ carry, uint32_t *__restrict__ status)
+{
+  __shared__ uint32_t rleBits[8];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t expIn = ld32(s);
+  if (lane < 8u) rleBits[lane] = ld32(s + 8u + 4u * lane);
+  __syncthreads();
+  uint32_t listedCount = s[8u + 32u];
+  if (listedCount == 0u) listedCount = 255u;
+  const uint32_t dataStart = 8u + 33u + listedCount;
+  const uint32_t k = blockIdx.x * 64u + lane;
+  if (k >= Q || expIn > streamBytes || dataStart > expIn) return;
+  uint32_t cnt = 0;
+  if (k != 0u)
+  {
+    const uint64_t begin = (uint64_t)dataStart + (uint64_t)k * G;
+    for (uint64_t i = begin; i > dataStart && cnt < kLeCarryLimit; i--)
+    {
+      const uint32_t b = s[i - 1u];
+      if (!((rleBits[b >> 5] >> (b & 31u)) & 1u)) break;
+      cnt++;
+    }
+    if (cnt >= kLeCarryLimit && status) atomicOr(status + 1, 1u);
+  }
+  carry[k] = cnt & 1u;
+}
+
+// k_rle8m_decode_wave over the pieces of ONE stream.  DRY: sizes[k] = the piece's output bytes, nothing is written; else the piece writes
+// out + outStart[k] .. outStart[k + 1].  A flagged symbol in a piece's last byte leaves its repeats to the next piece (whose carry is 1).
+template <bool DRY>
+__global__ __launch_bounds__(64) void k_le_decode_wave(const uint8_t *__restrict__ s, uint64_t streamBytes, uint8_t *__restrict__ out, uint32_t *__restrict__ status, uint32_t wantOut,
+                                                        uint32_t G, uint32_t Q, const uint32_t *__restrict__ carryIn, const uint64_t *__restrict__ outStart, uint32_t *__restrict__ sizes)
+{
+  __shared__ uint32_t rleBits[8];
+  __shared__ uint8_t codeToCount[256];
+  __shared__ uint8_t listed[256];
+  __shared__ uint32_t hdr[4];
+
+  const uint32_t lane = threadIdx.x;
+  const uint32_t expIn = ld32(s), expOut = ld32(s + 4);
+  const uint32_t dataStart = le_tables(s, streamBytes, lane, rleBits, codeToCount, listed, hdr);
+  const uint32_t k = blockIdx.x;
+  if (dataStart == 0u || expOut != wantOut)
+  {
+    if (k == 0u && lane == 0u && status) atomicOr(status, RLE8M_ERR_HEADER);
+    return;
+  }
+  if (k >= Q) return;
+  const uint64_t begin64 = (uint64_t)dataStart + (uint64_t)k * G;
+  if (begin64 >= (uint64_t)expIn) { if (DRY && lane == 0u) sizes[k] = 0u; return; }
+  const uint32_t begin = (uint32_t)begin64;
+  const uint32_t end = ((uint64_t)begin + G < (uint64_t)expIn) ? begin + G : expIn;
+  const bool lastPiece = end == expIn;
+  uint64_t o0 = 0, want = 0xFFFFFFFFull;
+  if constexpr (!DRY)
+  {
+    if (outStart[Q] != (uint64_t)expOut)                                   // the dry pass's sizes do not add up to the header's: nothing is written
+    {
+      if (k == 0u && lane == 0u && status) atomicOr(status, RLE8M_ERR_STREAM);
+      return;
+    }
+    o0 = outStart[k]; want = outStart[k + 1] - o0;
+  }
+  uint8_t *const o = out + o0;
+
+  uint32_t op = 0, carry = carryIn[k], pendSym = (carry != 0u) ? (uint32_t)s[begin - 1u] : 0u;
+  bool err = false;
+  uint32_t bNext = (begin + lane < end) ? (uint32_t)s[begin + lane] : 0u;
+  for (uint32_t ip = begin; ip < end; ip += 64u)
+  {
+    const uint32_t pos = ip + lane;
+    const bool valid = pos < end;
+    const uint32_t b = bNext;
+    bNext = (pos + 64u < end) ? (uint32_t)s[pos + 64u] : 0u;
+    const bool fl = valid && ((rleBits[b >> 5] >> (b & 31u)) & 1u);
+    const uint64_t F = __builtin_amdgcn_ballot_w64(fl);
+    if (F == 0ull && carry == 0u)
+    {
+      const uint32_t nv = (end - ip < 64u) ? end - ip : 64u;
+      if ((uint64_t)nv > want - op) { err = true; break; }
+      if constexpr (!DRY) { if (valid) o[op + lane] = (uint8_t)b; }
+      op += nv;
+      continue;
+    }
+    uint32_t below = 0;
+    if (lane != 0u)
+    {
+      const uint64_t x = ~F << (64u - lane);
+      below = (x == 0ull) ? lane : (uint32_t)__builtin_clzll(x);
+      if (below > lane) below = lane;
+    }
+    const bool isCode = valid && (((below + ((below == lane) ? carry : 0u)) & 1u) != 0u);
+    const bool isSym = valid && !isCode;
+    const uint32_t nb = (uint32_t)__shfl_down((int)b, 1);
+    uint32_t runLen = 0, v = b;
+    bool bad = false;
+    if (isSym)
+    {
+      runLen = 1u;
+      if (fl)
+      {
+        if (pos + 1u >= end) bad = lastPiece;                             // the stream's last byte is a flagged symbol without its code; in any other piece the next one writes the repeats
+        else if (lane != 63u) runLen += codeToCount[nb];
+      }
+    }
+    else if (isCode && lane == 0u)
+    {
+      runLen = codeToCount[b];
+      v = pendSym;
+    }
+    uint32_t incl = runLen;
+#pragma unroll
+    for (uint32_t dd = 1; dd < 64u; dd <<= 1)
+    {
+      const uint32_t tt = (uint32_t)__shfl_up((int)incl, dd);
+      if (lane >= dd) incl += tt;
+    }
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull || (uint64_t)total > want - op) { err = true; break; }
+    if constexpr (!DRY)
+    {
+      uint8_t *q = o + op + (incl - runLen);
+      uint32_t left = runLen;
+      const uint32_t vv = v * 0x01010101u;
+      const u32x4 line{ vv, vv, vv, vv };
+      const uint64_t v8 = (uint64_t)vv * 0x0000000100000001ull;
+      if (((uintptr_t)q & 1u) && left >= 1u) { *q = (uint8_t)v; q += 1; left -= 1u; }
+      if (((uintptr_t)q & 2u) && left >= 2u) { st16(q, vv & 0xFFFFu); q += 2; left -= 2u; }
+      if (((uintptr_t)q & 4u) && left >= 4u) { st32(q, vv); q += 4; left -= 4u; }
+      if (((uintptr_t)q & 8u) && left >= 8u) { st64(q, v8); q += 8; left -= 8u; }
+      for (; left >= 16u; left -= 16u, q += 16) st128(q, line);
+      if (left & 8u) { st64(q, v8); q += 8; }
+      if (left & 4u) { st32(q, vv); q += 4; }
+      if (left & 2u) { st16(q, vv & 0xFFFFu); q += 2; }
+      if (left & 1u) *q = (uint8_t)v;
+    }
+    op += total;
+    const uint32_t top = (F == ~0ull) ? 64u : (uint32_t)__builtin_clzll(~F);
+    carry = (top + ((top == 64u) ? carry : 0u)) & 1u;
+    pendSym = (uint32_t)__builtin_amdgcn_readlane((int)b, 63);
+  }
+  if constexpr (DRY) { if (lane == 0u) sizes[k] = err ? 0u : op; }
+  else if (!err && ((uint64_t)op != want || (lastPiece && carry != 0u))) err = true;
+  if (err && lane == 0u && status) atomicOr(status, RLE8M_ERR_STREAM);
+}
+
 } // namespace hsrle
+

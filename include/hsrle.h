@@ -419,10 +419,10 @@ uint32_t rle8m_compress(const uint32_t subSections, const uint8_t *pIn, const ui
  * src/rle8_low_entropy_short_cpu.c:16-124): [u32 compressedSize][u32 uncompressedSize][info][ONE stream], i.e. an rle8m stream of one
  * section without its section-count field.  Same names, arguments and return convention as the reference (0 = failure); the streams are
  * the reference's byte for byte, the decoders read the reference's streams.  The Short form cuts runs every 32 bytes instead of 255;
- * *_only_max_frequency lets one symbol -- the one that saves the most -- carry repeat codes.  They run on the rle8m kernels with one
- * section: ONE wave walks the whole input / stream, so these calls are functional, not fast (a single low-entropy stream offers no
- * independent units; rle8m is the form the format has for parallel hardware).  Unlike the reference a stream that outgrows `outSize`
- * is a failure, never a write behind the caller's buffer (rle8_low_entropy_cpu.c:476 only asks for outSize >= inSize).
+ * *_only_max_frequency lets one symbol -- the one that saves the most -- carry repeat codes.  The one stream is worked on by many waves:
+ * the encoder cuts its input at run boundaries (no token crosses one), the decoder cuts the stream anywhere and finds out from the byte
+ * values in front of a cut whether it starts with a symbol or a repeat code (csrc/hsrle_rle8m.hip.h).  Unlike the reference a stream that
+ * outgrows `outSize` is a failure, never a write behind the caller's buffer (rle8_low_entropy_cpu.c:476 only asks for outSize >= inSize).
  * Not provided: the split-phase helpers that pass the codec's tables through host structs (rle8_low_entropy_get_compress_info*,
  * _write_compress_info, _compress_with_info, _read_decompress_info, _decompress_with_info and their Short twins, src/rle.h:67-96). */
 uint32_t rle8_low_entropy_compress_bounds(const uint32_t inSize);
@@ -434,6 +434,13 @@ uint32_t rle8_low_entropy_short_compress_bounds(const uint32_t inSize);
 uint32_t rle8_low_entropy_short_compress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize);
 uint32_t rle8_low_entropy_short_compress_only_max_frequency(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize);
 uint32_t rle8_low_entropy_short_decompress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize);
+
+/* The same, device resident (variant: bit 0 the Short form, bit 1 only_max_frequency).  Compress only enqueues (the stream's size is its
+ * first u32; *dStatus != 0: the stream did not fit `outCapacity`); decompress reads the header and the verdict (two stream synchronisations). */
+uint64_t hsrle_low_entropy_workspace_size(uint32_t inSize);
+int hsrle_low_entropy_compress_dev_async(const void *dIn, uint32_t inSize, int variant, void *dOut, uint64_t outCapacity, void *dWorkspace, uint64_t workspaceSize, uint32_t *dStatus, void *stream);
+uint64_t hsrle_low_entropy_decompress_workspace_size(uint64_t streamSize);
+int hsrle_low_entropy_decompress_dev(const void *dStream, uint64_t streamSize, void *dOut, uint64_t outCapacity, void *dWorkspace, uint64_t workspaceSize, uint32_t *pUncompressedSize, void *stream);
 
 uint64_t hsrle_rle8m_compress_workspace_size(uint32_t inSize, uint32_t sections);
 int hsrle_rle8m_compress_dev_async(const void *dIn, uint32_t inSize, uint32_t sections, void *dOut, uint64_t outCapacity, void *dWorkspace, uint64_t workspaceSize,

@@ -338,7 +338,12 @@ def test_low_entropy_unsectioned_forms_match_the_oracle(hs, oracle):
     lib.rle8_low_entropy_decompressed_size.restype = ctypes.c_uint32
     inputs = [mixed_runs(rng, 200000, alphabet=3), single_symbol_mix(rng, 9000), bytes([5]) * 100000 + mixed_runs(rng, 3000), mixed_runs(rng, 333),
               bytes(range(256)) * 40 + b"\x00" * 5000, b"\x00" * 70000, b"\x07", b"ab" * 2000 + b"a" * 4000, bytes(rng.randrange(256) for _ in range(5000)),
-              mixed_runs(rng, 1 << 20, alphabet=4)]
+              mixed_runs(rng, 1 << 20, alphabet=4),
+              # many pieces (the one stream is cut every 16 KiB, hsrle_rle8m.hip.h): one run across 64 pieces, runs that straddle the cuts, a stream
+              # whose bytes are ALL flagged values (symbol, code, symbol ... with codes that are flagged symbols themselves: the decoder cannot
+              # find a piece's parity within its look-back and falls back to one wave), flagged runs of 32 / 255 + 1 bytes at the cuts
+              b"\x00" * (1 << 20), mixed_runs(rng, 300000, alphabet=2), b"\x00\x00\x01\x01" * 100000,
+              (b"\x07" * 16383 + b"\x09" + b"\x07" * 33 + b"ab" * 100) * 9, b"q" * 16384 + b"q" * 256 + bytes(rng.randrange(256) for _ in range(40000)) + b"z" * 70000]
     for it in range(120):
         length = rng.choice([1, 2, 3, 15, 16, 17, 31, 32, 33, 34, 63, 64, 65, 100, 254, 255, 256, 257, 258, 300, 511, 512, 513, 700, 1000, 3000])
         alphabet = [rng.randrange(256) for _ in range(rng.choice([1, 2, 3, 5, 17]))]
