@@ -329,15 +329,20 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
       // bit, never as a wild read -- the lane then sees an empty stream at offset 0, which fails the header check
       const uint64_t payloadBytes = (uint64_t)(payloadEnd - payload);
       if (off0 > off1 || off1 > payloadBytes || off1 - off0 > 0xFFFFFF00ull) { off0 = 0; off1 = 0; }   // -> DEC_ERR_HEADER below
-      g0 = (uint32_t)((uintptr_t)(payload + off0) & (uintptr_t)((R < Q ? R : Q) - 1));   // (< R: the header is read from the ring's first fill)
-      g0 = umin(g0, (uint32_t)(off0 < 0xFFFFFFFFull ? off0 : 0xFFFFFFFFull) + 64u) & ~15u; // never reach in front of the container (>= 64 header bytes precede the payload)
-      base0 = off0 - g0;                                               // may be "negative" for block 0: wraps, added to `payload` again below
+      // Round 4: position 0 is EXACTLY the Q-byte (128-byte) aligned address below the stream start -- until round 3 it was that address plus
+      // (start & 15), which put every window of 8 chunks across two memory lines: the serving lanes' loads touched two lines per row and
+      // instruction.  The ring starts at floor16(g0) (E0 below; the first fill reaches over one line boundary, once), so nothing in front
+      // of the stream's first chunk is ever requested and g0 needs neither be a multiple of 16 nor lie below R.
+      g0 = (uint32_t)((uintptr_t)(payload + off0) & (uintptr_t)(Q - 1));
+      base0 = off0 - g0;                                               // may be "negative" for the first blocks: wraps, added to `payload` again below
       slen = (uint32_t)(off1 - off0) + g0;
       const uint64_t start = (uint64_t)b * B;
       blen = (uint32_t)((U - start) < (uint64_t)B ? (U - start) : (uint64_t)B);
       const uint64_t room = (uint64_t)(payloadEnd - payload) - base0;
       lim = (uint32_t)(room > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : room) & ~15u;
       lim = umin(lim, (slen + 15u) & ~15u);                            // nothing behind the stream's last chunk is ever requested
+      E = g0 & ~15u;                                                   // the ring's first fill starts at the stream's first chunk
+      sp = g0;
       done = false;
     }
     myBase0 = base0;
@@ -452,8 +457,10 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   {
     const int r = (int)((uint32_t)q * RPL + lane / LPR);
     const uint32_t rowLim = (uint32_t)__shfl((int)lim, r, 64);
+    const uint32_t rowE0 = (uint32_t)__shfl((int)E, r, 64);             // (floor16(g0) of that row)
     if constexpr (!kPackLim) limq[q] = rowLim;
-    pfPos[q] = (lane % LPR) * 16u;                                    // the first Q bytes of every stream ...
+    pfPos[q] = (lane % LPR) * 16u;                                    // the first Q bytes of every stream from its first chunk on ...
+    if (pfPos[q] < rowE0) pfPos[q] += (uint32_t)Q;                     // (this lane's chunk of the first line lies in front of the stream: the next line's)
 #ifdef HSRLE_REQ_STATS
     count_requests(pfPos[q] < rowLim);
 #endif
@@ -479,24 +486,25 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   else if (active)
   {
     sp = g0 + TR::kHeaderSize;
-    const uint8_t *hd = ring + (rowx ^ g0);                            // g0 is a multiple of 16 and < R: one whole chunk
+    const u32x4 hdv = ring_win16(g0);                                  // the stream header: 16 bytes at the stream's first byte
+    const uint32_t hd8 = hdv.z & 0xFFu, hd9 = (hdv.z >> 8) & 0xFFu;    // bytes 8 and 9: mode / the Single symbol
 
-    if (slen < g0 + TR::kHeaderSize + 2u || ld32(hd) != blen || ld32(hd + 4) != slen - g0)
+    if (slen < g0 + TR::kHeaderSize + 2u || hdv.x != blen || hdv.y != slen - g0)
     {
       err |= DEC_ERR_HEADER;
       done = true;
     }
     else if constexpr (TR::kShortSingle)
     {
-      set_sym(u32x4{ hd[8], 0, 0, 0 });                                  // the stream's one symbol sits behind the header (rleX_Xsl_short.h:1211-1216)
+      set_sym(u32x4{ hd8, 0, 0, 0 });                                    // the stream's one symbol sits behind the header (rleX_Xsl_short.h:1211-1216)
       sp = g0 + 9;
     }
     else if constexpr (S == 1 && !TR::kLut && !TR::kShort)
     {
-      const uint32_t mode = hd[8];
+      const uint32_t mode = hd8;
       if (mode == 1u)
       {
-        if constexpr (SGL) { singleVar = true; set_sym(u32x4{ hd[9], 0, 0, 0 }); sp = g0 + 10; }
+        if constexpr (SGL) { singleVar = true; set_sym(u32x4{ hd9, 0, 0, 0 }); sp = g0 + 10; }
         else { err |= DEC_ERR_MODE; done = true; }
       }
       else if (mode != 0u) { err |= DEC_ERR_MODE; done = true; }
