@@ -816,7 +816,7 @@ struct MonoPlan
 {
   uint32_t G, M, B, R, KE;
   uint64_t nb;
-  uint64_t offG, offE, offOlen, offT, offEntry, offOutStart, offStateIn, offFix, offList, offMark, offCtrl, offRec, total;
+  uint64_t offG, offE, offOlen, offT, offEntry, offOutStart, offStateIn, offFix, offList, offMark, offCtrl, offRec, offFast, offBatch, total;
   bool range7;
 };
 
@@ -866,17 +866,32 @@ static MonoPlan plan_mono(int codec, uint32_t U, uint32_t C, uint32_t p0)
   m.offMark = at; at += align_up(4ull * m.R, 256);
   m.offCtrl = at; at += 256;
   m.offRec = at; at += align_up(4ull * kEntryRecDwords * m.nb, 256);
+  m.offFast = at; at += 256;                                             // the parallel resolve passes: flag + carries, totals per batch of 1 024 regions
+  m.offBatch = at; at += align_up(4ull * kFastBatchWords * ((uint64_t)m.R / kResolveThreads + 1ull), 256);
   m.total = at;
   return m;
 }
 
 static hipError_t launch_resolve(const MonoPlan &m, uint8_t *ws, uint32_t p0, uint64_t U, uint32_t roundTag, hipStream_t st)
 {
+  // the full batches but the last in parallel when every guess is right (hsrle_index.hip.h: k_resolve_fast_*); k_index_resolve finishes -- or, when
+  // a region failed the check, does everything
+  const uint32_t fastBatches = (m.R > 2u * (uint32_t)kResolveThreads) ? (m.R - 1u) / (uint32_t)kResolveThreads : 0u;
+  uint32_t *fast = (uint32_t *)(ws + m.offFast), *batch = (uint32_t *)(ws + m.offBatch);
+  const uint32_t *cg = (const uint32_t *)(ws + m.offG), *ce = (const uint32_t *)(ws + m.offE), *ct = (const uint32_t *)(ws + m.offT);
+  const uint64_t *col = (const uint64_t *)(ws + m.offOlen);
+  if (fastBatches != 0u && hipMemsetD32Async((hipDeviceptr_t)fast, 1, 1, st) != hipSuccess) return hipErrorUnknown;
 #define HSRLE_RESOLVE(KE)                                                                                                                                        \
-  hipLaunchKernelGGL(k_index_resolve<KE>, dim3(1), dim3(kResolveThreads), 0, st, (const uint32_t *)(ws + m.offG), (const uint32_t *)(ws + m.offE),               \
-                     (const uint64_t *)(ws + m.offOlen), (const uint32_t *)(ws + m.offT), m.R, p0, m.G, U, (uint32_t *)(ws + m.offEntry),                         \
+  if (fastBatches != 0u)                                                                                                                                         \
+  {                                                                                                                                                              \
+    hipLaunchKernelGGL(k_resolve_fast_totals<KE>, dim3(fastBatches), dim3(kResolveThreads), 0, st, cg, ce, col, ct, p0, m.G, fast, batch);                       \
+    hipLaunchKernelGGL(k_resolve_fast_carries<KE>, dim3(1), dim3(kResolveThreads), 0, st, fast, batch, fastBatches);                                             \
+    hipLaunchKernelGGL(k_resolve_fast_emit<KE>, dim3(fastBatches), dim3(kResolveThreads), 0, st, cg, col, ct, (const uint32_t *)fast, (const uint32_t *)batch,    \
+                       (uint32_t *)(ws + m.offEntry), (uint64_t *)(ws + m.offOutStart), (uint32_t *)(ws + m.offStateIn));                                        \
+  }                                                                                                                                                              \
+  hipLaunchKernelGGL(k_index_resolve<KE>, dim3(1), dim3(kResolveThreads), 0, st, cg, ce, col, ct, m.R, p0, m.G, U, (uint32_t *)(ws + m.offEntry),               \
                      (uint64_t *)(ws + m.offOutStart), (uint32_t *)(ws + m.offStateIn), (uint32_t *)(ws + m.offFix), (uint32_t *)(ws + m.offList),                \
-                     (uint32_t *)(ws + m.offCtrl), (uint32_t *)(ws + m.offMark), roundTag)
+                     (uint32_t *)(ws + m.offCtrl), (uint32_t *)(ws + m.offMark), roundTag, fastBatches ? (const uint32_t *)fast : (const uint32_t *)nullptr, fastBatches)
   switch (m.KE)
   {
   case 0: HSRLE_RESOLVE(0); break;

@@ -320,16 +320,248 @@ __device__ __forceinline__ void state_compose(uint32_t (&out)[KE > 0 ? KE : 1], 
   }
 }
 
+// ---- pass 2, the common case in parallel (round 4).  k_index_resolve below is ONE workgroup that goes through the regions 1 024 at a time:
+//      243 us for the 71 096 regions of the 1 GiB config-2 stream, and proportionally more with smaller regions -- which is what kept the
+//      regions at 8 KiB and the walks (latency chains of one lane per region) long.  When every guess is right -- the walk of region r
+//      starts where the walk of region r - 1 ended, which only needs e[r - 1] == g[r] -- the pass is three scans: output sizes, state
+//      transformers, nothing else.  Three small kernels do that for all FULL batches but the last (which holds the end of the chain and
+//      stays with k_index_resolve); `fast` = [ok flag, -, carry out lo, hi, carry state x KS]; per batch: [out sum lo, hi, T x KS].
+//      Any region that fails the check clears the flag: k_index_resolve then does everything, as before.
+constexpr uint32_t kFastBatchWords = 2u + 8u;       // per batch: out sum (2 words) + up to 7 transformer words (+ pad)
+
+// inclusive scan of (output bytes, transformer) over the workgroup's 1 024 regions; returns this thread's EXCLUSIVE prefix and the totals
+template <int KE>
+__device__ __forceinline__ void resolve_batch_scan(uint32_t tid, uint64_t v, const uint32_t (&myT)[KE > 0 ? KE : 1], uint64_t *swave, uint32_t *sWaveT,
+                                                   uint64_t &exclOut, uint64_t &allOut, uint32_t (&exclT)[KE > 0 ? KE : 1], uint32_t (&allT)[KE > 0 ? KE : 1])
+{
+  constexpr int NT = kResolveThreads;
+  constexpr int KS = KE > 0 ? KE : 1;
+  const uint32_t lane = tid & 63u, wave = tid >> 6;
+  uint64_t xsum = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1)
+  {
+    const uint64_t y = __shfl_up(xsum, d, 64);
+    if ((int)lane >= d) xsum += y;
+  }
+  if (lane == 63u) swave[wave] = xsum;
+  uint32_t tInc[KS];
+#pragma unroll
+  for (int j = 0; j < KS; j++) tInc[j] = myT[j];
+  if constexpr (KE > 0)
+  {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+      uint32_t left[KS], tmp[KS];
+#pragma unroll
+      for (int j = 0; j < KE; j++) left[j] = (uint32_t)__shfl_up((int)tInc[j], d, 64);
+      state_compose<KE>(tmp, left, tInc);
+      if ((int)lane >= d)
+      {
+#pragma unroll
+        for (int j = 0; j < KE; j++) tInc[j] = tmp[j];
+      }
+    }
+    if (lane == 63u)
+    {
+#pragma unroll
+      for (int j = 0; j < KE; j++) sWaveT[wave * KS + j] = tInc[j];
+    }
+  }
+  __syncthreads();
+  uint64_t wbase = 0, wall = 0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; w++)
+  {
+    const uint64_t t = swave[w];
+    if ((uint32_t)w < wave) wbase += t;
+    wall += t;
+  }
+  exclOut = wbase + xsum - v;
+  allOut = wall;
+  uint32_t tWaves[KS];
+#pragma unroll
+  for (int j = 0; j < KS; j++) { tWaves[j] = IDX_OLD | (uint32_t)j; allT[j] = IDX_OLD | (uint32_t)j; exclT[j] = IDX_OLD | (uint32_t)j; }
+  if constexpr (KE > 0)
+  {
+    uint32_t wt[KS];
+#pragma unroll
+    for (int j = 0; j < KE; j++) wt[j] = (lane < (uint32_t)(NT / 64)) ? sWaveT[lane * KS + j] : (IDX_OLD | (uint32_t)j);
+#pragma unroll
+    for (int d = 1; d < NT / 64; d <<= 1)
+    {
+      uint32_t left[KS], tmp[KS];
+#pragma unroll
+      for (int j = 0; j < KE; j++) left[j] = (uint32_t)__shfl_up((int)wt[j], d, 64);
+      state_compose<KE>(tmp, left, wt);
+      if ((int)lane >= d)
+      {
+#pragma unroll
+        for (int j = 0; j < KE; j++) wt[j] = tmp[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < KE; j++)
+    {
+      const uint32_t before = (uint32_t)__shfl((int)wt[j], (int)(wave > 0u ? wave - 1u : 0u), 64);
+      tWaves[j] = (wave > 0u) ? before : (IDX_OLD | (uint32_t)j);
+      allT[j] = (uint32_t)__shfl((int)wt[j], NT / 64 - 1, 64);
+    }
+    uint32_t tLane[KS];
+#pragma unroll
+    for (int j = 0; j < KE; j++)
+    {
+      const uint32_t prevLane = (uint32_t)__shfl_up((int)tInc[j], 1, 64);
+      tLane[j] = (lane == 0u) ? (IDX_OLD | (uint32_t)j) : prevLane;
+    }
+    state_compose<KE>(exclT, tWaves, tLane);
+  }
+  __syncthreads();
+}
+
+// A: one workgroup per full batch: the parallel check and the batch's totals
+template <int KE>
+__global__ __launch_bounds__(kResolveThreads) void k_resolve_fast_totals(const uint32_t *__restrict__ g, const uint32_t *__restrict__ e, const uint64_t *__restrict__ olen,
+                                                                         const uint32_t *__restrict__ tIn, uint32_t p0, uint32_t G, uint32_t *__restrict__ fast, uint32_t *__restrict__ batch)
+{
+  constexpr int NT = kResolveThreads;
+  constexpr int KS = KE > 0 ? KE : 1;
+  __shared__ uint64_t swave[NT / 64];
+  __shared__ uint32_t sWaveT[(NT / 64) * KS];
+  const uint32_t tid = threadIdx.x, r = blockIdx.x * (uint32_t)NT + tid;
+  const uint32_t gg = g[r], ee = e[r];
+  const uint32_t prev = (r == 0u) ? p0 : e[r - 1u];
+  const bool ok = prev == gg && gg < p0 + (r + 1u) * G && ee < IDX_SKIP;
+  const int allok = __syncthreads_and(ok ? 1 : 0);
+  if (!allok) { if (tid == 0u) atomicAnd(fast, 0u); return; }
+  uint32_t myT[KS], exclT[KS], allT[KS];
+#pragma unroll
+  for (int j = 0; j < KS; j++) myT[j] = (KE > 0) ? tIn[(uint64_t)r * KS + j] : (IDX_OLD | (uint32_t)j);
+  uint64_t exclOut, allOut;
+  resolve_batch_scan<KE>(tid, olen[r], myT, swave, sWaveT, exclOut, allOut, exclT, allT);
+  if (tid == 0u)
+  {
+    uint32_t *w = batch + (uint64_t)blockIdx.x * kFastBatchWords;
+    w[0] = (uint32_t)allOut; w[1] = (uint32_t)(allOut >> 32);
+#pragma unroll
+    for (int j = 0; j < KS; j++) w[2 + j] = allT[j];
+  }
+}
+
+// B: ONE workgroup: exclusive scan of the batch totals -> every batch's carries (in place), the carries behind the last one into fast[2 ..]
+template <int KE>
+__global__ __launch_bounds__(kResolveThreads) void k_resolve_fast_carries(uint32_t *__restrict__ fast, uint32_t *__restrict__ batch, uint32_t batches)
+{
+  constexpr int NT = kResolveThreads;
+  constexpr int KS = KE > 0 ? KE : 1;
+  __shared__ uint64_t swave[NT / 64];
+  __shared__ uint32_t sWaveT[(NT / 64) * KS];
+  __shared__ uint64_t sCarryOut;
+  __shared__ uint32_t sCarryT[KS];
+  if (fast[0] != 1u) return;
+  const uint32_t tid = threadIdx.x;
+  if (tid == 0u)
+  {
+    sCarryOut = 0;
+#pragma unroll
+    for (int j = 0; j < KS; j++) sCarryT[j] = IDX_INIT | (uint32_t)j;
+  }
+  __syncthreads();
+  for (uint32_t base = 0; base < batches; base += NT)
+  {
+    const uint32_t i = base + tid;
+    const bool valid = i < batches;
+    uint32_t *w = batch + (uint64_t)i * kFastBatchWords;
+    const uint64_t v = valid ? ((uint64_t)w[0] | ((uint64_t)w[1] << 32)) : 0ull;
+    uint32_t myT[KS], exclT[KS], allT[KS];
+#pragma unroll
+    for (int j = 0; j < KS; j++) myT[j] = (KE > 0 && valid) ? w[2 + j] : (IDX_OLD | (uint32_t)j);
+    uint64_t exclOut, allOut;
+    resolve_batch_scan<KE>(tid, v, myT, swave, sWaveT, exclOut, allOut, exclT, allT);
+    if (valid)
+    {
+      const uint64_t o = sCarryOut + exclOut;
+      w[0] = (uint32_t)o; w[1] = (uint32_t)(o >> 32);
+      if constexpr (KE > 0)
+      {
+        uint32_t carry[KS], st[KS];
+#pragma unroll
+        for (int j = 0; j < KE; j++) carry[j] = sCarryT[j];
+        state_compose<KE>(st, carry, exclT);
+#pragma unroll
+        for (int j = 0; j < KE; j++) w[2 + j] = st[j];
+      }
+    }
+    __syncthreads();
+    if (tid == 0u)
+    {
+      sCarryOut += allOut;
+      if constexpr (KE > 0)
+      {
+        uint32_t carry[KS], st[KS];
+#pragma unroll
+        for (int j = 0; j < KE; j++) carry[j] = sCarryT[j];
+        state_compose<KE>(st, carry, allT);
+#pragma unroll
+        for (int j = 0; j < KE; j++) sCarryT[j] = st[j];
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0u)
+  {
+    fast[2] = (uint32_t)sCarryOut; fast[3] = (uint32_t)(sCarryOut >> 32);
+#pragma unroll
+    for (int j = 0; j < KS; j++) fast[4 + j] = sCarryT[j];
+  }
+}
+
+// C: one workgroup per full batch: what k_index_resolve writes for a region that passed -- entry, output position, state in front of it
+template <int KE>
+__global__ __launch_bounds__(kResolveThreads) void k_resolve_fast_emit(const uint32_t *__restrict__ g, const uint64_t *__restrict__ olen, const uint32_t *__restrict__ tIn,
+                                                                       const uint32_t *__restrict__ fast, const uint32_t *__restrict__ batch,
+                                                                       uint32_t *__restrict__ entry, uint64_t *__restrict__ outStart, uint32_t *__restrict__ stateIn)
+{
+  constexpr int NT = kResolveThreads;
+  constexpr int KS = KE > 0 ? KE : 1;
+  __shared__ uint64_t swave[NT / 64];
+  __shared__ uint32_t sWaveT[(NT / 64) * KS];
+  if (fast[0] != 1u) return;
+  const uint32_t tid = threadIdx.x, r = blockIdx.x * (uint32_t)NT + tid;
+  uint32_t myT[KS], exclT[KS], allT[KS];
+#pragma unroll
+  for (int j = 0; j < KS; j++) myT[j] = (KE > 0) ? tIn[(uint64_t)r * KS + j] : (IDX_OLD | (uint32_t)j);
+  uint64_t exclOut, allOut;
+  resolve_batch_scan<KE>(tid, olen[r], myT, swave, sWaveT, exclOut, allOut, exclT, allT);
+  const uint32_t *w = batch + (uint64_t)blockIdx.x * kFastBatchWords;
+  entry[r] = g[r];
+  outStart[r] = ((uint64_t)w[0] | ((uint64_t)w[1] << 32)) + exclOut;
+  if constexpr (KE > 0)
+  {
+    uint32_t carry[KS], st[KS];
+#pragma unroll
+    for (int j = 0; j < KE; j++) carry[j] = w[2 + j];
+    state_compose<KE>(st, carry, exclT);
+#pragma unroll
+    for (int j = 0; j < KE; j++) stateIn[(uint64_t)r * KE + j] = st[j];
+  }
+}
+
 template <int KE>
 __global__ __launch_bounds__(kResolveThreads) void k_index_resolve(const uint32_t *__restrict__ g, const uint32_t *__restrict__ e, const uint64_t *__restrict__ olen,
                                                                    const uint32_t *__restrict__ tIn, uint32_t R, uint32_t p0, uint32_t G, uint64_t U,
                                                                    uint32_t *__restrict__ entry, uint64_t *__restrict__ outStart, uint32_t *__restrict__ stateIn,
                                                                    uint32_t *__restrict__ fix, uint32_t *__restrict__ list, uint32_t *__restrict__ ctrl,
-                                                                   uint32_t *__restrict__ mark, uint32_t roundTag)
+                                                                   uint32_t *__restrict__ mark, uint32_t roundTag, const uint32_t *__restrict__ fast, uint32_t fastBatches)
 {
+  // fast != nullptr: the parallel passes (k_resolve_fast_*) may have done the first fastBatches batches -- fast[0] == 1 says they did: every
+  // region of those batches passed the parallel check, their records are written, and this kernel goes on behind them from the carries
+  // fast[2 ..] (output bytes, state) with the chain standing at e[fastBatches * NT - 1].  fast[0] == 0: nothing was done, start at region 0.
   constexpr int NT = kResolveThreads;
   constexpr int KS = KE > 0 ? KE : 1;
   constexpr uint8_t F_NONE = 0, F_OK = 1, F_SKIP = 2, F_DIRTY = 3;
+  const uint32_t base0 = (fast != nullptr && fast[0] == 1u) ? fastBatches * (uint32_t)NT : 0u;
   __shared__ uint32_t sg[NT], se[NT];
   __shared__ uint8_t sflag[NT];
   __shared__ uint64_t sokMask[NT / 64];                                 // bit: the region passed the parallel check
@@ -345,17 +577,25 @@ __global__ __launch_bounds__(kResolveThreads) void k_index_resolve(const uint32_
     sCur = p0; sEnded = 0; sTrusted = 1; sDirty = 0; sStatus = 0; sCarryOut = 0;
 #pragma unroll
     for (int j = 0; j < KS; j++) sCarryState[j] = IDX_INIT | (uint32_t)j;
+    if (base0 != 0u)
+    {
+      sCur = e[base0 - 1u];
+      sCarryOut = (uint64_t)fast[2] | ((uint64_t)fast[3] << 32);
+#pragma unroll
+      for (int j = 0; j < KS; j++) sCarryState[j] = (KE > 0) ? fast[4 + j] : (IDX_INIT | (uint32_t)j);
+    }
   }
   __syncthreads();
 
   // the next batch's walk results are requested while this batch is worked on (the pass is one workgroup: nothing else hides the latency)
-  uint32_t nG = (tid < R) ? g[tid] : 0u, nE = (tid < R) ? e[tid] : 0u;
-  uint64_t nOl = (tid < R) ? olen[tid] : 0ull;
+  const uint32_t r0 = base0 + tid;
+  uint32_t nG = (r0 < R) ? g[r0] : 0u, nE = (r0 < R) ? e[r0] : 0u;
+  uint64_t nOl = (r0 < R) ? olen[r0] : 0ull;
   uint32_t nT[KS];
 #pragma unroll
-  for (int j = 0; j < KS; j++) nT[j] = (KE > 0 && tid < R) ? tIn[(uint64_t)tid * KS + j] : (IDX_OLD | (uint32_t)j);
+  for (int j = 0; j < KS; j++) nT[j] = (KE > 0 && r0 < R) ? tIn[(uint64_t)r0 * KS + j] : (IDX_OLD | (uint32_t)j);
 
-  for (uint32_t base = 0; base < R; base += NT)
+  for (uint32_t base = base0; base < R; base += NT)
   {
     const uint32_t r = base + tid;
     const bool valid = r < R;
