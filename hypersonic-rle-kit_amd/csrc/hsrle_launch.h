@@ -129,7 +129,7 @@ inline hipError_t launch_decode(KERNEL k, const DecodeArgs &a, hipStream_t st)
 // on run-distributed data 9 - 25 %.  Blocks decoded from entry records (monolithic streams, split decode) keep the 128-byte ring.
 // HSRLE_DEC_RING=64 / 128 in the environment forces one (tests, A/B).
 // (PER_MILLE: the ratio below which the small ring is taken.  1 / 2 byte symbols: 250 -- rle16_sym at 0.23 still gains 6 %; wider symbols:
-//  3 / 4 byte symbols: 200 -- 8 GiB video-shaped rle32_3symlut_byte (0.17) +16 %, rle24_7symlut_byte_short (0.19) +12 %, every 24 / 32 bit
+//  3 / 4 byte symbols: 215 (round 4; 200 before: rle32_3symlut_sym video-shaped at 0.2042 gains 9 % with the small ring) -- 8 GiB video-shaped rle32_3symlut_byte (0.17) +16 %, rle24_7symlut_byte_short (0.19) +12 %, every 24 / 32 bit
 //  row of the sweep below 0.2 gains 10 - 20 %, but rle24_sym (0.26) -3 %, rle32_sym (0.30) -8 %.  6 / 8 byte symbols: never)
 template <int PER_MILLE = 250, typename K128, typename K64>
 inline hipError_t launch_decode_ring(K128 k128, K64 k64, const DecodeArgs &a, hipStream_t st)
