@@ -31,13 +31,14 @@ namespace hsrle {
 template <int FAM, int S, int AL, bool MONO = false, int RING = HSRLE_ENCS_RING_OF(S)>
 __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t nBlocks,
                                                        uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes,
-                                                       const uint64_t *__restrict__ monoStarts, const uint64_t *__restrict__ monoSyms,
-                                                       const uint64_t *__restrict__ monoSlotOff, uint32_t monoSteps, uint64_t *__restrict__ monoListOut, uint32_t monoDry,
+                                                       const uint64_t *__restrict__ monoStarts, uint64_t *monoSyms,
+                                                       const uint64_t *__restrict__ monoSlotOff, uint32_t monoSteps, uint64_t *monoListOut, uint32_t monoDry,
                                                        const uint32_t *__restrict__ ringSel)
 {
   if (!MONO && ringSel != nullptr && ringSel[0] != (uint32_t)RING) return;          // (S = 2: the host launches both rings, k_ring_decide chose: hsrle_encode8.hip.h)
   // (codecs with a move-to-front list: monoSyms[8 * c + k] = entry k of the list in front of chunk c, monoListOut likewise the list behind it;
-  //  monoDry: no stores, only the list -- see k_encode8_blocks)
+  //  monoDry: no stores, only the list -- see k_encode8_blocks.  Neither is const nor __restrict__: when the lists are settled in the kernel
+  //  (grp != 0 below) the lanes of a wave rewrite monoSyms and read each other's monoListOut between rounds.)
   [[maybe_unused]] const bool dry = MONO && monoDry != 0u;
   using TR = Traits<FAM, S, AL>;
   static_assert(S == 2 || S == 3 || S == 4 || S == 6 || S == 8, "8 bit and 128 bit symbols have their own kernels");
@@ -722,14 +723,17 @@ __global__ __launch_bounds__(64) void k_encodeS_blocks(const uint8_t *__restrict
         a.add(t, (uint32_t)K);
       }
       for (uint32_t k = 0; k < (uint32_t)K && a.n < (uint32_t)K; k++) a.add_one(mono_default_entry(k, (uint32_t)S), (uint32_t)K);
-      uint64_t *const g = const_cast<uint64_t *>(monoSyms) + 8ull * b;
+      uint64_t *const g = monoSyms + 8ull * b;
 #pragma unroll
       for (int k = 0; k < 7; k++)
         if (k < K && ld_fresh64(g + k) != a.e[k]) { changed = true; g[k] = a.e[k]; }
       g[7] = changed ? 1ull : 0ull;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (__ballot(changed) == 0ull || listRound >= 64u) break;           // (a block's chunks settle one per round at worst)
+    if (__ballot(changed) == 0ull) break;
+    // a block's chunks settle one per round at worst and a wave holds 64 chunks at most: round 64 cannot find a change.  Should it ever,
+    // the launch dies (the host sees a launch failure) rather than leave a stream behind that was encoded from a wrong list
+    if (listRound >= 64u) __builtin_trap();
     wave_sync();
   }
   else

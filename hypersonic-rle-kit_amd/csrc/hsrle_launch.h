@@ -65,7 +65,7 @@ struct EncodeArgs
 // chunks of ONE monolithic stream (hsrle_mono_encode.hip.h): EncodeArgs with nBlocks = chunks, plus the chunk table
 struct MonoEncodeArgs
 {
-  const uint64_t *starts; const uint64_t *syms; const uint64_t *slotOff; uint32_t steps;
+  const uint64_t *starts; uint64_t *syms; const uint64_t *slotOff; uint32_t steps;   // (syms: rewritten by k_encodeS_blocks when it settles the lists itself)
   uint64_t *listOut = nullptr; uint32_t dry = 0;     // codecs with a move-to-front list: syms / listOut hold 8 words per chunk
   const uint32_t *pick = nullptr;                    // 8 bit Single: the stream's symbol (device)
   uint64_t *jobs = nullptr; uint32_t *jobCount = nullptr; uint32_t jobCap = 0;   // 8 bit Single: literal stretches noted for k_copy_jobs
@@ -207,7 +207,7 @@ inline hipError_t launch_encode(KERNEL k, const EncodeArgs &a, hipStream_t st, i
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(a.residentWorkgroups, k, 64, capResidency ? ldsCap : lds8);
   if constexpr (kernel_arity(KERNEL{}) == 14)   // kernels with a MONO mode (hsrle_encode8.hip.h): block mode = no chunk table
     hipLaunchKernelGGL(k, dim3(grid), dim3(64), capResidency ? ldsCap : lds8, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, (const uint64_t *)nullptr,
-                       (const uint64_t *)nullptr, (const uint64_t *)nullptr, 0u, (uint64_t *)nullptr, 0u, (const uint32_t *)nullptr);
+                       (uint64_t *)nullptr, (const uint64_t *)nullptr, 0u, (uint64_t *)nullptr, 0u, (const uint32_t *)nullptr);
   else
     hipLaunchKernelGGL(k, dim3(grid), dim3(64), capResidency ? ldsCap : lds8, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes);
   return hipGetLastError();
@@ -230,9 +230,9 @@ inline hipError_t launch_encode_ring(K256 k256, K128 k128, const EncodeArgs &a, 
   hipLaunchKernelGGL((k_ring_probe<S>), dim3(samples), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.ringSel);
   hipLaunchKernelGGL((k_ring_decide<S>), dim3(1), dim3(64), 0, st, a.ringSel);
   const uint32_t grid = (a.nBlocks + 63u) / 64u;
-  hipLaunchKernelGGL(k256, dim3(grid), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, (const uint64_t *)nullptr, (const uint64_t *)nullptr, (const uint64_t *)nullptr, 0u,
+  hipLaunchKernelGGL(k256, dim3(grid), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, (const uint64_t *)nullptr, (uint64_t *)nullptr, (const uint64_t *)nullptr, 0u,
                      (uint64_t *)nullptr, 0u, (const uint32_t *)a.ringSel);
-  hipLaunchKernelGGL(k128, dim3(grid), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, (const uint64_t *)nullptr, (const uint64_t *)nullptr, (const uint64_t *)nullptr, 0u,
+  hipLaunchKernelGGL(k128, dim3(grid), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, (const uint64_t *)nullptr, (uint64_t *)nullptr, (const uint64_t *)nullptr, 0u,
                      (uint64_t *)nullptr, 0u, (const uint32_t *)a.ringSel);
   return hipGetLastError();
 }

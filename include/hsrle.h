@@ -376,7 +376,10 @@ int hsrle_device_count(void);
  * take their scratch stream-ordered from a memory pool the LIBRARY owns on the calling thread's device -- never from the device's default
  * pool, whose settings belong to the application.  Freed scratch stays in that pool up to the retention (default 2 GiB; UINT64_MAX keeps
  * everything, 0 returns everything at the next synchronisation); hsrle_trim() returns what the pool holds to the driver now.  Calls that
- * are handed their workspace (the *_async forms) allocate nothing. */
+ * are handed their workspace (the *_async forms) allocate nothing.
+ * hsrle_scratch_retention(bytes) applies the value to the pool of the calling thread's CURRENT device and makes it the default of every
+ * pool the library creates later (one per device, on first use); pools that already exist on other devices keep their setting until the
+ * function is called with that device current.  hsrle_trim() likewise acts on the current device's pool only. */
 int hsrle_scratch_retention(uint64_t bytes);
 int hsrle_trim(void);
 

@@ -505,6 +505,12 @@ def test_reference_cli_runs_on_the_gpu_library(tmp_path):
     out = r.stdout.replace("\r", "\n")
     assert r.returncode == 0, out[-3000:] + r.stderr[-2000:]
     assert "FAILED" not in out and "Short" in out
+    # the unsectioned low-entropy rows: rle8_low_entropy[_short]_{compress, compress_only_max_frequency, decompress}
+    for flag, name in (("--low-entropy", "Low Entropy"), ("--low-entropy-short", "Low Entropy Short")):
+        r = subprocess.run([exe, str(sample), flag, "--runs", "1", "--min-time", "0", "--test"], capture_output=True, text=True, timeout=900)
+        out = r.stdout.replace("\r", "\n")
+        assert r.returncode == 0, out[-3000:] + r.stderr[-2000:]
+        assert "FAILED" not in out and name in out, out[-2000:]
 
 
 def test_first_compress_of_a_process_under_graph_capture():
