@@ -208,11 +208,15 @@ def side_measurements(hsrle, torch, src, dev):
     enc_frame_ms = timed(lambda: hsrle.compress_async("rle64_3symlut_byte", frame, cdst, 4096, workspace=cws), 10)
     del cdst, cws
     plain_ms = timed(lambda: hsrle.decompress_async(cont, info, dec, st), 10)
+    plain_ok = int(st[0].item()) == 0 and torch.equal(dec, frame)
+    dec.zero_()
     split_ms = timed(lambda: hsrle.decompress_split_async(cont, info, dec, ws, st, sub_block=0), 10)
-    ok = int(st[0].item()) == 0 and torch.equal(dec, frame)
+    ok = plain_ok and int(st[0].item()) == 0 and torch.equal(dec, frame)
+    mode = int(hsrle.lib().hsrle_split_sub_block_size(info, 0))
     out["config3_frame"] = {"codec": "rle64_3symlut_byte", "bytes": fsize, "block_size": 4096, "ratio": round(info.totalSize / fsize, 4), "encode_us": round(enc_frame_ms * 1e3, 1), "decode_us": round(plain_ms * 1e3, 1),
                             "split_decode_us": round(split_ms * 1e3, 1), "split_GiBps": round(fsize / 2**30 / (split_ms * 1e-3), 1),
-                            "split_algorithmic_TBps": round((fsize + info.totalSize) / (split_ms * 1e-3) / 1e12, 3), "exact": bool(ok)}
+                            "split_algorithmic_TBps": round((fsize + info.totalSize) / (split_ms * 1e-3) / 1e12, 3),
+                            "split_mode": "packet list (one entry per packet, then 16 output bytes per lane)" if mode == 1 else f"records every {mode} bytes", "exact": bool(ok)}
     del frame, cont, dec, ws
 
     n = 1 << 30

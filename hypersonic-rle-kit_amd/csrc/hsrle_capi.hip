@@ -8,6 +8,7 @@
 #include "hsrle_common.hip.h"
 #include "hsrle_launch.h"
 #include "hsrle_index.hip.h"
+#include "hsrle_expand.hip.h"
 #include "hsrle_mono_encode.hip.h"
 #ifdef HSRLE_EXPERIMENTS
 #include "experiments/hsrle_encode8w.hip.h"
@@ -52,6 +53,17 @@ static const char *const kCodecNames[kCodecCount] = {
 };
 
 static inline bool codec_is_lut(int c) { return c == 2 || c == 3 || (c >= 6 && c < 46 && (((c - 6) & 3) >= 2)) || c >= kShortBase8; }   // 8-byte stream header
+static inline int codec_symbol_bytes(int c)
+{
+  static const int widths[5] = { 2, 3, 4, 6, 8 };
+  if (c < 6) return 1;
+  if (c < 46) return widths[(c - 6) >> 3];
+  if (c < 50) return 16;
+  if (c < kShortBaseW) return 1;
+  if (c < kGreedyBase) return widths[(c - kShortBaseW) >> 3];
+  if (c < kSingleShort) return widths[(c - kGreedyBase) / 3];
+  return 1;
+}
 static inline uint32_t codec_header_size(int c) { return (c < 6 && !codec_is_lut(c)) ? 9u : 8u; }
 
 static DecodeLaunch g_dec[kCodecCount];
@@ -710,9 +722,20 @@ static int decompress_blocks_async(const void *dContainer, const hsrle_container
 // containers with too few blocks to fill the GPU with one lane per block (an 88 MB frame in 4 KiB blocks has 21 600): the block size,
 // and with it the compression ratio, stays what it is.
 
+constexpr uint32_t kPacketListBelow = 81920u;     // blocks: up to here the packet list decode is the library's choice for small containers
 static uint32_t split_sub_block(const hsrle_container_info_t *info, uint32_t want)
 {
   const uint32_t B = info->blockSize;
+  // the packet-list decode (hsrle_index.hip.h: k_container_packets, hsrle_expand.hip.h): the library's choice for blocks of up to 16 KiB --
+  // the 88 MB frame: 102 us against 180 with records at every 1 KiB and 322 with one lane per block.  It wins up to ~65 536 blocks (256 MiB
+  // in 4 KiB blocks: 183 / 186 us video-shaped rle64_3symlut_byte / run-distributed rle8_packed against 329 / 212 plain) and loses at 131 072
+  // (408 / 591 against 361 / 274): from 81 920 blocks on one lane per block has the waves it needs.  Records were never the fastest of the
+  // three at any size (experiments/r04/call24.sh); they remain for blocks above 16 KiB, whose offsets do not fit the list entries.
+  const bool listFits = B <= kPacketListMaxBlock && B >= 256u;
+  if (want == HSRLE_SPLIT_PACKET_LIST)
+    return listFits ? HSRLE_SPLIT_PACKET_LIST : B;
+  if (want == 0u && listFits)
+    return info->blockCount <= kPacketListBelow ? HSRLE_SPLIT_PACKET_LIST : B;
   if (want == 0u)
   {
     want = pow2_floor(info->uncompressedSize >> 16);                 // ~2^16 .. 2^17 lanes (measured on the 88 MB frame: 1 KiB sub-blocks 187 us, 512 / 256 bytes 206)
@@ -744,6 +767,20 @@ static int decompress_split_async(const void *dContainer, const hsrle_container_
   init_tables();
   if (!g_dec[info->codec] || !g_sub[info->codec])
     return HSRLE_ERR_UNSUPPORTED;
+
+  if (SB == HSRLE_SPLIT_PACKET_LIST)
+  {
+    const uint64_t countsBytes = packet_list_counts_bytes(count);
+    if (dWs == nullptr || ((uintptr_t)dWs & 15u) != 0u || wsSize < countsBytes + (uint64_t)count * packet_list_cap(info->blockSize) * 8ull)
+      return HSRLE_ERR_CAPACITY;
+    const uint8_t *container = (const uint8_t *)dContainer;
+    const uint8_t *payload = container + HSRLE_CONTAINER_HEADER_SIZE + 8ull * ((uint64_t)info->blockCount + 1ull);
+    DecodeArgs da{ payload, (const uint64_t *)(container + HSRLE_CONTAINER_HEADER_SIZE), payload + info->payloadSize + HSRLE_CONTAINER_TAIL_PAD,
+                   (uint8_t *)dOut, info->uncompressedSize, info->blockSize, first, count, dStatus };
+    if (g_sub[info->codec](da, kSubPacketList, (uint32_t *)dWs, st) != hipSuccess)
+      return HSRLE_ERR_DEVICE;
+    return launch_expand_packets(codec_symbol_bytes((int)info->codec), da, (const uint64_t *)((const uint8_t *)dWs + countsBytes), (const uint32_t *)dWs, st) == hipSuccess ? HSRLE_OK : HSRLE_ERR_DEVICE;
+  }
 
   const uint32_t per = info->blockSize / SB;
   const uint64_t subFirst = (uint64_t)first * per;
@@ -2084,6 +2121,7 @@ uint64_t hsrle_decompress_split_workspace_size(const hsrle_container_info_t *inf
   if (!info || !valid_block_size(info->blockSize)) return 0;
   const uint32_t SB = split_sub_block(info, subBlockSize);
   if (SB == info->blockSize) return 0;
+  if (SB == HSRLE_SPLIT_PACKET_LIST) return packet_list_counts_bytes(blockCount) + (uint64_t)blockCount * packet_list_cap(info->blockSize) * 8ull;
   return (uint64_t)blockCount * (info->blockSize / SB) * 4ull * kEntryRecDwords;
 }
 

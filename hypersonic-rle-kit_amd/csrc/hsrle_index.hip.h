@@ -1002,6 +1002,144 @@ __global__ __launch_bounds__(64) void k_container_records(const uint8_t *__restr
   if (err != 0u && status != nullptr) atomicOr(status, err);
 }
 
+// ---- PACKET LISTS: the split decode of small containers without records and without a second chain ----
+// k_container_records + k_decode_blocks walk every packet chain twice (the record walk, then the sub-block lanes), and both walks are latency
+// chains with a few thousand lanes on a device that holds half a million.  Only finding the packet boundaries is sequential; what a packet
+// PRODUCES is known from its header alone.  So one lane per block hops through the block's packets once (k_container_packets; the block's
+// stream staged in LDS as above) and leaves, per packet, one 64-bit entry
+//     output position in the block (15 bits) | literal bytes (15) | stream offset of the literals (15) | symbol field (15)
+// (symbol field: stream offset of the run's symbol -- the walk tracks the move-to-front lists as offsets, state_apply -- or kPktInitField | b
+// for a symbol b b b ... the decoder starts with), closed by a sentinel entry whose output position is the end of what the list covers.
+// k_expand_packets (hsrle_expand.hip.h) then builds the output with one lane per 16 OUTPUT bytes: binary search in the block's list, literal
+// bytes straight from the stream, run bytes from the symbol -- no chain, whole lines stored.  Blocks of up to 16 KiB (15-bit fields).
+// A block with more than B / 8 packets (fewer than 8 output bytes per packet on average) does not fit its list: the lane closes the list
+// where it stands and decodes the rest of the block itself, byte by byte (slow, correct, and rare: adversarial inputs).
+constexpr uint32_t kPktInitField = 0x7F00u;
+constexpr uint32_t kPacketListMaxBlock = 16384u;
+__host__ __device__ inline uint32_t packet_list_cap(uint32_t B) { return B / 8u + 2u; }
+constexpr uint32_t kSubPacketList = 1u;          // what the codec tables' sub-block launchers take as "sub-block size" for this path
+inline uint64_t packet_list_counts_bytes(uint32_t blockCount) { return ((uint64_t)blockCount * 4ull + 15ull) & ~15ull; }
+__device__ __forceinline__ uint64_t pkt_entry(uint32_t outStart, uint32_t lit, uint32_t body, uint32_t symf)
+{
+  return (uint64_t)outStart | ((uint64_t)lit << 15) | ((uint64_t)body << 30) | ((uint64_t)symf << 45);
+}
+
+// returns 1 (the stream's last packet was walked; count entries written incl. the sentinel) or 2 (malformed)
+template <int FAM, int S, int AL, typename READER>
+__device__ __forceinline__ uint32_t walk_emit_packets(const READER &s, uint32_t C, uint32_t x, bool sgl, uint32_t blen, uint64_t *__restrict__ list, uint32_t cap,
+                                                      uint32_t &count, uint8_t *__restrict__ out)
+{
+  using TR = Traits<FAM, S, AL>;
+  constexpr int KE = IndexState<FAM>::KE;
+  constexpr int KS = KE > 0 ? KE : 1;
+  constexpr uint64_t kInit7 = 0x00FE807E01FF7F00ull;                    // rleX_Xsl.h:533-543, as in index_symbol
+  uint32_t st[KS];
+#pragma unroll
+  for (int j = 0; j < KS; j++) st[j] = IDX_INIT | (uint32_t)j;
+  uint32_t curSym = IDX_INIT;
+  uint32_t o = 0, n = 0;
+  bool direct = false;                                                  // the list is full: this lane writes the output itself
+  for (;;)
+  {
+    const Pkt k = parse_packet<FAM, S, AL>(s, x, C, sgl);
+    if (k.bad || k.lit > blen - o || k.run > blen - o - k.lit) return 2u;
+    state_apply<KE>(st, k.op, k.symAt);
+    if (k.hasSym) curSym = k.symAt;
+    uint32_t ref;
+    if (sgl) ref = 9u;
+    else if constexpr (TR::kShortSingle) ref = 8u;
+    else if constexpr (KE > 0) ref = st[0];
+    else ref = curSym;
+    const uint32_t body = x + k.used;
+    if (!direct && n + 2u > cap)
+    {
+      list[n++] = pkt_entry(o, 0u, 0u, 0u);                              // sentinel: the list covers [0, o)
+      direct = true;
+    }
+    if (!direct)
+    {
+      const uint32_t initByte = (KE > 0 && FAM != PACKED) ? (uint32_t)(kInit7 >> (8u * ((ref & 15u) % 7u))) & 0xFFu : 0u;
+      const uint32_t symf = ((ref >> 30) == 3u) ? (kPktInitField | initByte) : ref;
+      list[n++] = pkt_entry(o, k.lit, body, symf);
+    }
+    else
+    {
+      const u32x4 sv = index_symbol<S>(s, ref, (KE > 0) ? (FAM == PACKED) : true);
+      const uint32_t sw[4] = { sv.x, sv.y, sv.z, sv.w };
+      for (uint32_t j = 0; j < k.lit; j++) out[o + j] = (uint8_t)(s.load32(body + j) & 0xFFu);
+      for (uint32_t j = 0; j < k.run; j++) { const uint32_t q = j % (uint32_t)S; out[o + k.lit + j] = (uint8_t)(sw[q >> 2] >> (8u * (q & 3u))); }
+    }
+    o += k.lit + k.run;
+    if (k.last) break;
+    x = body + k.lit;
+  }
+  if (o != blen) return 2u;
+  if (!direct) list[n++] = pkt_entry(o, 0u, 0u, 0u);
+  count = n;
+  return 1u;
+}
+
+template <int FAM, int S, int AL>
+__global__ __launch_bounds__(64) void k_container_packets(const uint8_t *__restrict__ payload, const uint64_t *__restrict__ offsets, const uint8_t *__restrict__ payloadEnd,
+                                                          uint8_t *__restrict__ out, uint64_t U, uint32_t B, uint32_t firstBlock, uint32_t blockCount, uint32_t allowSingle,
+                                                          uint32_t NB, uint32_t ldsBytes, uint64_t *__restrict__ lists, uint32_t *__restrict__ counts, uint32_t *__restrict__ status)
+{
+  using TR = Traits<FAM, S, AL>;
+  extern __shared__ __attribute__((aligned(16))) uint8_t window[];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t i0 = xcd_tile(blockIdx.x, gridDim.x) * NB;
+  if (i0 >= blockCount) return;
+  const uint32_t cnt = (blockCount - i0 < NB) ? blockCount - i0 : NB;
+  const uint64_t payloadBytes = (uint64_t)(payloadEnd - payload);
+
+  // the wave's piece of the payload -> LDS (as k_container_records)
+  const uint64_t w0raw = offsets[firstBlock + i0], w1 = offsets[firstBlock + i0 + cnt];
+  const uint64_t w0 = w0raw & ~15ull;
+  const bool staged = w0raw <= w1 && w1 <= payloadBytes && w1 - w0 + 96u <= (uint64_t)ldsBytes;
+  if (staged)
+  {
+    const uint32_t total = (uint32_t)(w1 - w0) + 64u;
+    for (uint32_t c = lane * 16u; c < total; c += 64u * 16u)
+      lds_st128(window + c, (w0 + c + 16u <= payloadBytes + HSRLE_TAIL_PAD_BYTES) ? ld128(payload + w0 + c) : u32x4{ 0, 0, 0, 0 });
+  }
+  wave_sync();
+  if (lane >= cnt) return;
+
+  const uint32_t local = i0 + lane, b = firstBlock + local;
+  const uint32_t cap = packet_list_cap(B);
+  uint32_t err = 0, n = 0;
+  const uint64_t off0 = offsets[b], off1 = offsets[b + 1];
+  const uint64_t start = (uint64_t)b * B;
+  const uint32_t blen = (uint32_t)((U - start) < (uint64_t)B ? (U - start) : (uint64_t)B);
+  if (off0 > off1 || off1 > payloadBytes || off1 - off0 >= (uint64_t)kPktInitField) err = DEC_ERR_HEADER;   // (a stream whose offsets do not fit the entries' 15 bits is not a block of <= 16 KiB)
+  else
+  {
+    const uint8_t *const s = payload + off0;
+    const uint32_t C = (uint32_t)(off1 - off0);
+    uint32_t p0 = TR::kHeaderSize, sgl = 0;
+    if (C < TR::kHeaderSize + 2u || ld32(s) != blen || ld32(s + 4) != C) err = DEC_ERR_HEADER;
+    else if constexpr (TR::kShortSingle) { p0 = 9; }
+    else if constexpr (S == 1 && !TR::kLut && !TR::kShort)
+    {
+      const uint32_t mode = s[8];
+      if (mode == 1u) { if (allowSingle) { sgl = 1; p0 = 10; } else err = DEC_ERR_MODE; }
+      else if (mode != 0u) err = DEC_ERR_MODE;
+    }
+    if (err == 0u)
+    {
+      uint64_t *const list = lists + (uint64_t)local * cap;
+      uint32_t how;
+      if (staged && off0 >= w0 && off1 <= w1)
+        how = walk_emit_packets<FAM, S, AL>(LdsReader{ window, (uint32_t)(off0 - w0) }, C, p0, sgl != 0u, blen, list, cap, n, out + start);
+      else
+        how = walk_emit_packets<FAM, S, AL>(GlobalReader{ s }, C, p0, sgl != 0u, blen, list, cap, n, out + start);
+      if (how != 1u) { err = DEC_ERR_STREAM; n = 0; }
+    }
+  }
+  counts[local] = n;                                                     // (0: nothing of this block is expanded)
+  if (err != 0u && status != nullptr) atomicOr(status, err);
+}
+
 // host side: walk (records == 0) or record pass (records != 0) of one codec grammar
 template <int FAM, int S, int AL>
 inline hipError_t launch_index(const IndexArgs &a, int records, hipStream_t st)
@@ -1036,6 +1174,28 @@ inline hipError_t launch_container_records(const DecodeArgs &a, uint32_t SB, uin
   return hipGetLastError();
 }
 
+// lists: blockCount x packet_list_cap(B) entries; counts: blockCount words (the caller's workspace)
+template <int FAM, int S, int AL>
+inline hipError_t launch_container_packets(const DecodeArgs &a, uint32_t allowSingle, uint64_t *lists, uint32_t *counts, hipStream_t st)
+{
+  const uint64_t payloadBytes = (uint64_t)(a.payloadEnd - a.payload);
+  const uint64_t total = a.firstBlock + (uint64_t)a.blockCount;
+  const uint64_t avg = payloadBytes / (total ? total : 1u) + 16u;
+  uint32_t NB = 64u;
+  while (NB > 8u && (uint64_t)NB * avg * 3u / 2u > 49152ull) NB /= 2u;
+  uint64_t lds = (uint64_t)NB * avg * 3u / 2u + 128u;
+  lds = lds > 49152ull ? 49152ull : (lds < 4096ull ? 4096ull : lds);
+  lds = (lds + 255ull) & ~255ull;
+  // The LDS window only pays while ALL waves are resident at once (3 per CU at 48 KB) and carry at least 32 chains each: beyond that the
+  // walk runs in rounds of a latency chain, and 64 chains per wave straight from global memory (the lines of a stream are hit ~9 times
+  // in a row) are faster -- 88 MB frame, rle64_3symlut_byte (21 MB payload): 103 us staged / 112 global; the same size run-distributed,
+  // rle8_packed (48 MB): 171 / 98; 256 MiB: 283 / 183 and 418 / 186 (experiments/r04/call25.sh).
+  if (NB < 32u || payloadBytes > (24ull << 20)) { NB = 64u; lds = 0; }
+  hipLaunchKernelGGL((k_container_packets<FAM, S, AL>), dim3((a.blockCount + NB - 1u) / NB), dim3(64), (uint32_t)lds, st, a.payload, a.offsets, a.payloadEnd, a.out, a.U, a.B,
+                     a.firstBlock, a.blockCount, allowSingle, NB, (uint32_t)lds, lists, counts, a.status);
+  return hipGetLastError();
+}
+
 } // namespace hsrle
 
 #ifdef HSRLE_EXPERIMENTS
@@ -1054,6 +1214,8 @@ inline hipError_t launch_sub_or_wave(const DecodeArgs &a, uint32_t SB, uint32_t 
 #else
   if (SB == 0u) return hipErrorNotSupported;                        // not in the shipped build
 #endif
+  if (SB == kSubPacketList)                                           // rec = [counts: blockCount words, padded to 16 bytes | lists]
+    return launch_container_packets<FAM, S, AL>(a, allowSingle, (uint64_t *)((uint8_t *)rec + packet_list_counts_bytes(a.blockCount)), rec, st);
   return launch_container_records<FAM, S, AL>(a, SB, allowSingle, rec, st);
 }
 

@@ -298,10 +298,16 @@ int hsrle_decompress_blocks_dev_async(const void *dContainer, const hsrle_contai
  * ~10^5 blocks are needed; BASELINE config 3, an 88 MB frame in 4 KiB blocks, has 21 600).  One lane per block first walks the block's
  * packets and leaves the decoder state at every subBlockSize output bytes (csrc/hsrle_index.hip.h), then the block kernel runs one lane
  * per SUB-block.  The container, its block size and its compression ratio are what they are: nothing is re-encoded.
- *   subBlockSize: multiple of 128 that divides blockSize; 0 = the library's choice (hsrle_split_sub_block_size tells which; when it
- *   returns blockSize no split happens and no workspace is needed).  dWorkspace >= hsrle_decompress_split_workspace_size(info,
- *   blockCount, subBlockSize) bytes.  Only enqueues kernels: graph-capturable.  dStatus as in hsrle_decompress_dev_async.
+ * Round 4 -- the packet list decode (subBlockSize = HSRLE_SPLIT_PACKET_LIST, the library's choice for blocks of 256 bytes .. 16 KiB): the
+ * walk leaves one 64-bit entry per PACKET (where its output starts, its literals, its symbol) instead of decoder states, and a second kernel
+ * builds the output with one lane per 16 output bytes -- the packet chain is walked once, nothing else is sequential.
+ *   subBlockSize: HSRLE_SPLIT_PACKET_LIST, or a multiple of 128 that divides blockSize (records at every subBlockSize bytes); 0 = the
+ *   library's choice (hsrle_split_sub_block_size tells which; when it returns blockSize no split happens and no workspace is needed).
+ *   dWorkspace (16-byte aligned) >= hsrle_decompress_split_workspace_size(info, blockCount, subBlockSize) bytes -- for the packet list
+ *   about the uncompressed size of the blocks (blockSize / 8 + 2 entries per block: a block with more packets than that is finished by
+ *   the walking lane, byte by byte).  Only enqueues kernels: graph-capturable.  dStatus as in hsrle_decompress_dev_async.
  */
+#define HSRLE_SPLIT_PACKET_LIST 1u
 uint32_t hsrle_split_sub_block_size(const hsrle_container_info_t *info, uint32_t subBlockSize);
 uint64_t hsrle_decompress_split_workspace_size(const hsrle_container_info_t *info, uint32_t blockCount, uint32_t subBlockSize);
 int hsrle_decompress_split_dev_async(const void *dContainer, const hsrle_container_info_t *info, uint32_t firstBlock, uint32_t blockCount, void *dOut, uint64_t outCapacity,

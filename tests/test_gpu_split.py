@@ -1,5 +1,6 @@
 """Split decode of block containers (hsrle_decompress_split_dev_async): one lane per block walks the block's packets and leaves the
-decoder state every SB output bytes, then one lane per SUB-block decodes.  Bar: the same bytes as the plain block decode (= the input),
+decoder state every SB output bytes, then one lane per SUB-block decodes -- or (sub-block size 1 = HSRLE_SPLIT_PACKET_LIST, the library's
+choice for blocks of up to 16 KiB) leaves one entry per packet, from which a second kernel builds the output 16 bytes per lane.  Bar: the same bytes as the plain block decode (= the input),
 for every codec and every legal sub-block size; malformed blocks are reported, nothing outside the output is written."""
 import random
 import struct
@@ -9,6 +10,8 @@ import pytest
 from hsrle_testlib import CODECS, CODEC_BY_KEY, SYNTH_VIDEO, mixed_runs, single_symbol_mix, fuzz_sections, FUZZ_LENGTHS
 
 pytestmark = pytest.mark.gpu
+
+PACKET_LIST = 1          # include/hsrle.h: HSRLE_SPLIT_PACKET_LIST
 
 
 @pytest.fixture(scope="module")
@@ -52,7 +55,7 @@ def test_split_decode_equals_the_input(hs, codec):
 
     data = _data(99 + CODECS.index(codec), 150000 + 77)
     src = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
-    for block, subs in ((1024, (128, 256, 512)), (4096, (512, 0)), (1536, (128, 768))):
+    for block, subs in ((1024, (128, 256, 512, PACKET_LIST)), (4096, (512, 0, PACKET_LIST)), (1536, (128, 768, PACKET_LIST)), (16384, (PACKET_LIST, 0)), (256, (PACKET_LIST,))):
         container, info = hs.compress(codec.key, src, block_size=block)
         for sub in subs:
             out, status = _split(hs, container, info, len(data), sub, guard=512)
@@ -67,10 +70,34 @@ def test_split_decode_of_a_block_range(hs):
     src = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
     container, info = hs.compress("rle8_packed_multi", src, block_size=2048)
     first, count = 17, 50
-    out, status = _split(hs, container, info, len(data), 256, first=first, count=count)
+    for sub in (256, PACKET_LIST):
+        out, status = _split(hs, container, info, len(data), sub, first=first, count=count)
+        host = out.cpu().numpy().tobytes()
+        assert status == 0 and host[first * 2048 : (first + count) * 2048] == data[first * 2048 : (first + count) * 2048]
+        assert set(host[: first * 2048]) == {0xA5} and set(host[(first + count) * 2048 :]) == {0xA5}
+    # the last blocks, the last one partial
+    first = info.blockCount - 3
+    out, status = _split(hs, container, info, len(data), PACKET_LIST, first=first, count=3)
     host = out.cpu().numpy().tobytes()
-    assert status == 0 and host[first * 2048 : (first + count) * 2048] == data[first * 2048 : (first + count) * 2048]
-    assert set(host[: first * 2048]) == {0xA5} and set(host[(first + count) * 2048 :]) == {0xA5}
+    assert status == 0 and host[first * 2048 : len(data)] == data[first * 2048 :] and set(host[: first * 2048]) == {0xA5}
+
+
+def test_packet_list_of_a_block_with_more_packets_than_its_list(hs):
+    """A block whose packets produce fewer than 8 output bytes on average does not fit its list (blockSize / 8 + 2 entries): the walking lane
+    closes the list where it stands and writes the rest of the block itself.  Runs of three and four bytes back to back: ~1 200 packets per 4 KiB."""
+    import torch
+
+    rng = random.Random(12)
+    dense = b"".join(bytes([rng.randrange(256)]) * rng.choice((3, 4, 5)) for _ in range(30000))
+    wide = b"".join(bytes(rng.randrange(256) for _ in range(8)) * rng.choice((2, 3)) for _ in range(9000))
+    for key, data in (("rle8_packed_multi", dense), ("rle8_multi_short", dense), ("rle8_3symlut", dense), ("rle8_packed_single", b"".join(b"\x07" * rng.choice((3, 4)) + bytes([rng.randrange(1, 7)]) for _ in range(30000))),
+                      ("rle64_byte_packed", wide), ("rle64_7symlut_byte_short", wide), ("rle24_sym_packed", b"".join(bytes(rng.randrange(256) for _ in range(3)) * rng.choice((3, 4)) for _ in range(20000)))):
+        src = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+        for block in (4096, 1024, 16384):
+            container, info = hs.compress(key, src, block_size=block)
+            out, status = _split(hs, container, info, len(data), PACKET_LIST, guard=512)
+            assert status == 0 and out[: len(data)].cpu().numpy().tobytes() == data, f"{key} block {block}"
+            assert bool((out[len(data):] == 0xA5).all())
 
 
 def test_split_decode_reports_malformed_blocks(hs):
@@ -88,12 +115,18 @@ def test_split_decode_reports_malformed_blocks(hs):
             for j in range(a + 10, b):
                 host[j] = rng.randrange(256)
         bad = torch.frombuffer(host, dtype=torch.uint8).cuda()
-        out, status = _split(hs, bad, info, len(data), 256, guard=4096)
-        assert status != 0 and bool((out[len(data):] == 0xA5).all())
         host2 = bytearray(container.cpu().numpy().tobytes())
         host2[64 + 8 * 3 : 64 + 8 * 4] = struct.pack("<Q", 1 << 40)          # table entry outside the payload
-        out, status = _split(hs, torch.frombuffer(host2, dtype=torch.uint8).cuda(), info, len(data), 256, guard=4096)
-        assert status != 0 and bool((out[len(data):] == 0xA5).all())
+        bad2 = torch.frombuffer(host2, dtype=torch.uint8).cuda()
+        for sub in (256, PACKET_LIST):
+            out, status = _split(hs, bad, info, len(data), sub, guard=4096)
+            assert status != 0 and bool((out[len(data):] == 0xA5).all())
+            # the blocks that were left alone still decode
+            good = [i for i in range(info.blockCount) if i % 3 != 0]
+            host_out = out.cpu().numpy().tobytes()
+            assert all(host_out[i * 1024 : (i + 1) * 1024] == data[i * 1024 : (i + 1) * 1024] for i in good[:40]), f"{key} sub {sub}"
+            out, status = _split(hs, bad2, info, len(data), sub, guard=4096)
+            assert status != 0 and bool((out[len(data):] == 0xA5).all())
 
 
 def test_config3_frame_split_decode(hs, oracle):
@@ -103,7 +136,8 @@ def test_config3_frame_split_decode(hs, oracle):
     size = 88473600
     src = hs.synth(SYNTH_VIDEO, 8, 3, size, device="cuda")
     container, info = hs.compress("rle64_3symlut_byte", src, block_size=4096)
-    for sub in (0, 1024, 256):
+    assert hs.lib().hsrle_split_sub_block_size(__import__("ctypes").byref(info), 0) == PACKET_LIST
+    for sub in (0, PACKET_LIST, 1024, 256):
         out, status = _split(hs, container, info, size, sub)
         assert status == 0 and torch.equal(out[:size], src), f"sub {sub}"
 

@@ -17,7 +17,7 @@ def main():
     ap.add_argument("--synth", default="video")
     ap.add_argument("--size", type=int, default=88473600)
     ap.add_argument("--block", type=int, default=4096)
-    ap.add_argument("--subs", default="4096,2048,1024,512,256,0")
+    ap.add_argument("--subs", default="4096,2048,1024,512,256,1,0")     # 1 = HSRLE_SPLIT_PACKET_LIST
     ap.add_argument("--reps", type=int, default=20)
     args = ap.parse_args()
     import torch
@@ -34,6 +34,7 @@ def main():
         ws = torch.empty(max(hsrle.split_workspace_size(info, None, sub), 16), dtype=torch.uint8, device="cuda")
         eff = hsrle.lib().hsrle_split_sub_block_size(info, sub)
         run = lambda: hsrle.decompress_split_async(container, info, out, ws, status, sub_block=sub)
+        out.zero_()
         for _ in range(3):
             run()
         torch.cuda.synchronize()
