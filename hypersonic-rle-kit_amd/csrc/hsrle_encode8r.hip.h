@@ -47,8 +47,10 @@ constexpr uint32_t kRunListOutTile = 4352u;    // >= the slot of a 4 KiB block (
 
 template <int FAM>
 __global__ __launch_bounds__(64) void k_encode8_runlist(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t nBlocks,
-                                                        uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes, uint32_t bpw)
+                                                        uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes, uint32_t bpw,
+                                                        const uint32_t *__restrict__ sel)
 {
+  if (sel != nullptr && sel[0] != 1u) return;                          // (big containers of 3 / 4 byte symbols: k_list_decide chose the ring encoder, hsrle_ring_probe.hip.h)
   static_assert(FAM == PLAIN || FAM == PACKED || FAM == LUT3 || FAM == LUT7 || (FAM >= SHORT0 && FAM <= SHORT7), "rle8_multi / rle8_packed_multi / rle8_{3,7}symlut / their Short family");
   using TR = Traits<FAM, 1, 0>;
   constexpr bool PK = FAM == PACKED, LT = TR::kLut, SH = TR::kShort;

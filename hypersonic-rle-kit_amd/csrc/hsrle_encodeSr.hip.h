@@ -31,8 +31,10 @@ constexpr uint32_t run_list_cap(int S) { return S == 8 ? 512u : (S == 6 ? 640u :
 
 template <int FAM, int S, int AL>
 __global__ __launch_bounds__(64) void k_encodeS_runlist(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t nBlocks,
-                                                        uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes, uint32_t bpw)
+                                                        uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes, uint32_t bpw,
+                                                        const uint32_t *__restrict__ sel)
 {
+  if (sel != nullptr && sel[0] != 1u) return;                          // (big containers of 3 / 4 byte symbols: k_list_decide chose the ring encoder, hsrle_ring_probe.hip.h)
   static_assert(FAM == PLAIN || FAM == PACKED || FAM == LUT3 || FAM == LUT7 || (FAM >= SHORT0 && FAM <= SHORT7), "plain, Packed, LUT, Short");
   static_assert(S == 2 || S == 3 || S == 4 || S == 6 || S == 8, "2 .. 8 byte symbols");
   using TR = Traits<FAM, S, AL>;

@@ -66,9 +66,18 @@ struct Pkt
 // Where a walk reads its stream from: global memory (one 16-byte window per packet hop: a memory latency per hop), or a copy of a
 // piece of the payload in LDS (k_container_records: the streams of the blocks a wave walks are one contiguous piece).  LDS accesses must
 // be naturally aligned to be fast (tools/ubench/lds_align.hip), so the LDS reader funnels three aligned 8-byte reads.
+// 32 bits at byte offset pos (0..20) of the 24-byte little-endian value ex:hi:lo
+__device__ __forceinline__ uint32_t ex32x(uint64_t lo, uint64_t hi, uint64_t ex, uint32_t pos)
+{
+  const uint32_t sh = pos * 8u, s = sh & 63u;
+  const uint64_t w = sh < 64u ? lo : (sh < 128u ? hi : ex), wn = sh < 64u ? hi : (sh < 128u ? ex : 0ull);
+  return (uint32_t)((w >> s) | ((wn << 1) << (63u - s)));
+}
+
 struct GlobalReader
 {
   const uint8_t *s;
+  __device__ __forceinline__ void load24(uint32_t p, uint64_t &lo, uint64_t &hi, uint64_t &ex) const { lo = ld64(s + p); hi = ld64(s + p + 8); ex = ld64(s + p + 16); }
   __device__ __forceinline__ void load16(uint32_t p, uint64_t &lo, uint64_t &hi) const { lo = ld64(s + p); hi = ld64(s + p + 8); }
   __device__ __forceinline__ uint32_t load32(uint32_t p) const { return ld32(s + p); }
   __device__ __forceinline__ u32x4 load128(uint32_t p) const { return ld128(s + p); }
@@ -78,6 +87,20 @@ struct LdsReader
   const uint8_t *lds;      // 16-byte aligned
   uint32_t delta;          // LDS offset of the stream's byte 0
   __device__ __forceinline__ u32x4 load128(uint32_t p) const { return lds_read16_w8(lds, delta + p); }
+  // 24 bytes from four aligned 8-byte reads (one LDS round trip) and a byte funnel
+  __device__ __forceinline__ void load24(uint32_t p, uint64_t &lo, uint64_t &hi, uint64_t &ex) const
+  {
+    const uint32_t q = delta + p;
+    const uint8_t *const src = lds + (q & ~7u);
+    const uint64_t w0 = lds_ld64(src), w1 = lds_ld64(src + 8), w2 = lds_ld64(src + 16), w3 = lds_ld64(src + 24);
+    const bool d1 = (q & 4u) != 0u;
+    const uint32_t z0 = (uint32_t)w0, z1 = (uint32_t)(w0 >> 32), z2 = (uint32_t)w1, z3 = (uint32_t)(w1 >> 32), z4 = (uint32_t)w2, z5 = (uint32_t)(w2 >> 32), z6 = (uint32_t)w3, z7 = (uint32_t)(w3 >> 32);
+    const uint32_t y0 = d1 ? z1 : z0, y1 = d1 ? z2 : z1, y2 = d1 ? z3 : z2, y3 = d1 ? z4 : z3, y4 = d1 ? z5 : z4, y5 = d1 ? z6 : z5, y6 = d1 ? z7 : z6;
+    const uint32_t n = q & 3u;
+    lo = (uint64_t)alignbyte(y1, y0, n) | ((uint64_t)alignbyte(y2, y1, n) << 32);
+    hi = (uint64_t)alignbyte(y3, y2, n) | ((uint64_t)alignbyte(y4, y3, n) << 32);
+    ex = (uint64_t)alignbyte(y5, y4, n) | ((uint64_t)alignbyte(y6, y5, n) << 32);
+  }
   __device__ __forceinline__ void load16(uint32_t p, uint64_t &lo, uint64_t &hi) const
   {
     const u32x4 v = load128(p);
@@ -98,9 +121,15 @@ __device__ __forceinline__ Pkt parse_packet(const READER &rd, uint32_t p, uint32
   k.used = 1; k.lit = 0; k.run = 0; k.op = 0; k.symAt = p; k.hasSym = false; k.last = false; k.bad = false;
   if (p + 2u > C) { k.bad = true; return k; }
 
-  uint64_t lo, hi;
-  rd.load16(p, lo, hi);
-  auto u32at = [&](uint32_t pos) -> uint32_t { return pos <= 12u ? ex32(lo, hi, pos) : rd.load32(p + pos); };
+  // 24 header bytes in registers: every field of every header form of symbols up to 8 bytes lies below byte 20, so the parse needs no
+  // second read and -- written with selects -- no branch (a hop of the walks is a chain of ~200 dependent instructions in ONE wave per
+  // SIMD: exec-mask round trips cost more than the instructions they skip).  128-bit symbols keep a reload for fields beyond byte 20.
+  uint64_t lo, hi, ex;
+  rd.load24(p, lo, hi, ex);
+  auto u32at = [&](uint32_t pos) -> uint32_t {
+    if constexpr (S == 16) return pos <= 20u ? ex32x(lo, hi, ex, pos) : rd.load32(p + pos);
+    else return ex32x(lo, hi, ex, pos);
+  };
 
   uint32_t cnt, range, pos;
   bool endNow = false, hbad = false;
@@ -110,23 +139,21 @@ __device__ __forceinline__ Pkt parse_packet(const READER &rd, uint32_t p, uint32
     const uint32_t p1 = (uint32_t)lo & 0xFFu, p2 = ((uint32_t)lo >> 8) & 0xFFu, p3 = ((uint32_t)lo >> 16) & 0xFFu;
     const uint32_t idx = (TR::K > 0) ? p1 >> (TR::SCB + TR::SRBP) : 0u;
     const uint32_t c3 = (p1 >> TR::SRBP) & TR::SCINV;
-    if (c3 != TR::SCINV)
-    {
-      cnt = c3 + 2u;
-      range = (p1 & TR::SMAXPR) + 2u;
-      pos = 1;
-    }
-    else
-    {
-      cnt = (p2 >> (TR::SRB - 8u)) | ((p1 & TR::SMAXPR) << (16u - TR::SRB));
-      range = p3 | ((p2 & ((1u << (TR::SRB - 8u)) - 1u)) << 8);
-      pos = 3;
-      if (cnt == 0u) { cnt = u32at(3u); pos = 7; }
-      else if (cnt == 1u) { cnt = u32at(3u) & 0xFFFFu; pos = 5; }
-      const uint32_t rext = u32at(pos);
-      if (range == 0u) { range = rext; pos += 4; }
-      else if (range == 1u) { range = rext & 0xFFFFu; pos += 2; endNow = (range == 0u); }
-    }
+    const bool lf = c3 == TR::SCINV;                                     // the three-byte form (+ extensions)
+    uint32_t cntL = (p2 >> (TR::SRB - 8u)) | ((p1 & TR::SMAXPR) << (16u - TR::SRB));
+    uint32_t rngL = p3 | ((p2 & ((1u << (TR::SRB - 8u)) - 1u)) << 8);
+    const uint32_t cw = u32at(3u);
+    const bool c0 = lf && cntL == 0u, c1 = lf && cntL == 1u;
+    cntL = c0 ? cw : (c1 ? (cw & 0xFFFFu) : cntL);
+    uint32_t posL = c0 ? 7u : (c1 ? 5u : 3u);
+    const uint32_t rext = u32at(posL);
+    const bool r0 = lf && rngL == 0u, r1 = lf && rngL == 1u;
+    rngL = r0 ? rext : (r1 ? (rext & 0xFFFFu) : rngL);
+    posL += r0 ? 4u : (r1 ? 2u : 0u);
+    endNow = r1 && rngL == 0u;
+    cnt = lf ? cntL : c3 + 2u;
+    range = lf ? rngL : (p1 & TR::SMAXPR) + 2u;
+    pos = lf ? posL : 1u;
     if constexpr (TR::kShortSingle) { }
     else if constexpr (TR::K == 0)
     {
@@ -136,7 +163,8 @@ __device__ __forceinline__ Pkt parse_packet(const READER &rd, uint32_t p, uint32
     else
     {
       k.op = idx;
-      if (idx == (uint32_t)TR::K) { k.hasSym = true; k.symAt = p + pos; pos += S; }
+      const bool hs = idx == (uint32_t)TR::K;
+      k.hasSym = hs; k.symAt = hs ? p + pos : p; pos += hs ? (uint32_t)S : 0u;
     }
     hbad = !endNow && range < 2u;
     k.last = endNow || cnt == 0u;
@@ -149,13 +177,19 @@ __device__ __forceinline__ Pkt parse_packet(const READER &rd, uint32_t p, uint32
     const uint32_t idx = w16 >> (FAM == LUT3 ? 14 : 13);
     cnt = (w16 >> TR::RB) & 0x7Fu;
     range = w16 & ((1u << TR::RB) - 1u);
-    pos = 2;
     k.op = idx;
-    if (idx == (uint32_t)TR::K) { k.hasSym = true; k.symAt = p + 2u; pos += S; }
-    if (cnt == 0u) { cnt = u32at(pos); pos += 4; }
-    else if (cnt == 1u) { cnt = u32at(pos) & 0xFFFFu; pos += 2; }
-    if (range == 0u) { range = u32at(pos); pos += 4; }
-    else if (range == 1u) { range = u32at(pos) & 0xFFFFu; pos += 2; endNow = (range == 0u); }
+    const bool hs = idx == (uint32_t)TR::K;
+    k.hasSym = hs; k.symAt = hs ? p + 2u : p;
+    pos = hs ? 2u + (uint32_t)S : 2u;
+    const uint32_t cw = u32at(pos);
+    const bool c0 = cnt == 0u, c1 = cnt == 1u;
+    cnt = c0 ? cw : (c1 ? (cw & 0xFFFFu) : cnt);
+    pos += c0 ? 4u : (c1 ? 2u : 0u);
+    const uint32_t rw = u32at(pos);
+    const bool r0 = range == 0u, r1 = range == 1u;
+    range = r0 ? rw : (r1 ? (rw & 0xFFFFu) : range);
+    pos += r0 ? 4u : (r1 ? 2u : 0u);
+    endNow = r1 && range == 0u;
     hbad = !endNow && range < 2u;
     k.last = endNow || cnt == 0u;
     k.lit = (endNow || range < 2u) ? 0u : range - 2u;
@@ -168,28 +202,40 @@ __device__ __forceinline__ Pkt parse_packet(const READER &rd, uint32_t p, uint32
     {
       pos = sgl ? 0u : (uint32_t)S;
       k.hasSym = !sgl;
-      cnt = u32at(pos) & 0xFFu; pos += 1;
-      if (cnt == 0u) { cnt = u32at(pos); pos += 4; }
+      const uint32_t cw = u32at(pos);                                  // count byte, and (if it is 0) the 32-bit count behind it at pos + 1
+      const uint32_t cx = (S == 16) ? u32at(pos + 1u) : (uint32_t)((cw >> 8) | (u32at(pos + 4u) << 24));
+      cnt = cw & 0xFFu;
+      const bool c0 = cnt == 0u;
+      cnt = c0 ? cx : cnt;
+      pos += c0 ? 5u : 1u;
     }
     else
     {
       const uint32_t b0 = (uint32_t)lo & 0xFFu;
       cnt = sgl ? b0 : (b0 & 0x7Fu);
-      pos = 1;
-      if (cnt == 0u) { cnt = u32at(1u); pos = 5; }
-      if (!sgl && !(b0 & 0x80u)) { k.hasSym = true; k.symAt = p + pos; k.op = 1; pos += S; }
+      const bool c0 = cnt == 0u;
+      cnt = c0 ? u32at(1u) : cnt;
+      pos = c0 ? 5u : 1u;
+      const bool hs = !sgl && !(b0 & 0x80u);
+      k.hasSym = hs; k.symAt = hs ? p + pos : p; k.op = hs ? 1u : 0u;
+      pos += hs ? (uint32_t)S : 0u;
     }
     const uint32_t w = u32at(pos);
     const uint32_t r0 = w & 0xFFu;
     if (TR::kRange7 && !sgl)
     {
-      if (r0 & 1u) { range = w >> 1; pos += 4; endNow = (range == 0u); }
-      else { range = r0 >> 1; pos += 1; }
+      const bool lng = (r0 & 1u) != 0u;
+      range = lng ? (w >> 1) : (r0 >> 1);
+      pos += lng ? 4u : 1u;
+      endNow = lng && range == 0u;
     }
     else
     {
-      range = r0; pos += 1;
-      if (r0 == 0u) { range = u32at(pos); pos += 4; endNow = (range == 0u); }
+      const bool lng = r0 == 0u;
+      const uint32_t rx = (S == 16) ? (lng ? u32at(pos + 1u) : 0u) : (uint32_t)((w >> 8) | (u32at(pos + 4u) << 24));
+      range = lng ? rx : r0;
+      pos += lng ? 5u : 1u;
+      endNow = lng && range == 0u;
     }
     const uint32_t shortv = sgl ? (TR::kPacked ? 2u : 4u) : TR::SHORT;
     k.last = endNow || cnt == 0u;

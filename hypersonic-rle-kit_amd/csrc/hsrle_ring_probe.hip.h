@@ -28,8 +28,9 @@ __global__ __launch_bounds__(64) void k_ring_probe(const uint8_t *__restrict__ i
     const uint64_t lo = (uint64_t)x.x | ((uint64_t)x.y << 32), hi = (uint64_t)x.z | ((uint64_t)x.w << 32);
     const uint64_t nx = ld64(in + at + p + 16u);                         // the bytes behind the chunk (S <= 2 of them are needed, + 1 for the start test)
     // byte k of the chunk against byte k + S
-    const uint64_t slo = (S == 1) ? ((lo >> 8) | (hi << 56)) : ((lo >> 16) | (hi << 48));
-    const uint64_t shi = (S == 1) ? ((hi >> 8) | (nx << 56)) : ((hi >> 16) | (nx << 48));
+    static_assert(S >= 1 && S <= 4, "the bytes behind the chunk come from one 8-byte read");
+    const uint64_t slo = (lo >> (8 * S)) | (hi << (64 - 8 * S));
+    const uint64_t shi = (hi >> (8 * S)) | (nx << (64 - 8 * S));
     const uint64_t dl = lo ^ slo, dh = hi ^ shi;
     const uint64_t zl = ~(((dl & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | dl) & 0x8080808080808080ull;
     const uint64_t zh = ~(((dh & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | dh) & 0x8080808080808080ull;
@@ -64,6 +65,20 @@ __global__ void k_ring_decide(uint32_t *__restrict__ sel)
   }
   else if (n != 0u) pick = 128u;                                          // no runs at all: nothing is fetched either way, the waves count
   sel[0] = pick;
+}
+
+// 3 and 4 byte symbols, big containers: ring encoder (k_encodeS_blocks, sel[0] = 128 = its ring) or run list encoder (k_encodeS_runlist,
+// sel[0] = 1)?  The run list encoder's work grows with the number of candidates, the ring encoder's with the bytes: at 4 GiB the run list
+// is 11 - 17 % faster on run-distributed data (7 - 9 runs per KiB) and 22 - 48 % slower on video-shaped data (37 - 38 per KiB;
+// experiments/r04/call26.sh).  Runs per KiB from the same probe: the run list below kRunListRunsPerKiB.
+constexpr uint32_t kRunListRunsPerKiB = 16;
+constexpr uint32_t kSelRunList = 1;
+template <int S>
+__global__ void k_list_decide(uint32_t *__restrict__ sel)
+{
+  if (threadIdx.x != 0u) return;
+  const uint64_t n = sel[1], r = sel[3];
+  sel[0] = (n != 0u && r * 1024u / n < kRunListRunsPerKiB) ? kSelRunList : 128u;
 }
 
 } // namespace hsrle
