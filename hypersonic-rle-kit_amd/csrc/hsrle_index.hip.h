@@ -112,8 +112,37 @@ struct LdsReader
 // One packet header at stream offset p (the stream is readable up to C + 32).  The field rules are those of the decoder
 // (hsrle_decode.hip.h): the two must agree on every stream, which tests/test_gpu_mono.py checks by decoding through
 // the index what the block kernel decodes on its own.
+// 32 bits at the compile-time byte offset P (<= 20) of a 24-byte window given as six dwords: one v_alignbyte at most.  The parse below
+// extracts every field at EVERY position it can have (there are two to six) and selects: a handful of independent full-rate instructions
+// instead of a chain of position arithmetic and 64-bit shifts -- a hop of a walk is one wave's dependent chain, its depth is its time.
+template <int P>
+__device__ __forceinline__ uint32_t u32c(const uint32_t (&d)[6])
+{
+  static_assert(P >= 0 && P <= 20, "inside the 24-byte window");
+  if constexpr ((P & 3) == 0) return d[P >> 2];
+  else return alignbyte(d[(P >> 2) + 1], d[P >> 2], (uint32_t)(P & 3));
+}
+
+template <int FAM, int S, int AL, typename READER>
+__device__ __forceinline__ Pkt parse_window(const READER &rd, uint64_t lo, uint64_t hi, uint64_t ex, uint32_t p, uint32_t C, bool single);
+
 template <int FAM, int S, int AL, typename READER>
 __device__ __forceinline__ Pkt parse_packet(const READER &rd, uint32_t p, uint32_t C, bool single)
+{
+  if (p + 2u > C)
+  {
+    Pkt k;
+    k.used = 1; k.lit = 0; k.run = 0; k.op = 0; k.symAt = p; k.hasSym = false; k.last = false; k.bad = true;
+    return k;
+  }
+  uint64_t lo, hi, ex;
+  rd.load24(p, lo, hi, ex);
+  return parse_window<FAM, S, AL>(rd, lo, hi, ex, p, C, single);
+}
+
+// the same with the 24 header bytes given (walks that load the next packet's window while they book the current packet)
+template <int FAM, int S, int AL, typename READER>
+__device__ __forceinline__ Pkt parse_window(const READER &rd, uint64_t lo, uint64_t hi, uint64_t ex, uint32_t p, uint32_t C, bool single)
 {
   using TR = Traits<FAM, S, AL>;
   constexpr int KE = IndexState<FAM>::KE;
@@ -124,8 +153,6 @@ __device__ __forceinline__ Pkt parse_packet(const READER &rd, uint32_t p, uint32
   // 24 header bytes in registers: every field of every header form of symbols up to 8 bytes lies below byte 20, so the parse needs no
   // second read and -- written with selects -- no branch (a hop of the walks is a chain of ~200 dependent instructions in ONE wave per
   // SIMD: exec-mask round trips cost more than the instructions they skip).  128-bit symbols keep a reload for fields beyond byte 20.
-  uint64_t lo, hi, ex;
-  rd.load24(p, lo, hi, ex);
   auto u32at = [&](uint32_t pos) -> uint32_t {
     if constexpr (S == 16) return pos <= 20u ? ex32x(lo, hi, ex, pos) : rd.load32(p + pos);
     else return ex32x(lo, hi, ex, pos);
@@ -173,22 +200,22 @@ __device__ __forceinline__ Pkt parse_packet(const READER &rd, uint32_t p, uint32
   }
   else if constexpr (TR::kLut)
   {
-    const uint32_t w16 = (uint32_t)lo & 0xFFFFu;
+    static_assert(S <= 8, "LUT codecs have symbols of up to 8 bytes");
+    const uint32_t d[6] = { (uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32), (uint32_t)ex, (uint32_t)(ex >> 32) };
+    const uint32_t w16 = d[0] & 0xFFFFu;
     const uint32_t idx = w16 >> (FAM == LUT3 ? 14 : 13);
-    cnt = (w16 >> TR::RB) & 0x7Fu;
-    range = w16 & ((1u << TR::RB) - 1u);
+    const uint32_t c7 = (w16 >> TR::RB) & 0x7Fu, r7 = w16 & ((1u << TR::RB) - 1u);
     k.op = idx;
     const bool hs = idx == (uint32_t)TR::K;
     k.hasSym = hs; k.symAt = hs ? p + 2u : p;
-    pos = hs ? 2u + (uint32_t)S : 2u;
-    const uint32_t cw = u32at(pos);
-    const bool c0 = cnt == 0u, c1 = cnt == 1u;
-    cnt = c0 ? cw : (c1 ? (cw & 0xFFFFu) : cnt);
-    pos += c0 ? 4u : (c1 ? 2u : 0u);
-    const uint32_t rw = u32at(pos);
-    const bool r0 = range == 0u, r1 = range == 1u;
-    range = r0 ? rw : (r1 ? (rw & 0xFFFFu) : range);
-    pos += r0 ? 4u : (r1 ? 2u : 0u);
+    // extension fields sit at 2 (+ S with a symbol) (+ 2 / 4 behind a 16 / 32 bit count)
+    const uint32_t e0 = hs ? u32c<2 + S>(d) : u32c<2>(d), e2 = hs ? u32c<4 + S>(d) : u32c<4>(d), e4 = hs ? u32c<6 + S>(d) : u32c<6>(d);
+    const bool c0 = c7 == 0u, c1 = c7 == 1u;
+    cnt = c0 ? e0 : (c1 ? (e0 & 0xFFFFu) : c7);
+    const uint32_t rw = c0 ? e4 : (c1 ? e2 : e0);
+    const bool r0 = r7 == 0u, r1 = r7 == 1u;
+    range = r0 ? rw : (r1 ? (rw & 0xFFFFu) : r7);
+    pos = (hs ? 2u + (uint32_t)S : 2u) + (c0 ? 4u : (c1 ? 2u : 0u)) + (r0 ? 4u : (r1 ? 2u : 0u));
     endNow = r1 && range == 0u;
     hbad = !endNow && range < 2u;
     k.last = endNow || cnt == 0u;
@@ -198,6 +225,7 @@ __device__ __forceinline__ Pkt parse_packet(const READER &rd, uint32_t p, uint32
   else
   {
     const bool sgl = (S == 1) && single;
+    [[maybe_unused]] uint32_t wPacked = 0;
     if constexpr (!TR::kPacked)
     {
       pos = sgl ? 0u : (uint32_t)S;
@@ -219,8 +247,14 @@ __device__ __forceinline__ Pkt parse_packet(const READER &rd, uint32_t p, uint32
       const bool hs = !sgl && !(b0 & 0x80u);
       k.hasSym = hs; k.symAt = hs ? p + pos : p; k.op = hs ? 1u : 0u;
       pos += hs ? (uint32_t)S : 0u;
+      if constexpr (S <= 8)
+      {
+        // the range field at 1 / 5 (+ S with a symbol): all four, then select
+        const uint32_t d[6] = { (uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32), (uint32_t)ex, (uint32_t)(ex >> 32) };
+        wPacked = hs ? (c0 ? u32c<5 + S>(d) : u32c<1 + S>(d)) : (c0 ? u32c<5>(d) : u32c<1>(d));
+      }
     }
-    const uint32_t w = u32at(pos);
+    const uint32_t w = (TR::kPacked && S <= 8) ? wPacked : u32at(pos);
     const uint32_t r0 = w & 0xFFu;
     if (TR::kRange7 && !sgl)
     {
@@ -978,6 +1012,27 @@ __global__ __launch_bounds__(64) void k_index_records(const uint8_t *__restrict_
   (void)walk_emit_records<FAM, S, AL>(GlobalReader{ s }, 0ull, C, x, p0 + (r + 1u) * G, o, st, single != 0u, singleSym, U, B, rec);   // (cannot meet a malformed packet: k_index_walk walked this chain)
 }
 
+// A wave copies `total` bytes of the payload from w0 (16-byte aligned) into its LDS window: EIGHT 16-byte loads per lane in flight.  (Until
+// round 4 this was one load, wait, LDS store per trip: 32 memory latencies in a row for a 32 KB window -- 50 of the 68 us that
+// k_container_records / k_container_packets took on the 88 MB frame were this loop, not the walk.)
+__device__ __forceinline__ void stage_window(uint8_t *window, const uint8_t *__restrict__ payload, uint64_t w0, uint32_t total, uint64_t payloadBytes)
+{
+  const uint32_t lane = threadIdx.x;
+  for (uint32_t c0 = lane * 16u; c0 < total; c0 += 8u * 1024u)
+  {
+    u32x4 v[8];
+#pragma unroll
+    for (uint32_t j = 0; j < 8u; j++)
+    {
+      const uint32_t c = c0 + j * 1024u;
+      v[j] = (c < total && w0 + c + 16u <= payloadBytes + HSRLE_TAIL_PAD_BYTES) ? ld128(payload + w0 + c) : u32x4{ 0, 0, 0, 0 };
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < 8u; j++)
+      if (c0 + j * 1024u < total) lds_st128(window + c0 + j * 1024u, v[j]);
+  }
+}
+
 // ---- the same for a block container: one lane per block walks the block's stream from its first packet (known: no guessing, no
 //      resolve pass) and writes the decoder state at every SB output bytes, so that k_decode_blocks can put B / SB lanes on a block.
 //      What the block kernel checks in its prologue (table entry, stream header, mode byte) is checked here.
@@ -1004,11 +1059,7 @@ __global__ __launch_bounds__(64) void k_container_records(const uint8_t *__restr
   const uint64_t w0 = w0raw & ~15ull;
   const bool staged = w0raw <= w1 && w1 <= payloadBytes && w1 - w0 + 96u <= (uint64_t)ldsBytes;   // (+ what the aligned reads of a parse near the end may touch)
   if (staged)
-  {
-    const uint32_t total = (uint32_t)(w1 - w0) + 64u;                    // (+ what a parse may read behind the last packet; beyond the payload's 32-byte tail pad: zeros)
-    for (uint32_t c = lane * 16u; c < total; c += 64u * 16u)
-      lds_st128(window + c, (w0 + c + 16u <= payloadBytes + HSRLE_TAIL_PAD_BYTES) ? ld128(payload + w0 + c) : u32x4{ 0, 0, 0, 0 });
-  }
+    stage_window(window, payload, w0, (uint32_t)(w1 - w0) + 64u, payloadBytes);   // (+ 64: what a parse may read behind the last packet; beyond the payload's 32-byte tail pad: zeros)
   wave_sync();
   if (lane >= cnt) return;
 
@@ -1085,10 +1136,15 @@ __device__ __forceinline__ uint32_t walk_emit_packets(const READER &s, uint32_t 
   uint32_t curSym = IDX_INIT;
   uint32_t o = 0, n = 0;
   bool direct = false;                                                  // the list is full: this lane writes the output itself
+  // the window of the NEXT packet is requested as soon as this packet's header says where it is; booking this packet (list state, entry,
+  // store) then runs while that read is in flight
+  uint64_t lo, hi, ex;
+  s.load24(umin(x, C), lo, hi, ex);
   for (;;)
   {
-    const Pkt k = parse_packet<FAM, S, AL>(s, x, C, sgl);
+    const Pkt k = parse_window<FAM, S, AL>(s, lo, hi, ex, x, C, sgl);
     if (k.bad || k.lit > blen - o || k.run > blen - o - k.lit) return 2u;
+    s.load24(umin(x + k.used + k.lit, C), lo, hi, ex);                  // (k.lit <= C - x - k.used: the packet was checked; a last packet's window is not used)
     state_apply<KE>(st, k.op, k.symAt);
     if (k.hasSym) curSym = k.symAt;
     uint32_t ref;
@@ -1142,13 +1198,15 @@ __global__ __launch_bounds__(64) void k_container_packets(const uint8_t *__restr
   const uint64_t w0raw = offsets[firstBlock + i0], w1 = offsets[firstBlock + i0 + cnt];
   const uint64_t w0 = w0raw & ~15ull;
   const bool staged = w0raw <= w1 && w1 <= payloadBytes && w1 - w0 + 96u <= (uint64_t)ldsBytes;
+#ifdef HSRLE_PKT_STAMPS
+  const unsigned long long ts0 = __builtin_readcyclecounter();
+#endif
   if (staged)
-  {
-    const uint32_t total = (uint32_t)(w1 - w0) + 64u;
-    for (uint32_t c = lane * 16u; c < total; c += 64u * 16u)
-      lds_st128(window + c, (w0 + c + 16u <= payloadBytes + HSRLE_TAIL_PAD_BYTES) ? ld128(payload + w0 + c) : u32x4{ 0, 0, 0, 0 });
-  }
+    stage_window(window, payload, w0, (uint32_t)(w1 - w0) + 64u, payloadBytes);   // (+ 64: what a parse may read behind the last packet; beyond the payload's 32-byte tail pad: zeros)
   wave_sync();
+#ifdef HSRLE_PKT_STAMPS
+  const unsigned long long ts1 = __builtin_readcyclecounter();
+#endif
   if (lane >= cnt) return;
 
   const uint32_t local = i0 + lane, b = firstBlock + local;
@@ -1184,6 +1242,17 @@ __global__ __launch_bounds__(64) void k_container_packets(const uint8_t *__restr
   }
   counts[local] = n;                                                     // (0: nothing of this block is expanded)
   if (err != 0u && status != nullptr) atomicOr(status, err);
+#ifdef HSRLE_PKT_STAMPS
+  // diagnostic build: per wave (its first lane) cycles of staging and of the walk, and the packets of the lane -> lists area of block 0 is NOT used: status + 4..
+  if (status != nullptr)
+  {
+    const unsigned long long ts2 = __builtin_readcyclecounter();
+    const unsigned long long am = __ballot(true);
+    if (lane == (uint32_t)__builtin_ctzll(am)) { atomicAdd((unsigned long long *)(status + 2), ts1 - ts0); atomicAdd((unsigned long long *)(status + 4), ts2 - ts1); atomicAdd(status + 6, 1u); }
+    atomicMax(status + 7, n);
+    atomicAdd(status + 8, n);
+  }
+#endif
 }
 
 // host side: walk (records == 0) or record pass (records != 0) of one codec grammar
