@@ -104,10 +104,11 @@ constexpr int kScanThreads = 256;
 constexpr int kScanItems = 8;
 constexpr int kScanTile = kScanThreads * kScanItems; // 2048 elements per workgroup
 
+template <int THREADS = kScanThreads>
 __device__ __forceinline__ uint64_t wg_exclusive_scan_u64(uint64_t v, uint64_t *total)
 {
-  // wave scan by shuffles, then a scan of the (up to 4) wave totals through LDS
-  __shared__ uint64_t waveTotals[kScanThreads / 64];
+  // wave scan by shuffles, then a scan of the wave totals through LDS
+  __shared__ uint64_t waveTotals[THREADS / 64];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint64_t x = v;
 #pragma unroll
@@ -120,7 +121,7 @@ __device__ __forceinline__ uint64_t wg_exclusive_scan_u64(uint64_t v, uint64_t *
   __syncthreads();
   uint64_t base = 0, all = 0;
 #pragma unroll
-  for (int w = 0; w < kScanThreads / 64; w++)
+  for (int w = 0; w < THREADS / 64; w++)
   {
     const uint64_t t = waveTotals[w];
     if ((uint32_t)w < wave) base += t;
@@ -214,11 +215,69 @@ struct ContainerHeader
 };
 static_assert(sizeof(ContainerHeader) == HSRLE_CONTAINER_HEADER_SIZE, "container header is 64 bytes");
 
+__device__ __forceinline__ void finish_container(uint8_t *__restrict__ container, uint32_t codec, uint64_t U, uint32_t B, uint32_t nBlocks, uint64_t payloadSize);
+
 __global__ void k_finish_container(uint8_t *__restrict__ container, uint32_t codec, uint64_t U, uint32_t B, uint32_t nBlocks)
 {
   // offsets[nBlocks] was written by the scan; fill the header and the zero tail pad
   const uint64_t *offsets = (const uint64_t *)(container + HSRLE_CONTAINER_HEADER_SIZE);
-  const uint64_t payloadSize = offsets[nBlocks];
+  finish_container(container, codec, U, B, nBlocks, offsets[nBlocks]);
+}
+
+// Small containers (up to kScanSmallMax blocks): the size scan in ONE launch -- every workgroup first adds up all sizes in front of its tile
+// itself (at most 128 KB of coalesced reads from L2: cheaper than a launch), then scans its tile; the last one writes the container's header
+// and tail pad.  One launch where k_tile_sums + 2 x k_tile_scan + k_finish_container were four, ~5 us each on a call of 150 (BASELINE
+// config 3).  (A version with one workgroup of 1024 threads took 17 us: its loads and stores were strided by thread.)
+constexpr uint32_t kScanSmallMax = 32768u;
+__global__ __launch_bounds__(kScanThreads) void k_scan_small_finish(const uint32_t *__restrict__ sizes, uint32_t n, uint64_t *__restrict__ out, uint8_t *__restrict__ container, uint32_t codec,
+                                                                    uint64_t U, uint32_t B)
+{
+  const uint32_t tileFirst = blockIdx.x * (uint32_t)kScanTile;
+  // sum of sizes[0, tileFirst): 16 bytes per thread and load, four loads in flight (tileFirst is a multiple of 2048)
+  uint64_t before = 0;
+  for (uint32_t i = threadIdx.x * 4u; i < tileFirst; i += 4u * 4u * kScanThreads)
+  {
+    u32x4 q[4];
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; j++)
+    {
+      const uint32_t at = i + j * 4u * kScanThreads;
+      q[j] = *(const u32x4 *)(sizes + (at < tileFirst ? at : 0u));
+      if (at >= tileFirst) q[j] = u32x4{ 0, 0, 0, 0 };
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; j++) before += (uint64_t)q[j].x + q[j].y + q[j].z + q[j].w;
+  }
+  uint64_t beforeAll;
+  (void)wg_exclusive_scan_u64(before, &beforeAll);
+
+  const uint32_t base = tileFirst + threadIdx.x * (uint32_t)kScanItems;
+  static_assert(kScanItems == 8, "two 16-byte loads per thread");
+  const uint32_t lastVec = (n - 1u) >> 2;                                // (the size table is padded to 256 bytes: the vector that holds size n - 1 is readable)
+  const uint32_t v0 = base >> 2, v1 = v0 + 1u;
+  const u32x4 qa = *(const u32x4 *)(sizes + 4u * (v0 < lastVec ? v0 : lastVec)), qb = *(const u32x4 *)(sizes + 4u * (v1 < lastVec ? v1 : lastVec));
+  const uint32_t x[8] = { qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w };
+  uint32_t v[8];
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) { v[k] = (base + (uint32_t)k < n) ? x[k] : 0u; acc += v[k]; }
+  uint64_t total;
+  uint64_t run = wg_exclusive_scan_u64(acc, &total) + beforeAll;
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+  {
+    if (base + (uint32_t)k < n) out[base + (uint32_t)k] = run;
+    run += v[k];
+  }
+  if (blockIdx.x == gridDim.x - 1u)
+  {
+    if (threadIdx.x == 0) out[n] = beforeAll + total;
+    finish_container(container, codec, U, B, n, beforeAll + total);
+  }
+}
+
+__device__ __forceinline__ void finish_container(uint8_t *__restrict__ container, uint32_t codec, uint64_t U, uint32_t B, uint32_t nBlocks, uint64_t payloadSize)
+{
   const uint64_t payloadStart = HSRLE_CONTAINER_HEADER_SIZE + 8ull * ((uint64_t)nBlocks + 1ull);
 
   if (threadIdx.x == 0)
@@ -597,6 +656,7 @@ static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, ui
   const uint32_t stride = slot_stride(B);
   uint32_t *sizes = (uint32_t *)(ws + w.offSizes);
   int rc = HSRLE_OK;
+  bool finished = false;                                                // (small containers: the size scan's launch wrote header and tail pad)
 
   // HSRLE_ENCODE_WAVE=1: rle8_multi / rle8_packed_multi with blocks of at most 4 KiB by ONE WAVE PER BLOCK (hsrle_encode8w.hip.h: position
   // parallel run detection, offsets by decoupled look-back, the payload written once, no staging slots and no compaction pass).  Bit-exact
@@ -626,9 +686,16 @@ static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, ui
   {
     EncodeArgs ea{ (const uint8_t *)dIn, U, B, nBlocks, ws + w.offSlots, stride, sizes };
     ea.ringSel = (uint32_t *)(ws + w.offSlots + align_up((uint64_t)nBlocks * stride, 256));   // (in the wave encoder's counter area behind the slots: unused on this path)
-    if (g_enc[codec](ea, st) != hipSuccess || scan_sizes(sizes, nBlocks, offsets, ws, w, st) != hipSuccess)
+    if (g_enc[codec](ea, st) != hipSuccess)
       rc = HSRLE_ERR_DEVICE;
-    else
+    else if (nBlocks <= kScanSmallMax)
+    {
+      hipLaunchKernelGGL(k_scan_small_finish, dim3((nBlocks + kScanTile - 1u) / kScanTile), dim3(kScanThreads), 0, st, (const uint32_t *)sizes, nBlocks, offsets, container, (uint32_t)codec, U, B);
+      finished = true;
+    }
+    else if (scan_sizes(sizes, nBlocks, offsets, ws, w, st) != hipSuccess)
+      rc = HSRLE_ERR_DEVICE;
+    if (rc == HSRLE_OK)
       hipLaunchKernelGGL(k_compact, dim3((nBlocks + 3u) / 4u), dim3(256), 0, st, ea.slots, stride, (const uint64_t *)offsets, payload, nBlocks);
   }
   else
@@ -658,7 +725,7 @@ static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, ui
     if (compacted[1]) (void)hipEventDestroy(compacted[1]);
     if (!ok) rc = HSRLE_ERR_DEVICE;
   }
-  if (rc == HSRLE_OK)
+  if (rc == HSRLE_OK && !finished)
   {
     hipLaunchKernelGGL(k_finish_container, dim3(1), dim3(64), 0, st, container, (uint32_t)codec, U, B, nBlocks);
     if (hipGetLastError() != hipSuccess) rc = HSRLE_ERR_DEVICE;
@@ -881,9 +948,12 @@ static MonoPlan plan_mono(int codec, uint32_t U, uint32_t C, uint32_t p0)
   // one of its packet starts (1 hop in ~40 on random literals): they start with 4 KiB, and mono_decode_dev widens the look-back when
   // too many guesses turn out wrong.
   const bool range7 = (codec == 1 || (codec >= 6 && codec < 50 && (codec == 49 || (codec < 46 && ((codec - 6) & 7) == 5))));
+  // (range7 formats: regions of at most 4 KiB -- their guesses hold with a 2 KiB look-back, and the walk is one latency chain per region:
+  //  the 1 GiB stream 1.47 -> 1.32 ms with 142 191 regions instead of 71 096, none guessed wrong; round 4, since the resolve pass scales)
+  if (range7 && G > 4096u && !(tG >= 32u && tG <= (1u << 24))) { G = 4096u; m.G = G; }
   // (range7: 1 KiB leaves ~1 wrong guess in 7 000 on random literals, and each wrong guess costs a repair walk + a second resolve pass:
   //  2 KiB -- none in 71 096 -- where the regions are large enough to carry it: 1 GiB stream 2.28 -> 1.79 ms)
-  m.M = tM ? tM : (range7 ? (G >= 8192u ? 2048u : 1024u) : 4096u);
+  m.M = tM ? tM : (range7 ? (G >= 4096u ? 2048u : 1024u) : 4096u);
   m.range7 = range7;
   m.R = (uint32_t)(((uint64_t)(C - p0) + G - 1u) / G);
   if (m.R == 0u) m.R = 1u;

@@ -27,7 +27,14 @@ namespace hsrle {
 
 // candidates per wave and batch: any one 4 KiB block fits (a candidate takes S + 1 positions at least: 819 / 585 / 455), and no more than
 // that -- LDS is waves (S = 8: 14.7 KB, 10 waves per CU; S = 2: 21.6 KB, 7)
-constexpr uint32_t run_list_cap(int S) { return S == 8 ? 512u : (S == 6 ? 640u : (S == 4 ? 832u : (S == 3 ? 1024u : 1408u))); }
+#ifdef HSRLE_RL_STAMPS
+// diagnostic build: cycles per phase, summed over the waves' first lanes: [0] phase A, [1] phase B, [2] phase C, [3] waves, [4] flushes, [5] candidates
+__device__ unsigned long long g_rl_stamps[8];
+#define HS_RLSTAMP(i) { const unsigned long long t_ = __builtin_readcyclecounter(); rlst[i] += t_ - rlt; rlt = t_; }
+#else
+#define HS_RLSTAMP(i)
+#endif
+constexpr uint32_t run_list_cap(int S) { return S == 8 ? 832u : (S == 6 ? 832u : (S == 4 ? 832u : (S == 3 ? 1024u : 1408u))); }
 
 template <int FAM, int S, int AL>
 __global__ __launch_bounds__(64) void k_encodeS_runlist(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t nBlocks,
@@ -52,6 +59,9 @@ __global__ __launch_bounds__(64) void k_encodeS_runlist(const uint8_t *__restric
   __shared__ uint32_t bOff[65];               // first candidate of the batch's blocks
   uint8_t *const tile = (uint8_t *)info;      // the block under phase A (symbol lookups): phase A never touches info[]
 
+#ifdef HSRLE_RL_STAMPS
+  unsigned long long rlst[6] = { 0, 0, 0, 0, 0, 0 }, rlt = __builtin_readcyclecounter();
+#endif
   const uint32_t lane = threadIdx.x;
   const uint32_t wgFirst = xcd_tile(blockIdx.x, gridDim.x) * bpw;          // bpw (<= 64) blocks per wave
   const uint32_t wgLast = umin(wgFirst + bpw, nBlocks);
@@ -180,6 +190,10 @@ __global__ __launch_bounds__(64) void k_encodeS_runlist(const uint8_t *__restric
   // ---- phases B and C for the blocks [b0, b1) whose candidates are in the list ----
   auto flush = [&](uint32_t b0, uint32_t b1) __attribute__((always_inline)) {
     wave_sync();
+    HS_RLSTAMP(0)
+#ifdef HSRLE_RL_STAMPS
+    rlst[4] += 1; rlst[5] += bOff[b1 - b0];
+#endif
     // B: one lane per block
     const uint32_t myBlock = b0 + lane;
     const bool walker = myBlock < b1;
@@ -310,6 +324,7 @@ __global__ __launch_bounds__(64) void k_encodeS_runlist(const uint8_t *__restric
     const uint32_t endedI = ended ? 1u : 0u;
     if (walker) sizes[myBlock] = size;
     wave_sync();
+    HS_RLSTAMP(1)
 
     // C: as in k_encode8_runlist
     struct Stage
@@ -497,6 +512,7 @@ __global__ __launch_bounds__(64) void k_encodeS_runlist(const uint8_t *__restric
         stage2(sb, jb, cbb);
       }
     }
+    HS_RLSTAMP(2)
   };
 
   // ---- phase A over the wave's blocks ----
@@ -586,6 +602,9 @@ __global__ __launch_bounds__(64) void k_encodeS_runlist(const uint8_t *__restric
   }
   if (lane == 0u) bOff[wgLast - batchFirst] = used;
   flush(batchFirst, wgLast);
+#ifdef HSRLE_RL_STAMPS
+  if (lane == 0u) { for (int q = 0; q < 3; q++) atomicAdd(g_rl_stamps + q, rlst[q]); atomicAdd(g_rl_stamps + 3, 1ull); atomicAdd(g_rl_stamps + 4, rlst[4]); atomicAdd(g_rl_stamps + 5, rlst[5]); }
+#endif
 }
 
 } // namespace hsrle

@@ -77,7 +77,16 @@ __device__ __forceinline__ uint32_t ex32x(uint64_t lo, uint64_t hi, uint64_t ex,
 struct GlobalReader
 {
   const uint8_t *s;
-  __device__ __forceinline__ void load24(uint32_t p, uint64_t &lo, uint64_t &hi, uint64_t &ex) const { lo = ld64(s + p); hi = ld64(s + p + 8); ex = ld64(s + p + 16); }
+  // (a walk through global memory is bound by the NUMBER of its reads -- 64 lanes at 64 places, every read a request of its own: one
+  //  16-byte read, and 8 more bytes only for the header forms that can reach beyond byte 16)
+  template <bool EX>
+  __device__ __forceinline__ void loadw(uint32_t p, uint64_t &lo, uint64_t &hi, uint64_t &ex) const
+  {
+    const u32x4 v = ld128(s + p);
+    lo = (uint64_t)v.x | ((uint64_t)v.y << 32); hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+    if constexpr (EX) ex = ld64(s + p + 16); else ex = 0ull;
+  }
+  __device__ __forceinline__ void load24(uint32_t p, uint64_t &lo, uint64_t &hi, uint64_t &ex) const { loadw<true>(p, lo, hi, ex); }
   __device__ __forceinline__ void load16(uint32_t p, uint64_t &lo, uint64_t &hi) const { lo = ld64(s + p); hi = ld64(s + p + 8); }
   __device__ __forceinline__ uint32_t load32(uint32_t p) const { return ld32(s + p); }
   __device__ __forceinline__ u32x4 load128(uint32_t p) const { return ld128(s + p); }
@@ -101,6 +110,8 @@ struct LdsReader
     hi = (uint64_t)alignbyte(y3, y2, n) | ((uint64_t)alignbyte(y4, y3, n) << 32);
     ex = (uint64_t)alignbyte(y5, y4, n) | ((uint64_t)alignbyte(y6, y5, n) << 32);
   }
+  template <bool EX>
+  __device__ __forceinline__ void loadw(uint32_t p, uint64_t &lo, uint64_t &hi, uint64_t &ex) const { load24(p, lo, hi, ex); }
   __device__ __forceinline__ void load16(uint32_t p, uint64_t &lo, uint64_t &hi) const
   {
     const u32x4 v = load128(p);
@@ -126,6 +137,19 @@ __device__ __forceinline__ uint32_t u32c(const uint32_t (&d)[6])
 template <int FAM, int S, int AL, typename READER>
 __device__ __forceinline__ Pkt parse_window(const READER &rd, uint64_t lo, uint64_t hi, uint64_t ex, uint32_t p, uint32_t C, bool single);
 
+// does parse_window read header bytes at or beyond byte 16 of its window?  (Short: never -- fields end at byte 10; LUT: extension fields up to
+// 6 + S + 3; Packed: the range field up to 5 + S + 3, sym-aligned + 4; plain: up to S + 5 + 4 + 3)
+template <int FAM, int S, int AL>
+__host__ __device__ constexpr bool header_beyond_16()
+{
+  using TR = Traits<FAM, S, AL>;
+  if (S == 16) return true;
+  if (TR::kShort) return false;
+  if (TR::kLut) return 6 + S + 3 >= 16;
+  if (TR::kPacked) return (TR::kRange7 ? 5 + S + 3 : 5 + S + 7) >= 16;    // (sym-aligned Packed: the 32-bit range behind a zero range byte)
+  return S + 5 + 4 + 3 >= 16;
+}
+
 template <int FAM, int S, int AL, typename READER>
 __device__ __forceinline__ Pkt parse_packet(const READER &rd, uint32_t p, uint32_t C, bool single)
 {
@@ -136,7 +160,7 @@ __device__ __forceinline__ Pkt parse_packet(const READER &rd, uint32_t p, uint32
     return k;
   }
   uint64_t lo, hi, ex;
-  rd.load24(p, lo, hi, ex);
+  rd.template loadw<header_beyond_16<FAM, S, AL>()>(p, lo, hi, ex);
   return parse_window<FAM, S, AL>(rd, lo, hi, ex, p, C, single);
 }
 
@@ -1139,12 +1163,12 @@ __device__ __forceinline__ uint32_t walk_emit_packets(const READER &s, uint32_t 
   // the window of the NEXT packet is requested as soon as this packet's header says where it is; booking this packet (list state, entry,
   // store) then runs while that read is in flight
   uint64_t lo, hi, ex;
-  s.load24(umin(x, C), lo, hi, ex);
+  s.template loadw<header_beyond_16<FAM, S, AL>()>(umin(x, C), lo, hi, ex);
   for (;;)
   {
     const Pkt k = parse_window<FAM, S, AL>(s, lo, hi, ex, x, C, sgl);
     if (k.bad || k.lit > blen - o || k.run > blen - o - k.lit) return 2u;
-    s.load24(umin(x + k.used + k.lit, C), lo, hi, ex);                  // (k.lit <= C - x - k.used: the packet was checked; a last packet's window is not used)
+    s.template loadw<header_beyond_16<FAM, S, AL>()>(umin(x + k.used + k.lit, C), lo, hi, ex);   // (k.lit <= C - x - k.used: the packet was checked; a last packet's window is not used)
     state_apply<KE>(st, k.op, k.symAt);
     if (k.hasSym) curSym = k.symAt;
     uint32_t ref;
