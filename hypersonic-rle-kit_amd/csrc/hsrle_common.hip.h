@@ -159,18 +159,28 @@ __device__ __forceinline__ void copy_exact(uint8_t *dst, const uint8_t *src, uin
 
 // 16 input bytes at block position p of the block that starts at `blockAt` (p may reach below the block or beyond the input: those
 // bytes are never used and read as zero).  Kept out of line on purpose: it is the rare source of the ring encoders' literal copy.
+// the 16 bytes at in + g of an input of U bytes, zeros where g + k lies outside [0, U): the END-OF-INPUT path of every 16-byte input read.
+// A loop that is NOT unrolled on purpose: unrolled it is ~130 instructions at every one of its ~20 inline sites in the run list encoders
+// (20 KB of their 51 KB of code, against an instruction cache of 64 KB), and it runs for the last bytes of the last block only.
+__device__ __forceinline__ u32x4 load16_edge(const uint8_t *in, int64_t g, uint64_t U)
+{
+  uint64_t a = 0, b = 0;
+#pragma unroll 1
+  for (uint32_t k = 0; k < 16u; k++)
+  {
+    const int64_t gk = g + (int64_t)k;
+    const uint64_t v = (gk >= 0 && (uint64_t)gk < U) ? (uint64_t)in[gk] : 0ull;
+    if (k < 8u) a |= v << (8u * k); else b |= v << (8u * (k - 8u));
+  }
+  return u32x4{ (uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32) };
+}
+
 __device__ __forceinline__ u32x4 global_window16(const uint8_t *in, uint64_t blockAt, uint64_t U, uint32_t p)
 {
   const int64_t g = (int64_t)blockAt + (int64_t)(int32_t)p;
   if (g >= 0 && (uint64_t)g + 16u <= U)
     return ld128(in + g);
-  uint32_t t[4] = { 0, 0, 0, 0 };
-  for (uint32_t k = 0; k < 16u; k++)
-  {
-    const int64_t gk = g + (int64_t)k;
-    if (gk >= 0 && (uint64_t)gk < U) t[k >> 2] |= (uint32_t)in[gk] << (8u * (k & 3u));
-  }
-  return u32x4{ t[0], t[1], t[2], t[3] };
+  return load16_edge(in, g, U);
 }
 
 // Ring encoders: a literal stretch that has left the ring is copied by the whole wave (hsrle_encode8.hip.h: coop_flush) if it is at least

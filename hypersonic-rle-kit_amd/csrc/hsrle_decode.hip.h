@@ -33,6 +33,7 @@
 #pragma once
 
 #include "hsrle_common.hip.h"
+#include "hsrle_parse.hip.h"
 
 namespace hsrle {
 
@@ -824,9 +825,73 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
         if (avail0 - sp < MAXHDR && avail0 < lim) break;               // header not resident yet: continue next round
 
         // ---------------- packet header ----------------
-        uint32_t cnt, range, used;
+        [[maybe_unused]] uint32_t cnt, range, used;
         bool endNow = false;
 
+        if constexpr (S <= 8 && TR::kLut)
+        {
+          // Round 4, the 3 / 7 symbol LUT codecs: ONE ring read of 32 bytes and the header grammar of hsrle_parse.hip.h (every field extracted
+          // at the positions it can have, then selected -- no second / third ring read for the fields behind the count or the symbol, no
+          // nested branches that a wave executes on both sides as soon as one lane differs).  The same function the index walks use.
+          // Same-box A/B at 4 GiB (experiments/r04/call39.sh), run data / video-shaped: rle32_7symlut_byte +9.5 % / +3.0 %, rle24_3symlut_byte
+          // +4.2 / +4.1, rle16_7symlut_byte +2.8 / +5.3, rle64_3symlut_byte +1.7 / +2.5, rle16_3symlut_byte -4.2 / +5.3 (it had the
+          // one-read parse of the unextended packets below).  For plain / Packed / Short packets the same parse LOSES 2 ... 8 %: their
+          // general parse branches rarely diverge, and the selects are paid by every packet -- they keep the code below.
+          const uint32_t a = sp & ~7u;
+          const uint64_t w0 = lds_ld64(ring + (rowx ^ (a & RMASK))), w1 = lds_ld64(ring + (rowx ^ ((a + 8u) & RMASK)));
+          const uint64_t w2 = lds_ld64(ring + (rowx ^ ((a + 16u) & RMASK))), w3 = lds_ld64(ring + (rowx ^ ((a + 24u) & RMASK)));
+          const bool d1 = (sp & 4u) != 0u;
+          const uint32_t z0 = (uint32_t)w0, z1 = (uint32_t)(w0 >> 32), z2 = (uint32_t)w1, z3 = (uint32_t)(w1 >> 32), z4 = (uint32_t)w2, z5 = (uint32_t)(w2 >> 32), z6 = (uint32_t)w3, z7 = (uint32_t)(w3 >> 32);
+          const uint32_t y0 = d1 ? z1 : z0, y1 = d1 ? z2 : z1, y2 = d1 ? z3 : z2, y3 = d1 ? z4 : z3, y4 = d1 ? z5 : z4, y5 = d1 ? z6 : z5, y6 = d1 ? z7 : z6;
+          const uint32_t nb = sp & 3u;
+          const uint32_t dw[6] = { alignbyte(y1, y0, nb), alignbyte(y2, y1, nb), alignbyte(y3, y2, nb), alignbyte(y4, y3, nb), alignbyte(y5, y4, nb), alignbyte(y6, y5, nb) };
+          const uint64_t lo = (uint64_t)dw[0] | ((uint64_t)dw[1] << 32), hi = (uint64_t)dw[2] | ((uint64_t)dw[3] << 32), ex = (uint64_t)dw[4] | ((uint64_t)dw[5] << 32);
+          struct NoReader { __device__ __forceinline__ uint32_t load32(uint32_t) const { return 0u; } };
+          const Pkt k = parse_window<FAM, S, AL>(NoReader{}, lo, hi, ex, sp, slen, false);
+          if (k.bad) { err |= DEC_ERR_STREAM; fl |= F_DONE; break; }
+          // the S symbol bytes at window offset k.symAt - sp (<= 11: behind at most a three-byte header with two 32-bit fields)
+          const uint32_t so = k.symAt - sp;
+          u32x4 nv = u32x4{ ex32x(lo, hi, ex, so), 0u, 0u, 0u };
+          if constexpr (S > 4) nv.y = ex32x(lo, hi, ex, so + 4u);
+          nv = mask_symbol<S>(nv);
+          if constexpr (TR::kMtf)
+          {
+            // move-to-front list (rleX_Xsl.h:597-650): op < K takes slot op to the front, op == K pushes the packet's symbol
+            if (!(TR::kShort && k.last && k.run == 0u && k.lit == 0u))     // (a Short END terminator carries no list operation)
+            {
+              const uint32_t idx = k.op;
+              uint32_t tmp[TR::SW];
+#pragma unroll
+              for (int w = 0; w < TR::SW; w++) tmp[w] = nv[w];
+#pragma unroll
+              for (int kk = 0; kk < TR::K; kk++)
+                if (idx == (uint32_t)kk)
+                {
+#pragma unroll
+                  for (int w = 0; w < TR::SW; w++) tmp[w] = lut[kk][w];
+                }
+              const uint32_t limit = (idx >= (uint32_t)TR::K) ? (uint32_t)TR::K - 1u : idx;
+#pragma unroll
+              for (int kk = TR::K - 1; kk >= 1; kk--)
+                if ((uint32_t)kk <= limit)
+                {
+#pragma unroll
+                  for (int w = 0; w < TR::SW; w++) lut[kk][w] = lut[kk - 1][w];
+                }
+              u32x4 pv = u32x4{ 0, 0, 0, 0 };
+#pragma unroll
+              for (int w = 0; w < TR::SW; w++) { lut[0][w] = tmp[w]; pv[w] = tmp[w]; }
+              set_sym(pv);
+            }
+          }
+          else
+          {
+            if (k.hasSym) set_sym(nv);
+          }
+          used = k.used; lit = k.lit; run = k.run;
+          cnt = k.last ? 0u : 1u;                                         // (only feeds the F_LAST test below)
+        }
+        else
         {
 #define HS_RD16(off) ring_win16(sp + (off))
           // S > 1: the first 16 header bytes in one read; the (rare) fields behind them with a second read

@@ -79,9 +79,7 @@ __global__ __launch_bounds__(64) void k_encode8_runlist(const uint8_t *__restric
   // 16 input bytes (zeros beyond the input)
   auto load16 = [&](uint64_t g) __attribute__((always_inline)) -> u32x4 {
     if (g + 16u <= U) return ld128(in + g);
-    uint32_t t[4] = { 0, 0, 0, 0 };
-    for (uint32_t k = 0; k < 16u && g + k < U; k++) t[k >> 2] |= (uint32_t)in[g + k] << (8u * (k & 3u));
-    return u32x4{ t[0], t[1], t[2], t[3] };
+    return load16_edge(in, (int64_t)g, U);
   };
   struct Win { u32x4 a, b, c, d; };
   auto load_block = [&](uint32_t b) __attribute__((always_inline)) -> Win {

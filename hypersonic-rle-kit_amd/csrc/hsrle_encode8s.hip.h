@@ -463,12 +463,7 @@ __global__ __launch_bounds__(64) void k_encode8_single_blocks(const uint8_t *__r
         if (g + 16u <= U)
           v = ld128(in + g);
         else
-        {
-          uint32_t t[4] = { 0, 0, 0, 0 };
-          for (uint32_t k = 0; k < 16u && g + k < U; k++)
-            t[k >> 2] |= (uint32_t)in[g + k] << (8u * (k & 3u));
-          v = u32x4{ t[0], t[1], t[2], t[3] };
-        }
+          v = load16_edge(in, (int64_t)g, U);
       }
       pf[q] = v;
       pfAt[q] = (r * (uint32_t)H) ^ hsw_of(r) ^ ((e + c * 16u) & HM);
