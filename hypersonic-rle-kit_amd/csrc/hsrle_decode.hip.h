@@ -828,7 +828,68 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
         [[maybe_unused]] uint32_t cnt, range, used;
         bool endNow = false;
 
-        if constexpr (S <= 8 && TR::kLut)
+        if constexpr (S <= 8 && !TR::kLut && !TR::kShort)
+        {
+          // Round 4, plain and Packed packets of 2 .. 8 byte symbols: the header in ONE ring read of 32 bytes, every field at a compile-time
+          // position of the window (shifted by one dword behind a 32-bit count) -- the code below reads the ring up to three times (first
+          // window, fields behind the count, the symbol).  rleX_extreme_cpu_decode.h:129-162, rle8_extreme_cpu.h:1849-1899 (Packed).
+          const uint32_t a = sp & ~7u;
+          const uint64_t w0 = lds_ld64(ring + (rowx ^ (a & RMASK))), w1 = lds_ld64(ring + (rowx ^ ((a + 8u) & RMASK)));
+          const uint64_t w2 = lds_ld64(ring + (rowx ^ ((a + 16u) & RMASK))), w3 = lds_ld64(ring + (rowx ^ ((a + 24u) & RMASK)));
+          const bool d1 = (sp & 4u) != 0u;
+          const uint32_t z0 = (uint32_t)w0, z1 = (uint32_t)(w0 >> 32), z2 = (uint32_t)w1, z3 = (uint32_t)(w1 >> 32), z4 = (uint32_t)w2, z5 = (uint32_t)(w2 >> 32), z6 = (uint32_t)w3, z7 = (uint32_t)(w3 >> 32);
+          const uint32_t y0 = d1 ? z1 : z0, y1 = d1 ? z2 : z1, y2 = d1 ? z3 : z2, y3 = d1 ? z4 : z3, y4 = d1 ? z5 : z4, y5 = d1 ? z6 : z5, y6 = d1 ? z7 : z6;
+          const uint32_t nb = sp & 3u;
+          const uint32_t d[6] = { alignbyte(y1, y0, nb), alignbyte(y2, y1, nb), alignbyte(y3, y2, nb), alignbyte(y4, y3, nb), alignbyte(y5, y4, nb), alignbyte(y6, y5, nb) };
+          if constexpr (!TR::kPacked)
+          {
+            // [symbol S] [count 8, or 0 + count 32] [range 8, or 0 + range 32]
+            set_sym(mask_symbol<S>(u32x4{ d[0], d[1], 0u, 0u }));
+            const uint32_t cb = u32c<S>(d) & 0xFFu;
+            const bool longc = cb == 0u;
+            cnt = longc ? u32c<S + 1>(d) : cb;
+            const uint32_t w = longc ? u32c<S + 5>(d) : u32c<S + 1>(d);
+            const uint32_t r0 = w & 0xFFu;
+            const bool longr = r0 == 0u;
+            const uint32_t r32 = longc ? u32c<S + 6>(d) : u32c<S + 2>(d);
+            range = longr ? r32 : r0;
+            endNow = longr && range == 0u;
+            used = (uint32_t)S + (longc ? 5u : 1u) + (longr ? 5u : 1u);
+          }
+          else
+          {
+            // [count 7 | same-symbol flag] [count 32 if count 7 == 0] [symbol S unless same] [range: 7 bits | long flag or 32 bits (byte-aligned),
+            //  8 bits or 0 + 32 bits (symbol-aligned)]
+            const uint32_t b0 = d[0] & 0xFFu, c7 = b0 & 0x7Fu;
+            const bool longc = c7 == 0u;
+            cnt = longc ? u32c<1>(d) : c7;
+            const uint32_t e[6] = { longc ? d[1] : d[0], longc ? d[2] : d[1], longc ? d[3] : d[2], longc ? d[4] : d[3], longc ? d[5] : d[4], d[5] };
+            const bool newSym = (b0 & 0x80u) == 0u;
+            if (newSym) set_sym(mask_symbol<S>(u32x4{ u32c<1>(e), u32c<5>(e), 0u, 0u }));
+            const uint32_t w = newSym ? u32c<1 + S>(e) : u32c<1>(e);
+            const uint32_t r0 = w & 0xFFu;
+            uint32_t rl;
+            if constexpr (TR::kRange7)
+            {
+              const bool longr = (r0 & 1u) != 0u;
+              range = longr ? (w >> 1) : (r0 >> 1);
+              rl = longr ? 4u : 1u;
+              endNow = longr && range == 0u;
+            }
+            else
+            {
+              const bool longr = r0 == 0u;
+              const uint32_t r32 = newSym ? u32c<2 + S>(e) : u32c<2>(e);
+              range = longr ? r32 : r0;
+              rl = longr ? 5u : 1u;
+              endNow = longr && range == 0u;
+            }
+            used = 1u + (longc ? 4u : 0u) + (newSym ? (uint32_t)S : 0u) + rl;
+          }
+          lit = (range == 0u) ? 0u : range - 1u;
+          run = (cnt == 0u) ? 0u : (TR::kAligned ? (cnt + TR::SHORT / (uint32_t)S - 1u) * (uint32_t)S : cnt + TR::SHORT - 1u);
+        }
+        else if constexpr (S <= 8 && TR::kLut)
         {
           // Round 4, the 3 / 7 symbol LUT codecs: ONE ring read of 32 bytes and the header grammar of hsrle_parse.hip.h (every field extracted
           // at the positions it can have, then selected -- no second / third ring read for the fields behind the count or the symbol, no
