@@ -290,6 +290,19 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     return funnel24(lds_ld64(ring + (rowx ^ (a & RMASK))), lds_ld64(ring + (rowx ^ ((a + 8u) & RMASK))), lds_ld64(ring + (rowx ^ ((a + 16u) & RMASK))), p & 7u);
   };
 
+  // 24 stream bytes at virtual position p as six dwords: ONE round trip of four aligned 8-byte reads + a byte funnel (the packet headers of
+  // the 2 .. 8 byte symbols: every field then sits at a compile-time position, hsrle_parse.hip.h)
+  auto ring_win24 = [&](uint32_t p, uint32_t (&d)[6]) {
+    const uint32_t a = p & ~7u;
+    const uint64_t w0 = lds_ld64(ring + (rowx ^ (a & RMASK))), w1 = lds_ld64(ring + (rowx ^ ((a + 8u) & RMASK)));
+    const uint64_t w2 = lds_ld64(ring + (rowx ^ ((a + 16u) & RMASK))), w3 = lds_ld64(ring + (rowx ^ ((a + 24u) & RMASK)));
+    const bool d1 = (p & 4u) != 0u;
+    const uint32_t z0 = (uint32_t)w0, z1 = (uint32_t)(w0 >> 32), z2 = (uint32_t)w1, z3 = (uint32_t)(w1 >> 32), z4 = (uint32_t)w2, z5 = (uint32_t)(w2 >> 32), z6 = (uint32_t)w3, z7 = (uint32_t)(w3 >> 32);
+    const uint32_t y0 = d1 ? z1 : z0, y1 = d1 ? z2 : z1, y2 = d1 ? z3 : z2, y3 = d1 ? z4 : z3, y4 = d1 ? z5 : z4, y5 = d1 ? z6 : z5, y6 = d1 ? z7 : z6;
+    const uint32_t nb = p & 3u;
+    d[0] = alignbyte(y1, y0, nb); d[1] = alignbyte(y2, y1, nb); d[2] = alignbyte(y3, y2, nb); d[3] = alignbyte(y4, y3, nb); d[4] = alignbyte(y5, y4, nb); d[5] = alignbyte(y6, y5, nb);
+  };
+
   // ---- per-lane stream state ----
   uint32_t slen = 0, blen = 0;
   uint32_t sp = 0;        // read position in the stream
@@ -833,14 +846,8 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
           // Round 4, plain and Packed packets of 2 .. 8 byte symbols: the header in ONE ring read of 32 bytes, every field at a compile-time
           // position of the window (shifted by one dword behind a 32-bit count) -- the code below reads the ring up to three times (first
           // window, fields behind the count, the symbol).  rleX_extreme_cpu_decode.h:129-162, rle8_extreme_cpu.h:1849-1899 (Packed).
-          const uint32_t a = sp & ~7u;
-          const uint64_t w0 = lds_ld64(ring + (rowx ^ (a & RMASK))), w1 = lds_ld64(ring + (rowx ^ ((a + 8u) & RMASK)));
-          const uint64_t w2 = lds_ld64(ring + (rowx ^ ((a + 16u) & RMASK))), w3 = lds_ld64(ring + (rowx ^ ((a + 24u) & RMASK)));
-          const bool d1 = (sp & 4u) != 0u;
-          const uint32_t z0 = (uint32_t)w0, z1 = (uint32_t)(w0 >> 32), z2 = (uint32_t)w1, z3 = (uint32_t)(w1 >> 32), z4 = (uint32_t)w2, z5 = (uint32_t)(w2 >> 32), z6 = (uint32_t)w3, z7 = (uint32_t)(w3 >> 32);
-          const uint32_t y0 = d1 ? z1 : z0, y1 = d1 ? z2 : z1, y2 = d1 ? z3 : z2, y3 = d1 ? z4 : z3, y4 = d1 ? z5 : z4, y5 = d1 ? z6 : z5, y6 = d1 ? z7 : z6;
-          const uint32_t nb = sp & 3u;
-          const uint32_t d[6] = { alignbyte(y1, y0, nb), alignbyte(y2, y1, nb), alignbyte(y3, y2, nb), alignbyte(y4, y3, nb), alignbyte(y5, y4, nb), alignbyte(y6, y5, nb) };
+          uint32_t d[6];
+          ring_win24(sp, d);
           if constexpr (!TR::kPacked)
           {
             // [symbol S] [count 8, or 0 + count 32] [range 8, or 0 + range 32]
@@ -898,14 +905,8 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
           // +4.2 / +4.1, rle16_7symlut_byte +2.8 / +5.3, rle64_3symlut_byte +1.7 / +2.5, rle16_3symlut_byte -4.2 / +5.3 (it had the
           // one-read parse of the unextended packets below).  For plain / Packed / Short packets the same parse LOSES 2 ... 8 %: their
           // general parse branches rarely diverge, and the selects are paid by every packet -- they keep the code below.
-          const uint32_t a = sp & ~7u;
-          const uint64_t w0 = lds_ld64(ring + (rowx ^ (a & RMASK))), w1 = lds_ld64(ring + (rowx ^ ((a + 8u) & RMASK)));
-          const uint64_t w2 = lds_ld64(ring + (rowx ^ ((a + 16u) & RMASK))), w3 = lds_ld64(ring + (rowx ^ ((a + 24u) & RMASK)));
-          const bool d1 = (sp & 4u) != 0u;
-          const uint32_t z0 = (uint32_t)w0, z1 = (uint32_t)(w0 >> 32), z2 = (uint32_t)w1, z3 = (uint32_t)(w1 >> 32), z4 = (uint32_t)w2, z5 = (uint32_t)(w2 >> 32), z6 = (uint32_t)w3, z7 = (uint32_t)(w3 >> 32);
-          const uint32_t y0 = d1 ? z1 : z0, y1 = d1 ? z2 : z1, y2 = d1 ? z3 : z2, y3 = d1 ? z4 : z3, y4 = d1 ? z5 : z4, y5 = d1 ? z6 : z5, y6 = d1 ? z7 : z6;
-          const uint32_t nb = sp & 3u;
-          const uint32_t dw[6] = { alignbyte(y1, y0, nb), alignbyte(y2, y1, nb), alignbyte(y3, y2, nb), alignbyte(y4, y3, nb), alignbyte(y5, y4, nb), alignbyte(y6, y5, nb) };
+          uint32_t dw[6];
+          ring_win24(sp, dw);
           const uint64_t lo = (uint64_t)dw[0] | ((uint64_t)dw[1] << 32), hi = (uint64_t)dw[2] | ((uint64_t)dw[3] << 32), ex = (uint64_t)dw[4] | ((uint64_t)dw[5] << 32);
           struct NoReader { __device__ __forceinline__ uint32_t load32(uint32_t) const { return 0u; } };
           const Pkt k = parse_window<FAM, S, AL>(NoReader{}, lo, hi, ex, sp, slen, false);
