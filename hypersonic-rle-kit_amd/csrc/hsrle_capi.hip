@@ -1164,6 +1164,16 @@ static uint32_t mono_cut_long(int codec, int *pS = nullptr, int *pAligned = null
       if (k == 0 || k == 4) longc = (uint32_t)S + 12u;                                  // 0-symbol Short codecs
       else { longc = (uint32_t)S + 11u; K = shortK[k & 3]; }                            // 1 / 3 / 7 symbol Short codecs
     }
+    else if (codec >= kGreedyBase && codec < kSingleShort)
+    {
+      // Greedy encoders (rleX_Xsl_short.h:746-1000): a run of SMINL = S + 11 bytes is stored whatever the state -- but the scan may enter a
+      // periodic stretch up to ~2 S bytes late (through a prefix of a listed symbol), so a stretch is a cut from S + 11 + 3 S bytes on
+      static const int kg[3] = { 1, 3, 7 };
+      S = widths[(codec - kGreedyBase) / 3];
+      al = 0;
+      K = kg[(codec - kGreedyBase) % 3];
+      longc = 4u * (uint32_t)S + 11u;
+    }
   }
   if (pS) *pS = S;
   if (pAligned) *pAligned = al;
@@ -1188,7 +1198,7 @@ static bool split_encode_applies(int codec, uint64_t nBlocks, uint32_t B)
   // the codecs whose ring encoders have the chunk mode (not Single, not 128 bit: their chunk encoders are the per-lane ones of the monolithic path)
   // rle8_multi / rle8_packed_multi / rle8_{3,7}symlut (ids 0 .. 3), the plain / Packed / LUT codecs of 2 .. 8 byte symbols (ids 6 .. 45) and their Short family (ids 50 .. 93): the run list encoders take these whole
   if (run_list_codec(codec) && run_list_applies(nBlocks, B, 1024u, knob_u32("HSRLE_RUNLIST", 0u))) return false;
-  if (nBlocks >= kSplitEncodeBelow || B < 1024u || B > (1u << 20) || (B % (kSplitPieces * 128u)) != 0u || codec == 4 || codec == 5 || (codec >= 46 && codec < 50)) return false;
+  if (nBlocks >= kSplitEncodeBelow || B < 1024u || B > (1u << 20) || (B % (kSplitPieces * 128u)) != 0u || codec == 4 || codec == 5 || (codec >= 46 && codec < 50) || codec >= kGreedyBase) return false;   // (Greedy: chunks of ONE stream only)
   init_tables();
   return mono_cut_long(codec) != 0u && g_menc[codec] != nullptr;
 }

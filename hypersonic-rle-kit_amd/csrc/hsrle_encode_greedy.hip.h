@@ -17,35 +17,71 @@
 
 namespace hsrle {
 
-template <int FAM, int S>
+// MONO (round 4): chunks of ONE monolithic stream (hsrle_mono_encode.hip.h).  The greedy scan, too, stores a run of SMINL bytes or more whatever
+// its state is, and it extends a run to the exact end of its periodic stretch; what it cannot know behind such a run is the LIST (which
+// rotation of the symbol went to the front depends on where the scan entered the stretch) -- the lists in front of the chunks are guessed,
+// checked and repaired like those of the other list codecs (monoSyms: 8 words per chunk, entry k = lut0 | lut1 << 32, word 7 = "encode this
+// chunk in this pass"; monoListOut: the list behind the chunk, word 7 = how many of its entries the chunk itself determined; monoDry: no
+// output, only the list).  A chunk ends with the packet of its boundary run (no terminator, no header: k_mono_finish writes the header);
+// the look-ahead of the scan sees the true input behind the chunk.
+template <int FAM, int S, bool MONO = false>
 __global__ __launch_bounds__(64) void k_encode_greedy_blocks(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t nBlocks,
-                                                             uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes)
+                                                             uint8_t *__restrict__ slots, uint32_t slotStride, uint32_t *__restrict__ sizes,
+                                                             const uint64_t *__restrict__ monoStarts, const uint64_t *monoSyms, const uint64_t *__restrict__ monoSlotOff,
+                                                             uint32_t monoSteps, uint64_t *monoListOut, uint32_t monoDry, const uint32_t *__restrict__ ringSel)
 {
   using TR = Traits<FAM, S, 0>;
   static_assert(TR::kShort && TR::K > 0 && S >= 2 && S <= 8, "1/3/7 symbol LUT Short codecs of the 16..64 bit symbols");
   constexpr int K = TR::K;
   constexpr uint32_t SU = (uint32_t)S;
+  (void)monoSteps; (void)ringSel; (void)B;
 
   __shared__ __attribute__((aligned(16))) uint8_t ringMem[64 * kLaneRingStride];
-  const uint32_t b = xcd_tile(blockIdx.x, gridDim.x) * 64u + threadIdx.x;
+  const uint32_t b = MONO ? blockIdx.x * 64u + threadIdx.x : xcd_tile(blockIdx.x, gridDim.x) * 64u + threadIdx.x;
+  // (no early return in MONO mode before the activity test: the ring's top-ups are wave-wide ballots, but lanes that are out simply do not vote)
   if (b >= nBlocks)
     return;
+  if constexpr (MONO) { if (ld_fresh64(monoSyms + 8ull * b + 7) == 0ull) return; }   // repair rounds switch most chunks off
+  const bool dry = MONO && monoDry != 0u;
 
-  const uint64_t start = (uint64_t)b * B;
-  const uint32_t n = (uint32_t)((U - start) < (uint64_t)B ? (U - start) : (uint64_t)B);
+  const uint64_t start = MONO ? monoStarts[b] : (uint64_t)b * B;
+  // n: where this lane's scan ends (block / chunk length); nT: the input the scan may LOOK at (block: the same; chunk: up to the true end)
+  const uint32_t n = MONO ? (uint32_t)(monoStarts[b + 1u] - start) : (uint32_t)((U - start) < (uint64_t)B ? (U - start) : (uint64_t)B);
+  const uint32_t nT = MONO ? (uint32_t)((U - start) < 0xFFFFFFFFull ? (U - start) : 0xFFFFFFFFull) : n;
+  const bool lastChunk = !MONO || start + n >= U;
   const uint8_t *const d = in + start;
   // the scan reads its symbols through the LaneRing (topped up by all lanes together whenever one of them runs low); reading behind
-  // the block (inside the input) is harmless, sym_at masks what lies beyond n
+  // the block (inside the input) is harmless, sym_at masks what lies beyond nT
   LaneRing ring{ d, (uint32_t)((U - start) < 0xFFFFFFFFull ? (U - start) : 0xFFFFFFFFull), ringMem + threadIdx.x * kLaneRingStride, 0u };
   auto ensure = [&](uint32_t i) {
     if (__builtin_amdgcn_ballot_w64(i + 64u > ring.loadedEnd) != 0ull) ring.template topup<8>(i);
   };
-  Sink s{ slots + (uint64_t)b * slotStride, 0u, in + U };
-  s.put32(n);
-  s.put32(0);
+  // output: the block's slot, or the chunk's place in the staging area; a dry pass only counts
+  struct Out
+  {
+    Sink s; bool dry;
+    __device__ __forceinline__ void put8(uint32_t v) { if (!dry) s.put8(v); else s.at += 1; }
+    __device__ __forceinline__ void put16(uint32_t v) { if (!dry) s.put16(v); else s.at += 2; }
+    __device__ __forceinline__ void put32(uint32_t v) { if (!dry) s.put32(v); else s.at += 4; }
+    __device__ __forceinline__ void putn(const uint8_t *src, uint32_t k) { if (!dry) s.putn(src, k); else s.at += k; }
+    __device__ __forceinline__ void put_sym(u32x4 v) { if (!dry) s.template put_sym<S>(v); else s.at += (uint32_t)S; }
+  };
+  Out s{ Sink{ MONO ? slots + monoSlotOff[b] : slots + (uint64_t)b * slotStride, 0u, in + U }, dry };
+  if constexpr (!MONO)
+  {
+    s.put32(n);
+    s.put32(0);
+  }
 
   // move-to-front list, entry k = {lut0[k], lut1[k]} (low S bytes); rleX_Xsl_short.h:759-774
   uint32_t lut0[K], lut1[K];
+  [[maybe_unused]] uint32_t mtfDepth = 0;
+  if constexpr (MONO)
+  {
+#pragma unroll
+    for (int k = 0; k < K; k++) { const uint64_t v = ld_fresh64(monoSyms + 8ull * b + k); lut0[k] = (uint32_t)v; lut1[k] = (uint32_t)(v >> 32); }
+  }
+  else
   {
     constexpr uint32_t init[7] = { 0x00u, 0x7Fu, 0xFFu, 0x01u, 0x7Eu, 0x80u, 0xFEu };
 #pragma unroll
@@ -59,10 +95,10 @@ __global__ __launch_bounds__(64) void k_encode_greedy_blocks(const uint8_t *__re
 
   uint32_t lastRLE = 0;
 
-  // the symbol at block position i, zero extended; bytes at or beyond n read as zero
+  // the symbol at position i, zero extended; bytes at or beyond nT read as zero
   auto sym_at = [&](uint32_t i, uint32_t &s0, uint32_t &s1) {
     if constexpr (S > 4) ring.get64(i, s0, s1); else { s0 = ring.get32(i); s1 = 0u; }
-    const uint32_t have = (n - i < SU) ? n - i : SU;                     // i < n
+    const uint32_t have = (nT - i < SU) ? nT - i : SU;                   // i < nT
     const uint64_t keep = (have >= 8u) ? ~0ull : ~(~0ull << (8u * have));
     s0 &= (uint32_t)keep; s1 &= (uint32_t)(keep >> 32);
   };
@@ -97,6 +133,7 @@ __global__ __launch_bounds__(64) void k_encode_greedy_blocks(const uint8_t *__re
     for (int k = K - 1; k >= 1; k--)
       if ((uint32_t)k <= limit) { lut0[k] = lut0[k - 1]; lut1[k] = lut1[k - 1]; }
     lut0[0] = s0; lut1[0] = s1;
+    if (m >= mtfDepth && mtfDepth < (uint32_t)K) mtfDepth++;             // (as the ring encoders count it: hsrle_encodeS.hip.h)
 
     const uint32_t mi = m << (TR::SCB + TR::SRBP);
     if (pack1)
@@ -112,7 +149,7 @@ __global__ __launch_bounds__(64) void k_encode_greedy_blocks(const uint8_t *__re
       if (scx != scu) { if (scu <= 0xFFFFu) s.put16(scu); else s.put32(scu); }
       if (rx != range) { if (range <= 0xFFFFu) s.put16(range); else s.put32(range); }
     }
-    if (m == (uint32_t)K) s.template put_sym<S>(u32x4{ s0, s1, 0u, 0u });
+    if (m == (uint32_t)K) s.put_sym(u32x4{ s0, s1, 0u, 0u });
     s.putn(d + lastRLE, gap);
     lastRLE = i;
     return true;
@@ -126,11 +163,14 @@ __global__ __launch_bounds__(64) void k_encode_greedy_blocks(const uint8_t *__re
   if constexpr (S < 4) y0 &= (1u << (8 * S)) - 1u;
   if constexpr (S <= 4) y1 = 0u; else if constexpr (S == 6) y1 &= 0xFFFFu;
   uint32_t count = 0, i = 0;
+  bool stopped = false;                                                // MONO: the boundary run's packet is out
 
-  while (i < n)
+  // (a chunk that is not the stream's last goes on until its boundary run's packet is out: the run may reach n in whole symbols, and the scan
+  //  only sees that it is over when it looks at position n)
+  while ((MONO && !lastChunk) ? !stopped : i < n)
   {
     ensure(i);
-    if (count != 0u && i + SU <= n)
+    if (count != 0u && i + SU <= nT)
     {
       uint32_t x0, x1;
       sym_at(i, x0, x1);
@@ -144,10 +184,11 @@ __global__ __launch_bounds__(64) void k_encode_greedy_blocks(const uint8_t *__re
     {
       ensure(i);
       if (count >= TR::SMINS) process(y0, y1, count, i);   // a shorter "run" (0 bytes between two literal positions) is never stored and changes no state
+      if (MONO && !lastChunk && i >= n) { stopped = true; break; }      // the chunk ends behind its boundary run: the next chunk takes the scan up at i
       sym_at(i, y0, y1);
-      const bool fits = i + SU <= n;
+      const bool fits = i + SU <= nT;
 
-      if (fits && i + 2u * SU <= n)
+      if (fits && i + 2u * SU <= nT)
       {
         uint32_t z0, z1;
         sym_at(i + SU, z0, z1);
@@ -180,19 +221,28 @@ __global__ __launch_bounds__(64) void k_encode_greedy_blocks(const uint8_t *__re
     }
   }
 
-  // ---- remaining bytes (rleX_Xsl_short.h:976-1032) ----
-  if (process(y0, y1, count, i))
+  if (lastChunk)
   {
-    s.put8(TR::SCINV << TR::SRBP); s.put8(TR::STB); s.put8(1); s.put16(0); s.put16(0);
+    // ---- remaining bytes (rleX_Xsl_short.h:976-1032) ----
+    if (process(y0, y1, count, i))
+    {
+      s.put8(TR::SCINV << TR::SRBP); s.put8(TR::STB); s.put8(1); s.put16(0); s.put16(0);
+    }
+    else
+    {
+      const uint32_t kLit = n - lastRLE;
+      s.put8(TR::SCINV << TR::SRBP); s.put8(TR::STB); s.put8(0); s.put16(0); s.put32(kLit + 2u);
+      s.putn(d + lastRLE, kLit);
+    }
   }
-  else
+  if constexpr (!MONO) s.s.patch32(4, s.s.at);
+  if (!dry) sizes[b] = s.s.at;
+  if constexpr (MONO)
   {
-    const uint32_t kLit = n - lastRLE;
-    s.put8(TR::SCINV << TR::SRBP); s.put8(TR::STB); s.put8(0); s.put16(0); s.put32(kLit + 2u);
-    s.putn(d + lastRLE, kLit);
+#pragma unroll
+    for (int k = 0; k < K; k++) monoListOut[8ull * b + k] = (uint64_t)lut0[k] | ((uint64_t)lut1[k] << 32);
+    monoListOut[8ull * b + 7] = mtfDepth;
   }
-  s.patch32(4, s.at);
-  sizes[b] = s.at;
 }
 
 // ------------------------------------------------------------------------------------------------------------------

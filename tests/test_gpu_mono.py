@@ -171,9 +171,9 @@ def test_device_resident_mono_decode_of_synthetic_workloads(hs, oracle, key, kin
 # ---- the encode side: ONE stream written by many lanes (csrc/hsrle_mono_encode.hip.h) ----
 
 # every multi-symbol codec of 8 .. 64 bit symbols: plain, Packed, LUT and the Short family (not Single, 128 bit, Greedy)
-# many-lane monolithic encode: every codec but the Greedy encoders and rle8_single_short (round 3: + 8 bit Single -- global symbol pick, cuts behind
-# long runs of the symbol -- and the 128 bit codecs)
-MONO_ENC_KEYS = [c.key for c in CODECS if "greedy" not in c.key and c.key != "rle8_single_short"]
+# many-lane monolithic encode: every codec but rle8_single_short (round 3: + 8 bit Single -- global symbol pick, cuts behind long runs of the
+# symbol -- and the 128 bit codecs; round 4: + the Greedy encoders -- cuts behind stretches the scan cannot enter too late, lists guessed and proven)
+MONO_ENC_KEYS = [c.key for c in CODECS if c.key != "rle8_single_short"]
 MONO_LIST_KEYS = [k for k in MONO_ENC_KEYS if "symlut" in k]
 
 
@@ -268,7 +268,8 @@ def test_mono_encode_lists_from_far_back(hs, oracle, key):
                                            ("rle8_packed_multi", SYNTH_RUNS, 64 << 20), ("rle8_packed_multi", SYNTH_VIDEO, 88473600), ("rle8_multi", SYNTH_RUNS, 32 << 20),
                                            ("rle8_multi_short", SYNTH_VIDEO, 32 << 20), ("rle16_sym_packed", SYNTH_RUNS, 32 << 20), ("rle24_byte", SYNTH_RUNS, 32 << 20),
                                            ("rle32_byte_packed", SYNTH_RUNS, 32 << 20), ("rle48_sym", SYNTH_RUNS, 32 << 20), ("rle64_byte_short", SYNTH_RUNS, 32 << 20),
-                                           ("rle64_sym_packed", SYNTH_VIDEO, 32 << 20)])
+                                           ("rle64_sym_packed", SYNTH_VIDEO, 32 << 20), ("rle16_3symlut_byte_short_greedy", SYNTH_RUNS, 32 << 20),
+                                           ("rle32_7symlut_byte_short_greedy", SYNTH_RUNS, 32 << 20), ("rle64_1symlut_byte_short_greedy", SYNTH_RUNS, 32 << 20)])
 def test_device_resident_mono_encode(hs, oracle, key, kind, size):
     import torch
 
@@ -278,3 +279,22 @@ def test_device_resident_mono_encode(hs, oracle, key, kind, size):
     expect = oracle.compress(codec, src.cpu().numpy().tobytes())
     assert stream.cpu().numpy().tobytes() == expect, f"{key}: stream differs from the oracle's ({chunks} chunks)"
     assert chunks > size // 32768
+
+
+def test_greedy_mono_encode_gives_up_cleanly_when_the_lists_do_not_settle(hs, oracle):
+    """The greedy scan's runs depend on the list in front of a chunk (it tries the listed symbols and their prefixes), so on data with many
+    short runs of many symbols a wrong guess moves one chunk per repair round: the device call then says UNSUPPORTED after its round limit
+    (nothing written that a caller could mistake for a stream), and the host entry point falls back to one lane -- same stream either way."""
+    import hsrle
+
+    codec = CODEC_BY_KEY["rle32_7symlut_byte_short_greedy"]
+    src = hs.synth(SYNTH_VIDEO, 4, 2, 4 << 20, device="cuda")
+    data = src.cpu().numpy().tobytes()
+    expect = oracle.compress(codec, data)
+    try:
+        stream = hs.mono_compress_dev(codec.key, src)
+        assert stream.cpu().numpy().tobytes() == expect
+    except hsrle.HsrleError as e:
+        assert e.status == hsrle.ERR_UNSUPPORTED
+    size, stream = hs.call_dropin(codec.cname, data, hs.compress_bounds(len(data)))
+    assert size == len(expect) and stream == expect
