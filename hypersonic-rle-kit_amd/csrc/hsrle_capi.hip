@@ -1135,7 +1135,8 @@ static uint32_t mono_cut_long(int codec, int *pS = nullptr, int *pAligned = null
   int S = 1, al = 0, K = 0;
   uint32_t longc = 0;
   static const int shortK[4] = { 0, 1, 3, 7 };
-  if (codec == 4) longc = 8u;                                   // 8 bit Single: runs of THE symbol with count >= LONG (rle8_extreme_cpu.h:10-11, :21-23)
+  if (codec == kSingleShort) longc = 27u;                        // rle8_single_short: runs of THE symbol of SMINL = 11 bytes are always stored; + 16, the body counts a run from where its search found it
+  else if (codec == 4) longc = 8u;                              // 8 bit Single: runs of THE symbol with count >= LONG (rle8_extreme_cpu.h:10-11, :21-23)
   else if (codec == 5) longc = 10u;
   else if (codec == HSRLE_RLE8_MULTI) longc = 6u;               // rle8_extreme_cpu.h:974: count >= 6 whatever the range
   else if (codec == HSRLE_RLE8_PACKED_MULTI) longc = 11u;       // :978 (body) and :122 (tail)
@@ -1342,7 +1343,7 @@ static int mono_encode_dev(int codec, const uint8_t *dIn, uint32_t U, uint8_t *d
   const uint32_t longc = mono_cut_long(codec, &S, &aligned, &listK);
   if (!g_menc[codec] || longc == 0u)
     return HSRLE_ERR_UNSUPPORTED;
-  const bool single = codec == 4 || codec == 5;
+  const bool single = codec == 4 || codec == 5 || codec == kSingleShort;
   const uint32_t hs = codec_header_size(codec) + (single ? 1u : 0u);   // (Single: the symbol byte follows the header)
   uint64_t *cutPos = (uint64_t *)(ws + m.offCutPos), *idx = (uint64_t *)(ws + m.offIdx), *starts = (uint64_t *)(ws + m.offStarts), *slotOff = (uint64_t *)(ws + m.offSlotOff);
   uint64_t *offsets = (uint64_t *)(ws + m.offOffsets);
@@ -1396,7 +1397,7 @@ static int mono_encode_dev(int codec, const uint8_t *dIn, uint32_t U, uint8_t *d
   EncodeArgs ea{ dIn, (uint64_t)U, 0u, chunks, ws + m.offSlots, 0u, sizes };
   MonoEncodeArgs ma{ starts, syms, slotOff, 2u * (longest / 64u) + 64u };
   ma.pick = ctrl + 8;
-  if (single) { ma.jobs = (uint64_t *)(ws + m.offJobs); ma.jobCount = ctrl + 12; ma.jobCap = m.jobCap; }   // (ctrl[12] was zeroed with the rest)
+  if (single && codec != kSingleShort) { ma.jobs = (uint64_t *)(ws + m.offJobs); ma.jobCount = ctrl + 12; ma.jobCap = m.jobCap; }   // (ctrl[12] was zeroed with the rest)
   if (listK == 0)
   {
     if (g_menc[codec](ea, ma, st) != hipSuccess)
@@ -1460,10 +1461,14 @@ static int mono_encode_dev(int codec, const uint8_t *dIn, uint32_t U, uint8_t *d
   if (scan_sizes(sizes, chunks, offsets, ws, w, st) != hipSuccess)
     return HSRLE_ERR_DEVICE;
   hipLaunchKernelGGL(k_compact_var, dim3((chunks + 3u) / 4u), dim3(256), 0, st, (const uint8_t *)(ws + m.offSlots), (const uint64_t *)slotOff, (const uint64_t *)offsets, dOut + hs, chunks);
-  hipLaunchKernelGGL(k_mono_finish, dim3(1), dim3(64), 0, st, dOut, U, hs, (const uint64_t *)offsets, (const uint32_t *)ctrl, ctrl);
-  uint32_t tail[2] = { 0, 0 };
-  if (hipGetLastError() != hipSuccess || hipMemcpyAsync(tail, ctrl + 2, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+  if (single)
+    hipLaunchKernelGGL(k_mono_zero_sizes, dim3((chunks + 255u) / 256u), dim3(256), 0, st, (const uint32_t *)sizes, chunks, ctrl + 5);
+  hipLaunchKernelGGL(k_mono_finish, dim3(1), dim3(64), 0, st, dOut, U, hs, (const uint64_t *)offsets, (const uint32_t *)ctrl, ctrl, codec == kSingleShort ? 1u : 0u);
+  uint32_t tail[4] = { 0, 0, 0, 0 };
+  if (hipGetLastError() != hipSuccess || hipMemcpyAsync(tail, ctrl + 2, 16, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
     return HSRLE_ERR_DEVICE;
+  if (tail[3] != 0u)
+    return HSRLE_ERR_UNSUPPORTED;                                        // (a Single chunk that did not end on its boundary run: one lane, by the caller)
   if (tail[1] != 0u || tail[0] == 0u)
     return HSRLE_ERR_DEVICE;
   *pSize = tail[0];

@@ -362,4 +362,119 @@ __global__ __launch_bounds__(64) void k_encode_single_short_blocks(const uint8_t
   sizes[b] = s.at;
 }
 
+// One CHUNK of a monolithic rle8_single_short stream (round 4; as encode_chunk_single of the extreme Single codecs, hsrle_encode.hip.h): behind any
+// stored run the body's state is its position alone, and a long run of the symbol is stored whatever the state -- the input is cut behind runs
+// of >= SMINL + 16 bytes of the symbol (the margin: the body counts a run from where its search found it), a chunk is the body started at
+// its first byte (not the symbol: the first trip falls through to the search), `end` is the TRUE end - 16, the scalar tail and the terminator
+// belong to the last chunk, no stream header; a chunk in front of the last ends with its boundary run's packet.  Returns the chunk's
+// stream bytes, 0 if the chunk did not end on a stored run at its boundary (the cut was wrong: the caller falls back to one lane).
+template <int FAM>
+__device__ inline uint32_t encode_chunk_single_short(const uint8_t *d, uint32_t nChunk, uint32_t nTrue32, uint32_t sym, Sink &s)
+{
+  using TR = Traits<FAM, 1, 0>;
+  const uint32_t bs = sym * 0x01010101u;
+  const bool finalChunk = nChunk == nTrue32;
+  uint32_t lastRLE = 0;
+  auto process = [&](int32_t count, uint32_t i) -> bool {
+    const uint32_t gap = i - lastRLE - (uint32_t)count;
+    const uint32_t range = gap + 2u;
+    const int32_t sc = count - (int32_t)TR::SMINS + 2;
+    const bool pack1 = gap <= TR::SMAXPR && (uint32_t)(sc - 2) <= TR::SMAXPC;
+    uint32_t pen = 0u;
+    if (!pack1)
+    {
+      pen = 2u;
+      if (!(sc <= (int32_t)TR::SMAXTC && range <= TR::SMAXTR))
+        pen += ((range <= 0xFFFFFu) ? (range <= TR::SMAXTR ? 0u : 2u) : 4u) + ((sc <= 0xFFFFF) ? (sc <= (int32_t)TR::SMAXTC ? 0u : 2u) : 4u);
+    }
+    if (!(count >= (int32_t)TR::SMINL || count >= (int32_t)(TR::SMINS + pen)))
+      return false;
+    if (pack1)
+      s.put8(((uint32_t)(sc - 2) << TR::SRBP) | gap);
+    else
+    {
+      const uint32_t scu = (uint32_t)sc;
+      const uint32_t scx = (scu <= TR::SMAXTC) ? scu : (scu <= 0xFFFFu ? 1u : 0u);
+      const uint32_t rx = (range <= TR::SMAXTR) ? range : (range <= 0xFFFFu ? 1u : 0u);
+      s.put8(((TR::SCINV << TR::SRBP) | ((scx << (TR::SRB - 8u)) >> 8)) & 0xFFu);
+      s.put8(((scx << (TR::SRB - 8u)) | (rx >> 8)) & 0xFFu);
+      s.put8(rx & 0xFFu);
+      if (scx != scu) { if (scu <= 0xFFFFu) s.put16(scu); else s.put32(scu); }
+      if (rx != range) { if (range <= 0xFFFFu) s.put16(range); else s.put32(range); }
+    }
+    s.putn(d + lastRLE, gap);
+    lastRLE = i;
+    return true;
+  };
+
+  int32_t count = 0;
+  int64_t i = 0;
+  const int64_t n = (int64_t)nTrue32, stopAt = (int64_t)nChunk;
+  const int64_t end = n - 16;
+
+  for (; i < end; i++)                                                  // compress_single_sse2 (rleX_Xsl_short.h:1058-1120)
+  {
+    const Cmp16 c(d + i, bs);
+    if (c.all()) { count += 16; i += 15; continue; }
+    if (c.any() || count > 1)
+    {
+      const uint32_t z = c.leading();
+      count += (int32_t)z;
+      i += z;
+      const bool stored = process(count, (uint32_t)i);
+      if (!finalChunk && i >= stopAt)
+        return (stored && i == stopAt) ? s.at : 0u;                     // the boundary run's packet ends the chunk
+    }
+    count = 0;
+    while (i < end)
+    {
+      const Cmp16 w(d + i, bs);
+      if (!w.any() || (!w.lastByte() && w.pop() < 2u))
+        i += 16;
+      else
+      {
+        i += w.first();
+        count = 1;
+        break;
+      }
+    }
+  }
+  if (!finalChunk)
+    return 0u;
+
+  for (; i < n; i++)                                                    // scalar tail (:452-466)
+  {
+    if (d[i] == sym)
+      count++;
+    else
+    {
+      process(count, (uint32_t)i);
+      count = 0;
+    }
+  }
+  if (process(count, (uint32_t)i))
+  {
+    s.put8(TR::SCINV << TR::SRBP); s.put8(TR::STB); s.put8(1); s.put16(0); s.put16(0);
+  }
+  else
+  {
+    const uint32_t kLit = (uint32_t)n - lastRLE;
+    s.put8(TR::SCINV << TR::SRBP); s.put8(TR::STB); s.put8(0); s.put16(0); s.put32(kLit + 2u);
+    s.putn(d + lastRLE, kLit);
+  }
+  return s.at;
+}
+
+template <int FAM>
+__global__ __launch_bounds__(64) void k_encode_single_short_chunks(const uint8_t *__restrict__ in, uint64_t U, uint32_t chunks, const uint64_t *__restrict__ starts,
+                                                                   const uint64_t *__restrict__ slotOff, uint8_t *__restrict__ slots, uint32_t *__restrict__ sizes,
+                                                                   const uint32_t *__restrict__ pick)
+{
+  const uint32_t c = blockIdx.x * 64u + threadIdx.x;
+  if (c >= chunks) return;
+  const uint64_t start = starts[c];
+  Sink s{ slots + slotOff[c], 0u, in + U };
+  sizes[c] = encode_chunk_single_short<FAM>(in + start, (uint32_t)(starts[c + 1u] - start), (uint32_t)(U - start), pick[0] & 0xFFu, s);
+}
+
 } // namespace hsrle

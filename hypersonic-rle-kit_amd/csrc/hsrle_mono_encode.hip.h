@@ -319,15 +319,25 @@ __global__ __launch_bounds__(256) void k_compact_var(const uint8_t *__restrict__
   if (lane < tail) d[head + body + lane] = src[head + body + lane];
 }
 
+// the Single chunk encoders return 0 for a chunk that did not end on a stored run at its boundary (a cut that was none): ctrl[5] = 1, the
+// host then falls back to one lane instead of handing out a stream with a hole
+__global__ __launch_bounds__(256) void k_mono_zero_sizes(const uint32_t *__restrict__ sizes, uint32_t chunks, uint32_t *__restrict__ flag)
+{
+  const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+  if (c < chunks && sizes[c] == 0u) *flag = 1u;
+}
+
 // stream header: {u32 uncompressed, u32 compressed (header included), [u8 mode = 0]}; ctrl[2..3] = the stream's size
-__global__ void k_mono_finish(uint8_t *__restrict__ out, uint32_t U, uint32_t headerSize, const uint64_t *__restrict__ offsets, const uint32_t *__restrict__ ctrlIn, uint32_t *__restrict__ ctrl)
+// symbolAt8: rle8_single_short -- an 8-byte header, then the stream's symbol
+__global__ void k_mono_finish(uint8_t *__restrict__ out, uint32_t U, uint32_t headerSize, const uint64_t *__restrict__ offsets, const uint32_t *__restrict__ ctrlIn, uint32_t *__restrict__ ctrl,
+                              uint32_t symbolAt8 = 0)
 {
   if (threadIdx.x == 0)
   {
     const uint64_t total = offsets[ctrlIn[0]] + headerSize;
     st32(out, U);
     st32(out + 4, (uint32_t)total);
-    if (headerSize == 9u) out[8] = 0;
+    if (headerSize == 9u) out[8] = symbolAt8 ? (uint8_t)ctrlIn[8] : (uint8_t)0;
     if (headerSize == 10u) { out[8] = 1; out[9] = (uint8_t)ctrlIn[8]; }  // 8 bit Single: mode 1 and the symbol (k_single_pick_final left it in ctrl[8])
     ctrl[2] = (uint32_t)total; ctrl[3] = (uint32_t)(total >> 32);
   }

@@ -100,6 +100,12 @@ static hipError_t menc_packed(const EncodeArgs &a, const MonoEncodeArgs &m, hipS
 static hipError_t menc_short0(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode(k_encode8_blocks<SHORT0, true>, a, m, st); }
 static hipError_t menc_lut3(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode(k_encode8_blocks<LUT3, true>, a, m, st); }
 static hipError_t menc_lut7(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st) { return launch_mono_encode(k_encode8_blocks<LUT7, true>, a, m, st); }
+// rle8_single_short as chunks of one monolithic stream (round 4; hsrle_encode_greedy.hip.h)
+static hipError_t menc_single_short(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st)
+{
+  hipLaunchKernelGGL((k_encode_single_short_chunks<SHORT_SINGLE>), dim3((a.nBlocks + 63u) / 64u), dim3(64), 0, st, a.in, a.U, a.nBlocks, m.starts, m.slotOff, a.slots, a.sizes, m.pick);
+  return hipGetLastError();
+}
 // 8 bit Single as chunks of one monolithic stream: the first-generation scanner, one lane per chunk (hsrle_encode.hip.h)
 template <bool PACKEDSINGLE>
 static hipError_t menc_single_any(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st)
@@ -126,7 +132,7 @@ void register_w8(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBloc
 #else
   (void)wenc;
 #endif
-  menc[4] = menc_single_any<false>; menc[5] = menc_single_any<true>;
+  menc[4] = menc_single_any<false>; menc[5] = menc_single_any<true>; menc[kSingleShort] = menc_single_short;
   menc[0] = menc_plain; menc[1] = menc_packed; menc[kShortBase8 + 0] = menc_short0;
   menc[2] = menc_lut3; menc[3] = menc_lut7; menc[kShortBase8 + 1] = menc_short1; menc[kShortBase8 + 2] = menc_short3; menc[kShortBase8 + 3] = menc_short7;
   sub[0] = sub_plain; sub[1] = sub_packed; sub[2] = sub_lut3; sub[3] = sub_lut7; sub[4] = sub_plain_any; sub[5] = sub_packed_any;

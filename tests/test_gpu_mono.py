@@ -171,9 +171,9 @@ def test_device_resident_mono_decode_of_synthetic_workloads(hs, oracle, key, kin
 # ---- the encode side: ONE stream written by many lanes (csrc/hsrle_mono_encode.hip.h) ----
 
 # every multi-symbol codec of 8 .. 64 bit symbols: plain, Packed, LUT and the Short family (not Single, 128 bit, Greedy)
-# many-lane monolithic encode: every codec but rle8_single_short (round 3: + 8 bit Single -- global symbol pick, cuts behind long runs of the
-# symbol -- and the 128 bit codecs; round 4: + the Greedy encoders -- cuts behind stretches the scan cannot enter too late, lists guessed and proven)
-MONO_ENC_KEYS = [c.key for c in CODECS if c.key != "rle8_single_short"]
+# many-lane monolithic encode: every codec (round 3: + 8 bit Single -- global symbol pick, cuts behind long runs of the symbol -- and the 128 bit
+# codecs; round 4: + the Greedy encoders -- cuts behind stretches the scan cannot enter too late, lists guessed and proven -- and rle8_single_short)
+MONO_ENC_KEYS = [c.key for c in CODECS]
 MONO_LIST_KEYS = [k for k in MONO_ENC_KEYS if "symlut" in k]
 
 
@@ -269,7 +269,8 @@ def test_mono_encode_lists_from_far_back(hs, oracle, key):
                                            ("rle8_multi_short", SYNTH_VIDEO, 32 << 20), ("rle16_sym_packed", SYNTH_RUNS, 32 << 20), ("rle24_byte", SYNTH_RUNS, 32 << 20),
                                            ("rle32_byte_packed", SYNTH_RUNS, 32 << 20), ("rle48_sym", SYNTH_RUNS, 32 << 20), ("rle64_byte_short", SYNTH_RUNS, 32 << 20),
                                            ("rle64_sym_packed", SYNTH_VIDEO, 32 << 20), ("rle16_3symlut_byte_short_greedy", SYNTH_RUNS, 32 << 20),
-                                           ("rle32_7symlut_byte_short_greedy", SYNTH_RUNS, 32 << 20), ("rle64_1symlut_byte_short_greedy", SYNTH_RUNS, 32 << 20)])
+                                           ("rle32_7symlut_byte_short_greedy", SYNTH_RUNS, 32 << 20), ("rle64_1symlut_byte_short_greedy", SYNTH_RUNS, 32 << 20),
+                                           ("rle8_single_short", SYNTH_RUNS, 32 << 20), ("rle8_single_short", SYNTH_VIDEO, 32 << 20)])
 def test_device_resident_mono_encode(hs, oracle, key, kind, size):
     import torch
 
