@@ -82,6 +82,24 @@ def test_split_decode_of_a_block_range(hs):
     assert status == 0 and host[first * 2048 : len(data)] == data[first * 2048 :] and set(host[: first * 2048]) == {0xA5}
 
 
+def test_split_decode_into_an_output_that_is_not_16_byte_aligned(hs):
+    """The expand kernel stores 16 bytes per lane; nothing says the caller's output is aligned."""
+    import torch
+
+    data = _data(6, 200000)
+    src = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    for key in ("rle8_packed_multi", "rle24_3symlut_byte", "rle64_sym_short"):
+        container, info = hs.compress(key, src, block_size=4096)
+        ws = torch.empty(max(hs.split_workspace_size(info, None, PACKET_LIST), 16), dtype=torch.uint8, device="cuda")
+        for shift in (1, 7, 8):
+            out = torch.full((len(data) + 64,), 0xA5, dtype=torch.uint8, device="cuda")
+            status = torch.zeros(1, dtype=torch.int32, device="cuda")
+            hs.decompress_split_async(container, info, out[shift : shift + len(data)], ws, status, sub_block=PACKET_LIST)
+            torch.cuda.synchronize()
+            host = out.cpu().numpy().tobytes()
+            assert int(status.item()) == 0 and host[shift : shift + len(data)] == data and set(host[:shift]) == {0xA5} and set(host[shift + len(data):]) == {0xA5}, f"{key} shift {shift}"
+
+
 def test_packet_list_of_a_block_with_more_packets_than_its_list(hs):
     """A block whose packets produce fewer than 8 output bytes on average does not fit its list (blockSize / 8 + 2 entries): the walking lane
     closes the list where it stands and writes the rest of the block itself.  Runs of three and four bytes back to back: ~1 200 packets per 4 KiB."""
