@@ -228,7 +228,7 @@ __global__ void k_finish_container(uint8_t *__restrict__ container, uint32_t cod
 // itself (at most 128 KB of coalesced reads from L2: cheaper than a launch), then scans its tile; the last one writes the container's header
 // and tail pad.  One launch where k_tile_sums + 2 x k_tile_scan + k_finish_container were four, ~5 us each on a call of 150 (BASELINE
 // config 3).  (A version with one workgroup of 1024 threads took 17 us: its loads and stores were strided by thread.)
-constexpr uint32_t kScanSmallMax = 32768u;
+constexpr uint32_t kScanSmallMax = 262144u;   // (128 workgroups, the last of which adds up 1 MiB of sizes: still cheaper than two more launches)
 __global__ __launch_bounds__(kScanThreads) void k_scan_small_finish(const uint32_t *__restrict__ sizes, uint32_t n, uint64_t *__restrict__ out, uint8_t *__restrict__ container, uint32_t codec,
                                                                     uint64_t U, uint32_t B)
 {
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_small_finish(const uint32
   if (blockIdx.x == gridDim.x - 1u)
   {
     if (threadIdx.x == 0) out[n] = beforeAll + total;
-    finish_container(container, codec, U, B, n, beforeAll + total);
+    if (container != nullptr) finish_container(container, codec, U, B, n, beforeAll + total);   // (nullptr: a scan only -- scan_sizes)
   }
 }
 
@@ -517,16 +517,19 @@ static uint32_t encode_chunk_blocks()
 constexpr uint32_t kSplitEncodeBelow = 131072u;   // blocks: from here on one lane per block fills the device
 constexpr uint32_t kSplitPieces = 4u, kSplitPiecesMax = 8u;             // (the workspace is planned for the larger number: split_pieces())
 static bool split_encode_applies(int codec, uint64_t nBlocks, uint32_t B);
+static bool split_codec_small(int codec);
 
 struct Workspace
 {
   uint64_t nBlocks, chunk, nChunks, t1, t2, t3;
   // split encode: cut finder results per piece, chunk table, sizes / offsets per chunk, lists (8 words per chunk), staging slots
-  uint64_t spCutPos, spCutSym, spFlags, spIdx, spStarts, spSyms, spSlotOff, spSizes, spChunkOff, spFirst, spCtrl, spGuess, spListOut, spSlots, spL1, spL2, spL3, spPieces, spMaxChunks;
+  uint64_t spCutPos, spCutSym, spFlags, spIdx, spStarts, spSyms, spSlotOff, spSizes, spChunkOff, spFirst, spCtrl, spGuess, spListOut, spSlots, spL1, spL2, spL3, spPieces, spMaxChunks, spPick, spJobs, spJobCap;
   uint64_t offSlots, offSizes, offL1, offL2, offL3, total;
 };
 
-static Workspace plan_workspace(uint64_t U, uint32_t B)
+// splitSmall: reserve the split-encode regions for blocks of 1 .. 4 KiB too (the codecs without a run list encoder -- 8 bit Single, 128 bit --
+// take the split encode there: split_codec_small(); hsrle_compress_workspace_size_codec)
+static Workspace plan_workspace(uint64_t U, uint32_t B, bool splitSmall = false)
 {
   Workspace w;
   w.nBlocks = block_count(U, B);
@@ -548,7 +551,8 @@ static Workspace plan_workspace(uint64_t U, uint32_t B)
   //  3x the input for nothing: ADVICE r3.  Experiment builds can send those containers to the split path too, HSRLE_RUNLIST=2.)
   w.spPieces = w.nBlocks * kSplitPiecesMax; w.spMaxChunks = w.spPieces + w.nBlocks;
   w.spCutPos = w.spCutSym = w.spFlags = w.spIdx = w.spStarts = w.spSyms = w.spSlotOff = w.spSizes = w.spChunkOff = w.spFirst = w.spCtrl = w.spGuess = w.spListOut = w.spSlots = w.spL1 = w.spL2 = w.spL3 = 0;
-  if (w.nBlocks < kSplitEncodeBelow && B >= 1024u && B <= (1u << 20) && (kExperiments || B > 4096u))
+  w.spPick = 0; w.spJobs = 0; w.spJobCap = 0;
+  if (w.nBlocks < kSplitEncodeBelow && B >= 1024u && B <= (1u << 20) && (kExperiments || B > 4096u || splitSmall))
   {
     const uint64_t np = w.spPieces, nc = w.spMaxChunks;
     const uint64_t s1 = (nc + 2 + kScanTile - 1) / kScanTile, s2 = (s1 + kScanTile - 1) / kScanTile, s3 = (s2 + kScanTile - 1) / kScanTile;
@@ -568,6 +572,9 @@ static Workspace plan_workspace(uint64_t U, uint32_t B)
     w.spL1 = at; at += align_up(8ull * (s1 + 1), 256);
     w.spL2 = at; at += align_up(8ull * (s2 + 1), 256);
     w.spL3 = at; at += align_up(8ull * (s3 + 1), 256);
+    w.spPick = at; at += align_up(w.nBlocks + 16ull, 256);               // 8 bit Single: a symbol per block
+    w.spJobCap = (U >> 10) + nc + 16ull;                                  // ... and its copy jobs (literal stretches of >= 1 KiB go to whole waves: k_copy_jobs)
+    w.spJobs = at; at += align_up(24ull * w.spJobCap, 256);
     w.spSlots = at; at += align_up(U + (U >> 7) + 256ull * (nc + 2) + 4096ull, 256);
   }
   w.total = at;
@@ -579,6 +586,12 @@ static hipError_t scan_sizes(const uint32_t *sizes, uint64_t n, uint64_t *out, u
 {
   uint64_t *l1 = (uint64_t *)(ws + w.offL1), *l2 = (uint64_t *)(ws + w.offL2), *l3 = (uint64_t *)(ws + w.offL3);
   const uint64_t t1 = (n + kScanTile - 1) / kScanTile, t2 = (t1 + kScanTile - 1) / kScanTile, t3 = (t2 + kScanTile - 1) / kScanTile;
+  if (carry == nullptr && n != 0 && n <= kScanSmallMax && (((uintptr_t)sizes) & 15u) == 0u)
+  {
+    // small tables (the split encode's flags and chunk sizes, small containers): one launch (k_scan_small_finish without the finish)
+    hipLaunchKernelGGL(k_scan_small_finish, dim3((uint32_t)t1), dim3(kScanThreads), 0, st, sizes, (uint32_t)n, out, (uint8_t *)nullptr, 0u, 0ull, 0u);
+    return hipGetLastError();
+  }
 
   if (t1 > 1)
   {
@@ -635,7 +648,14 @@ static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, ui
   if (!g_enc[codec])
     return HSRLE_ERR_UNSUPPORTED;
 
-  const Workspace w = plan_workspace(U, B);
+  // (8 bit Single / 128 bit, small containers of 1 .. 4 KiB blocks: the split encode needs regions the general workspace does not reserve --
+  //  the library's own scratch has them, a caller's workspace if it was sized by hsrle_compress_workspace_size_codec)
+  Workspace w = plan_workspace(U, B);
+  if (split_codec_small(codec) && B <= 4096u)
+  {
+    const Workspace w2 = plan_workspace(U, B, true);
+    if (w2.spSlots != 0 && (dWs == nullptr || wsSize >= w2.total)) w = w2;
+  }
 
   void *own = nullptr;
   if (dWs == nullptr)
@@ -1194,12 +1214,17 @@ static uint32_t split_pieces(uint32_t B)
 
 static bool run_list_codec(int codec) { return codec <= 3 || (codec >= 6 && codec <= 45) || (codec >= kShortBase8 && codec < kGreedyBase); }
 
+// the codecs that have a many-lane chunk encoder but no run list encoder: small containers of 1 .. 4 KiB blocks take the split encode IF the
+// caller's workspace has its regions (hsrle_compress_workspace_size_codec; the library's own scratch always has)
+static bool split_codec_small(int codec) { return codec == 4 || codec == 5 || (codec >= 46 && codec < 50); }
+
 static bool split_encode_applies(int codec, uint64_t nBlocks, uint32_t B)
 {
-  // the codecs whose ring encoders have the chunk mode (not Single, not 128 bit: their chunk encoders are the per-lane ones of the monolithic path)
+  // the codecs whose ring encoders have the chunk mode, and (round 4) 8 bit Single and 128 bit with the per-lane chunk encoders of the monolithic path
   // rle8_multi / rle8_packed_multi / rle8_{3,7}symlut (ids 0 .. 3), the plain / Packed / LUT codecs of 2 .. 8 byte symbols (ids 6 .. 45) and their Short family (ids 50 .. 93): the run list encoders take these whole
   if (run_list_codec(codec) && run_list_applies(nBlocks, B, 1024u, knob_u32("HSRLE_RUNLIST", 0u))) return false;
-  if (nBlocks >= kSplitEncodeBelow || B < 1024u || B > (1u << 20) || (B % (kSplitPieces * 128u)) != 0u || codec == 4 || codec == 5 || (codec >= 46 && codec < 50) || codec >= kGreedyBase) return false;   // (Greedy: chunks of ONE stream only)
+  if (nBlocks >= kSplitEncodeBelow || B < 1024u || B > (1u << 20) || (B % (kSplitPieces * 128u)) != 0u || codec >= kGreedyBase) return false;   // (Greedy, rle8_single_short: chunks of ONE stream only)
+  if ((codec == 4 || codec == 5) && B > 32768u) return false;           // (the per-block symbol pick holds a block in LDS: hsrle_encode8s.hip.h)
   init_tables();
   return mono_cut_long(codec) != 0u && g_menc[codec] != nullptr;
 }
@@ -1224,12 +1249,25 @@ static int compress_split(int codec, const uint8_t *dIn, uint64_t U, uint32_t B,
   if (hipMemsetAsync(ctrl, 0, 64, st) != hipSuccess || hipMemsetAsync(sizes, 0, 4ull * (maxChunks + 1ull), st) != hipSuccess)
     return HSRLE_ERR_DEVICE;
   const dim3 cgrid((pieces + 63u) / 64u);
+  const bool single = codec == 4 || codec == 5;
+  uint32_t *const pickTable = (uint32_t *)(ws + w.spPick);             // (8 bit Single: a byte per block)
+  if (single)
+  {
+    // every block's symbol first (k_single_pick through the codec's launcher): only its runs are cuts, and the chunk encoder needs it
+    EncodeArgs pa{ dIn, U, B, nBlocks, nullptr, 0u, nullptr };
+    MonoEncodeArgs pm{ nullptr, nullptr, nullptr, 0u };
+    pm.pick = pickTable; pm.phase = 1u;
+    pm.cutPos = cutPos; pm.cutSym = cutSym; pm.cutFlags = flags; pm.cutG = G; pm.cutLong = longc;   // (... and the blocks' cuts, by the same waves: the block is in LDS there)
+    if (g_menc[codec](pa, pm, st) != hipSuccess)
+      return HSRLE_ERR_DEVICE;
+  }
 #define HSRLE_CUTS(SS) \
   if (aligned) hipLaunchKernelGGL((k_mono_cutsS<SS, 1>), cgrid, dim3(64), 0, st, dIn, U, G, pieces, longc, cutPos, cutSym, flags, B); \
   else hipLaunchKernelGGL((k_mono_cutsS<SS, 0>), cgrid, dim3(64), 0, st, dIn, U, G, pieces, longc, cutPos, cutSym, flags, B)
   switch (S)
   {
-  case 1: hipLaunchKernelGGL(k_mono_cuts8, cgrid, dim3(64), 0, st, dIn, U, G, pieces, longc, cutPos, cutSym, flags, (const uint32_t *)nullptr, B); break;
+  case 1: if (!single) hipLaunchKernelGGL(k_mono_cuts8, cgrid, dim3(64), 0, st, dIn, U, G, pieces, longc, cutPos, cutSym, flags, (const uint32_t *)nullptr, B); break;
+  case 16: HSRLE_CUTS(16); break;
   case 2: HSRLE_CUTS(2); break;
   case 3: HSRLE_CUTS(3); break;
   case 4: HSRLE_CUTS(4); break;
@@ -1251,6 +1289,8 @@ static int compress_split(int codec, const uint8_t *dIn, uint64_t U, uint32_t B,
   ea.ringSel = ctrl;                                                     // chunk mode with B: ctrl[0] = the number of chunks, [1] = blocks per wave (0: chunks in a row), [2] = blocks
   MonoEncodeArgs ma{ starts, listK ? guess : syms, slotOff, 2u * (B / 64u) + 64u };
   ma.listOut = listK ? listOut : nullptr;
+  ma.pick = pickTable;                                                 // (8 bit Single: the blocks' symbols)
+  if (single) { ma.jobs = (uint64_t *)(ws + w.spJobs); ma.jobCount = ctrl + 12; ma.jobCap = (uint32_t)(w.spJobCap < 0xFFFFFFFFull ? w.spJobCap : 0xFFFFFFFFull); }   // (ctrl[12]: zeroed above)
   if (g_menc[codec](ea, ma, st) != hipSuccess)
     return HSRLE_ERR_DEVICE;
   if (listK != 0 && !inKernelLists)
@@ -2146,6 +2186,13 @@ uint64_t hsrle_compress_workspace_size(uint64_t inSize, uint32_t blockSize)
   if (blockSize == 0) blockSize = HSRLE_DEFAULT_BLOCK_SIZE;
   if (!valid_block_size(blockSize) || inSize == 0) return 0;
   return plan_workspace(inSize, blockSize).total;
+}
+
+uint64_t hsrle_compress_workspace_size_codec(int codec, uint64_t inSize, uint32_t blockSize)
+{
+  if (blockSize == 0) blockSize = HSRLE_DEFAULT_BLOCK_SIZE;
+  if (!valid_block_size(blockSize) || inSize == 0 || codec < 0 || codec >= kCodecCount) return 0;
+  return plan_workspace(inSize, blockSize, split_codec_small(codec) && blockSize <= 4096u).total;
 }
 
 int hsrle_compress_dev_async(int codec, const void *dIn, uint64_t inSize, void *dOut, uint64_t outCapacity, uint32_t blockSize, void *dWorkspace,

@@ -1199,17 +1199,30 @@ __device__ inline uint32_t encode_chunk_single(const uint8_t *d, uint32_t nChunk
 }
 
 // chunks of ONE monolithic 8 bit Single stream, one lane per chunk (pick[0]: the stream's symbol, k_single_pick_final)
+// B != 0 (round 4): chunks of the BLOCKS of a container (split encode, hsrle_capi.hip: compress_split) -- every block is a stream of its own:
+// its end is "the end of the input", its first chunk writes the stream header (size patched in at placement: k_split_finish), mode 1 and the
+// block's symbol (pick: a byte per block, k_single_pick)
 template <bool PACKEDSINGLE>
 __global__ __launch_bounds__(64) void k_encode_single_chunks(const uint8_t *__restrict__ in, uint64_t U, uint32_t chunks, const uint64_t *__restrict__ starts, const uint64_t *__restrict__ slotOff,
                                                              uint8_t *__restrict__ slots, uint32_t *__restrict__ sizes, const uint32_t *__restrict__ pick,
-                                                             uint64_t *__restrict__ jobList, uint32_t *__restrict__ jobCount, uint32_t jobCap)
+                                                             uint64_t *__restrict__ jobList, uint32_t *__restrict__ jobCount, uint32_t jobCap, uint32_t B,
+                                                             const uint32_t *__restrict__ chunkCount)
 {
   const uint32_t c = blockIdx.x * 64u + threadIdx.x;
+  if (B != 0u && chunkCount != nullptr) chunks = umin(chunks, chunkCount[0]);   // (split encode: the launch covers the most chunks there can be, the device knows how many there are)
   if (c >= chunks) return;
   const uint64_t start = starts[c];
   Sink s{ slots + slotOff[c], 0u, in + U };
   const CopyJobs jobs{ jobList, jobCount, jobCap, start, slotOff[c] };
-  sizes[c] = encode_chunk_single<PACKEDSINGLE>(in + start, (uint32_t)(starts[c + 1u] - start), (uint32_t)(U - start), pick[0] & 0xFFu, s, jobs);
+  if (B == 0u)
+  {
+    sizes[c] = encode_chunk_single<PACKEDSINGLE>(in + start, (uint32_t)(starts[c + 1u] - start), (uint32_t)(U - start), pick[0] & 0xFFu, s, jobs);
+    return;
+  }
+  const uint64_t blk = start / B, blockEnd = ((blk + 1ull) * B < U) ? (blk + 1ull) * B : U;
+  const uint32_t sym = ((const uint8_t *)pick)[blk];
+  if (start == blk * B) { s.put32((uint32_t)(blockEnd - start)); s.put32(0); s.put8(1); s.put8(sym); }
+  sizes[c] = encode_chunk_single<PACKEDSINGLE>(in + start, (uint32_t)(starts[c + 1u] - start), (uint32_t)(blockEnd - start), sym, s, jobs);
 }
 
 // the noted literal stretches of the chunk encoders: persistent waves, one job at a time, destination-aligned 16-byte stores
@@ -1242,15 +1255,26 @@ __global__ __launch_bounds__(256) void k_copy_jobs(const uint8_t *__restrict__ i
 }
 
 // chunks of ONE monolithic 128 bit stream, one lane per chunk (hsrle_mono_encode.hip.h; syms[c] = where the boundary run in front of chunk c starts)
+// B != 0 (round 4): chunks of the blocks of a container, as k_encode_single_chunks
 template <int FAM, int AL>
 __global__ __launch_bounds__(64) void k_encode128_chunks(const uint8_t *__restrict__ in, uint64_t U, uint32_t chunks, const uint64_t *__restrict__ starts, const uint64_t *__restrict__ syms,
-                                                         const uint64_t *__restrict__ slotOff, uint8_t *__restrict__ slots, uint32_t *__restrict__ sizes)
+                                                         const uint64_t *__restrict__ slotOff, uint8_t *__restrict__ slots, uint32_t *__restrict__ sizes, uint32_t B,
+                                                         const uint32_t *__restrict__ chunkCount)
 {
   const uint32_t c = blockIdx.x * 64u + threadIdx.x;
+  if (B != 0u && chunkCount != nullptr) chunks = umin(chunks, chunkCount[0]);   // (split encode: see k_encode_single_chunks)
   if (c >= chunks) return;
   const uint64_t start = starts[c];
   Sink s{ slots + slotOff[c], 0u, in + U };
-  sizes[c] = encode_chunk_128<FAM, AL>(in + start, (uint32_t)(starts[c + 1u] - start), (uint32_t)(U - start), c == 0u, in + syms[c], s);
+  if (B == 0u)
+  {
+    sizes[c] = encode_chunk_128<FAM, AL>(in + start, (uint32_t)(starts[c + 1u] - start), (uint32_t)(U - start), c == 0u, in + syms[c], s);
+    return;
+  }
+  const uint64_t blk = start / B, blockEnd = ((blk + 1ull) * B < U) ? (blk + 1ull) * B : U;
+  const bool opens = start == blk * B;
+  if (opens) { s.put32((uint32_t)(blockEnd - start)); s.put32(0); }
+  sizes[c] = encode_chunk_128<FAM, AL>(in + start, (uint32_t)(starts[c + 1u] - start), (uint32_t)(blockEnd - start), opens, in + syms[c], s);
 }
 
 } // namespace hsrle

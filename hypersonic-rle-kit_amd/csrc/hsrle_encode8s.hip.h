@@ -29,8 +29,12 @@ namespace hsrle {
 constexpr uint32_t kSinglePickMaxBlock = 32768u;   // larger blocks use the first-generation kernel (hsrle_encode.hip.h)
 
 // dynamic LDS: [0, 1024) table (prob | pcount << 16), then n bytes of the block (padded to 64), then the equality bits
+// cutPos != nullptr (round 4, split encode of a small container): the wave also finds its block's CUTS -- for each of the block's pieces of
+// cutG bytes the first run of the picked symbol of >= cutLong bytes that ends inside the piece (and 64 bytes in front of the block's end), as
+// k_mono_cuts8 does with one lane per piece; here the block is in LDS already and the 64 lanes look at 64 positions each.
 __global__ __launch_bounds__(64) void k_single_pick(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t nBlocks, uint8_t *__restrict__ slots, uint32_t slotStride,
-                                                    uint32_t symAt)
+                                                    uint32_t symAt, uint64_t *__restrict__ cutPos = nullptr, uint64_t *__restrict__ cutSym = nullptr, uint32_t *__restrict__ cutFlags = nullptr,
+                                                    uint32_t cutG = 0, uint32_t cutLong = 0)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t pickLds[];
   const uint32_t lane = threadIdx.x;
@@ -211,8 +215,75 @@ __global__ __launch_bounds__(64) void k_single_pick(const uint8_t *__restrict__ 
     const uint32_t a = (uint32_t)__shfl_xor((int)bestKey, dd, 64);
     bestKey = a > bestKey ? a : bestKey;
   }
+  const uint32_t picked = (bestKey >> 8) != 0u ? (255u - (bestKey & 0xFFu)) : 0u;
   if (lane == 0u)
-    slots[(uint64_t)b * slotStride + symAt] = (bestKey >> 8) != 0u ? (uint8_t)(255u - (bestKey & 0xFFu)) : (uint8_t)0;
+    slots[(uint64_t)b * slotStride + symAt] = (uint8_t)picked;
+
+  if (cutPos != nullptr)
+  {
+    // ---- the block's cuts: runs of `picked` of >= cutLong bytes, the first that ends in each piece ----
+    __syncthreads();
+    uint32_t *const firstCut = table;                                   // (the estimator's table is done with) one word per piece
+    const uint32_t ppb = B / cutG;
+    if (lane < 64u) for (uint32_t k = lane; k < ppb; k += 64u) firstCut[k] = 0xFFFFFFFFu;
+    __syncthreads();
+    const uint32_t lastCut = n > 64u ? n - 64u : 0u;
+    const uint32_t pv = picked * 0x01010101u;
+    uint32_t carry = 0;                                                 // bytes of the symbol that reach the start of this row of 64 words
+    for (uint32_t w0 = 0; w0 < words; w0 += 64u)
+    {
+      const uint32_t w = w0 + lane;
+      uint64_t m = 0;
+      if (w < words)
+      {
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; j++)
+        {
+          const u32x4 x = lds_ld128(bytes + w * 64u + j * 16u);
+          m |= (uint64_t)zero_mask16(x.x ^ pv, x.y ^ pv, x.z ^ pv, x.w ^ pv) << (16u * j);
+        }
+        const uint32_t left = n - w * 64u;                              // positions of the word inside the block
+        if (left < 64u) m &= (1ull << left) - 1ull;
+      }
+      // symbol bytes at the END of each word, and through whole words: inclusive scan of (length, "the word is all symbol")
+      uint32_t tl = (m == ~0ull) ? 64u : (uint32_t)__builtin_clzll(~m);
+      uint32_t full = (m == ~0ull) ? 1u : 0u;
+#pragma unroll
+      for (uint32_t d = 1; d < 64u; d <<= 1)
+      {
+        const uint32_t pl = (uint32_t)__shfl_up((int)tl, d, 64), pf = (uint32_t)__shfl_up((int)full, d, 64);
+        if (lane >= d) { tl += full ? pl : 0u; full &= pf; }
+      }
+      uint32_t cin = (uint32_t)__shfl_up((int)tl, 1, 64);
+      const uint32_t cfull = (uint32_t)__shfl_up((int)full, 1, 64);
+      if (lane == 0u) cin = carry; else if (cfull) cin += carry;       // (all words in front of this one in the row are symbol: the row's carry comes on top)
+      const uint32_t rowTail = (uint32_t)__builtin_amdgcn_readlane((int)tl, 63), rowFull = (uint32_t)__builtin_amdgcn_readlane((int)full, 63);
+      // run ends in this word: a clear bit whose left neighbour is set
+      uint64_t ends = ~m & ((m << 1) | (cin != 0u ? 1ull : 0ull));
+      if (w >= words) ends = 0ull;
+      while (ends != 0ull)
+      {
+        const uint32_t k = (uint32_t)__builtin_ctzll(ends);
+        ends &= ends - 1ull;
+        const uint64_t zerosBelow = ~m & ((1ull << k) - 1ull);
+        const uint32_t len = zerosBelow == 0ull ? k + cin : k - 64u + (uint32_t)__builtin_clzll(zerosBelow);
+        const uint32_t e = w * 64u + k;
+        if (len >= cutLong && e <= lastCut && e != 0u)
+          atomicMin(firstCut + (e - 1u) / cutG, e);
+      }
+      carry = rowFull ? carry + rowTail : rowTail;
+    }
+    __syncthreads();
+    for (uint32_t k = lane; k < ppb; k += 64u)
+    {
+      const uint32_t e = firstCut[k];
+      const uint64_t pieceAt = at + (uint64_t)k * cutG;
+      const bool have = e != 0xFFFFFFFFu && pieceAt < U;
+      cutPos[(uint64_t)b * ppb + k] = have ? at + e : ~0ull;             // (MONO_NO_CUT)
+      cutSym[(uint64_t)b * ppb + k] = have ? (uint64_t)picked : 0ull;
+      cutFlags[(uint64_t)b * ppb + k] = have ? 1u : 0u;
+    }
+  }
 }
 
 // MODE 0: rle8_single, 1: rle8_packed_single, 2: rle8_single_short (rleX_Xsl_short.h with SINGLE: wrapper :380-523, body :1058-1120 -- the

@@ -67,7 +67,9 @@ struct MonoEncodeArgs
 {
   const uint64_t *starts; uint64_t *syms; const uint64_t *slotOff; uint32_t steps;   // (syms: rewritten by k_encodeS_blocks when it settles the lists itself)
   uint64_t *listOut = nullptr; uint32_t dry = 0;     // codecs with a move-to-front list: syms / listOut hold 8 words per chunk
-  const uint32_t *pick = nullptr;                    // 8 bit Single: the stream's symbol (device)
+  const uint32_t *pick = nullptr;                    // 8 bit Single: the stream's symbol (device); split encode of a container: a BYTE per block
+  uint32_t phase = 0;                                // split encode, Single codecs: 1 = only pick the blocks' symbols into `pick` -- and find the blocks' cuts:
+  uint64_t *cutPos = nullptr, *cutSym = nullptr; uint32_t *cutFlags = nullptr; uint32_t cutG = 0, cutLong = 0;   // (phase 1) per piece of cutG bytes, as k_mono_cuts8 leaves them
   uint64_t *jobs = nullptr; uint32_t *jobCount = nullptr; uint32_t jobCap = 0;   // 8 bit Single: literal stretches noted for k_copy_jobs
 };
 typedef hipError_t (*MonoEncodeLaunch)(const EncodeArgs &, const MonoEncodeArgs &, hipStream_t);

@@ -33,8 +33,9 @@ __global__ __launch_bounds__(64) void k_mono_cuts8(const uint8_t *__restrict__ i
   // the piece's block, and "the end of the input" is the end of that block
   const uint32_t c = blockIdx.x * 64u + threadIdx.x;
   if (c >= pieces) return;
-  const uint32_t want = onlySym != nullptr ? (onlySym[0] & 0xFFu) : 0x100u;                // 0x100: any symbol
   const uint64_t x = (uint64_t)c * G;
+  // (split encode: onlySym is a BYTE per block -- every block of a Single container has its own symbol)
+  const uint32_t want = onlySym == nullptr ? 0x100u : (blockB ? (uint32_t)((const uint8_t *)onlySym)[x / blockB] : (onlySym[0] & 0xFFu));   // 0x100: any symbol
   if (x >= U) { cutPos[c] = MONO_NO_CUT; cutSym[c] = 0; flags[c] = 0u; return; }   // (split encode: a piece behind the last, short block)
   const uint64_t lo = blockB ? (x / blockB) * blockB : 0ull;
   if (blockB) { const uint64_t be = lo + blockB; if (be < U) U = be; }
@@ -51,9 +52,33 @@ __global__ __launch_bounds__(64) void k_mono_cuts8(const uint8_t *__restrict__ i
   const uint64_t stop = (hiEnd < lastCut) ? hiEnd : lastCut;             // run ends behind `stop` are of no use
   while (i <= stop)
   {
+    if (want != 0x100u && sy != want && i + 32u <= U && i + 32u <= stop)
+    {
+      // Single codecs, 32 bytes at a time (two loads in flight: the loop is one memory latency per trip): no byte of the symbol, no cut
+      const u32x4 a = ld128(in + i), b = ld128(in + i + 16u);
+      const uint32_t ws = want * 0x01010101u;
+      if ((zero_bytes(a.x ^ ws) | zero_bytes(a.y ^ ws) | zero_bytes(a.z ^ ws) | zero_bytes(a.w ^ ws) | zero_bytes(b.x ^ ws) | zero_bytes(b.y ^ ws) | zero_bytes(b.z ^ ws) | zero_bytes(b.w ^ ws)) == 0u)
+      {
+        st = i + 31u; sy = b.w >> 24;
+        i += 32u;
+        continue;
+      }
+    }
     if (i + 9u <= U)
     {
       const uint64_t w = ld64(in + i - 1), w1 = ld64(in + i);
+      if (want != 0x100u && sy != want)
+      {
+        // Single codecs: eight bytes without the symbol (and no run of it open) hold no cut and leave nothing to remember but the last byte --
+        // on data its symbol is rare in this is nearly every trip (64 MiB run-distributed: the cut finder 294 -> 209 us; with the 32-byte trips above R4CUTS)
+        const uint64_t t = w1 ^ ((uint64_t)want * 0x0101010101010101ull);
+        if (((((t & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | t) & 0x8080808080808080ull) == 0x8080808080808080ull)
+        {
+          st = i + 7u; sy = (uint32_t)(w1 >> 56);
+          i += 8u;
+          continue;
+        }
+      }
       const uint64_t d = w ^ w1;                                        // byte k: in[i - 1 + k] ^ in[i + k]
       const uint64_t z = ((d & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | d;
       const uint64_t eq = ~z & 0x8080808080808080ull;                   // 0x80 in byte k: in[i + k] continues the run of its left neighbour

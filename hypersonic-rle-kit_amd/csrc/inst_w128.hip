@@ -39,7 +39,7 @@ static hipError_t sub_byte_packed(const DecodeArgs &a, uint32_t SB, uint32_t *re
 template <int FAM, int AL>
 static hipError_t menc_any(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st)
 {
-  hipLaunchKernelGGL((k_encode128_chunks<FAM, AL>), dim3((a.nBlocks + 63u) / 64u), dim3(64), 0, st, a.in, a.U, a.nBlocks, m.starts, m.syms, m.slotOff, a.slots, a.sizes);
+  hipLaunchKernelGGL((k_encode128_chunks<FAM, AL>), dim3((a.nBlocks + 63u) / 64u), dim3(64), 0, st, a.in, a.U, a.nBlocks, m.starts, m.syms, m.slotOff, a.slots, a.sizes, a.B, (const uint32_t *)a.ringSel);
   return hipGetLastError();
 }
 

@@ -64,7 +64,8 @@ static hipError_t enc_single_any(const EncodeArgs &a, hipStream_t st)
   {
     const uint32_t padded = (a.B + 63u) & ~63u;
     const uint32_t lds = 1024u + padded + 64u + (padded / 64u + 1u) * 8u;
-    hipLaunchKernelGGL(k_single_pick, dim3(a.nBlocks), dim3(64), lds, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, MODE == 2 ? 8u : 9u);
+    hipLaunchKernelGGL(k_single_pick, dim3(a.nBlocks), dim3(64), lds, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, MODE == 2 ? 8u : 9u, (uint64_t *)nullptr, (uint64_t *)nullptr,
+                       (uint32_t *)nullptr, 0u, 0u);
     if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
   }
   return launch_encode(k_encode8_single_blocks<MODE>, a, st, 0);
@@ -110,8 +111,18 @@ static hipError_t menc_single_short(const EncodeArgs &a, const MonoEncodeArgs &m
 template <bool PACKEDSINGLE>
 static hipError_t menc_single_any(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st)
 {
+  if (m.phase == 1u)
+  {
+    // split encode of a container: the blocks' symbols first (a byte per block; a.nBlocks = blocks here), the cut finder needs them
+    if (a.B > kSinglePickMaxBlock) return hipErrorInvalidValue;
+    const uint32_t padded = (a.B + 63u) & ~63u;
+    const uint32_t lds = 1024u + padded + 64u + (padded / 64u + 1u) * 8u;
+    hipLaunchKernelGGL(k_single_pick, dim3(a.nBlocks), dim3(64), lds, st, a.in, a.U, a.B, a.nBlocks, (uint8_t *)const_cast<uint32_t *>(m.pick), 1u, 0u, m.cutPos, m.cutSym, m.cutFlags,
+                       m.cutG, m.cutLong);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL((k_encode_single_chunks<PACKEDSINGLE>), dim3((a.nBlocks + 63u) / 64u), dim3(64), 0, st, a.in, a.U, a.nBlocks, m.starts, m.slotOff, a.slots, a.sizes, m.pick,
-                     m.jobs, m.jobCount, m.jobCap);
+                     m.jobs, m.jobCount, m.jobCap, a.B, (const uint32_t *)a.ringSel);
   if (m.jobs != nullptr)
     hipLaunchKernelGGL((k_copy_jobs<0>), dim3(2048), dim3(256), 0, st, a.in, a.slots, (const uint64_t *)m.jobs, (const uint32_t *)m.jobCount, m.jobCap);
   return hipGetLastError();

@@ -88,6 +88,8 @@ def _lib():
     L.hsrle_container_bound.argtypes = [u64, u32]
     L.hsrle_compress_workspace_size.restype = u64
     L.hsrle_compress_workspace_size.argtypes = [u64, u32]
+    L.hsrle_compress_workspace_size_codec.restype = u64
+    L.hsrle_compress_workspace_size_codec.argtypes = [ctypes.c_int, u64, u32]
     L.hsrle_compress_dev_async.restype = ci
     L.hsrle_compress_dev_async.argtypes = [ci, vp, u64, vp, u64, u32, vp, u64, vp]
     L.hsrle_compress_dev.restype = ci
@@ -197,8 +199,12 @@ def container_bound(n, block_size=DEFAULT_BLOCK_SIZE):
     return _lib().hsrle_container_bound(n, block_size)
 
 
-def workspace_size(n, block_size=DEFAULT_BLOCK_SIZE):
-    return _lib().hsrle_compress_workspace_size(n, block_size)
+def workspace_size(n, block_size=DEFAULT_BLOCK_SIZE, codec=None):
+    """Bytes of workspace for compress_async; with a codec (key or id): hsrle_compress_workspace_size_codec (8 bit Single / 128 bit: small containers
+    then take the split encode)."""
+    if codec is None:
+        return _lib().hsrle_compress_workspace_size(n, block_size)
+    return _lib().hsrle_compress_workspace_size_codec(codec_id(codec), n, block_size)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

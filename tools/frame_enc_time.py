@@ -5,7 +5,7 @@ from hsrle_testlib import CODEC_BY_KEY
 key=sys.argv[1]; S=CODEC_BY_KEY[key].S
 for kind,size in ((1,88473600),(0,64<<20)):
     src=hsrle.synth(kind,S,2,size,device="cuda")
-    dst=torch.empty(hsrle.container_bound(size,4096),dtype=torch.uint8,device="cuda"); ws=torch.empty(hsrle.workspace_size(size,4096),dtype=torch.uint8,device="cuda")
+    dst=torch.empty(hsrle.container_bound(size,4096),dtype=torch.uint8,device="cuda"); ws=torch.empty(hsrle.workspace_size(size,4096,codec=key),dtype=torch.uint8,device="cuda")
     for _ in range(3): hsrle.compress_async(key,src,dst,4096,workspace=ws)
     torch.cuda.synchronize(); e0,e1=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True); e0.record()
     for _ in range(20): hsrle.compress_async(key,src,dst,4096,workspace=ws)

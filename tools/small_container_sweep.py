@@ -10,7 +10,7 @@ from hsrle_testlib import CODECS
 def encode_us(key, src, reps=20):
     size = src.numel()
     dst = torch.empty(hsrle.container_bound(size, 4096), dtype=torch.uint8, device="cuda")
-    ws = torch.empty(hsrle.workspace_size(size, 4096), dtype=torch.uint8, device="cuda")
+    ws = torch.empty(hsrle.workspace_size(size, 4096, codec=key), dtype=torch.uint8, device="cuda")   # (8 bit Single / 128 bit: with the split encode regions)
     for _ in range(3): info = hsrle.compress_async(key, src, dst, 4096, workspace=ws)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
