@@ -1205,7 +1205,8 @@ static uint32_t mono_cut_long(int codec, int *pS = nullptr, int *pAligned = null
 // pieces per block (= cut finder lanes; a block has at most pieces + 1 chunks).  8 pieces were measured for the list codecs that settle their
 // lists inside the encode kernel (88 MB frame / 64 MiB runs, us: rle64_3symlut_byte 4: 310 / 378, 8: 341 / 485; rle32_7symlut_sym 4: 411 / 355,
 // 8: 409 / 328; rle16_3symlut_byte 4: 434 / 315, 8: 497 / 327): the kernel's time follows its total trips, not the trips per wave, so
-// shorter chunks buy nothing.  The workspace is planned for kSplitPiecesMax so that experiment builds can try (HSRLE_SPLIT_PIECES).
+// shorter chunks buy nothing; the per-lane chunk encoders (Single, 128 bit, Greedy with a one-symbol list), 4 / 8 pieces: rle8_single 285 / 290 and 379 / 365,
+// rle128_sym 380 / 374 and 282 / 324, rle64_1symlut greedy 732 / 689 and 775 / 1029 (experiments/r04/call61.sh).  The workspace is planned for kSplitPiecesMax so that experiment builds can try (HSRLE_SPLIT_PIECES).
 static uint32_t split_pieces(uint32_t B)
 {
   const uint32_t k = knob_u32("HSRLE_SPLIT_PIECES", kSplitPieces);
@@ -1216,14 +1217,19 @@ static bool run_list_codec(int codec) { return codec <= 3 || (codec >= 6 && code
 
 // the codecs that have a many-lane chunk encoder but no run list encoder: small containers of 1 .. 4 KiB blocks take the split encode IF the
 // caller's workspace has its regions (hsrle_compress_workspace_size_codec; the library's own scratch always has)
-static bool split_codec_small(int codec) { return codec == 4 || codec == 5 || (codec >= 46 && codec < 50); }
+static bool greedy_one_symbol_list(int codec) { return codec >= kGreedyBase && codec < kSingleShort && (codec - kGreedyBase) % 3 == 0; }
+static bool split_codec_small(int codec) { return codec == 4 || codec == 5 || (codec >= 46 && codec < 50) || greedy_one_symbol_list(codec); }
 
 static bool split_encode_applies(int codec, uint64_t nBlocks, uint32_t B)
 {
   // the codecs whose ring encoders have the chunk mode, and (round 4) 8 bit Single and 128 bit with the per-lane chunk encoders of the monolithic path
   // rle8_multi / rle8_packed_multi / rle8_{3,7}symlut (ids 0 .. 3), the plain / Packed / LUT codecs of 2 .. 8 byte symbols (ids 6 .. 45) and their Short family (ids 50 .. 93): the run list encoders take these whole
   if (run_list_codec(codec) && run_list_applies(nBlocks, B, 1024u, knob_u32("HSRLE_RUNLIST", 0u))) return false;
-  if (nBlocks >= kSplitEncodeBelow || B < 1024u || B > (1u << 20) || (B % (kSplitPieces * 128u)) != 0u || codec >= kGreedyBase) return false;   // (Greedy, rle8_single_short: chunks of ONE stream only)
+  if (nBlocks >= kSplitEncodeBelow || B < 1024u || B > (1u << 20) || (B % (kSplitPieces * 128u)) != 0u || codec == kSingleShort) return false;   // (rle8_single_short: chunks of ONE stream only)
+  // Greedy: the lists of 3 / 7 symbols decide which runs the scan stores, so a chunk's list is only known when the chunk in front of it is final --
+  // measured (88 MB frame, rle32_7symlut: two full passes + three repair rounds 3.7 ms against 3.1 ms with one lane per block); a list of ONE symbol
+  // behind a stored run is that run's symbol, and the first guess is right
+  if (codec >= kGreedyBase && !greedy_one_symbol_list(codec)) return false;
   if ((codec == 4 || codec == 5) && B > 32768u) return false;           // (the per-block symbol pick holds a block in LDS: hsrle_encode8s.hip.h)
   init_tables();
   return mono_cut_long(codec) != 0u && g_menc[codec] != nullptr;
@@ -1281,9 +1287,9 @@ static int compress_split(int codec, const uint8_t *dIn, uint64_t U, uint32_t B,
     hipLaunchKernelGGL(k_mono_list_default, dim3((maxChunks + 255u) / 256u), dim3(256), 0, st, maxChunks, (uint32_t)listK, (uint32_t)S, guess);
   // list codecs of 2 .. 8 byte symbols settle their lists INSIDE the encode kernel: a wave takes the chunks of kSplitGroup whole blocks (k_encodeS_blocks)
   const uint32_t kSplitGroup = 64u / (ppb + 1u);                         // blocks per wave: x (ppb + 1) chunks at most <= a wave's 64 lanes
-  const bool inKernelLists = listK != 0 && S > 1;
+  const bool inKernelLists = listK != 0 && S > 1 && codec < kGreedyBase;   // (Greedy: one lane per chunk, lists between launches like the 8 bit codecs)
   hipLaunchKernelGGL(k_split_scatter, dim3((pieces + 255u) / 256u), dim3(256), 0, st, (const uint64_t *)cutPos, (const uint64_t *)cutSym, (const uint32_t *)flags, (const uint64_t *)idx, pieces,
-                     ppb, nBlocks, U, B, starts, listK ? guess : syms, slotOff, firstChunk, ctrl, (uint32_t)listK, inKernelLists ? kSplitGroup : 0u);
+                     ppb, nBlocks, U, B, starts, listK ? guess : syms, slotOff, firstChunk, ctrl, (uint32_t)listK | ((codec >= kGreedyBase && listK == 1) ? kSplitGuessCutSym : 0u), inKernelLists ? kSplitGroup : 0u);
 
   EncodeArgs ea{ dIn, U, B, inKernelLists ? ((nBlocks + kSplitGroup - 1u) / kSplitGroup) * 64u : maxChunks, ws + w.spSlots, 0u, sizes };
   ea.ringSel = ctrl;                                                     // chunk mode with B: ctrl[0] = the number of chunks, [1] = blocks per wave (0: chunks in a row), [2] = blocks

@@ -34,17 +34,26 @@ __global__ __launch_bounds__(64) void k_encode_greedy_blocks(const uint8_t *__re
   static_assert(TR::kShort && TR::K > 0 && S >= 2 && S <= 8, "1/3/7 symbol LUT Short codecs of the 16..64 bit symbols");
   constexpr int K = TR::K;
   constexpr uint32_t SU = (uint32_t)S;
-  (void)monoSteps; (void)ringSel; (void)B;
+  // MONO with B != 0 ("split encode" of a container with small blocks, hsrle_capi.hip compress_split): the chunks are pieces of the container's
+  // BLOCKS -- a chunk that opens its block writes the block stream's header, the block's end is the end of the input, ringSel[0] = the
+  // number of chunks, and a repair round (monoSteps >> 16) that has nothing to do returns at once (ringSel[7 + round]: how many chunks it has)
+  const bool blocks = MONO && B != 0u;
+  if constexpr (MONO) { if (blocks && ringSel != nullptr && (monoSteps >> 16) != 0u && ringSel[7u + (monoSteps >> 16)] == 0u) return; }
 
   __shared__ __attribute__((aligned(16))) uint8_t ringMem[64 * kLaneRingStride];
   const uint32_t b = MONO ? blockIdx.x * 64u + threadIdx.x : xcd_tile(blockIdx.x, gridDim.x) * 64u + threadIdx.x;
   // (no early return in MONO mode before the activity test: the ring's top-ups are wave-wide ballots, but lanes that are out simply do not vote)
   if (b >= nBlocks)
     return;
+  if constexpr (MONO) { if (blocks && ringSel != nullptr && b >= ringSel[0]) return; }
   if constexpr (MONO) { if (ld_fresh64(monoSyms + 8ull * b + 7) == 0ull) return; }   // repair rounds switch most chunks off
   const bool dry = MONO && monoDry != 0u;
 
   const uint64_t start = MONO ? monoStarts[b] : (uint64_t)b * B;
+  if constexpr (MONO)
+  {
+    if (blocks) { const uint64_t blockEnd = (start / B + 1ull) * B; if (blockEnd < U) U = blockEnd; }   // (U: from here on the end of this chunk's world)
+  }
   // n: where this lane's scan ends (block / chunk length); nT: the input the scan may LOOK at (block: the same; chunk: up to the true end)
   const uint32_t n = MONO ? (uint32_t)(monoStarts[b + 1u] - start) : (uint32_t)((U - start) < (uint64_t)B ? (U - start) : (uint64_t)B);
   const uint32_t nT = MONO ? (uint32_t)((U - start) < 0xFFFFFFFFull ? (U - start) : 0xFFFFFFFFull) : n;
@@ -70,6 +79,11 @@ __global__ __launch_bounds__(64) void k_encode_greedy_blocks(const uint8_t *__re
   if constexpr (!MONO)
   {
     s.put32(n);
+    s.put32(0);
+  }
+  else if (blocks && (start % B) == 0ull)
+  {
+    s.put32((uint32_t)(U - start));                                      // the block's uncompressed length; compressedLength: k_split_finish
     s.put32(0);
   }
 

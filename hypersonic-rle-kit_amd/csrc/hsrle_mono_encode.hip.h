@@ -382,6 +382,7 @@ __global__ void k_mono_finish(uint8_t *__restrict__ out, uint32_t U, uint32_t he
 // ---- split encode: the chunk table of a CONTAINER (blocks of B bytes, pieces of G = B / ppb bytes).  Chunk starts = the block starts and the
 //      cuts; idx = exclusive scan of the pieces' cut flags.  Piece p's cut opens chunk idx[p] + p / ppb + 1 (every block start up to and including
 //      p's block comes first), block b opens chunk idx[b * ppb] + b.  ctrl[0] = the number of chunks.
+constexpr uint32_t kSplitGuessCutSym = 0x100u;   // listWords flag: the first guess of a cut-born chunk's list leads with the boundary run's symbol
 __global__ __launch_bounds__(256) void k_split_scatter(const uint64_t *__restrict__ cutPos, const uint64_t *__restrict__ cutSym, const uint32_t *__restrict__ flags,
                                                        const uint64_t *__restrict__ idx, uint32_t pieces, uint32_t ppb, uint32_t nBlocks, uint64_t U, uint32_t B,
                                                        uint64_t *__restrict__ starts, uint64_t *__restrict__ syms, uint64_t *__restrict__ slotOff, uint32_t *__restrict__ firstChunk,
@@ -411,6 +412,7 @@ __global__ __launch_bounds__(256) void k_split_scatter(const uint64_t *__restric
     const uint64_t k = idx[p] + b + 1ull;
     starts[k] = cutPos[p]; slotOff[k] = slot_of(cutPos[p], k);
     if (listWords == 0u) syms[k] = cutSym[p];
+    else if (listWords == (1u | kSplitGuessCutSym)) syms[8ull * k] = cutSym[p];   // a list of ONE symbol behind a stored run is that run's symbol
   }
 }
 

@@ -79,7 +79,7 @@ def test_pure_host_helpers(lib):
 def test_encode_path_selection(lib):
     """hsrle_encode_path (no device): which encoder a container takes.  Big containers: one lane per block; small ones of 1 .. 4 KiB blocks: the
     run list encoders for the multi-symbol 8 bit codecs, the 2 .. 8 byte codecs and their Short family, the split encode for the rest that
-    can be cut (Single and 128 bit cannot: they stay with the ring encoders); other block sizes: split encode or ring."""
+    can be cut (Single, 128 bit and Greedy only with a workspace sized for the codec); other block sizes: split encode or ring."""
     lib.hsrle_encode_path.restype = ctypes.c_int
     lib.hsrle_encode_path.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_uint32]
     lib.hsrle_codec_from_name.restype = ctypes.c_int
@@ -96,7 +96,7 @@ def test_encode_path_selection(lib):
         assert lib.hsrle_encode_path(cid(name), frame, 512) == RING, name
     for name in ("rle8_single", "rle8_packed_single", "rle128_sym", "rle128_byte_packed", "rle16_3symlut_byte_short_greedy"):
         assert lib.hsrle_encode_path(cid(name), frame, 4096) == RING, name          # (Single / 128 bit: split only with a workspace sized for the codec -- the host cannot know)
-    for name in ("rle8_single", "rle8_packed_single", "rle128_sym", "rle128_byte_packed"):
+    for name in ("rle8_single", "rle8_packed_single", "rle128_sym", "rle128_byte_packed", "rle16_1symlut_byte_short_greedy", "rle64_1symlut_byte_short_greedy"):
         assert lib.hsrle_encode_path(cid(name), frame, 8192) == SPLIT, name         # round 4: their chunk encoders take the blocks of a container too
     lib.hsrle_compress_workspace_size.restype = ctypes.c_uint64
     lib.hsrle_compress_workspace_size.argtypes = [ctypes.c_uint64, ctypes.c_uint32]
@@ -105,6 +105,9 @@ def test_encode_path_selection(lib):
     general = lib.hsrle_compress_workspace_size(frame, 4096)
     assert lib.hsrle_compress_workspace_size_codec(cid("rle8_packed_multi"), frame, 4096) == general
     assert lib.hsrle_compress_workspace_size_codec(cid("rle8_single"), frame, 4096) > 2 * frame > general
+    assert lib.hsrle_compress_workspace_size_codec(cid("rle32_1symlut_byte_short_greedy"), frame, 4096) > 2 * frame
+    for name in ("rle16_3symlut_byte_short_greedy", "rle64_7symlut_byte_short_greedy"):     # lists of 3 / 7 symbols decide the greedy scan's runs: one lane per block
+        assert lib.hsrle_encode_path(cid(name), frame, 8192) == RING and lib.hsrle_compress_workspace_size_codec(cid(name), frame, 4096) == general
     assert lib.hsrle_compress_workspace_size_codec(cid("rle128_sym"), 8 << 30, 4096) == lib.hsrle_compress_workspace_size(8 << 30, 4096)
     assert lib.hsrle_encode_path(cid("rle8_single_short"), frame, 4096) in (RING, SPLIT)
     assert lib.hsrle_encode_path(-1, frame, 4096) == -1 and lib.hsrle_encode_path(0, frame, 1000) == -1 and lib.hsrle_encode_path(0, 0, 4096) == -1

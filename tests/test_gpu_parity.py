@@ -767,6 +767,27 @@ def test_rle128_blocks_stress(hs, oracle, key):
         assert size == len(expect) and stream == expect, f"{key}: one-block stream of {n} bytes differs from the oracle"
 
 
+@pytest.mark.parametrize("key", ["rle16_1symlut_byte_short_greedy", "rle24_1symlut_byte_short_greedy", "rle32_1symlut_byte_short_greedy", "rle48_1symlut_byte_short_greedy",
+                                 "rle64_1symlut_byte_short_greedy", "rle32_7symlut_byte_short_greedy"])
+def test_greedy_small_containers_take_the_split_encode_bit_exact(hs, oracle, key):
+    """Small containers of the Greedy encoders with a list of ONE symbol (round 4): chunks inside the blocks, one lane each; the list in front of a
+    chunk is the symbol of the run it starts behind, guessed so, then proven round by round (csrc/hsrle_capi.hip compress_split).  (Lists of 3 / 7
+    symbols decide which runs the greedy scan stores: measured slower than one lane per block, they stay there -- one of them is here as the control.)"""
+    codec = CODEC_BY_KEY[key]
+    assert hs.lib().hsrle_encode_path(CODECS.index(codec), 4 << 20, 8192) == (1 if "_1symlut" in key else 0)     # SPLIT / RING
+    for kind, sym in ((SYNTH_VIDEO_KIND, codec.S), (0, codec.S), (SYNTH_VIDEO_KIND, 1)):
+        src = hs.synth(kind, sym, 5, (4 << 20) + 1234, device="cuda")
+        data = src.cpu().numpy().tobytes()
+        for block_size in (4096, 1024, 8192, 65536):
+            container, info = hs.compress(key, src, block_size=block_size)
+            cinfo, streams = hs.split_container(container.cpu().numpy().tobytes())
+            expect = oracle.compress_blocks(codec, np.frombuffer(data, dtype=np.uint8), block_size)
+            assert len(streams) == len(expect)
+            for i, (a, b) in enumerate(zip(streams, expect)):
+                assert a == b, f"{key} block {i} of size {block_size} (kind {kind}, symbol {sym}) differs from the oracle"
+            assert hs.decompress(container).cpu().numpy().tobytes() == data
+
+
 @pytest.mark.parametrize("key", ["rle8_multi", "rle8_packed_multi", "rle8_7symlut", "rle8_3symlut_short", "rle16_sym_packed", "rle16_3symlut_byte", "rle16_1symlut_sym_short"])
 def test_ring_chosen_per_input(hs, oracle, key):
     """Containers of >= 131 072 blocks: the encoders of 1 / 2 byte symbols probe the input and run with a 128- or a 256-byte history ring
