@@ -693,7 +693,7 @@ static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, ui
     unsigned long long *tiles = (unsigned long long *)(ws + w.offSlots + kTicketBytes);
     WaveEncodeArgs wa{ (const uint8_t *)dIn, U, B, nBlocks, offsets, payload, tiles, ticket };
     if (w.offSizes - w.offSlots < kTicketBytes + 8ull * nBlocks) rc = HSRLE_ERR_CAPACITY;
-    else if (hipMemsetAsync(ticket, 0, kTicketBytes + 8ull * nBlocks, st) != hipSuccess || g_wenc[codec](wa, st) != hipSuccess)
+    else if (zero_async(ticket, kTicketBytes + 8ull * nBlocks, st) != hipSuccess || g_wenc[codec](wa, st) != hipSuccess)
       rc = HSRLE_ERR_DEVICE;
   }
   else
@@ -1252,7 +1252,7 @@ static int compress_split(int codec, const uint8_t *dIn, uint64_t U, uint32_t B,
   uint32_t *flags = (uint32_t *)(ws + w.spFlags), *sizes = (uint32_t *)(ws + w.spSizes), *firstChunk = (uint32_t *)(ws + w.spFirst), *ctrl = (uint32_t *)(ws + w.spCtrl);
   Workspace sw{};
   sw.offL1 = w.spL1; sw.offL2 = w.spL2; sw.offL3 = w.spL3;
-  if (hipMemsetAsync(ctrl, 0, 64, st) != hipSuccess || hipMemsetAsync(sizes, 0, 4ull * (maxChunks + 1ull), st) != hipSuccess)
+  if (zero_async(ctrl, 64, st) != hipSuccess || zero_async(sizes, 4ull * (maxChunks + 1ull), st) != hipSuccess)   // (graph capturable: not hipMemsetAsync, see zero_async)
     return HSRLE_ERR_DEVICE;
   const dim3 cgrid((pieces + 63u) / 64u);
   const bool single = codec == 4 || codec == 5;
@@ -1622,7 +1622,7 @@ static int rle8m_decode_async(const void *dStream, uint64_t streamSize, uint32_t
   // the caller has checked device_ok()
   if (!dStream || !dOut || streamSize < 12 || sections == 0 || uncompressedSize == 0 || outCapacity < uncompressedSize)
     return HSRLE_ERR_ARGUMENT;
-  if (dStatus && hipMemsetAsync(dStatus, 0, 4, st) != hipSuccess)
+  if (dStatus && zero_async(dStatus, 4, st) != hipSuccess)               // (a kernel, not hipMemsetAsync: graph capturable, see zero_async)
     return HSRLE_ERR_DEVICE;
   // few, large sections: one wave per section (one lane per section needs ~1e5 sections to fill the GPU)
   static const int forced = (int)knob_u32("HSRLE_RLE8M_DECODE", 0);   // 1 = lane, 2 = wave kernel (A/B runs)
@@ -1686,7 +1686,7 @@ static int rle8m_encode_async(const void *dIn, uint32_t n, uint32_t sections, vo
   Rle8mTables *t = (Rle8mTables *)(ws + p.offTables);
   uint64_t *offsets = (uint64_t *)(ws + p.offOffsets);
   uint32_t *sizes = (uint32_t *)(ws + p.w.offSizes);
-  if (hipMemsetAsync(t, 0, sizeof(Rle8mTables), st) != hipSuccess || (dStatus && hipMemsetAsync(dStatus, 0, 4, st) != hipSuccess))
+  if (zero_async(t, sizeof(Rle8mTables), st) != hipSuccess || (dStatus && zero_async(dStatus, 4, st) != hipSuccess))
     return HSRLE_ERR_DEVICE;
   const uint32_t grid = (sections + 63u) / 64u;
   // the statistics are over the whole input: one lane per 4 KiB piece, whatever the section count
@@ -1915,7 +1915,7 @@ static int le_encode_async(const void *dIn, uint32_t n, void *dOut, uint64_t out
   Rle8mTables *t = (Rle8mTables *)(ws + p.offTables);
   uint32_t *cuts = (uint32_t *)(ws + p.offCuts), *sizes = (uint32_t *)(ws + p.offSizes);
   uint64_t *offsets = (uint64_t *)(ws + p.offOffsets);
-  if (hipMemsetAsync(t, 0, sizeof(Rle8mTables), st) != hipSuccess || (dStatus && hipMemsetAsync(dStatus, 0, 8, st) != hipSuccess))
+  if (zero_async(t, sizeof(Rle8mTables), st) != hipSuccess || (dStatus && zero_async(dStatus, 8, st) != hipSuccess))
     return HSRLE_ERR_DEVICE;
   {
     const uint32_t waves = (uint32_t)(((uint64_t)n + 4095u) / 4096u);
@@ -1949,7 +1949,7 @@ static int le_decode_async(const void *dStream, uint32_t streamSize, uint32_t da
   uint8_t *ws = (uint8_t *)dWs;
   uint32_t *carry = (uint32_t *)(ws + p.offCuts), *sizes = (uint32_t *)(ws + p.offSizes);
   uint64_t *outStart = (uint64_t *)(ws + p.offOffsets);
-  if (hipMemsetAsync(dStatus, 0, 8, st) != hipSuccess)
+  if (zero_async(dStatus, 8, st) != hipSuccess)
     return HSRLE_ERR_DEVICE;
   hipLaunchKernelGGL(k_le_carry, dim3((p.pieces + 63u) / 64u), dim3(64), 0, st, (const uint8_t *)dStream, (uint64_t)streamSize, G, p.pieces, carry, dStatus);
   hipLaunchKernelGGL(k_le_decode_wave<true>, dim3(p.pieces), dim3(64), 0, st, (const uint8_t *)dStream, (uint64_t)streamSize, (uint8_t *)dOut, dStatus, expOut, G, p.pieces,

@@ -105,6 +105,23 @@ __device__ __forceinline__ uint32_t zero_mask16(uint32_t t0, uint32_t t1, uint32
   return ~(((a23 << 8) | a01) >> 7) & 0xFFFFu;
 }
 
+// Zeroing of small tables on a stream by a KERNEL.  hipMemsetAsync is correct in eager mode, but captured into a HIP graph its node was seen to act on
+// the first replay only (ROCm 7.2, MI355X: experiments/r04/graph_single_repro2.py -- the second replay of a captured compress found its counters
+// not zeroed); a kernel node has no such surprise.  p: 4-byte aligned, bytes: rounded up to whole words.
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void k_zero_words(uint32_t *__restrict__ p, uint64_t words)
+{
+  for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < words; i += (uint64_t)gridDim.x * 256u) p[i] = 0u;
+}
+inline hipError_t zero_async(void *p, uint64_t bytes, hipStream_t st)
+{
+  const uint64_t words = (bytes + 3u) / 4u;
+  if (words == 0u) return hipSuccess;
+  const uint64_t wg = (words + 255u) / 256u;
+  hipLaunchKernelGGL((k_zero_words<0>), dim3((uint32_t)(wg < 2048u ? wg : 2048u)), dim3(256), 0, st, (uint32_t *)p, words);
+  return hipGetLastError();
+}
+
 // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs of the MI355X (workgroup i runs on XCD i % 8), each with
 // its own L2 and TLBs.  Mapping workgroup i to tile (i % 8) * (n / 8) + i / 8 gives every XCD one contiguous eighth of the tiles
 // instead of every eighth tile, so the waves resident on an XCD work on one compact region of their buffers: 8x fewer pages and

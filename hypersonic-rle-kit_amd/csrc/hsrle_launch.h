@@ -227,7 +227,7 @@ inline hipError_t launch_encode_ring(K256 k256, K128 k128, const EncodeArgs &a, 
     return launch_encode(k256, a, st, 0);
   if (forced == 128)
     return launch_encode(k128, a, st, 0);
-  if (hipMemsetAsync(a.ringSel, 0, 16, st) != hipSuccess) return hipErrorUnknown;
+  if (zero_async(a.ringSel, 16, st) != hipSuccess) return hipErrorUnknown;   // (a kernel, not hipMemsetAsync: hsrle_common.hip.h zero_async)
   const uint32_t samples = a.nBlocks < 256u ? a.nBlocks : 256u;
   hipLaunchKernelGGL((k_ring_probe<S>), dim3(samples), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.ringSel);
   hipLaunchKernelGGL((k_ring_decide<S>), dim3(1), dim3(64), 0, st, a.ringSel);
@@ -248,7 +248,7 @@ inline hipError_t launch_encode_list_or_ring(KRING kring, KLIST klist, const Enc
   static const uint32_t forced = knob_u32("HSRLE_RUNLIST", 0u);
   if (a.residentWorkgroups != nullptr || a.ringSel == nullptr || forced == 2u || a.B < 1024u || a.B > 4096u || a.nBlocks < 131072u)
     return launch_encode(kring, a, st, 0);
-  if (hipMemsetAsync(a.ringSel, 0, 16, st) != hipSuccess) return hipErrorUnknown;
+  if (zero_async(a.ringSel, 16, st) != hipSuccess) return hipErrorUnknown;   // (a kernel, not hipMemsetAsync: hsrle_common.hip.h zero_async)
   hipLaunchKernelGGL((k_ring_probe<S>), dim3(256), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.ringSel);
   hipLaunchKernelGGL((k_list_decide<S>), dim3(1), dim3(64), 0, st, a.ringSel);
   hipLaunchKernelGGL(kring, dim3((a.nBlocks + 63u) / 64u), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, (const uint64_t *)nullptr, (uint64_t *)nullptr,

@@ -119,6 +119,27 @@ __global__ __launch_bounds__(64) void k_mono_cuts8(const uint8_t *__restrict__ i
 // rotated symbol); so a stretch is a cut only if its start is CLEAN: no stretch of >= S set bits ends within the S positions in front
 // of it (then the encoder's search position is at or in front of q when it gets there, and the run is [q, e) with symbol d[q, q + S)).
 // cutSym[c] = that symbol (low S bytes).  Stretches that begin in front of the lane's look-back are not used.
+// bit j: m[j .. j + S) are all set (bits beyond 31 count as clear)
+template <int S>
+__device__ __forceinline__ uint32_t stretch_of_s(uint32_t m)
+{
+  const uint32_t a = m & (m >> 1);                                       // 2
+  if constexpr (S == 2) return a;
+  else if constexpr (S == 3) return a & (m >> 2);
+  else
+  {
+    const uint32_t b = a & (a >> 2);                                     // 4
+    if constexpr (S == 4) return b;
+    else if constexpr (S == 6) return b & (a >> 4);
+    else
+    {
+      const uint32_t c = b & (b >> 4);                                   // 8
+      if constexpr (S == 8) return c;
+      else { static_assert(S == 16, "symbols of 2, 3, 4, 6, 8 or 16 bytes"); return c & (c >> 8); }
+    }
+  }
+}
+
 template <int S, int ALIGNED>
 __global__ __launch_bounds__(64) void k_mono_cutsS(const uint8_t *__restrict__ in, uint64_t U, uint32_t G, uint32_t pieces, uint32_t LONGC, uint64_t *__restrict__ cutPos,
                                                    uint64_t *__restrict__ cutSym, uint32_t *__restrict__ flags, uint32_t blockB = 0)
@@ -175,6 +196,21 @@ __global__ __launch_bounds__(64) void k_mono_cutsS(const uint8_t *__restrict__ i
     {
       m = 0u; have = (uint32_t)(U - SU - j);
       for (uint32_t k = 0; k < have; k++) m |= (in[j + k] == in[j + k + SU]) ? (1ull << k) : 0ull;
+    }
+    // Most windows of noisy data hold no stretch of S set bits and end none: then all that happens is that the stretch open at the window's end
+    // (if any) begins -- straight-line code instead of a divergent trip per stretch (88 MB frame, 16 byte symbols: the finder 93 us, half of it
+    // in the stretch loop).  Not taken near the piece's end (the loop below knows when to stop there).
+    if (have == 32u && (uint32_t)m != 0xFFFFFFFFu && j + 32u <= hiEnd)
+    {
+      const uint32_t m32 = (uint32_t)m, lead = (uint32_t)__builtin_ctz(~m32);
+      if (ones + lead < SU && stretch_of_s<S>(m32) == 0u)
+      {
+        const uint32_t trail = (m32 >> 31) ? (uint32_t)__builtin_clz(~m32) : 0u;
+        ones = trail;
+        if (trail != 0u) stretch_begins(j + 32u - trail);
+        j += 32u;
+        continue;
+      }
     }
     uint32_t pos = 0;
     while (pos < have)

@@ -547,16 +547,19 @@ print("CAPTURE_OK")
     assert r.returncode == 0 and "CAPTURE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
-def test_compress_and_decompress_are_graph_capturable(hs):
+@pytest.mark.parametrize("key,block", [("rle8_packed_multi", 4096), ("rle64_3symlut_byte", 4096), ("rle8_7symlut", 8192), ("rle8_single", 4096), ("rle128_sym_packed", 2048),
+                                       ("rle32_1symlut_byte_short_greedy", 4096), ("rle24_7symlut_byte_short_greedy", 4096)])
+def test_compress_and_decompress_are_graph_capturable(hs, key, block):
     """With a caller-provided workspace the async entry points only enqueue kernels on the given stream (no allocation, no
-    synchronisation), so they can be captured into a HIP graph and replayed (include/hsrle.h)."""
+    synchronisation), so they can be captured into a HIP graph and replayed (include/hsrle.h) -- whatever encoder the
+    container takes: run list (small containers of 1 .. 4 KiB blocks), split encode (other block sizes; Single, 128 bit and Greedy with one listed
+    symbol when the workspace is sized for the codec) or one lane per block."""
     import torch
 
-    size, block = (8 << 20) + 4096 * 3 + 77, 4096
-    key = "rle8_packed_multi"
-    src = hs.synth(hs.SYNTH_RUNS, 1, 9, size)
+    size = (8 << 20) + 4096 * 3 + 77
+    src = hs.synth(hs.SYNTH_RUNS, CODEC_BY_KEY[key].S, 9, size)
     dst = torch.empty(hs.container_bound(size, block), dtype=torch.uint8, device="cuda")
-    ws = torch.empty(hs.workspace_size(size, block), dtype=torch.uint8, device="cuda")
+    ws = torch.empty(hs.workspace_size(size, block, key), dtype=torch.uint8, device="cuda")
     out = torch.zeros(size, dtype=torch.uint8, device="cuda")
     status = torch.zeros(16, dtype=torch.int32, device="cuda")
     # eager run: fixes the container layout (sizes are data dependent, the data is not going to change its shape below)
@@ -576,6 +579,7 @@ def test_compress_and_decompress_are_graph_capturable(hs):
 
     for rep in range(3):
         dst.zero_(); out.zero_(); status.zero_()
+        ws.fill_(0xA5 + rep)            # nothing may depend on what an earlier run left in the workspace (a captured hipMemsetAsync acts on the FIRST replay only: csrc zero_async)
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(dst[: info.totalSize], eager), f"replay {rep}: container differs from the eager run"
