@@ -249,7 +249,7 @@ def mono_compress_dev(codec, src, dst=None, workspace=None, return_chunks=False)
     if need == 0:
         raise HsrleError(ERR_UNSUPPORTED, "hsrle_compress_mono_dev")
     if workspace is None or workspace.numel() < need:
-        workspace = torch.empty(need, dtype=torch.uint8, device=src.device)
+        workspace = _scratch(need, src.device)
     size, chunks = ctypes.c_uint32(0), ctypes.c_uint32(0)
     rc = _lib().hsrle_compress_mono_dev(cid, ctypes.c_void_p(src.data_ptr()), n, ctypes.c_void_p(dst.data_ptr()), dst.numel(), ctypes.c_void_p(workspace.data_ptr()),
                                         workspace.numel(), ctypes.byref(size), ctypes.byref(chunks), _stream_ptr())
@@ -278,7 +278,7 @@ def mono_decompress_dev(codec, stream_tensor, dst=None, workspace=None, return_s
     cid = codec_id(codec)
     need = _lib().hsrle_decompress_mono_workspace_size(cid, usize, csize)
     if workspace is None or workspace.numel() < need:
-        workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=stream_tensor.device)
+        workspace = _scratch(max(need, 256), stream_tensor.device)
     n = ctypes.c_uint32(0)
     stats = (ctypes.c_uint32 * 4)()
     rc = _lib().hsrle_decompress_mono_dev(cid, ctypes.c_void_p(stream_tensor.data_ptr()), csize, ctypes.c_void_p(dst.data_ptr()), dst.numel(),
@@ -308,6 +308,16 @@ def _stream_ptr(stream=None):
 
     s = stream if stream is not None else torch.cuda.current_stream()
     return ctypes.c_void_p(s.cuda_stream)
+
+
+def _scratch(n, device):
+    """A workspace tensor.  HSRLE_POISON_WORKSPACE=1 (the test suite sets it) fills it with garbage first: the library must not rely on
+    a workspace that happens to be zero."""
+    import torch
+
+    if os.environ.get("HSRLE_POISON_WORKSPACE") == "1":
+        return torch.full((n,), 0xC3, dtype=torch.uint8, device=device)
+    return torch.empty(n, dtype=torch.uint8, device=device)
 
 
 def _check_u8_cuda(t, what):

@@ -6,6 +6,7 @@ import pytest
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "tests"))
 sys.path.insert(0, os.path.join(REPO, "hypersonic-rle-kit_amd", "python"))
+os.environ.setdefault("HSRLE_POISON_WORKSPACE", "1")   # workspaces the Python layer allocates for the tests start as garbage, not as fresh (zero) pages
 
 
 def pytest_configure(config):

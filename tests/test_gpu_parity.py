@@ -285,7 +285,7 @@ def test_rle8m_encode_matches_the_oracle(hs, oracle):
         # device resident: encode + decode without leaving the GPU
         src = _to_dev(data)
         dst = torch.empty(hs.rle8m_bounds(sections, len(data)), dtype=torch.uint8, device="cuda")
-        ws = torch.empty(hs.rle8m_workspace_size(len(data), sections), dtype=torch.uint8, device="cuda")
+        ws = torch.full((hs.rle8m_workspace_size(len(data), sections),), 0xC3, dtype=torch.uint8, device="cuda")   # (garbage: nothing may rely on a zeroed workspace)
         status = torch.ones(1, dtype=torch.int32, device="cuda")
         hs.rle8m_compress_async(src, sections, dst, ws, status)
         torch.cuda.synchronize()
@@ -559,7 +559,7 @@ def test_compress_and_decompress_are_graph_capturable(hs, key, block):
     size = (8 << 20) + 4096 * 3 + 77
     src = hs.synth(hs.SYNTH_RUNS, CODEC_BY_KEY[key].S, 9, size)
     dst = torch.empty(hs.container_bound(size, block), dtype=torch.uint8, device="cuda")
-    ws = torch.empty(hs.workspace_size(size, block, key), dtype=torch.uint8, device="cuda")
+    ws = torch.full((hs.workspace_size(size, block, key),), 0xC3, dtype=torch.uint8, device="cuda")
     out = torch.zeros(size, dtype=torch.uint8, device="cuda")
     status = torch.zeros(16, dtype=torch.int32, device="cuda")
     # eager run: fixes the container layout (sizes are data dependent, the data is not going to change its shape below)

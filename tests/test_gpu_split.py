@@ -41,7 +41,7 @@ def _split(hs, container, info, n, sub, first=0, count=None, guard=0):
     import torch
 
     count = info.blockCount - first if count is None else count
-    ws = torch.empty(max(hs.split_workspace_size(info, count, sub), 16), dtype=torch.uint8, device="cuda")
+    ws = torch.full((max(hs.split_workspace_size(info, count, sub), 16),), 0xC3, dtype=torch.uint8, device="cuda")   # (garbage: nothing may rely on a zeroed workspace)
     out = torch.full((n + guard,), 0xA5, dtype=torch.uint8, device="cuda")
     status = torch.zeros(1, dtype=torch.int32, device="cuda")
     hs.decompress_split_async(container, info, out[:n], ws, status, sub_block=sub, first_block=first, block_count=count)
@@ -90,7 +90,7 @@ def test_split_decode_into_an_output_that_is_not_16_byte_aligned(hs):
     src = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
     for key in ("rle8_packed_multi", "rle24_3symlut_byte", "rle64_sym_short"):
         container, info = hs.compress(key, src, block_size=4096)
-        ws = torch.empty(max(hs.split_workspace_size(info, None, PACKET_LIST), 16), dtype=torch.uint8, device="cuda")
+        ws = torch.full((max(hs.split_workspace_size(info, None, PACKET_LIST), 16),), 0xC3, dtype=torch.uint8, device="cuda")
         for shift in (1, 7, 8):
             out = torch.full((len(data) + 64,), 0xA5, dtype=torch.uint8, device="cuda")
             status = torch.zeros(1, dtype=torch.int32, device="cuda")
