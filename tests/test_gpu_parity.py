@@ -808,3 +808,29 @@ def test_ring_chosen_per_input(hs, oracle, key):
         for i in list(range(0, len(streams), 97)) + [len(streams) - 1]:
             assert streams[i] == oracle.compress(codec, data[i * 1024 : (i + 1) * 1024]), f"{key} kind {kind}: block {i} differs from the oracle"
         assert torch.equal(hs.decompress(container), src)
+
+
+@pytest.mark.parametrize("key", ["rle8_packed_multi", "rle8_3symlut", "rle8_single", "rle8_single_short", "rle16_sym", "rle24_7symlut_byte", "rle32_byte_packed", "rle48_3symlut_sym_short",
+                                 "rle64_3symlut_byte", "rle128_sym_packed", "rle32_1symlut_byte_short_greedy", "rle64_7symlut_byte_short_greedy"])
+def test_input_and_output_need_no_alignment(hs, oracle, key):
+    """Device pointers into the middle of a caller's buffers: the input of the encoders and the output of the decoders at byte offsets 1, 3, 8
+    (the container itself is the library's layout and 16-byte aligned by contract).  Small and mid-size containers, so that the run list / split
+    encoders and the ring encoders are all on the path; streams == the oracle's, decode == the input, nothing written outside the output."""
+    import torch
+
+    codec = CODEC_BY_KEY[key]
+    for size, block in (((1 << 20) + 333, 4096), ((3 << 20) + 5, 1024), ((2 << 20) + 77, 16384), (200001, 384)):
+        base = hs.synth(hs.SYNTH_RUNS if size & 1 else SYNTH_VIDEO_KIND, codec.S, 11, size + 64, device="cuda")
+        for off in (1, 3, 8):
+            src = base[off : off + size]
+            data = src.cpu().numpy().tobytes()
+            container, info = hs.compress(key, src, block_size=block)
+            cinfo, streams = hs.split_container(container.cpu().numpy().tobytes())
+            expect = oracle.compress_blocks(codec, np.frombuffer(data, dtype=np.uint8), block)
+            assert streams == expect, f"{key}: input at offset {off}, block size {block}: streams differ from the oracle"
+            outbuf = torch.full((size + 64,), 0xA5, dtype=torch.uint8, device="cuda")
+            status = torch.zeros(4, dtype=torch.int32, device="cuda")
+            hs.decompress_async(container, info, outbuf[off : off + size], status)
+            torch.cuda.synchronize()
+            host = outbuf.cpu().numpy().tobytes()
+            assert int(status[0].item()) == 0 and host[off : off + size] == data and set(host[:off]) == {0xA5} and set(host[off + size :]) == {0xA5}, f"{key}: output at offset {off}, block size {block}"
