@@ -699,7 +699,10 @@ static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, ui
   else
 #endif
   if (w.nChunks <= 1 && w.spSlots != 0 && split_encode_applies(codec, w.nBlocks, B))
+  {
     rc = compress_split(codec, (const uint8_t *)dIn, U, B, nBlocks, ws, w, offsets, payload, st);
+    finished = true;                                                    // (k_split_finish wrote header and tail pad)
+  }
   else if (w.nChunks > 1 && aux == nullptr)
     rc = HSRLE_ERR_DEVICE;
   else if (w.nChunks <= 1)
@@ -1252,7 +1255,7 @@ static int compress_split(int codec, const uint8_t *dIn, uint64_t U, uint32_t B,
   uint32_t *flags = (uint32_t *)(ws + w.spFlags), *sizes = (uint32_t *)(ws + w.spSizes), *firstChunk = (uint32_t *)(ws + w.spFirst), *ctrl = (uint32_t *)(ws + w.spCtrl);
   Workspace sw{};
   sw.offL1 = w.spL1; sw.offL2 = w.spL2; sw.offL3 = w.spL3;
-  if (zero_async(ctrl, 64, st) != hipSuccess || zero_async(sizes, 4ull * (maxChunks + 1ull), st) != hipSuccess)   // (graph capturable: not hipMemsetAsync, see zero_async)
+  if (zero2_async(ctrl, 64, sizes, 4ull * (maxChunks + 1ull), st) != hipSuccess)   // (graph capturable: not hipMemsetAsync, see zero_async)
     return HSRLE_ERR_DEVICE;
   const dim3 cgrid((pieces + 63u) / 64u);
   const bool single = codec == 4 || codec == 5;
@@ -1323,8 +1326,12 @@ static int compress_split(int codec, const uint8_t *dIn, uint64_t U, uint32_t B,
   }
   if (scan_sizes(sizes, maxChunks, chunkOff, ws, sw, st) != hipSuccess)
     return HSRLE_ERR_DEVICE;
-  hipLaunchKernelGGL(k_compact_var, dim3((maxChunks + 3u) / 4u), dim3(256), 0, st, (const uint8_t *)(ws + w.spSlots), (const uint64_t *)slotOff, (const uint64_t *)chunkOff, payload, maxChunks);
-  hipLaunchKernelGGL(k_split_finish, dim3((nBlocks + 255u) / 256u), dim3(256), 0, st, (const uint32_t *)firstChunk, (const uint64_t *)chunkOff, nBlocks, offsets, payload);
+  launch_compact_var(G <= 2048u, (const uint8_t *)(ws + w.spSlots), (const uint64_t *)slotOff, (const uint64_t *)chunkOff, payload, maxChunks, st);
+  // (... and the container's header and tail pad: the caller does not launch k_finish_container behind a split encode)
+  uint8_t *const container = (uint8_t *)offsets - HSRLE_CONTAINER_HEADER_SIZE;
+  const uint32_t codecId = (uint32_t)codec;
+  auto finish = [=] __device__(uint64_t payloadSize) { finish_container(container, codecId, U, B, nBlocks, payloadSize); };
+  hipLaunchKernelGGL((k_split_finish<decltype(finish)>), dim3((nBlocks + 255u) / 256u), dim3(256), 0, st, (const uint32_t *)firstChunk, (const uint64_t *)chunkOff, nBlocks, offsets, payload, finish);
   return hipGetLastError() == hipSuccess ? HSRLE_OK : HSRLE_ERR_DEVICE;
 }
 
@@ -1506,7 +1513,7 @@ static int mono_encode_dev(int codec, const uint8_t *dIn, uint32_t U, uint8_t *d
   }
   if (scan_sizes(sizes, chunks, offsets, ws, w, st) != hipSuccess)
     return HSRLE_ERR_DEVICE;
-  hipLaunchKernelGGL(k_compact_var, dim3((chunks + 3u) / 4u), dim3(256), 0, st, (const uint8_t *)(ws + m.offSlots), (const uint64_t *)slotOff, (const uint64_t *)offsets, dOut + hs, chunks);
+  launch_compact_var(false, (const uint8_t *)(ws + m.offSlots), (const uint64_t *)slotOff, (const uint64_t *)offsets, dOut + hs, chunks, st);
   if (single)
     hipLaunchKernelGGL(k_mono_zero_sizes, dim3((chunks + 255u) / 256u), dim3(256), 0, st, (const uint32_t *)sizes, chunks, ctrl + 5);
   hipLaunchKernelGGL(k_mono_finish, dim3(1), dim3(64), 0, st, dOut, U, hs, (const uint64_t *)offsets, (const uint32_t *)ctrl, ctrl, codec == kSingleShort ? 1u : 0u);

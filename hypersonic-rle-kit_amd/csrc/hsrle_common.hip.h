@@ -113,6 +113,21 @@ __global__ __launch_bounds__(256) void k_zero_words(uint32_t *__restrict__ p, ui
 {
   for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < words; i += (uint64_t)gridDim.x * 256u) p[i] = 0u;
 }
+// ... two tables in one launch (a launch is ~5 us of a call of 270)
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void k_zero_words2(uint32_t *__restrict__ p, uint64_t words, uint32_t *__restrict__ q, uint64_t qwords)
+{
+  for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < words + qwords; i += (uint64_t)gridDim.x * 256u)
+    if (i < words) p[i] = 0u; else q[i - words] = 0u;
+}
+inline hipError_t zero2_async(void *p, uint64_t bytes, void *q, uint64_t qbytes, hipStream_t st)
+{
+  const uint64_t words = (bytes + 3u) / 4u, qwords = (qbytes + 3u) / 4u;
+  const uint64_t wg = (words + qwords + 255u) / 256u;
+  if (wg == 0u) return hipSuccess;
+  hipLaunchKernelGGL((k_zero_words2<0>), dim3((uint32_t)(wg < 2048u ? wg : 2048u)), dim3(256), 0, st, (uint32_t *)p, words, (uint32_t *)q, qwords);
+  return hipGetLastError();
+}
 inline hipError_t zero_async(void *p, uint64_t bytes, hipStream_t st)
 {
   const uint64_t words = (bytes + 3u) / 4u;

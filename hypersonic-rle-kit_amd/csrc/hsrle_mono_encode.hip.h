@@ -11,7 +11,7 @@
 //                   piece (the lane looks LONG bytes back, so a run that began in an earlier piece is seen long enough)
 //   k_mono_scatter  the pieces that found one, compacted: chunk starts, the symbol in front of every chunk, staging slot offsets
 //   k_encode*_blocks<.., MONO>   one lane per chunk
-//   k_compact_var   one wave per chunk: staging slot -> its place behind the 9 / 8 byte stream header
+//   k_compact_var_t a wave (or, for the small chunks of a container's blocks, a quarter wave) per chunk: staging slot -> its place behind the 9 / 8 byte stream header
 //   k_mono_finish   the stream header
 // Data without long runs (random bytes) gives few chunks or one: then one lane walks it all, as the block kernel would a huge block.
 #pragma once
@@ -370,12 +370,16 @@ __global__ __launch_bounds__(256) void k_mono_list_verify(uint64_t *__restrict__
   if (wrong) atomicAdd(bad, 1u);
 }
 
-// one wave per chunk: staging slot -> dst + offsets[c]
-__global__ __launch_bounds__(256) void k_compact_var(const uint8_t *__restrict__ slots, const uint64_t *__restrict__ slotOff, const uint64_t *__restrict__ offsets,
-                                                     uint8_t *__restrict__ dst, uint32_t chunks)
+// LANES lanes per chunk: staging slot -> dst + offsets[c].  A wave per chunk for the chunks of a monolithic stream (kilobytes each); a quarter wave for
+// the chunks of a small container's blocks (a 1 KiB piece of a video-shaped frame is ~170 bytes of stream: 11 of a wave's 64 lanes had work,
+// 88 MB frame 29 us)
+template <int LANES>
+__global__ __launch_bounds__(256) void k_compact_var_t(const uint8_t *__restrict__ slots, const uint64_t *__restrict__ slotOff, const uint64_t *__restrict__ offsets,
+                                                       uint8_t *__restrict__ dst, uint32_t chunks)
 {
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t c = blockIdx.x * 4u + (threadIdx.x >> 6);
+  static_assert(LANES == 16 || LANES == 64, "a quarter wave or a wave per chunk");
+  const uint32_t lane = threadIdx.x % (uint32_t)LANES;
+  const uint32_t c = blockIdx.x * (256u / (uint32_t)LANES) + threadIdx.x / (uint32_t)LANES;
   if (c >= chunks) return;
   const uint64_t off = offsets[c];
   const uint64_t size = offsets[c + 1u] - off;
@@ -385,10 +389,15 @@ __global__ __launch_bounds__(256) void k_compact_var(const uint8_t *__restrict__
   if (head > size) head = size;
   if (lane < head) d[lane] = src[lane];
   const uint64_t body = (size - head) & ~15ull;
-  for (uint64_t k = (uint64_t)lane * 16u; k < body; k += 64u * 16u)
+  for (uint64_t k = (uint64_t)lane * 16u; k < body; k += (uint64_t)LANES * 16u)
     st128(d + head + k, ld128(src + head + k));
   const uint64_t tail = size - head - body;
   if (lane < tail) d[head + body + lane] = src[head + body + lane];
+}
+inline void launch_compact_var(bool smallChunks, const uint8_t *slots, const uint64_t *slotOff, const uint64_t *offsets, uint8_t *dst, uint32_t chunks, hipStream_t st)
+{
+  if (smallChunks) hipLaunchKernelGGL((k_compact_var_t<16>), dim3((chunks + 15u) / 16u), dim3(256), 0, st, slots, slotOff, offsets, dst, chunks);
+  else hipLaunchKernelGGL((k_compact_var_t<64>), dim3((chunks + 3u) / 4u), dim3(256), 0, st, slots, slotOff, offsets, dst, chunks);
 }
 
 // the Single chunk encoders return 0 for a chunk that did not end on a stored run at its boundary (a cut that was none): ctrl[5] = 1, the
@@ -491,11 +500,14 @@ __global__ __launch_bounds__(256) void k_split_list_verify(uint64_t *__restrict_
   if (wrong) atomicAdd(bad, 1u);
 }
 
-// after the placement of the chunks: the container's offset table and every block stream's compressedLength field
+// after the placement of the chunks: the container's offset table, every block stream's compressedLength field, and (the workgroup of the last block)
+// the container's header and tail pad (FINISH: finish_container of hsrle_capi.hip -- one launch less)
+template <typename FINISH>
 __global__ __launch_bounds__(256) void k_split_finish(const uint32_t *__restrict__ firstChunk, const uint64_t *__restrict__ chunkOff, uint32_t nBlocks, uint64_t *__restrict__ offsets,
-                                                      uint8_t *__restrict__ payload)
+                                                      uint8_t *__restrict__ payload, FINISH finish)
 {
   const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+  if (blockIdx.x == (nBlocks - 1u) / 256u) finish(chunkOff[firstChunk[nBlocks]]);     // (every thread of this workgroup: finish_container hands out roles by threadIdx)
   if (b >= nBlocks) return;
   const uint64_t off = chunkOff[firstChunk[b]], next = chunkOff[firstChunk[b + 1u]];
   offsets[b] = off;
