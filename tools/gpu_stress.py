@@ -1,6 +1,6 @@
 # differential stress test on the GPU: python tools/gpu_stress.py [seconds] [seed]
-# random inputs of many shapes x all 110 codecs (+ rle8m) x several block sizes: every block stream must equal the oracle's, the decode must
-# equal the input, the status word must be 0.  Prints the first mismatches and a summary; exit code 1 on any failure.
+# random inputs of many shapes x all 110 codecs (+ rle8m) x several block sizes: every block stream must equal the oracle's, the decode (plain and
+# split: packet list / entry records) must equal the input, the status word must be 0; the drop-in functions' monolithic streams likewise.  Prints the first mismatches and a summary; exit code 1 on any failure.
 import sys, os, time, random
 sys.path.insert(0,'tests'); sys.path.insert(0,'hypersonic-rle-kit_amd/python')
 import numpy as np, torch, hsrle
@@ -45,6 +45,27 @@ while time.time()-t0<budget:
             hsrle.decompress_async(cont,info,out,st); torch.cuda.synchronize()
             if int(st[0].item())!=0 or not torch.equal(out,src):
                 bad+=1; print('DECODE MISMATCH',c.key,'block size',bs,'input len',len(data),'status',int(st[0].item()),'seed',seed,flush=True)
+            # the split decode of the same container: packet list (blocks of 256 B .. 16 KiB) or entry records every `sub` bytes; garbage workspace
+            if bs>=256 and rng.random()<0.5:
+                sub=1 if bs<=16384 and rng.random()<0.6 else rng.choice([s_ for s_ in (128,256,512,1024) if s_<=bs and bs%s_==0])
+                ws=torch.full((max(hsrle.split_workspace_size(info,None,sub),16),),0xC3,dtype=torch.uint8,device='cuda')
+                out.zero_(); st.zero_()
+                hsrle.decompress_split_async(cont,info,out,ws,st[:1],sub_block=sub); torch.cuda.synchronize()
+                cases+=1
+                if int(st[0].item())!=0 or not torch.equal(out,src):
+                    bad+=1; print('SPLIT DECODE MISMATCH',c.key,'block size',bs,'sub',sub,'input len',len(data),'status',int(st[0].item()),'seed',seed,flush=True)
+    # the drop-in functions (host pointers, ONE monolithic stream: many-lane encode, index + block decode): stream == oracle's, round trip
+    if len(data)<=(1<<20):
+        for c in rng.sample(CODECS,min(3,len(CODECS))):
+            want=ora.compress(c,data)
+            size,got=hsrle.call_dropin(c.cname,data,hsrle.compress_bounds(len(data)))
+            cases+=1
+            if size!=len(want) or got!=want:
+                bad+=1; print('DROP-IN ENCODE MISMATCH',c.key,'input len',len(data),'gpu',size,'oracle',len(want),'seed',seed,flush=True)
+            else:
+                n2,back=hsrle.call_dropin(c.dname,want,len(data))
+                if n2!=len(data) or back!=data:
+                    bad+=1; print('DROP-IN DECODE MISMATCH',c.key,'input len',len(data),'gpu',n2,'seed',seed,flush=True)
     # rle8m: stream == oracle's (None where the reference gives up or overruns its output), decode == input
     for sections in rng.sample([1,2,3,7,16,64,255,1024,max(1,len(data)//rng.choice([5,64,333,4096]))],3):
         if len(data)//sections==0 or len(data)>(1<<22): continue
