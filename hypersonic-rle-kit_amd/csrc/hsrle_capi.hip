@@ -1221,19 +1221,19 @@ static bool run_list_codec(int codec) { return codec <= 3 || (codec >= 6 && code
 // the codecs that have a many-lane chunk encoder but no run list encoder: small containers of 1 .. 4 KiB blocks take the split encode IF the
 // caller's workspace has its regions (hsrle_compress_workspace_size_codec; the library's own scratch always has)
 static bool greedy_one_symbol_list(int codec) { return codec >= kGreedyBase && codec < kSingleShort && (codec - kGreedyBase) % 3 == 0; }
-static bool split_codec_small(int codec) { return codec == 4 || codec == 5 || (codec >= 46 && codec < 50) || greedy_one_symbol_list(codec); }
+static bool split_codec_small(int codec) { return codec == 4 || codec == 5 || codec == kSingleShort || (codec >= 46 && codec < 50) || greedy_one_symbol_list(codec); }
 
 static bool split_encode_applies(int codec, uint64_t nBlocks, uint32_t B)
 {
   // the codecs whose ring encoders have the chunk mode, and (round 4) 8 bit Single and 128 bit with the per-lane chunk encoders of the monolithic path
   // rle8_multi / rle8_packed_multi / rle8_{3,7}symlut (ids 0 .. 3), the plain / Packed / LUT codecs of 2 .. 8 byte symbols (ids 6 .. 45) and their Short family (ids 50 .. 93): the run list encoders take these whole
   if (run_list_codec(codec) && run_list_applies(nBlocks, B, 1024u, knob_u32("HSRLE_RUNLIST", 0u))) return false;
-  if (nBlocks >= kSplitEncodeBelow || B < 1024u || B > (1u << 20) || (B % (kSplitPieces * 128u)) != 0u || codec == kSingleShort) return false;   // (rle8_single_short: chunks of ONE stream only)
+  if (nBlocks >= kSplitEncodeBelow || B < 1024u || B > (1u << 20) || (B % (kSplitPieces * 128u)) != 0u) return false;
   // Greedy: the lists of 3 / 7 symbols decide which runs the scan stores, so a chunk's list is only known when the chunk in front of it is final --
   // measured (88 MB frame, rle32_7symlut: two full passes + three repair rounds 3.7 ms against 3.1 ms with one lane per block); a list of ONE symbol
   // behind a stored run is that run's symbol, and the first guess is right
-  if (codec >= kGreedyBase && !greedy_one_symbol_list(codec)) return false;
-  if ((codec == 4 || codec == 5) && B > 32768u) return false;           // (the per-block symbol pick holds a block in LDS: hsrle_encode8s.hip.h)
+  if (codec >= kGreedyBase && codec < kSingleShort && !greedy_one_symbol_list(codec)) return false;
+  if ((codec == 4 || codec == 5 || codec == kSingleShort) && B > 32768u) return false;   // (the per-block symbol pick holds a block in LDS: hsrle_encode8s.hip.h)
   init_tables();
   return mono_cut_long(codec) != 0u && g_menc[codec] != nullptr;
 }
@@ -1258,7 +1258,7 @@ static int compress_split(int codec, const uint8_t *dIn, uint64_t U, uint32_t B,
   if (zero2_async(ctrl, 64, sizes, 4ull * (maxChunks + 1ull), st) != hipSuccess)   // (graph capturable: not hipMemsetAsync, see zero_async)
     return HSRLE_ERR_DEVICE;
   const dim3 cgrid((pieces + 63u) / 64u);
-  const bool single = codec == 4 || codec == 5;
+  const bool single = codec == 4 || codec == 5 || codec == kSingleShort;
   uint32_t *const pickTable = (uint32_t *)(ws + w.spPick);             // (8 bit Single: a byte per block)
   if (single)
   {
@@ -1450,7 +1450,7 @@ static int mono_encode_dev(int codec, const uint8_t *dIn, uint32_t U, uint8_t *d
   EncodeArgs ea{ dIn, (uint64_t)U, 0u, chunks, ws + m.offSlots, 0u, sizes };
   MonoEncodeArgs ma{ starts, syms, slotOff, 2u * (longest / 64u) + 64u };
   ma.pick = ctrl + 8;
-  if (single && codec != kSingleShort) { ma.jobs = (uint64_t *)(ws + m.offJobs); ma.jobCount = ctrl + 12; ma.jobCap = m.jobCap; }   // (ctrl[12] was zeroed with the rest)
+  if (single) { ma.jobs = (uint64_t *)(ws + m.offJobs); ma.jobCount = ctrl + 12; ma.jobCap = m.jobCap; }   // (ctrl[12] was zeroed with the rest)
   if (listK == 0)
   {
     if (g_menc[codec](ea, ma, st) != hipSuccess)

@@ -337,11 +337,22 @@ __global__ __launch_bounds__(64) void k_encode_single_short_blocks(const uint8_t
       process(count, (uint32_t)i);
     }
     count = 0;
+    bool streak = false;                                                // the last window was skipped: four at a time (one dependent load per window otherwise)
     while (i < end)
     {
+      if (streak && i + 48 < end)
+      {
+        const Cmp16 b0(d + i, bs), b1(d + i + 16, bs), b2(d + i + 32, bs), b3(d + i + 48, bs);
+        const bool s0 = !b0.any() || (!b0.lastByte() && b0.pop() < 2u), s1 = !b1.any() || (!b1.lastByte() && b1.pop() < 2u);
+        const bool s2 = !b2.any() || (!b2.lastByte() && b2.pop() < 2u), s3 = !b3.any() || (!b3.lastByte() && b3.pop() < 2u);
+        if (s0 && s1 && s2 && s3) { i += 64; continue; }
+      }
       const Cmp16 w(d + i, bs);
       if (!w.any() || (!w.lastByte() && w.pop() < 2u))
+      {
         i += 16;
+        streak = true;
+      }
       else
       {
         i += w.first();
@@ -383,12 +394,29 @@ __global__ __launch_bounds__(64) void k_encode_single_short_blocks(const uint8_t
 // belong to the last chunk, no stream header; a chunk in front of the last ends with its boundary run's packet.  Returns the chunk's
 // stream bytes, 0 if the chunk did not end on a stored run at its boundary (the cut was wrong: the caller falls back to one lane).
 template <int FAM>
-__device__ inline uint32_t encode_chunk_single_short(const uint8_t *d, uint32_t nChunk, uint32_t nTrue32, uint32_t sym, Sink &s)
+__device__ inline uint32_t encode_chunk_single_short(const uint8_t *d, uint32_t nChunk, uint32_t nTrue32, uint32_t sym, Sink &s, const CopyJobs &jobs)
 {
   using TR = Traits<FAM, 1, 0>;
   const uint32_t bs = sym * 0x01010101u;
   const bool finalChunk = nChunk == nTrue32;
   uint32_t lastRLE = 0;
+  // long literal stretches are NOTED for k_copy_jobs, not copied by this one lane (as encode_chunk_single, hsrle_encode.hip.h: data its symbol is rare in
+  // is all literals -- 64 MiB run-distributed in 4 KiB blocks: 709 us with the lanes copying)
+  auto put_literals = [&](uint32_t from, uint32_t len) {
+    if (len >= kCopyJobMin && jobs.list != nullptr)
+    {
+      const uint32_t k = atomicAdd(jobs.count, 1u);
+      if (k < jobs.cap)
+      {
+        jobs.list[3ull * k] = jobs.srcBase + from;
+        jobs.list[3ull * k + 1] = jobs.dstBase + s.at;
+        jobs.list[3ull * k + 2] = len;
+        s.at += len;
+        return;
+      }
+    }
+    s.putn(d + from, len);
+  };
   auto process = [&](int32_t count, uint32_t i) -> bool {
     const uint32_t gap = i - lastRLE - (uint32_t)count;
     const uint32_t range = gap + 2u;
@@ -416,7 +444,7 @@ __device__ inline uint32_t encode_chunk_single_short(const uint8_t *d, uint32_t 
       if (scx != scu) { if (scu <= 0xFFFFu) s.put16(scu); else s.put32(scu); }
       if (rx != range) { if (range <= 0xFFFFu) s.put16(range); else s.put32(range); }
     }
-    s.putn(d + lastRLE, gap);
+    put_literals(lastRLE, gap);
     lastRLE = i;
     return true;
   };
@@ -440,11 +468,22 @@ __device__ inline uint32_t encode_chunk_single_short(const uint8_t *d, uint32_t 
         return (stored && i == stopAt) ? s.at : 0u;                     // the boundary run's packet ends the chunk
     }
     count = 0;
+    bool streak = false;                                                // the last window was skipped: four at a time (one dependent load per window otherwise)
     while (i < end)
     {
+      if (streak && i + 48 < end)
+      {
+        const Cmp16 b0(d + i, bs), b1(d + i + 16, bs), b2(d + i + 32, bs), b3(d + i + 48, bs);
+        const bool s0 = !b0.any() || (!b0.lastByte() && b0.pop() < 2u), s1 = !b1.any() || (!b1.lastByte() && b1.pop() < 2u);
+        const bool s2 = !b2.any() || (!b2.lastByte() && b2.pop() < 2u), s3 = !b3.any() || (!b3.lastByte() && b3.pop() < 2u);
+        if (s0 && s1 && s2 && s3) { i += 64; continue; }
+      }
       const Cmp16 w(d + i, bs);
       if (!w.any() || (!w.lastByte() && w.pop() < 2u))
+      {
         i += 16;
+        streak = true;
+      }
       else
       {
         i += w.first();
@@ -474,21 +513,34 @@ __device__ inline uint32_t encode_chunk_single_short(const uint8_t *d, uint32_t 
   {
     const uint32_t kLit = (uint32_t)n - lastRLE;
     s.put8(TR::SCINV << TR::SRBP); s.put8(TR::STB); s.put8(0); s.put16(0); s.put32(kLit + 2u);
-    s.putn(d + lastRLE, kLit);
+    put_literals(lastRLE, kLit);
   }
   return s.at;
 }
 
+// B != 0 (round 4): chunks of the blocks of a container (split encode of small containers, as k_encode_single_chunks: the block's end is the end of
+// the input, a block's first chunk writes the stream header and the symbol byte, pick = a symbol byte per block, chunkCount[0] = how many chunks there are)
 template <int FAM>
 __global__ __launch_bounds__(64) void k_encode_single_short_chunks(const uint8_t *__restrict__ in, uint64_t U, uint32_t chunks, const uint64_t *__restrict__ starts,
                                                                    const uint64_t *__restrict__ slotOff, uint8_t *__restrict__ slots, uint32_t *__restrict__ sizes,
-                                                                   const uint32_t *__restrict__ pick)
+                                                                   const uint32_t *__restrict__ pick, uint64_t *__restrict__ jobList, uint32_t *__restrict__ jobCount, uint32_t jobCap,
+                                                                   uint32_t B, const uint32_t *__restrict__ chunkCount)
 {
   const uint32_t c = blockIdx.x * 64u + threadIdx.x;
+  if (B != 0u && chunkCount != nullptr) chunks = umin(chunks, chunkCount[0]);
   if (c >= chunks) return;
   const uint64_t start = starts[c];
   Sink s{ slots + slotOff[c], 0u, in + U };
-  sizes[c] = encode_chunk_single_short<FAM>(in + start, (uint32_t)(starts[c + 1u] - start), (uint32_t)(U - start), pick[0] & 0xFFu, s);
+  const CopyJobs jobs{ jobList, jobCount, jobCap, start, slotOff[c] };
+  if (B == 0u)
+  {
+    sizes[c] = encode_chunk_single_short<FAM>(in + start, (uint32_t)(starts[c + 1u] - start), (uint32_t)(U - start), pick[0] & 0xFFu, s, jobs);
+    return;
+  }
+  const uint64_t blk = start / B, blockEnd = ((blk + 1ull) * B < U) ? (blk + 1ull) * B : U;
+  const uint32_t sym = ((const uint8_t *)pick)[blk];
+  if (start == blk * B) { s.put32((uint32_t)(blockEnd - start)); s.put32(0); s.put8(sym); }     // (rleX_Xsl_short.h:1211-1216: 8 bytes, then the symbol)
+  sizes[c] = encode_chunk_single_short<FAM>(in + start, (uint32_t)(starts[c + 1u] - start), (uint32_t)(blockEnd - start), sym, s, jobs);
 }
 
 } // namespace hsrle

@@ -104,7 +104,20 @@ static hipError_t menc_lut7(const EncodeArgs &a, const MonoEncodeArgs &m, hipStr
 // rle8_single_short as chunks of one monolithic stream (round 4; hsrle_encode_greedy.hip.h)
 static hipError_t menc_single_short(const EncodeArgs &a, const MonoEncodeArgs &m, hipStream_t st)
 {
-  hipLaunchKernelGGL((k_encode_single_short_chunks<SHORT_SINGLE>), dim3((a.nBlocks + 63u) / 64u), dim3(64), 0, st, a.in, a.U, a.nBlocks, m.starts, m.slotOff, a.slots, a.sizes, m.pick);
+  if (m.phase == 1u)
+  {
+    // split encode of a container: the blocks' symbols (a byte per block) and their cuts, as menc_single_any
+    if (a.B > kSinglePickMaxBlock) return hipErrorInvalidValue;
+    const uint32_t padded = (a.B + 63u) & ~63u;
+    const uint32_t lds = 1024u + padded + 64u + (padded / 64u + 1u) * 8u;
+    hipLaunchKernelGGL(k_single_pick, dim3(a.nBlocks), dim3(64), lds, st, a.in, a.U, a.B, a.nBlocks, (uint8_t *)const_cast<uint32_t *>(m.pick), 1u, 0u, m.cutPos, m.cutSym, m.cutFlags,
+                       m.cutG, m.cutLong);
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL((k_encode_single_short_chunks<SHORT_SINGLE>), dim3((a.nBlocks + 63u) / 64u), dim3(64), 0, st, a.in, a.U, a.nBlocks, m.starts, m.slotOff, a.slots, a.sizes, m.pick,
+                     m.jobs, m.jobCount, m.jobCap, a.B, (const uint32_t *)a.ringSel);
+  if (m.jobs != nullptr)
+    hipLaunchKernelGGL((k_copy_jobs<0>), dim3(2048), dim3(256), 0, st, a.in, a.slots, (const uint64_t *)m.jobs, (const uint32_t *)m.jobCount, m.jobCap);
   return hipGetLastError();
 }
 // 8 bit Single as chunks of one monolithic stream: the first-generation scanner, one lane per chunk (hsrle_encode.hip.h)

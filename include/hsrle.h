@@ -258,7 +258,7 @@ uint32_t hsrle_suggest_block_size(uint64_t inSize);
 uint64_t hsrle_container_bound(uint64_t inSize, uint32_t blockSize);
 /* Scratch the compressor needs in device memory (per-block staging streams, sizes, scan partials). */
 uint64_t hsrle_compress_workspace_size(uint64_t inSize, uint32_t blockSize);
-/* The same for ONE codec.  Equal to the above except for the 8-bit Single codecs, the 128-bit codecs and the Greedy encoders with a one-symbol
+/* The same for ONE codec.  Equal to the above except for the 8-bit Single codecs (rle8_single_short too), the 128-bit codecs and the Greedy encoders with a one-symbol
  * list (rle{16..64}_1symlut_byte_short_compress_greedy) on containers of fewer than 131 072 blocks of 1 .. 4 KiB: they have no run list encoder, and their small containers are encoded chunk by chunk (cuts behind long runs inside the blocks)
  * only if the workspace holds the chunk tables and staging area (about 2.3 x the input); with the general size they take one lane per block. */
 uint64_t hsrle_compress_workspace_size_codec(int codec, uint64_t inSize, uint32_t blockSize);

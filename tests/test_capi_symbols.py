@@ -96,7 +96,7 @@ def test_encode_path_selection(lib):
         assert lib.hsrle_encode_path(cid(name), frame, 512) == RING, name
     for name in ("rle8_single", "rle8_packed_single", "rle128_sym", "rle128_byte_packed", "rle16_3symlut_byte_short_greedy"):
         assert lib.hsrle_encode_path(cid(name), frame, 4096) == RING, name          # (Single / 128 bit: split only with a workspace sized for the codec -- the host cannot know)
-    for name in ("rle8_single", "rle8_packed_single", "rle128_sym", "rle128_byte_packed", "rle16_1symlut_byte_short_greedy", "rle64_1symlut_byte_short_greedy"):
+    for name in ("rle8_single", "rle8_packed_single", "rle128_sym", "rle128_byte_packed", "rle16_1symlut_byte_short_greedy", "rle64_1symlut_byte_short_greedy", "rle8_single_short"):
         assert lib.hsrle_encode_path(cid(name), frame, 8192) == SPLIT, name         # round 4: their chunk encoders take the blocks of a container too
     lib.hsrle_compress_workspace_size.restype = ctypes.c_uint64
     lib.hsrle_compress_workspace_size.argtypes = [ctypes.c_uint64, ctypes.c_uint32]
@@ -109,7 +109,7 @@ def test_encode_path_selection(lib):
     for name in ("rle16_3symlut_byte_short_greedy", "rle64_7symlut_byte_short_greedy"):     # lists of 3 / 7 symbols decide the greedy scan's runs: one lane per block
         assert lib.hsrle_encode_path(cid(name), frame, 8192) == RING and lib.hsrle_compress_workspace_size_codec(cid(name), frame, 4096) == general
     assert lib.hsrle_compress_workspace_size_codec(cid("rle128_sym"), 8 << 30, 4096) == lib.hsrle_compress_workspace_size(8 << 30, 4096)
-    assert lib.hsrle_encode_path(cid("rle8_single_short"), frame, 4096) in (RING, SPLIT)
+    assert lib.hsrle_encode_path(cid("rle8_single_short"), frame, 4096) == RING and lib.hsrle_compress_workspace_size_codec(cid("rle8_single_short"), frame, 4096) > 2 * frame
     assert lib.hsrle_encode_path(-1, frame, 4096) == -1 and lib.hsrle_encode_path(0, frame, 1000) == -1 and lib.hsrle_encode_path(0, 0, 4096) == -1
 
 
