@@ -408,6 +408,7 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
     avail = umin(avail + (take << 4), n);
   };
 
+  [[maybe_unused]] uint32_t nrec = 0;
   // ---- one finished run [p, e): decide, and if emitted write the packet ----
   auto handle_run = [&](uint32_t p, uint32_t e) {
     const uint32_t count = e - p;
@@ -478,6 +479,23 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
 
     if (!k)
       return;
+
+#ifdef HSRLE_ENC_DECIDE_ONLY   // timing-only diagnostic build (round 5 pricing): decisions and sizes only, no header assembly, no literal emission
+    if constexpr (TR::kPacked && !TR::kLut && !TR::kShort)
+    {
+      if (body) lastSym = sym;
+      const uint32_t c = count - 3u + 1u;
+      const uint32_t hbytes = (c <= 127u ? 1u : 5u) + (same ? 0u : 1u) + (k == 1 ? 1u : 4u);
+#if HSRLE_ENC_DECIDE_ONLY >= 2  // + one 8-byte packet record per stored run
+      *(uint64_t *)(slot + 16u + 8u * nrec) = (uint64_t)opos | ((uint64_t)lastRLE << 20) | ((uint64_t)gap << 36) | ((uint64_t)(same ? 1u : 0u) << 52) | ((uint64_t)(c & 0xFFu) << 56);
+      nrec++;
+#endif
+      opos += hbytes + gap;
+      lastRLE = e;
+      if (e >= nTrue) { opos += 9u; ended = true; }
+      return;
+    }
+#endif
 
     // ---- header ----
     if constexpr (TR::kShort)
@@ -555,6 +573,9 @@ __global__ __launch_bounds__(64) void k_encode8_blocks(const uint8_t *__restrict
   // literal terminator carrying the bytes behind the last emitted run
   auto finish_literals = [&]() {
     const uint32_t kLit = n - lastRLE;
+#ifdef HSRLE_ENC_DECIDE_ONLY
+    if constexpr (TR::kPacked && !TR::kLut && !TR::kShort) { opos += 9u + kLit; return; }
+#endif
     if constexpr (TR::kShort) { hb(TR::SCINV << TR::SRBP); hb(TR::STB); hb(0); h16(0); h32(kLit + 2u); if (K == 0) hb(0); }   // :503-523
     else if constexpr (TR::kLut) { h16(1u << TR::RB); h16(0); h32(kLit + 2u); }
     else if constexpr (TR::kPacked) { hb(0x80); h32(0); h32(((kLit + 1u) << 1) | 1u); }

@@ -82,6 +82,15 @@ struct WaveEncodeArgs
   int *residentWorkgroups = nullptr;                // query mode
 };
 typedef hipError_t (*WaveEncodeLaunch)(const WaveEncodeArgs &, hipStream_t);
+// position-parallel encoder (hsrle_encode8p.hip.h): phase 3 = ONE launch (sizes, places by look-back, streams; offsets[] is written); phases 0 / 1 =
+// sizes[], then -- behind the caller's scan -- the streams at payload + offsets[b].  ctrl: pp_ctrl_bytes(nBlocks) of scratch, zeroed by the caller (phase 3)
+struct PpArgs
+{
+  const uint8_t *in; uint64_t U; uint32_t B, nBlocks;
+  uint32_t *sizes; uint64_t *offsets; uint8_t *payload; uint32_t *ctrl;
+};
+inline uint64_t pp_ctrl_bytes(uint64_t nBlocks) { return 4ull * kPpCtrlWords + 16ull * ((nBlocks + 63ull) / 64ull) + 4ull * nBlocks; }
+typedef hipError_t (*PpLaunch)(const PpArgs &, int phase, hipStream_t);
 typedef hipError_t (*DecodeLaunch)(const DecodeArgs &, hipStream_t);
 typedef hipError_t (*EncodeLaunch)(const EncodeArgs &, hipStream_t);
 
@@ -105,6 +114,7 @@ constexpr int kDecodeTile = HSRLE_DECODE_TILE; // bytes produced per lane and ro
 constexpr int kDecodeRing = HSRLE_DECODE_RING; // per-lane stream ring in LDS (k_decode_blocks R)
 
 void register_w8(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub, MonoEncodeLaunch *menc, WaveEncodeLaunch *wenc);
+void register_pp8(PpLaunch *pp);
 void register_w16(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub, MonoEncodeLaunch *menc);
 void register_w24(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub, MonoEncodeLaunch *menc);
 void register_w32(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub, MonoEncodeLaunch *menc);

@@ -1,0 +1,91 @@
+"""Position-parallel 8 bit encoder (csrc/hsrle_encode8p.hip.h: rle8_multi, rle8_packed_multi, containers of >= 1 024 blocks of <= 4 KiB):
+every block stream == the oracle's, whatever the data does to its phases (runs across lanes and block ends, chains of short runs without a
+long one, more candidates than the small list holds, ragged tails, unaligned stream starts).  Reference: src/rle8_extreme_cpu.h:86-344, :936-1099."""
+import numpy as np
+import pytest
+
+from hsrle_testlib import CODEC_BY_KEY, SYNTH_RUNS, SYNTH_VIDEO
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ["rle8_multi", "rle8_packed_multi"]
+
+
+@pytest.fixture(scope="module")
+def hs():
+    import torch
+
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    import hsrle
+
+    hsrle.lib()  # fails loudly if the HIP library is missing
+    return hsrle
+
+
+def _dense(rng, n, lengths, alphabet, literal_max):
+    """runs of the given lengths over a small alphabet with short literal gaps: chains of candidates that wait for their left neighbour"""
+    out = np.empty(n + 4096, dtype=np.uint8)
+    at = 0
+    while at < n:
+        L = int(rng.integers(0, literal_max + 1))
+        out[at : at + L] = rng.integers(0, 256, L, dtype=np.uint8)
+        at += L
+        R = int(rng.choice(lengths))
+        out[at : at + R] = rng.integers(0, alphabet)
+        at += R
+    return out[:n].copy()
+
+
+def _cases():
+    rng = np.random.default_rng(20251003)
+    n = 4 << 20
+    cases = {
+        "zeros": np.zeros(n, dtype=np.uint8),
+        "random": rng.integers(0, 256, n, dtype=np.uint8),
+        "two_symbols": rng.integers(0, 2, n, dtype=np.uint8),                      # runs every other byte: > 448 candidates per 4 KiB block
+        "threes": np.repeat(rng.integers(0, 3, n // 3 + 1, dtype=np.uint8), 3)[:n],  # runs of 3, 6, 9 ... of three symbols: one candidate per 3 bytes at most
+        "short_chains": _dense(rng, n, [3, 3, 4, 5, 9, 10], 4, 3),                  # no run of 11: one pass per candidate
+        "mixed": _dense(rng, n, [2, 3, 4, 5, 6, 7, 10, 11, 12, 31, 32, 33, 64, 65, 127, 128, 129, 130, 300, 5000], 256, 140),
+        "long_literals": _dense(rng, n, [3, 4, 11, 40], 256, 900),                   # ranges beyond 127 / 255: the long range form
+        "same_symbol": _dense(rng, n, [3, 3, 3, 4, 11, 12], 1, 5),                   # every run the last symbol again
+    }
+    return cases
+
+
+@pytest.fixture(scope="module")
+def cases():
+    return _cases()
+
+
+def _check(hs, oracle, key, data, block):
+    import torch
+
+    codec = CODEC_BY_KEY[key]
+    src = torch.from_numpy(data).cuda()
+    container, info = hs.compress(key, src, block_size=block)
+    cinfo, streams = hs.split_container(container.cpu().numpy().tobytes())
+    expect = oracle.compress_blocks(codec, data, block)
+    assert len(streams) == len(expect)
+    bad = [i for i, (a, b) in enumerate(zip(streams, expect)) if a != b]
+    assert not bad, f"{key} block size {block}: {len(bad)} of {len(expect)} block streams differ from the oracle, first {bad[:8]}"
+    assert torch.equal(hs.decompress(container), src)
+
+
+@pytest.mark.parametrize("key", KEYS)
+@pytest.mark.parametrize("name", ["zeros", "random", "two_symbols", "threes", "short_chains", "mixed", "long_literals", "same_symbol"])
+def test_position_parallel_encoder_bit_exact(hs, oracle, cases, key, name):
+    _check(hs, oracle, key, cases[name], 4096)
+
+
+@pytest.mark.parametrize("key", KEYS)
+@pytest.mark.parametrize("block,cut", [(128, 0), (256, 1), (1024, 77), (1536, 1535), (2048, 2047), (3968, 13), (4096, 4095), (4096, 4064), (4096, 4033)])
+def test_position_parallel_encoder_block_sizes_and_ragged_tails(hs, oracle, cases, key, block, cut):
+    data = np.concatenate([cases["mixed"][: 3 << 20], cases["short_chains"][: 1 << 20], cases["two_symbols"][: 1 << 20]])
+    _check(hs, oracle, key, data[: data.size - cut], block)
+
+
+@pytest.mark.parametrize("key", KEYS)
+@pytest.mark.parametrize("kind", [SYNTH_RUNS, SYNTH_VIDEO])
+def test_position_parallel_encoder_synthetic_workloads(hs, oracle, key, kind):
+    data = oracle.synth(kind, 1, 11, (16 << 20) + 999)
+    _check(hs, oracle, key, data, 4096)
