@@ -633,12 +633,12 @@ static hipStream_t aux_stream()
 static int compress_split(int codec, const uint8_t *dIn, uint64_t U, uint32_t B, uint32_t nBlocks, uint8_t *ws, const Workspace &w, uint64_t *offsets, uint8_t *payload, hipStream_t st);
 
 // the position-parallel encoder takes the containers of its codecs whose blocks it can hold (HSRLE_PP=1 / 2 in experiment builds: always / never)
-constexpr uint32_t kPpMinBlocks = 1024u;
+constexpr uint32_t kPpMinBlocks = 1u;       // (faster than the ring and the run list encoders from 1 MiB to 8 GiB: experiments/r05, call 20)
 static bool pp_applies(int codec, uint32_t nBlocks, uint32_t B)
 {
   static const uint32_t force = knob_u32("HSRLE_PP", 0u);
   if (codec < 0 || codec >= kCodecCount || !g_pp[codec] || B > kPpMaxBlock || force == 2u) return false;
-  // (the slot area holds the look-back words: pp_ctrl_bytes(nBlocks) < nBlocks slots)
+  // (the slot area holds the records: pp_scratch_bytes() is less than nBlocks staging slots for every block size)
   return force == 1u || nBlocks >= kPpMinBlocks;
 }
 
@@ -712,31 +712,20 @@ static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, ui
 #endif
   if (w.nChunks <= 1 && pp_applies(codec, nBlocks, B))
   {
-    // position-parallel encoder (hsrle_encode8p.hip.h): sizes (+ one record per stored run), scan, then every stream written once to its final place --
-    // no staging slots, no compaction.  Its scratch (records, look-back words of the single-pass experiment) lives in the (unused) slot area.
-    // HSRLE_PP_SINGLE_PASS=1 (experiment builds): one launch, places by look-back (bit-exact, 2.3x slower: LAB_NOTEBOOK.md round 5)
-    static const bool singlePass = knob_u32("HSRLE_PP_SINGLE_PASS", 0u) != 0u;
-    uint32_t *ctrl = (uint32_t *)(ws + w.offSlots);
-    PpArgs pa{ (const uint8_t *)dIn, U, B, nBlocks, sizes, offsets, payload, ctrl };
-    if (singlePass)
+    // position-parallel encoder (hsrle_encode8p.hip.h): sizes + one record per stored run, scan, then every stream written once to its final place --
+    // no staging slots, no compaction.  The records live in the (otherwise unused) slot area.
+    PpArgs pa{ (const uint8_t *)dIn, U, B, nBlocks, sizes, offsets, payload, ws + w.offSlots };
+    if (g_pp[codec](pa, 0, st) != hipSuccess)
+      rc = HSRLE_ERR_DEVICE;
+    else if (nBlocks <= kScanSmallMax)
     {
-      if (zero_async(ctrl, pp_ctrl_bytes(nBlocks), st) != hipSuccess || g_pp[codec](pa, 3, st) != hipSuccess)
-        rc = HSRLE_ERR_DEVICE;
+      hipLaunchKernelGGL(k_scan_small_finish, dim3((nBlocks + kScanTile - 1u) / kScanTile), dim3(kScanThreads), 0, st, (const uint32_t *)sizes, nBlocks, offsets, container, (uint32_t)codec, U, B);
+      finished = true;
     }
-    else
-    {
-      if (g_pp[codec](pa, 0, st) != hipSuccess)
-        rc = HSRLE_ERR_DEVICE;
-      else if (nBlocks <= kScanSmallMax)
-      {
-        hipLaunchKernelGGL(k_scan_small_finish, dim3((nBlocks + kScanTile - 1u) / kScanTile), dim3(kScanThreads), 0, st, (const uint32_t *)sizes, nBlocks, offsets, container, (uint32_t)codec, U, B);
-        finished = true;
-      }
-      else if (scan_sizes(sizes, nBlocks, offsets, ws, w, st) != hipSuccess)
-        rc = HSRLE_ERR_DEVICE;
-      if (rc == HSRLE_OK && g_pp[codec](pa, 1, st) != hipSuccess)
-        rc = HSRLE_ERR_DEVICE;
-    }
+    else if (scan_sizes(sizes, nBlocks, offsets, ws, w, st) != hipSuccess)
+      rc = HSRLE_ERR_DEVICE;
+    if (rc == HSRLE_OK && g_pp[codec](pa, 1, st) != hipSuccess)
+      rc = HSRLE_ERR_DEVICE;
   }
   else if (w.nChunks <= 1 && w.spSlots != 0 && split_encode_applies(codec, w.nBlocks, B))
   {

@@ -220,9 +220,9 @@ __device__ __forceinline__ u32x4 global_window16(const uint8_t *in, uint64_t blo
 // a lane would need many loads for (with 48, and noting between stored runs too, the 16 - 64 bit codecs lost 30 % on run data).
 constexpr uint32_t kNotedLiteralMin = 256;
 
-// position-parallel encoder (hsrle_encode8p.hip.h): largest block, and its control words (ctrl[0]: noted blocks; their list follows the control words)
+// position-parallel encoder (hsrle_encode8p.hip.h): largest block; records (one per stored run) a block may leave between its two launches
 constexpr uint32_t kPpMaxBlock = 4096u;
-constexpr uint32_t kPpCtrlWords = 16u;
+constexpr uint32_t kPpRecords = 256u;
 
 constexpr uint32_t kLaneRingStride = 132;  // bytes per lane in the input ring: 128 + one dword, so that the lanes' rows start in different banks
 

@@ -82,14 +82,15 @@ struct WaveEncodeArgs
   int *residentWorkgroups = nullptr;                // query mode
 };
 typedef hipError_t (*WaveEncodeLaunch)(const WaveEncodeArgs &, hipStream_t);
-// position-parallel encoder (hsrle_encode8p.hip.h): phase 3 = ONE launch (sizes, places by look-back, streams; offsets[] is written); phases 0 / 1 =
-// sizes[], then -- behind the caller's scan -- the streams at payload + offsets[b].  ctrl: pp_ctrl_bytes(nBlocks) of scratch, zeroed by the caller (phase 3)
+// position-parallel encoder (hsrle_encode8p.hip.h): phase 0 = sizes[] and the blocks' records, phase 1 = -- behind the caller's scan -- the streams at
+// payload + offsets[b].  scratch: pp_scratch_bytes(nBlocks), 256-byte aligned; it needs no initialisation
 struct PpArgs
 {
   const uint8_t *in; uint64_t U; uint32_t B, nBlocks;
-  uint32_t *sizes; uint64_t *offsets; uint8_t *payload; uint32_t *ctrl;
+  uint32_t *sizes; const uint64_t *offsets; uint8_t *payload; uint8_t *scratch;
 };
-inline uint64_t pp_ctrl_bytes(uint64_t nBlocks) { return 4ull * kPpCtrlWords + 16ull * ((nBlocks + 63ull) / 64ull) + 4ull * nBlocks; }
+inline uint32_t pp_record_stride(uint32_t B) { return B / 4u < kPpRecords ? B / 4u : kPpRecords; }      // (4 * stride + 4 bytes per block: less than a staging slot of B + 193)
+inline uint64_t pp_scratch_bytes(uint64_t nBlocks, uint32_t B) { return (4ull * pp_record_stride(B) + 4ull) * nBlocks + 256ull; }
 typedef hipError_t (*PpLaunch)(const PpArgs &, int phase, hipStream_t);
 typedef hipError_t (*DecodeLaunch)(const DecodeArgs &, hipStream_t);
 typedef hipError_t (*EncodeLaunch)(const EncodeArgs &, hipStream_t);
