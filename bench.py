@@ -498,10 +498,16 @@ def main():
         streams_ok = gpu_streams == ora.compress_blocks(codec, host_sample, args.block)
         parity = {"blocks_compared": int(sample_blocks), "against": "oracle (no manifest for this workload)"}
     ok = ok and streams_ok
-    if distributed:  # bit_exact is a statement about every rank's shard
-        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        ok = bool(t.item())
+    per_rank_exact, per_rank_build = [bool(ok)], [hsrle.build_id()]
+    if distributed:  # bit_exact is a statement about every rank's shard; the line also says which rank said what, and which library each rank ran
+        flags = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(world)]
+        dist.all_gather(flags, torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev))
+        per_rank_exact = [bool(f.item()) for f in flags]
+        ok = all(per_rank_exact)
+        mine = torch.tensor(list(hsrle.build_id().encode()[:32].ljust(32, b" ")), dtype=torch.uint8, device=dev)
+        ids = [torch.zeros(32, dtype=torch.uint8, device=dev) for _ in range(world)]
+        dist.all_gather(ids, mine)
+        per_rank_build = [bytes(i.cpu().tolist()).decode().strip() for i in ids]
 
     # ---- encode throughput of the same buffer (untimed for `value`) ----
     for _ in range(2):
@@ -534,6 +540,9 @@ def main():
         use_c = os.environ.get("HSRLE_DIST_C") == "1"                      # the library's own communicator (hsrle_gather_container_rccl) instead of torch's
         if use_c:
             hd.c_comm()                                                    # (communicator creation is setup, not gather time)
+        # how many ranks the COMMUNICATOR spans (not WORLD_SIZE): ncclCommCount of the library's communicator, or the size of torch's RCCL process group
+        rccl_ranks = hd.c_comm_ranks()[0] if use_c else dist.get_world_size()
+        rccl_via = "hsrle_gather_container_rccl (ncclCommCount)" if use_c else f"torch.distributed backend {dist.get_backend()} (process group size)"
         barrier()
         g0 = time.perf_counter()
         full = hd.gather_container_c(container, size * world, root=0) if use_c else hd.gather_container(container, size * world, root=0)
@@ -590,6 +599,10 @@ def main():
             line["gather_link_ceiling_GBps"] = 7 * 153
             line["value_with_gather"] = round(total_units / 2**30 / (wall / args.steps + gather_ms * 1e-3), 2)
             line["per_rank_ms_per_step"] = per_rank_ms
+            line["rccl_ranks"] = int(rccl_ranks)
+            line["rccl_ranks_source"] = rccl_via
+            line["per_rank_bit_exact"] = per_rank_exact
+            line["per_rank_library_build_id"] = per_rank_build
         line["library_build_id"] = hsrle.build_id()
         if extras:
             line["extras"] = extras

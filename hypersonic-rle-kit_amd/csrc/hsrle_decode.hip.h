@@ -838,7 +838,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
         if (avail0 - sp < MAXHDR && avail0 < lim) break;               // header not resident yet: continue next round
 
         // ---------------- packet header ----------------
-        [[maybe_unused]] uint32_t cnt, range, used;
+        [[maybe_unused]] uint32_t cnt = 0, range = 0, used = 0;   // (every path that reads them assigns them first; the zeros only silence -Wsometimes-uninitialized: they are dead stores the compiler removes)
         bool endNow = false;
 
         if constexpr (S <= 8 && !TR::kLut && !TR::kShort)

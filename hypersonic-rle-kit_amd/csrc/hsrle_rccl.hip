@@ -144,6 +144,14 @@ int hsrle_rccl_comm_create(const void *id128, int worldSize, int rank, void **pC
   return HSRLE_OK;
 }
 
+int hsrle_rccl_comm_ranks(void *comm, int *pWorldSize, int *pRank)
+{
+  if (!comm || !pWorldSize || !pRank) return HSRLE_ERR_ARGUMENT;
+  if (!rccl_ready()) return HSRLE_ERR_UNSUPPORTED;
+  if (g_rccl.commCount((ncclComm_t)comm, pWorldSize) != ncclSuccess || g_rccl.commUserRank((ncclComm_t)comm, pRank) != ncclSuccess) return HSRLE_ERR_DEVICE;
+  return HSRLE_OK;
+}
+
 int hsrle_rccl_comm_destroy(void *comm)
 {
   if (!comm) return HSRLE_ERR_ARGUMENT;

@@ -241,6 +241,22 @@ def c_comm(group=None):
     return comm
 
 
+def c_comm_ranks(group=None):
+    """(ranks, this rank) as the library's communicator itself reports them (ncclCommCount / ncclCommUserRank through hsrle_rccl_comm_ranks)."""
+    import ctypes
+
+    import hsrle
+
+    L = hsrle.lib()
+    L.hsrle_rccl_comm_ranks.restype = ctypes.c_int
+    L.hsrle_rccl_comm_ranks.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    world, rank = ctypes.c_int(0), ctypes.c_int(0)
+    rc = L.hsrle_rccl_comm_ranks(c_comm(group), ctypes.byref(world), ctypes.byref(rank))
+    if rc != 0:
+        raise hsrle.HsrleError(rc, "hsrle_rccl_comm_ranks")
+    return world.value, rank.value
+
+
 def destroy_c_comms():
     """hsrle_rccl_comm_destroy for every communicator c_comm() made (call before destroy_process_group; also runs at exit)."""
     import hsrle

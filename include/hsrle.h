@@ -359,6 +359,8 @@ int hsrle_rccl_unique_id(void *id128);
 /* every rank, on its current HIP device: ncclCommInitRank.  *pComm is an ncclComm_t; a communicator the program already has works too */
 int hsrle_rccl_comm_create(const void *id128, int worldSize, int rank, void **pComm);
 int hsrle_rccl_comm_destroy(void *comm);
+/* what the communicator itself says it spans (ncclCommCount / ncclCommUserRank): the figure a benchmark line should carry, not WORLD_SIZE */
+int hsrle_rccl_comm_ranks(void *comm, int *pWorldSize, int *pRank);
 /*
  * Collective over `comm`.  dLocal / localSize: this rank's container (device memory; NULL / 0 if the rank owns no block).  On the root,
  * dOut (device, capacity >= the sum of the parts, at most hsrle_container_bound(totalUncompressedSize, blockSize)) receives the one

@@ -120,3 +120,6 @@ def test_bench_distributed_leg_runs_as_a_world_of_one(c_abi):
     assert j["value_with_gather"] < j["value"] and len(j["per_rank_ms_per_step"]) == 1
     assert j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["matches_gpu_input"] and j["encode"]["cpu_baseline"]["streams_match_gpu"]
     assert j["roofline"]["frac"] > 0 and j["config"]["sharding"] == "blocks x1"
+    # the line says what the communicator spans, and what every rank found and ran
+    assert j["rccl_ranks"] == 1 and ("ncclCommCount" in j["rccl_ranks_source"]) == bool(c_abi)
+    assert j["per_rank_bit_exact"] == [True] and j["per_rank_library_build_id"] == [j["library_build_id"]]

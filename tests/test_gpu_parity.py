@@ -4,6 +4,7 @@ Bit-exact bar (integer / byte work): every block stream must equal the oracle's 
 test_oracle_vs_ref.py / test_oracle_golden.py) stream for that block, and every decode must reproduce the input exactly.
 """
 import os
+import re
 import ctypes
 import random
 import struct
@@ -511,6 +512,37 @@ def test_reference_cli_runs_on_the_gpu_library(tmp_path):
         out = r.stdout.replace("\r", "\n")
         assert r.returncode == 0, out[-3000:] + r.stderr[-2000:]
         assert "FAILED" not in out and name in out, out[-2000:]
+
+
+@pytest.mark.parametrize("mode,seconds", [("--fuzz-iterative", 100), ("--fuzz-random", 40)])
+def test_reference_fuzzer_runs_on_the_gpu_library(tmp_path, mode, seconds):
+    """The reference's OWN fuzzer (src/rle_fuzz.c:533-757, started by src/main.c:755-770) pointed at the GPU library: oracle/_ref/hsrlekit_dropin links
+    rle_fuzz.o, so `hsrlekit_dropin x --fuzz-iterative` walks its structured inputs (alternating random / repeating sections, every length class,
+    symbols of 1 .. 16 bytes, bound and unbound) through every drop-in compress / decompress pair and validates each round trip itself.  It never
+    finishes on its own account within a test's patience: it gets a wall-clock budget, and being stopped without a complaint is the pass."""
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "hsrlekit_dropin")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/hsrlekit_dropin not built")
+    proc = subprocess.Popen([exe, "x", mode], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        out, _ = proc.communicate(timeout=seconds)
+        finished = True
+    except subprocess.TimeoutExpired:
+        proc.kill()                                   # (the exact process started above)
+        out, _ = proc.communicate()
+        finished = False
+    out = out.replace("\r", "\n")
+    for bad in ("Fuzzer Failed", "Validation Failed", "Failed to compress", "Input Buffer Corrupted", "Decompressed to incorrect size", "First invalid char"):
+        assert bad not in out, out[-4000:]
+    if finished:
+        assert proc.returncode == 0 and "Fuzzer Completed" in out, out[-3000:]
+    # it got somewhere: the progress line is printed every 256 inputs
+    inputs = [int(m) for m in re.findall(r"Input (\d+):", out)]
+    assert inputs and max(inputs) >= 256, f"the fuzzer made no progress in {seconds} s: {out[-500:]!r}"
+    failure = tmp_path / "fuzz-failure.bin"          # (opened at start, written on a failure only)
+    assert not failure.exists() or failure.stat().st_size == 0
 
 
 def test_first_compress_of_a_process_under_graph_capture():
