@@ -665,8 +665,9 @@ static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, ui
   Workspace w = plan_workspace(U, B);
   if (split_codec_small(codec) && B <= 4096u)
   {
+    // (only where the split encode will really run: its regions are 2 - 3 x the input -- ADVICE r4)
     const Workspace w2 = plan_workspace(U, B, true);
-    if (w2.spSlots != 0 && (dWs == nullptr || wsSize >= w2.total)) w = w2;
+    if (w2.spSlots != 0 && split_encode_applies(codec, w2.nBlocks, B) && (dWs == nullptr || wsSize >= w2.total)) w = w2;
   }
 
   void *own = nullptr;
@@ -717,7 +718,7 @@ static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, ui
     PpArgs pa{ (const uint8_t *)dIn, U, B, nBlocks, sizes, offsets, payload, ws + w.offSlots };
     if (g_pp[codec](pa, 0, st) != hipSuccess)
       rc = HSRLE_ERR_DEVICE;
-    else if (nBlocks <= kScanSmallMax)
+    else if (nBlocks <= kScanSmallMax && (((uintptr_t)sizes) & 15u) == 0u)   // (the one-launch scan reads the sizes 16 bytes at a time: a caller's workspace may sit anywhere)
     {
       hipLaunchKernelGGL(k_scan_small_finish, dim3((nBlocks + kScanTile - 1u) / kScanTile), dim3(kScanThreads), 0, st, (const uint32_t *)sizes, nBlocks, offsets, container, (uint32_t)codec, U, B);
       finished = true;
@@ -740,7 +741,7 @@ static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, ui
     ea.ringSel = (uint32_t *)(ws + w.offSlots + align_up((uint64_t)nBlocks * stride, 256));   // (in the wave encoder's counter area behind the slots: unused on this path)
     if (g_enc[codec](ea, st) != hipSuccess)
       rc = HSRLE_ERR_DEVICE;
-    else if (nBlocks <= kScanSmallMax)
+    else if (nBlocks <= kScanSmallMax && (((uintptr_t)sizes) & 15u) == 0u)   // (the one-launch scan reads the sizes 16 bytes at a time: a caller's workspace may sit anywhere)
     {
       hipLaunchKernelGGL(k_scan_small_finish, dim3((nBlocks + kScanTile - 1u) / kScanTile), dim3(kScanThreads), 0, st, (const uint32_t *)sizes, nBlocks, offsets, container, (uint32_t)codec, U, B);
       finished = true;
@@ -1353,6 +1354,9 @@ static int compress_split(int codec, const uint8_t *dIn, uint64_t U, uint32_t B,
         return HSRLE_ERR_DEVICE;
     }
   }
+  const bool laneChunks = single || S == 16 || codec >= kGreedyBase;     // per-lane chunk encoders: a chunk that missed its boundary run says so with size 0
+  if (laneChunks)
+    hipLaunchKernelGGL(k_split_check, dim3((nBlocks + 255u) / 256u), dim3(256), 0, st, (const uint32_t *)firstChunk, (const uint64_t *)starts, (const uint32_t *)sizes, nBlocks, ctrl + 15);   // (ctrl[15]: zeroed above)
   if (scan_sizes(sizes, maxChunks, chunkOff, ws, sw, st) != hipSuccess)
     return HSRLE_ERR_DEVICE;
   launch_compact_var(G <= 2048u, (const uint8_t *)(ws + w.spSlots), (const uint64_t *)slotOff, (const uint64_t *)chunkOff, payload, maxChunks, st);
@@ -1361,6 +1365,8 @@ static int compress_split(int codec, const uint8_t *dIn, uint64_t U, uint32_t B,
   const uint32_t codecId = (uint32_t)codec;
   auto finish = [=] __device__(uint64_t payloadSize) { finish_container(container, codecId, U, B, nBlocks, payloadSize); };
   hipLaunchKernelGGL((k_split_finish<decltype(finish)>), dim3((nBlocks + 255u) / 256u), dim3(256), 0, st, (const uint32_t *)firstChunk, (const uint64_t *)chunkOff, nBlocks, offsets, payload, finish);
+  if (laneChunks)
+    hipLaunchKernelGGL(k_split_verdict, dim3(1), dim3(64), 0, st, (const uint32_t *)(ctrl + 15), container);
   return hipGetLastError() == hipSuccess ? HSRLE_OK : HSRLE_ERR_DEVICE;
 }
 
@@ -1543,7 +1549,7 @@ static int mono_encode_dev(int codec, const uint8_t *dIn, uint32_t U, uint8_t *d
   if (scan_sizes(sizes, chunks, offsets, ws, w, st) != hipSuccess)
     return HSRLE_ERR_DEVICE;
   launch_compact_var(false, (const uint8_t *)(ws + m.offSlots), (const uint64_t *)slotOff, (const uint64_t *)offsets, dOut + hs, chunks, st);
-  if (single)
+  if (single || codec >= kGreedyBase)
     hipLaunchKernelGGL(k_mono_zero_sizes, dim3((chunks + 255u) / 256u), dim3(256), 0, st, (const uint32_t *)sizes, chunks, ctrl + 5);
   hipLaunchKernelGGL(k_mono_finish, dim3(1), dim3(64), 0, st, dOut, U, hs, (const uint64_t *)offsets, (const uint32_t *)ctrl, ctrl, codec == kSingleShort ? 1u : 0u);
   uint32_t tail[4] = { 0, 0, 0, 0 };
@@ -1970,7 +1976,7 @@ static int le_encode_async(const void *dIn, uint32_t n, void *dOut, uint64_t out
   return hipGetLastError() == hipSuccess ? HSRLE_OK : HSRLE_ERR_DEVICE;
 }
 
-// dStream: the stream (readable up to streamSize + 64), dataStart = 8 + 33 + listed symbols (the caller has read the header).  dStatus: two
+// dStream: the stream (nothing at or beyond streamSize is read), dataStart = 8 + 33 + listed symbols (the caller has read the header).  dStatus: two
 // words ([0] error bits, [1] "a piece's parity could not be found within kLeCarryLimit bytes").  onePiece: decode with ONE wave (the fallback).
 static int le_decode_async(const void *dStream, uint32_t streamSize, uint32_t dataStart, uint32_t expOut, void *dOut, uint64_t outCapacity, void *dWs, uint64_t wsSize, uint32_t *dStatus,
                            bool onePiece, hipStream_t st)
@@ -2085,7 +2091,7 @@ int hsrle_low_entropy_decompress_dev(const void *dStream, uint64_t streamSize, v
   memcpy(&expIn, head, 4); memcpy(&expOut, head + 4, 4);
   uint32_t listed = head[40]; if (listed == 0u) listed = 255u;
   const uint32_t dataStart = 8u + 33u + listed;
-  if ((uint64_t)expIn > streamSize || dataStart > expIn || expOut == 0u) return HSRLE_ERR_FORMAT;
+  if ((uint64_t)expIn > streamSize || dataStart > expIn || expOut == 0u || expIn > 0xFFFFFF00u) return HSRLE_ERR_FORMAT;   // (the last: the piece arithmetic of le_decode_async is 32 bit, as on the host path)
   if (outCapacity < expOut) return HSRLE_ERR_CAPACITY;
   uint32_t *dStatus = (uint32_t *)dWorkspace;                              // the first 256 bytes of the workspace: the status words
   uint32_t status[2] = { 1, 0 };

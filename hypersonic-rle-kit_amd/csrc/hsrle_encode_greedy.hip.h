@@ -250,7 +250,10 @@ __global__ __launch_bounds__(64) void k_encode_greedy_blocks(const uint8_t *__re
     }
   }
   if constexpr (!MONO) s.s.patch32(4, s.s.at);
-  if (!dry) sizes[b] = s.s.at;
+  // (a chunk that is not its stream's last must end exactly on its boundary: a scan that ran past it would write bytes the next chunk writes again.
+  //  The cut rule -- stretches of >= 4 S + 11 bytes -- makes that impossible as far as anyone has seen; size 0 is how a chunk says "not me", and the
+  //  callers check it: k_mono_zero_sizes / k_split_check)
+  if (!dry) sizes[b] = (MONO && !lastChunk && i != n) ? 0u : s.s.at;
   if constexpr (MONO)
   {
 #pragma unroll

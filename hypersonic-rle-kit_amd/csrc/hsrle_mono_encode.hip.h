@@ -500,6 +500,24 @@ __global__ __launch_bounds__(256) void k_split_list_verify(uint64_t *__restrict_
   if (wrong) atomicAdd(bad, 1u);
 }
 
+// The per-lane chunk encoders of the split encode (8 bit Single, rle8_single_short, 128 bit, Greedy) report a chunk that did not end on its boundary
+// run with size 0 (the cut heuristics make that impossible as far as anyone has seen; the monolithic path checks the same thing with
+// k_mono_zero_sizes and falls back).  A hole in a block's stream must not leave the library as a valid container: a non-final, non-empty chunk of
+// size 0 raises the flag, and k_split_verdict then strikes the container's magic -- every decoder refuses it.
+__global__ __launch_bounds__(256) void k_split_check(const uint32_t *__restrict__ firstChunk, const uint64_t *__restrict__ starts, const uint32_t *__restrict__ sizes, uint32_t nBlocks,
+                                                     uint32_t *__restrict__ flag)
+{
+  const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+  if (b >= nBlocks) return;
+  const uint32_t c0 = firstChunk[b], c1 = firstChunk[b + 1u];
+  for (uint32_t c = c0; c + 1u < c1; c++)
+    if (sizes[c] == 0u && starts[c + 1u] > starts[c]) *flag = 1u;
+}
+__global__ void k_split_verdict(const uint32_t *__restrict__ flag, uint8_t *__restrict__ container)
+{
+  if (threadIdx.x < 8u && *flag != 0u) container[threadIdx.x] = 0;
+}
+
 // after the placement of the chunks: the container's offset table, every block stream's compressedLength field, and (the workgroup of the last block)
 // the container's header and tail pad (FINISH: finish_container of hsrle_capi.hip -- one launch less)
 template <typename FINISH>

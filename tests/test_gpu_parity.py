@@ -514,7 +514,7 @@ def test_reference_cli_runs_on_the_gpu_library(tmp_path):
         assert "FAILED" not in out and name in out, out[-2000:]
 
 
-@pytest.mark.parametrize("mode,seconds", [("--fuzz-iterative", 100), ("--fuzz-random", 40)])
+@pytest.mark.parametrize("mode,seconds", [("--fuzz-iterative", 100), ("--fuzz-random", 150)])
 def test_reference_fuzzer_runs_on_the_gpu_library(tmp_path, mode, seconds):
     """The reference's OWN fuzzer (src/rle_fuzz.c:533-757, started by src/main.c:755-770) pointed at the GPU library: oracle/_ref/hsrlekit_dropin links
     rle_fuzz.o, so `hsrlekit_dropin x --fuzz-iterative` walks its structured inputs (alternating random / repeating sections, every length class,
@@ -525,14 +525,29 @@ def test_reference_fuzzer_runs_on_the_gpu_library(tmp_path, mode, seconds):
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "hsrlekit_dropin")
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/hsrlekit_dropin not built")
-    proc = subprocess.Popen([exe, "x", mode], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    try:
-        out, _ = proc.communicate(timeout=seconds)
-        finished = True
-    except subprocess.TimeoutExpired:
-        proc.kill()                                   # (the exact process started above)
-        out, _ = proc.communicate()
-        finished = False
+    # (its progress line has no newline, and into a pipe stdio would hold everything back until 4 KiB have gathered: stdbuf -o0 where there is one)
+    import select
+    import shutil
+    import time
+
+    cmd = [exe, "x", mode]
+    if shutil.which("stdbuf"):
+        cmd = ["stdbuf", "-o0", "-e0"] + cmd
+    proc = subprocess.Popen(cmd, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    fd = proc.stdout.fileno()
+    buf, deadline = b"", time.time() + seconds
+    while time.time() < deadline:
+        ready, _, _ = select.select([fd], [], [], 1.0)
+        if ready:
+            chunk = os.read(fd, 65536)
+            if not chunk:
+                break                                 # (it closed its output: it is through)
+            buf += chunk
+    finished = proc.poll() is not None
+    if not finished:
+        proc.kill()                                   # (the exact process started above; stdbuf execs the program, so this IS the program)
+        proc.wait()
+    out = buf.decode(errors="replace")
     out = out.replace("\r", "\n")
     for bad in ("Fuzzer Failed", "Validation Failed", "Failed to compress", "Input Buffer Corrupted", "Decompressed to incorrect size", "First invalid char"):
         assert bad not in out, out[-4000:]

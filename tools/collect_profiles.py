@@ -19,9 +19,25 @@ with open(f"{P}/{tag}_rocprof_summary.txt", "w") as f:
     for r in rows:
         f.write("%-90s %8s %12.1f %12.1f %12.1f %7s\n" % (r["Name"][:90], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
     f.write("\nper-launch durations of the headline kernels (us, launch order):\n")
-    for key in ("k_decode_blocks<", "k_encode8_blocks<", "k_compact("):
+    steady = {}
+    for key in ("k_decode_blocks<", "k_encode8_pp<1, 0>", "k_encode8_pp<1, 1>"):
         ds = [(int(t["End_Timestamp"]) - int(t["Start_Timestamp"])) / 1e3 for t in trace if key in t["Kernel_Name"]]
         f.write("  %-20s n=%d  %s\n" % (key, len(ds), " ".join("%.1f" % x for x in ds[:60])))
+        steady[key] = ds
+    # the steady state: the timed launches only (bench.py runs `warmup` untimed steps first; the stats table above averages over all of them)
+    k = int(d["steps"])
+    dec = steady["k_decode_blocks<"][-k:]
+    alg = float(d["roofline"]["algorithmic_bytes"])
+    if dec:
+        avg = sum(dec) / len(dec)
+        f.write("\nSTEADY STATE (the last %d launches = the timed steps): k_decode_blocks avg %.1f us -> %.1f GB/s of C + U = %.4f of 8 TB/s   (bench line: kernel_ms %.4f, frac %.4f)\n"
+                % (len(dec), avg, alg / (avg * 1e-6) / 1e9, alg / (avg * 1e-6) / 8e12, d["roofline"]["kernel_ms"], d["roofline"]["frac"]))
+    e0, e1 = steady["k_encode8_pp<1, 0>"], steady["k_encode8_pp<1, 1>"]
+    if e0 and e1:
+        n = min(len(e0), len(e1), max(3, k // 4))
+        a0, a1 = sum(e0[-n:]) / n, sum(e1[-n:]) / n
+        f.write("STEADY STATE encode (the last %d calls): k_encode8_pp<.., 0> (sizes + records) %.1f us + k_encode8_pp<.., 1> (emission) %.1f us (+ the size scan) -> %.4f of 8 TB/s for the two kernels   (bench line: encode.ms %.4f, frac %.4f)\n"
+                % (n, a0, a1, alg / ((a0 + a1) * 1e-6) / 8e12, d["encode"]["ms"], d["encode"]["roofline"]["frac"]))
 frows = list(csv.DictReader(open(src + "/frame/f_kernel_stats.csv")))
 with open(f"{P}/{tag}_config3_encode_kernel_stats.txt", "w") as f:
     f.write("rocprofv3 --kernel-trace --stats -- python3 tools/frame_prof.py rle64_3symlut_byte   (10 encodes of the 88 MB frame, 4 KiB blocks)\n")

@@ -27,16 +27,17 @@ vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(O + "/pmc_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        name = "decode" if "k_decode_blocks<" in k else ("encode" if "k_encode8_blocks<" in k else ("compact" if "k_compact" in k else None))
+        # (round 5: the headline encode is two launches of the position-parallel kernel -- <.., 0> sizes + records, <.., 1> emission -- and no compaction)
+        name = "decode" if "k_decode_blocks<" in k else ("encode_sizes" if "k_encode8_pp<1, 0>" in k else ("encode_emit" if "k_encode8_pp<1, 1>" in k else None))
         if name:
             vals[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 def per(name, counter, launches):
     v = vals[name].get(counter, [])
     return sum(v) / launches if v and launches else None
 n_dec = len(vals["decode"].get("FETCH_SIZE", []))
-n_enc = len(vals["compact"].get("FETCH_SIZE", []))          # one compaction per compress call (the encoder launches two instantiations, one returns at once)
+n_enc = len(vals["encode_emit"].get("FETCH_SIZE", []))      # one emission launch per compress call
 d = {c: per("decode", c, n_dec) for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum")}
-e = {k: {c: per(k, c, n_enc) for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum")} for k in ("encode", "compact")}
+e = {k: {c: per(k, c, n_enc) for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum")} for k in ("encode_sizes", "encode_emit")}
 fetch_raw = int(d["FETCH_SIZE"] * 1024); write = int(d["WRITE_SIZE"] * 1024); req = int(d["TCC_EA0_RDREQ_sum"])
 lo, hi = container, req * 128
 enc_lo = sum(int((e[k]["FETCH_SIZE"] + e[k]["WRITE_SIZE"]) * 1024) for k in e)
@@ -48,7 +49,7 @@ out = {"codec": line["config"]["codec"], "size": size, "block": int(line["config
        "fetch_lower_bound_bytes": lo, "fetch_upper_bound_bytes": hi, "traffic_lower_bound_bytes": lo + write, "traffic_upper_bound_bytes": hi + write,
        "algorithmic_bytes": size + container,
        "encode": {"raw_counters_per_call": e, "payload_bytes": int(line["config"]["blocks_per_gpu"]) and container, "traffic_bounds": [enc_lo, enc_hi],
-                  "encode_kernel_write_over_payload": round(e["encode"]["WRITE_SIZE"] * 1024 / container, 3)},
+                  "encode_kernel_write_over_payload": round(e["encode_emit"]["WRITE_SIZE"] * 1024 / container, 3)},
        "note": "FETCH_SIZE counts 64 B per fabric read request whether it asks for 64 or 128 bytes (profiles/r02_fetch_calibration.txt): the read side lies between the container (every byte once) and 128 B x requests; WRITE_SIZE is exact for whole-line streaming stores."}
 json.dump(out, open(O + "/traffic.json", "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("library_build_id", "launches", "traffic_lower_bound_bytes", "traffic_upper_bound_bytes", "algorithmic_bytes")}))
