@@ -70,11 +70,11 @@ constexpr uint32_t kPpCoopMin = 80u;                            // literal stret
 constexpr uint32_t kPpJobs = kPpMaxBlock / (kPpCoopMin + 4u) + 2u;
 constexpr uint32_t kPpInPad = 16u;                              // the input image starts 16 bytes into its buffer (a literal window may begin up to 15 bytes in front of its stretch)
 // LDS of one wave's block
-template <bool EMIT>
+template <bool EMIT, bool INPUT = EMIT>
 struct PpShared
 {
   uint8_t img[EMIT ? (kPpMaxBlock + 193u + 15u + 16u + 15u) / 16u * 16u : 16u] __attribute__((aligned(16)));   // the stream under construction
-  uint8_t inb[EMIT ? kPpInPad + kPpMaxBlock + 32u : 16u] __attribute__((aligned(16)));   // the block's input: literals and run symbols come from here, not from L2 (0.8 us per gather under load)
+  uint8_t inb[INPUT ? kPpInPad + kPpMaxBlock + 32u : 16u] __attribute__((aligned(16)));   // the block's input: literals and run symbols come from here, not from L2 (0.8 us per gather under load)
   uint8_t mlut[EMIT ? 17u * 16u : 16u] __attribute__((aligned(16)));   // entry c: the low c bytes, c = 0 .. 16
   uint64_t starts[64];                                                  // run-start bits of every lane's 64 positions
   uint64_t jobs[EMIT ? kPpJobs : 1u];                                   // literal stretches for the whole wave

@@ -1,0 +1,37 @@
+// inst_ppS.hip -- instantiations of the position-parallel encoder of 2 .. 8 byte symbols (hsrle_encodeSp.hip.h): plain and Packed, sym- and byte-aligned
+#include "hsrle_launch.h"
+#include "hsrle_encodeSp.hip.h"
+
+namespace hsrle {
+
+template <int FAM, int S, int AL>
+static hipError_t ppS_launch(const PpArgs &a, int phase, hipStream_t st)
+{
+  PpScratch sc;
+  sc.recs = (uint32_t *)a.scratch;
+  sc.recStride = pp_record_stride(a.B);
+  sc.recCount = sc.recs + (uint64_t)sc.recStride * a.nBlocks + 64u;
+  sc.stamps = nullptr;
+  if (phase == 0)
+    hipLaunchKernelGGL((k_encodeS_pp<FAM, S, AL, 0>), dim3(a.nBlocks), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.sizes, a.offsets, a.payload, sc);
+  else
+    hipLaunchKernelGGL((k_encodeS_pp<FAM, S, AL, 1>), dim3(a.nBlocks), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.sizes, a.offsets, a.payload, sc);
+  return hipGetLastError();
+}
+
+// codec ids 6 + 8 * w + v: w = width index (16, 24, 32, 48, 64 bit), v = 0 sym, 1 sym_packed, 4 byte, 5 byte_packed
+template <int S, int W>
+static void reg_width(PpLaunch *pp)
+{
+  pp[6 + 8 * W + 0] = ppS_launch<PLAIN, S, 1>;
+  pp[6 + 8 * W + 1] = ppS_launch<PACKED, S, 1>;
+  pp[6 + 8 * W + 4] = ppS_launch<PLAIN, S, 0>;
+  pp[6 + 8 * W + 5] = ppS_launch<PACKED, S, 0>;
+}
+
+void register_ppS(PpLaunch *pp)
+{
+  reg_width<2, 0>(pp); reg_width<3, 1>(pp); reg_width<4, 2>(pp); reg_width<6, 3>(pp); reg_width<8, 4>(pp);
+}
+
+} // namespace hsrle

@@ -89,3 +89,49 @@ def test_position_parallel_encoder_block_sizes_and_ragged_tails(hs, oracle, case
 def test_position_parallel_encoder_synthetic_workloads(hs, oracle, key, kind):
     data = oracle.synth(kind, 1, 11, (16 << 20) + 999)
     _check(hs, oracle, key, data, 4096)
+
+
+# ---- 2 .. 8 byte symbols, plain and Packed (csrc/hsrle_encodeSp.hip.h; reference: src/rleX_extreme_cpu_encode.h:14-609) ----
+WIDE_KEYS = [f"rle{w}_{v}" for w in (16, 24, 32, 48, 64) for v in ("sym", "sym_packed", "byte", "byte_packed")]
+
+
+def _periodic(rng, n, periods, alphabet, literal_max, lengths):
+    """stretches with the given periods (in bytes; not only the codec's own symbol width), cut mid-symbol, butting against each other and against
+    stretches of another period that share bytes with them: run starts that depend on where the run before ended"""
+    out = np.empty(n + 8192, dtype=np.uint8)
+    at = 0
+    while at < n:
+        L = int(rng.integers(0, literal_max + 1))
+        out[at : at + L] = rng.integers(0, 256, L, dtype=np.uint8)
+        at += L
+        P = int(rng.choice(periods))
+        sym = rng.integers(0, alphabet, P, dtype=np.uint8)
+        R = int(rng.choice(lengths))
+        out[at : at + R] = np.tile(sym, R // P + 2)[:R]
+        at += R
+    return out[:n].copy()
+
+
+@pytest.fixture(scope="module")
+def wide_cases():
+    rng = np.random.default_rng(7051)
+    n = 3 << 20
+    return {
+        "periods": _periodic(rng, n, [1, 2, 3, 4, 6, 8, 12, 16], 256, 40, [4, 5, 6, 7, 8, 9, 11, 12, 13, 16, 17, 18, 19, 23, 24, 25, 40, 64, 100, 300, 2000, 9000]),
+        "butting": _periodic(rng, n, [2, 3, 4, 6, 8], 3, 0, [4, 6, 7, 8, 9, 12, 13, 14, 16, 17, 20, 24, 25, 33]),       # no literals, tiny alphabet: overlapping stretches everywhere
+        "far_apart": _periodic(rng, n, [2, 3, 4, 6, 8], 256, 700, [8, 12, 16, 19, 24, 36, 48]),                         # ranges beyond 127 / 255
+        "two_symbols": rng.integers(0, 2, n, dtype=np.uint8),
+    }
+
+
+@pytest.mark.parametrize("key", WIDE_KEYS)
+@pytest.mark.parametrize("name", ["periods", "butting", "far_apart", "two_symbols"])
+def test_position_parallel_wide_encoder_bit_exact(hs, oracle, wide_cases, key, name):
+    _check(hs, oracle, key, wide_cases[name], 4096)
+
+
+@pytest.mark.parametrize("key", ["rle16_byte_packed", "rle24_sym", "rle32_sym_packed", "rle48_byte", "rle64_byte_packed"])
+@pytest.mark.parametrize("block,cut", [(128, 0), (384, 5), (1024, 77), (1536, 1535), (4096, 4095), (4096, 4033), (4096, 4081)])
+def test_position_parallel_wide_encoder_block_sizes_and_ragged_tails(hs, oracle, wide_cases, key, block, cut):
+    data = np.concatenate([wide_cases["periods"][: 2 << 20], wide_cases["butting"][: 1 << 19]])
+    _check(hs, oracle, key, data[: data.size - cut], block)
