@@ -70,13 +70,14 @@ constexpr uint32_t kPpCoopMin = 80u;                            // literal stret
 constexpr uint32_t kPpJobs = kPpMaxBlock / (kPpCoopMin + 4u) + 2u;
 constexpr uint32_t kPpInPad = 16u;                              // the input image starts 16 bytes into its buffer (a literal window may begin up to 15 bytes in front of its stretch)
 // LDS of one wave's block
-template <bool EMIT, bool INPUT = EMIT>
+template <bool EMIT, bool INPUT = EMIT, bool MTF = false>
 struct PpShared
 {
   uint8_t img[EMIT ? (kPpMaxBlock + 193u + 15u + 16u + 15u) / 16u * 16u : 16u] __attribute__((aligned(16)));   // the stream under construction
   uint8_t inb[INPUT ? kPpInPad + kPpMaxBlock + 32u : 16u] __attribute__((aligned(16)));   // the block's input: literals and run symbols come from here, not from L2 (0.8 us per gather under load)
   uint8_t mlut[EMIT ? 17u * 16u : 16u] __attribute__((aligned(16)));   // entry c: the low c bytes, c = 0 .. 16
   uint64_t starts[64];                                                  // run-start bits of every lane's 64 positions
+  uint64_t mtfScratch[MTF ? 152u : 1u];                                 // LUT codecs: the round's run symbols and list heads
   uint64_t jobs[EMIT ? kPpJobs : 1u];                                   // literal stretches for the whole wave
   uint16_t lst[64];                                                     // the round's candidates (last byte positions), handed from the lanes that found them to the lanes that judge them
   uint16_t carryStart[64];                                              // start of the run that is open where a lane's positions begin

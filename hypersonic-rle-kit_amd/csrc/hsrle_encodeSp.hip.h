@@ -1,5 +1,7 @@
 // hsrle_encodeSp.hip.h -- POSITION-PARALLEL encoder for the plain and Packed codecs of 2, 3, 4, 6 and 8 byte symbols (rle16 / 24 / 32 / 48 / 64
-// _sym, _sym_packed, _byte, _byte_packed: 20 codecs), blocks of at most 4 KiB.  The 8 bit kernel (hsrle_encode8p.hip.h) with the run discovery,
+// _sym, _sym_packed, _byte, _byte_packed: 20 codecs) and the 3 symbol LUT codecs of 3, 4, 6 and 8 byte symbols (rle24 / 32 / 48 / 64 _3symlut_sym /
+// _3symlut_byte: 8 codecs, src/rleX_Xsl.h:114-346 -- every run of theirs is stored, only the symbol's list index depends on what came before), blocks
+// of at most 4 KiB.  The 8 bit kernel (hsrle_encode8p.hip.h) with the run discovery,
 // the emit rule and the packet forms of the wide codecs; everything that file's header says about the division of labour holds here.
 //
 // Replaces: src/rleX_extreme_cpu_encode.h:14-609 (run discovery :315-371, extension :79-163, emit rule :174-311, terminators :384-603; the 24 / 48 bit
@@ -48,16 +50,19 @@ __device__ __forceinline__ void pp_or_bytes(uint8_t *img, uint32_t at, uint64_t 
 
 template <int FAM, int S, int AL, int MODE>
 __device__ __forceinline__ void ppS_block(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t b, uint32_t *__restrict__ sizes, const uint64_t *__restrict__ offsets,
-                                          uint8_t *__restrict__ payload, const PpScratch &sc, PpShared<MODE != 0, true> &sh, const u32x4 (&x)[4], uint32_t rec0)
+                                          uint8_t *__restrict__ payload, const PpScratch &sc, PpShared<MODE != 0, true, FAM == LUT3> &sh, const u32x4 (&x)[4], uint32_t rec0)
 {
-  static_assert(FAM == PLAIN || FAM == PACKED, "plain and Packed");
+  static_assert(FAM == PLAIN || FAM == PACKED || FAM == LUT3, "plain, Packed, 3 symbol LUT");
   static_assert(S == 2 || S == 3 || S == 4 || S == 6 || S == 8, "symbols of 2, 3, 4, 6 or 8 bytes");
+  static_assert(FAM != LUT3 || S >= 3, "the LUT codecs of 1 and 2 byte symbols have runs whose storing depends on the list");
   using TR = Traits<FAM, S, AL>;
   constexpr bool PK = FAM == PACKED;
+  constexpr bool LUT = FAM == LUT3;
   constexpr uint32_t SU = (uint32_t)S;
   constexpr uint32_t SHORT = TR::SHORT, MEDIUM = TR::MEDIUM, LONG = TR::LONG, MAXR = TR::MAXRANGE;
   constexpr bool R7 = TR::kRange7;
-  constexpr uint32_t TERM = (PK ? 5u : SU + 5u) + (R7 ? 4u : 5u);     // bytes of either terminator's fixed part
+  constexpr uint32_t TERM = LUT ? 8u : (PK ? 5u : SU + 5u) + (R7 ? 4u : 5u);     // bytes of the literal terminator's fixed part (plain / Packed: of either terminator's)
+  constexpr uint32_t TERM_END = LUT ? 6u : TERM;                       // LUT: the end terminator is shorter (rleX_Xsl.h:319-338)
   constexpr uint32_t HDR = 8u;                                          // stream header: u32 uncompressed, u32 compressed
   const uint32_t lane = threadIdx.x;
   const uint64_t at = (uint64_t)b * B;
@@ -175,6 +180,9 @@ __device__ __forceinline__ void ppS_block(const uint8_t *__restrict__ in, uint64
   uint32_t carL = 0;                                 // lastRLE in front of the round's first candidate
   uint64_t carY = 0;                                 // Packed: the last stored symbol (starts as zeros)
   uint32_t carE = 0;                                 // end of the last run found (stored or not): where the scan for the next one resumes
+  // LUT: the move-to-front list [lA, lB, lY] (rleX_Xsl.h:279-287: 0x00, 0x7F, 0xFF in every symbol byte)
+  constexpr uint64_t SMASK = (S >= 8) ? ~0ull : ((1ull << (8 * (S & 7))) - 1ull);
+  [[maybe_unused]] uint64_t lA = 0ull, lB = 0x7F7F7F7F7F7F7F7Full & SMASK, lY = 0xFFFFFFFFFFFFFFFFull & SMASK;
   uint32_t pos = HDR;
   uint32_t K = 0;
   bool ended = false;
@@ -186,12 +194,14 @@ __device__ __forceinline__ void ppS_block(const uint8_t *__restrict__ in, uint64
     uint64_t sym = 0;
     bool same = false;
     int k = 0;
+    [[maybe_unused]] uint32_t mtf = 0;                                   // LUT: the symbol's place in the list (3: not there)
     if (fromRecs)
     {
       const uint32_t rec = (r0 == 0u) ? rec0 : (have ? myRecs[r0 + lane] : 0u);
       p = rec & 0xFFFu; e = ((rec >> 12) & 0xFFFu) + 1u;
       same = ((rec >> 24) & 1u) != 0u;
       k = have ? 1 + (int)((rec >> 25) & 1u) : 0;
+      if constexpr (LUT) { mtf = (rec >> 24) & 3u; k = have ? 1 : 0; }
       outL = e;
       inL = wave_shr1(outL, carL);
       sym = pp_symbol<S>(sh.inb, kPpInPad + (have ? p : 0u));
@@ -250,8 +260,11 @@ __device__ __forceinline__ void ppS_block(const uint8_t *__restrict__ in, uint64
       sym = pp_symbol<S>(sh.inb, kPpInPad + (isRun ? p : 0u));
 
       // -- emit decisions (rleX_extreme_cpu_encode.h:174-311): a chain through (lastRLE, last symbol)
-      const bool sure = isRun && count >= LONG;
+      // (LUT, symbols of 3 bytes and more: EVERY run is stored -- count >= 2 S >= 6 >= 3 + the largest penalty a block can produce, rleX_Xsl.h:116-132 --
+      //  so the chain below only hands lastRLE through the candidates without a run; what the list decides is the symbol's index, further down)
+      const bool sure = isRun && (LUT || count >= LONG);
       auto decide = [&](uint32_t iL, uint64_t iY, bool &sm) __attribute__((always_inline)) -> int {
+        if constexpr (LUT) { sm = false; return 1; }
         const uint32_t rng = p - iL + 1u;
         sm = PK && sym == iY;
         const bool shortOk = rng <= MAXR && (PK ? (sm || count >= MEDIUM) : count >= SHORT);   // (count >= 2 S >= the Packed SHORT of 3)
@@ -276,21 +289,56 @@ __device__ __forceinline__ void ppS_block(const uint8_t *__restrict__ in, uint64
       }
       k = isRun ? decide(inL, inY, same) : 0;
       carY = (uint64_t)wave_lane((uint32_t)outY, lastLane) | ((uint64_t)wave_lane((uint32_t)(outY >> 32), lastLane) << 32);
+      if constexpr (LUT)
+      {
+        // The list holds the three most recent DISTINCT symbols.  A run whose symbol is the one before it has index 0 and changes nothing; the others
+        // ("heads" u_0, u_1, ...: consecutive heads differ) see the list [u_t-1, u_t-2, y_t] with y_t = (u_t-1 == u_t-3) ? y_t-1 : u_t-3 -- "copy from the
+        // left unless reset": a prefix maximum over the reset positions, no chain.  The list in front of the round is three heads in front of head 0.
+        uint64_t *const symList = sh.mtfScratch, *const headList = symList + 72;
+        const uint32_t runIncl = wave_scan_add(isRun ? 1u : 0u), rho = runIncl - (isRun ? 1u : 0u);
+        if (lane == 0u) { symList[0] = lA; headList[0] = lY; headList[1] = lB; headList[2] = lA; }
+        if (isRun) symList[1u + rho] = sym;
+        wave_sync();
+        const uint64_t prevSym = symList[isRun ? rho : 0u];
+        const bool head = isRun && sym != prevSym;
+        const uint32_t headIncl = wave_scan_add(head ? 1u : 0u), t = headIncl - (head ? 1u : 0u);
+        if (head) headList[3u + t] = sym;
+        wave_sync();
+        const uint64_t u1 = headList[2u + (head ? t : 0u)], u2 = headList[1u + (head ? t : 0u)], u3 = headList[head ? t : 0u];
+        const int32_t key = (head && u1 != u3) ? (int32_t)t : -1;
+        const int32_t tr = wave_scan_max(key);                           // (>= 0 for every head: head 0 resets -- the list's three entries differ)
+        const uint64_t y = headList[head ? (uint32_t)tr : 0u];
+        mtf = !head ? 0u : (sym == u2 ? 1u : (sym == y ? 2u : 3u));
+        // the list behind the round: behind its last head
+        const unsigned long long heads = __ballot(head);
+        if (heads != 0ull)
+        {
+          const int hl_ = 63 - __builtin_clzll(heads);
+          const uint64_t yNext = (sym == u2) ? y : u2;
+          lA = (uint64_t)wave_lane((uint32_t)sym, hl_) | ((uint64_t)wave_lane((uint32_t)(sym >> 32), hl_) << 32);
+          lB = (uint64_t)wave_lane((uint32_t)u1, hl_) | ((uint64_t)wave_lane((uint32_t)(u1 >> 32), hl_) << 32);
+          lY = (uint64_t)wave_lane((uint32_t)yNext, hl_) | ((uint64_t)wave_lane((uint32_t)(yNext >> 32), hl_) << 32);
+        }
+        wave_sync();
+      }
     }
-    const uint32_t count = e - p, gap = p - inL, rng = gap + 1u;
+    const uint32_t count = e - p, gap = p - inL, rng = gap + (LUT ? 2u : 1u);
 
-    // ---- packet header (rleX_extreme_cpu_encode.h:174-311): [count | same] [symbol] [range] (Packed) / [symbol] [count] [range] (plain) ----
-    const uint32_t cfield = AL ? count / SU - SHORT / SU + 1u : count - SHORT + 1u;
-    const uint32_t cMax = PK ? 127u : 255u;
-    const uint32_t cBytes = cfield <= cMax ? 1u : 5u, sBytes = (PK && same) ? 0u : SU, rBytes = (k == 1) ? 1u : (R7 ? 4u : 5u);
-    const uint32_t hl = k ? cBytes + sBytes + rBytes : 0u;
+    // ---- packet header (rleX_extreme_cpu_encode.h:174-311): [count | same] [symbol] [range] (Packed) / [symbol] [count] [range] (plain);
+    //      LUT (rleX_Xsl.h:190-250): u16 {index, count, range}, [symbol if new], [u16 count], [u16 range] ----
+    const uint32_t cfield = LUT ? (AL ? count / SU - 3u / SU + 2u : count - 1u) : (AL ? count / SU - SHORT / SU + 1u : count - SHORT + 1u);
+    const uint32_t cMax = (PK || LUT) ? 127u : 255u;
+    const uint32_t cBytes = LUT ? (cfield <= 127u ? 0u : 2u) : (cfield <= cMax ? 1u : 5u);
+    const uint32_t sBytes = LUT ? (mtf == 3u ? SU : 0u) : ((PK && same) ? 0u : SU);
+    const uint32_t rBytes = LUT ? (rng <= 127u ? 0u : 2u) : ((k == 1) ? 1u : (R7 ? 4u : 5u));
+    const uint32_t hl = k ? (LUT ? 2u : 0u) + cBytes + sBytes + rBytes : 0u;
     const uint32_t myBytes = k ? hl + gap : 0u;
     const uint32_t incl = wave_scan_add(myBytes | (k ? 0x10000u : 0u));
     const uint32_t tot = wave_lane(incl, 63);
     if constexpr (MODE == 0)
     {
       const uint32_t idx = K + (incl >> 16) - 1u;
-      if (k && idx < sc.recStride) sc.recs[(uint64_t)b * sc.recStride + idx] = p | ((e - 1u) << 12) | (same ? 1u << 24 : 0u) | (k == 2 ? 1u << 25 : 0u);
+      if (k && idx < sc.recStride) sc.recs[(uint64_t)b * sc.recStride + idx] = p | ((e - 1u) << 12) | (LUT ? mtf << 24 : ((same ? 1u << 24 : 0u) | (k == 2 ? 1u << 25 : 0u)));
     }
     else
     {
@@ -298,20 +346,31 @@ __device__ __forceinline__ void ppS_block(const uint8_t *__restrict__ in, uint64
       uint32_t nch = 0, ds = 0;
       if (k)
       {
-        const uint64_t cval = cfield <= cMax ? (uint64_t)(cfield | ((PK && same) ? 0x80u : 0u)) : (((uint64_t)cfield << 8) | ((PK && same) ? 0x80u : 0u));
-        const uint64_t rval = (k == 1) ? (uint64_t)(R7 ? (rng << 1) & 0xFFu : rng) : (R7 ? (uint64_t)((rng << 1) | 1u) : ((uint64_t)rng << 8));
         uint32_t a = at0;
-        if constexpr (PK)
+        if constexpr (LUT)
         {
-          pp_or_bytes(sh.img, a, cval, cBytes); a += cBytes;
-          if (!same) { pp_or_bytes(sh.img, a, sym, SU); a += SU; }
+          const uint32_t c7 = cfield <= 127u ? cfield : 1u, r7 = rng <= 127u ? rng : 1u;   // (1: a 16 bit field follows; nothing in a block needs 32)
+          pp_or_bytes(sh.img, a, (uint64_t)((mtf << 14) | (c7 << 7) | r7), 2u); a += 2u;
+          if (mtf == 3u) { pp_or_bytes(sh.img, a, sym, SU); a += SU; }
+          if (cBytes) { pp_or_bytes(sh.img, a, (uint64_t)cfield, 2u); a += 2u; }
+          if (rBytes) pp_or_bytes(sh.img, a, (uint64_t)rng, 2u);
         }
         else
         {
-          pp_or_bytes(sh.img, a, sym, SU); a += SU;
-          pp_or_bytes(sh.img, a, cval, cBytes); a += cBytes;
+          const uint64_t cval = cfield <= cMax ? (uint64_t)(cfield | ((PK && same) ? 0x80u : 0u)) : (((uint64_t)cfield << 8) | ((PK && same) ? 0x80u : 0u));
+          const uint64_t rval = (k == 1) ? (uint64_t)(R7 ? (rng << 1) & 0xFFu : rng) : (R7 ? (uint64_t)((rng << 1) | 1u) : ((uint64_t)rng << 8));
+          if constexpr (PK)
+          {
+            pp_or_bytes(sh.img, a, cval, cBytes); a += cBytes;
+            if (!same) { pp_or_bytes(sh.img, a, sym, SU); a += SU; }
+          }
+          else
+          {
+            pp_or_bytes(sh.img, a, sym, SU); a += SU;
+            pp_or_bytes(sh.img, a, cval, cBytes); a += cBytes;
+          }
+          pp_or_bytes(sh.img, a, rval, rBytes);
         }
-        pp_or_bytes(sh.img, a, rval, rBytes);
         ds = at0 + hl;
         if (gap > kPpCoopMin) { const uint32_t slot = atomicAdd(&sh.jobCount, 1u); sh.jobs[slot] = (uint64_t)inL | ((uint64_t)ds << 13) | ((uint64_t)gap << 26); }
         else if (gap != 0u) nch = ((ds + gap - 1u) >> 4) - (ds >> 4) + 1u;
@@ -330,7 +389,7 @@ __device__ __forceinline__ void ppS_block(const uint8_t *__restrict__ in, uint64
 
   // ---- 3. terminator, stream size (rleX_extreme_cpu_encode.h:384-603) ----
   const uint32_t kLit = ended ? 0u : n - carL;
-  const uint32_t streamSize = pos + TERM + kLit;
+  const uint32_t streamSize = pos + (ended ? TERM_END : TERM) + kLit;
   if constexpr (MODE == 0)
   {
     if (lane == 0u) { sizes[b] = streamSize; sc.recCount[b] = (K <= sc.recStride) ? K : kPpNoRecords; }
@@ -345,13 +404,22 @@ __device__ __forceinline__ void ppS_block(const uint8_t *__restrict__ in, uint64
     }
     if (lane == 16u)
     {
-      // plain: S zero bytes, 00, u32 0 | Packed: 80, u32 0;  then the range field: (u32 value << 1 | 1) where the codec has 7-bit ranges, else 00, u32 value;
-      // value = 0 (end) or literals + 1
-      const uint32_t a0 = pos + (PK ? 0u : SU);
-      if constexpr (PK) sh.img[a0] = 0x80;
-      const uint32_t val = ended ? 0u : kLit + 1u;
-      if constexpr (R7) pp_or_bytes(sh.img, a0 + 5u, (uint64_t)((val << 1) | 1u), 4u);
-      else pp_or_bytes(sh.img, a0 + 5u, (uint64_t)val << 8, 5u);
+      if constexpr (LUT)
+      {
+        // end: u16 (1 << 7) | 1, u16 0, u16 0;  literals: u16 1 << 7, u16 0, u32 literals + 2  (rleX_Xsl.h:319-338)
+        sh.img[pos] = ended ? 0x81 : 0x80;
+        if (!ended) pp_or_bytes(sh.img, pos + 4u, (uint64_t)(kLit + 2u), 4u);
+      }
+      else
+      {
+        // plain: S zero bytes, 00, u32 0 | Packed: 80, u32 0;  then the range field: (u32 value << 1 | 1) where the codec has 7-bit ranges, else 00, u32 value;
+        // value = 0 (end) or literals + 1
+        const uint32_t a0 = pos + (PK ? 0u : SU);
+        if constexpr (PK) sh.img[a0] = 0x80;
+        const uint32_t val = ended ? 0u : kLit + 1u;
+        if constexpr (R7) pp_or_bytes(sh.img, a0 + 5u, (uint64_t)((val << 1) | 1u), 4u);
+        else pp_or_bytes(sh.img, a0 + 5u, (uint64_t)val << 8, 5u);
+      }
     }
     wave_sync();
     {
@@ -379,7 +447,7 @@ template <int FAM, int S, int AL, int MODE>
 __global__ __launch_bounds__(64) void k_encodeS_pp(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t nBlocks, uint32_t *__restrict__ sizes,
                                                    const uint64_t *__restrict__ offsets, uint8_t *__restrict__ payload, PpScratch sc)
 {
-  __shared__ PpShared<MODE != 0, true> sh;
+  __shared__ PpShared<MODE != 0, true, FAM == LUT3> sh;
   if (MODE != 0 && threadIdx.x < 17u)
   {
     const uint32_t c = threadIdx.x;

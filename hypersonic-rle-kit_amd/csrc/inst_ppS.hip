@@ -29,9 +29,18 @@ static void reg_width(PpLaunch *pp)
   pp[6 + 8 * W + 5] = ppS_launch<PACKED, S, 0>;
 }
 
+// ... v = 2 3symlut_sym, 6 3symlut_byte: symbols of 3 bytes and more (hsrle_encodeSp.hip.h)
+template <int S, int W>
+static void reg_lut3(PpLaunch *pp)
+{
+  pp[6 + 8 * W + 2] = ppS_launch<LUT3, S, 1>;
+  pp[6 + 8 * W + 6] = ppS_launch<LUT3, S, 0>;
+}
+
 void register_ppS(PpLaunch *pp)
 {
   reg_width<2, 0>(pp); reg_width<3, 1>(pp); reg_width<4, 2>(pp); reg_width<6, 3>(pp); reg_width<8, 4>(pp);
+  reg_lut3<3, 1>(pp); reg_lut3<4, 2>(pp); reg_lut3<6, 3>(pp); reg_lut3<8, 4>(pp);
 }
 
 } // namespace hsrle

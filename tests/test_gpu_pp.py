@@ -135,3 +135,31 @@ def test_position_parallel_wide_encoder_bit_exact(hs, oracle, wide_cases, key, n
 def test_position_parallel_wide_encoder_block_sizes_and_ragged_tails(hs, oracle, wide_cases, key, block, cut):
     data = np.concatenate([wide_cases["periods"][: 2 << 20], wide_cases["butting"][: 1 << 19]])
     _check(hs, oracle, key, data[: data.size - cut], block)
+
+
+# ---- 3 symbol LUT codecs of 3 .. 8 byte symbols (every run stored; the symbol's list index through streak heads) ----
+LUT_KEYS = [f"rle{w}_3symlut_{a}" for w in (24, 32, 48, 64) for a in ("sym", "byte")]
+
+
+@pytest.fixture(scope="module")
+def lut_cases(wide_cases):
+    rng = np.random.default_rng(991)
+    n = 3 << 20
+    few = _periodic(rng, n, [3, 4, 6, 8], 2, 6, [6, 8, 9, 12, 16, 17, 24, 32, 48, 130, 400])          # two byte values: the same few symbols come back all the time (indices 0 .. 2)
+    defaults = np.frombuffer(bytes([0x00, 0x7F, 0xFF, 0x01]), dtype=np.uint8)
+    init = _periodic(rng, n, [1], 4, 9, [6, 8, 12, 16, 24, 48])                                    # runs of single byte values ...
+    init = defaults[init % 4]                                                                      # ... out of the list's initial entries and one more
+    return dict(wide_cases, few_symbols=few, initial_entries=init)
+
+
+@pytest.mark.parametrize("key", LUT_KEYS)
+@pytest.mark.parametrize("name", ["periods", "butting", "far_apart", "two_symbols", "few_symbols", "initial_entries"])
+def test_position_parallel_lut3_encoder_bit_exact(hs, oracle, lut_cases, key, name):
+    _check(hs, oracle, key, lut_cases[name], 4096)
+
+
+@pytest.mark.parametrize("key", ["rle24_3symlut_sym", "rle64_3symlut_byte"])
+@pytest.mark.parametrize("block,cut", [(128, 0), (1024, 77), (1536, 1535), (4096, 4095), (4096, 4081)])
+def test_position_parallel_lut3_encoder_block_sizes_and_ragged_tails(hs, oracle, lut_cases, key, block, cut):
+    data = np.concatenate([lut_cases["few_symbols"][: 2 << 20], lut_cases["butting"][: 1 << 19]])
+    _check(hs, oracle, key, data[: data.size - cut], block)
