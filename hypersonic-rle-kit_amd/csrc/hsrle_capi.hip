@@ -1889,6 +1889,8 @@ int hsrle_encode_path(int codec, uint64_t uncompressedSize, uint32_t blockSize)
 {
   if (codec < 0 || codec >= kCodecCount || uncompressedSize == 0 || !valid_block_size(blockSize)) return -1;
   const Workspace w = plan_workspace(uncompressedSize, blockSize);
+  init_tables();
+  if (w.nChunks <= 1 && pp_applies(codec, (uint32_t)w.nBlocks, blockSize)) return HSRLE_PATH_POSITION_PARALLEL;
   if (w.nChunks <= 1 && w.spSlots != 0 && split_encode_applies(codec, w.nBlocks, blockSize)) return HSRLE_PATH_SPLIT;
   if (w.nChunks <= 1 && run_list_codec(codec) && run_list_applies(w.nBlocks, blockSize, uncompressedSize, knob_u32("HSRLE_RUNLIST", 0u))) return HSRLE_PATH_RUN_LIST;
   return HSRLE_PATH_RING;

@@ -168,7 +168,7 @@ def build_id():
     return _lib().hsrle_build_id().decode()
 
 
-PATH_RING, PATH_SPLIT, PATH_RUN_LIST = 0, 1, 2
+PATH_RING, PATH_SPLIT, PATH_RUN_LIST, PATH_POSITION_PARALLEL = 0, 1, 2, 3
 
 
 def encode_path(codec, size, block_size):
