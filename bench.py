@@ -241,6 +241,21 @@ def side_measurements(hsrle, torch, src, dev):
 
     enc_ms = wall(lambda: hsrle.mono_compress_dev("rle8_packed_multi", part, dst=edst, workspace=ews), 3)
     dec_ms = wall(lambda: hsrle.mono_decompress_dev("rle8_packed_multi", t, dst=dout, workspace=dws), 3)
+    mono_exact = bool(torch.equal(dout, part))
+    # the same stream through hsrle_decompress_mono_dev_async (nothing between the passes waits for the host), called and as a replayed HIP graph
+    head16 = t[:16].cpu().numpy().tobytes()
+    mstatus = torch.full((1,), 77, dtype=torch.int32, device=dev)
+    dout.zero_()
+    async_ms = wall(lambda: hsrle.mono_decompress_dev_async("rle8_packed_multi", t, head16, dout, dws, mstatus), 5)
+    async_ok = int(mstatus.item()) == hsrle.MONO_DONE and bool(torch.equal(dout, part))
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        hsrle.mono_decompress_dev_async("rle8_packed_multi", t, head16, dout, dws, mstatus)
+    dout.zero_(); mstatus.fill_(77)
+    graph_ms = wall(graph.replay, 5)
+    graph_ok = int(mstatus.item()) == hsrle.MONO_DONE and bool(torch.equal(dout, part))
+    del graph
     from hsrle_testlib import big_manifest
 
     import hashlib
@@ -253,8 +268,11 @@ def side_measurements(hsrle, torch, src, dev):
     out["mono_1GiB"] = {"codec": "rle8_packed_multi", "stream_bytes": int(stream.numel()), "encode_ms": round(enc_ms, 3), "encode_GiBps": round(1024 / enc_ms, 1),
                         "decode_ms": round(dec_ms, 3), "decode_GiBps": round(1024 / dec_ms, 1),
                         "decode_frac": round((n + int(stream.numel())) / (dec_ms * 1e-3) / 8e12, 4), "encode_frac": round((n + int(stream.numel())) / (enc_ms * 1e-3) / 8e12, 4),
-                        "stream_is_the_references": same, "decode_exact": bool(torch.equal(dout, part)),
-                        "note": "one monolithic reference stream, device resident, host verdict reads included; frac = (C + U) / t against 8 TB/s"}
+                        "decode_async_ms": round(async_ms, 3), "decode_async_exact": async_ok, "decode_graph_replay_ms": round(graph_ms, 3), "decode_graph_exact": graph_ok,
+                        "stream_is_the_references": same, "decode_exact": mono_exact,
+                        "note": "one monolithic reference stream, device resident; decode_ms = hsrle_decompress_mono_dev (header read, one verdict read at the end), "
+                                "decode_async_ms = hsrle_decompress_mono_dev_async + one synchronize, decode_graph_replay_ms = the same call captured in a HIP graph; "
+                                "frac = (C + U) / t against 8 TB/s"}
 
     # (3) the HOST-pointer drop-in path, as a caller of the reference gets it without changing a line (src/main.c:835, :970 call these names): the
     # same 1 GiB through rle8_packed_multi_compress / rle8_packed_decompress with numpy buffers -- H2D + kernels + D2H, PCIe-bound by construction

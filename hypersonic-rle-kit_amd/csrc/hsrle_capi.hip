@@ -1033,6 +1033,8 @@ static MonoPlan plan_mono(int codec, uint32_t U, uint32_t C, uint32_t p0)
   return m;
 }
 
+__global__ void k_set_word(uint32_t *p, uint32_t v) { *p = v; }
+
 static hipError_t launch_resolve(const MonoPlan &m, uint8_t *ws, uint32_t p0, uint64_t U, uint32_t roundTag, hipStream_t st)
 {
   // the full batches but the last in parallel when every guess is right (hsrle_index.hip.h: k_resolve_fast_*); k_index_resolve finishes -- or, when
@@ -1041,7 +1043,7 @@ static hipError_t launch_resolve(const MonoPlan &m, uint8_t *ws, uint32_t p0, ui
   uint32_t *fast = (uint32_t *)(ws + m.offFast), *batch = (uint32_t *)(ws + m.offBatch);
   const uint32_t *cg = (const uint32_t *)(ws + m.offG), *ce = (const uint32_t *)(ws + m.offE), *ct = (const uint32_t *)(ws + m.offT);
   const uint64_t *col = (const uint64_t *)(ws + m.offOlen);
-  if (fastBatches != 0u && hipMemsetD32Async((hipDeviceptr_t)fast, 1, 1, st) != hipSuccess) return hipErrorUnknown;
+  if (fastBatches != 0u) hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, fast, 1u);      // (a kernel, not a memset node: see mono_prepare)
 #define HSRLE_RESOLVE(KE)                                                                                                                                        \
   if (fastBatches != 0u)                                                                                                                                         \
   {                                                                                                                                                              \
@@ -1097,17 +1099,39 @@ static bool mono_header(int codec, const uint8_t *h16, uint32_t inSize, uint32_t
   return true;
 }
 
-// dStream: 128-byte aligned, readable up to C + 64.  stats (optional): [0] regions, [1] repair rounds, [2] regions walked again.
-// Synchronises the stream (the repair loop reads the resolve pass's verdict).  Returns HSRLE_OK / HSRLE_ERR_FORMAT / HSRLE_ERR_DEVICE.
-static int mono_decode_dev(const MonoHeader &mh, const uint8_t *dStream, uint8_t *dOut, uint8_t *ws, const MonoPlan &m, uint32_t *stats, hipStream_t st)
+// ---- monolithic decode.  The passes in stream order: walk (every region from a guessed entry) -> resolve (chains the regions, checks the
+//      guesses; verdict in ctrl[0..3]) -> records (decoder state at every B output bytes) -> decode.  Since round 5 the records pass is GATED on
+//      the verdict on the device and the whole sequence is enqueued without the host in between: a stream whose guesses all hold (the normal
+//      case) costs ONE host read at the end instead of two round trips (and none at all through hsrle_decompress_mono_dev_async, which a
+//      HIP graph can capture); a stream that needs repair finds zero records, its decode lanes end at once, and the host-driven repair loop
+//      takes over where the resolve pass stopped.
+__global__ __launch_bounds__(256) void k_mono_clear(u32x4 *__restrict__ p, uint64_t n16)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (i < n16) p[i] = u32x4{ 0, 0, 0, 0 };
+}
+
+struct MonoRun
+{
+  IndexArgs ia;
+  uint32_t *ctrl;
+  DecodeArgs da;
+};
+
+static int mono_prepare(const MonoHeader &mh, const uint8_t *dStream, uint8_t *dOut, uint8_t *ws, const MonoPlan &m, MonoRun *run, hipStream_t st)
 {
   init_tables();
   if (!g_dec[mh.codec] || !g_idx[mh.codec])
     return HSRLE_ERR_UNSUPPORTED;
   uint32_t *ctrl = (uint32_t *)(ws + m.offCtrl);
-  if (hipMemsetAsync(ctrl, 0, 256, st) != hipSuccess || hipMemsetAsync(ws + m.offRec, 0, 4ull * kEntryRecDwords * m.nb, st) != hipSuccess ||
-      hipMemsetAsync(ws + m.offMark, 0, 4ull * m.R, st) != hipSuccess)
-    return HSRLE_ERR_DEVICE;
+  // mark | ctrl | records are neighbours in the workspace (plan_mono), every piece a multiple of 256 bytes: ONE clearing launch.  (Not
+  // hipMemsetAsync, whose node misbehaves in a captured and replayed HIP graph -- hsrle_common.hip.h zero_async; seen again here: junk in ctrl[4..15].)
+  {
+    const uint64_t bytes = m.offFast - m.offMark;
+    hipLaunchKernelGGL(k_mono_clear, dim3((uint32_t)((bytes / 16u + 255u) / 256u)), dim3(256), 0, st, (u32x4 *)(ws + m.offMark), bytes / 16u);
+    if (hipGetLastError() != hipSuccess)
+      return HSRLE_ERR_DEVICE;
+  }
 
   IndexArgs ia{};
   ia.stream = dStream; ia.C = mh.C; ia.p0 = mh.p0; ia.G = m.G; ia.M = m.M; ia.R = m.R; ia.single = mh.single; ia.singleSym = mh.singleSym;
@@ -1115,9 +1139,46 @@ static int mono_decode_dev(const MonoHeader &mh, const uint8_t *dStream, uint8_t
   ia.g = (uint32_t *)(ws + m.offG); ia.e = (uint32_t *)(ws + m.offE); ia.olen = (uint64_t *)(ws + m.offOlen); ia.t = (uint32_t *)(ws + m.offT);
   ia.entry = (const uint32_t *)(ws + m.offEntry); ia.outStart = (const uint64_t *)(ws + m.offOutStart); ia.stateIn = (const uint32_t *)(ws + m.offStateIn);
   ia.U = mh.U; ia.B = m.B; ia.rec = (uint32_t *)(ws + m.offRec);
-
   ia.mark = (uint32_t *)(ws + m.offMark); ia.roundTag = 0;
   { static const uint32_t ext = env_u32("HSRLE_MONO_REPAIR_EXTEND", 48); ia.extMax = ext; }
+  run->ia = ia;
+  run->ctrl = ctrl;
+  run->da = DecodeArgs{ dStream, nullptr, dStream + mh.C + HSRLE_CONTAINER_TAIL_PAD, dOut, mh.U, m.B, 0u, (uint32_t)m.nb, ctrl + 8 };
+  run->da.entries = (const uint32_t *)(ws + m.offRec);
+  run->da.entryBase = 0;
+  return HSRLE_OK;
+}
+
+// walk of every region, resolve round 1, gated records, decode: nothing here waits for the host
+static int mono_enqueue_first_try(const MonoHeader &mh, uint8_t *ws, const MonoPlan &m, MonoRun &run, hipStream_t st)
+{
+  if (g_idx[mh.codec](run.ia, 0, st) != hipSuccess || launch_resolve(m, ws, mh.p0, mh.U, 1u, st) != hipSuccess)
+    return HSRLE_ERR_DEVICE;
+  run.ia.gate = run.ctrl;
+  const hipError_t e = g_idx[mh.codec](run.ia, 1, st);
+  run.ia.gate = nullptr;
+  if (e != hipSuccess || g_dec[mh.codec](run.da, st) != hipSuccess)
+    return HSRLE_ERR_DEVICE;
+  return HSRLE_OK;
+}
+
+// ctrl[0] regions whose guess failed, ctrl[1] malformed stream, ctrl[8] the decode kernel's error bits -> one word for the caller
+__global__ void k_mono_status(const uint32_t *__restrict__ ctrl, uint32_t *__restrict__ status)
+{
+  *status = ctrl[1] != 0u ? (uint32_t)HSRLE_MONO_MALFORMED : (ctrl[0] != 0u ? (uint32_t)HSRLE_MONO_NEEDS_REPAIR : (ctrl[8] != 0u ? (uint32_t)HSRLE_MONO_MALFORMED : (uint32_t)HSRLE_MONO_DONE));
+}
+
+// dStream: 128-byte aligned, readable up to C + 64.  stats (optional): [0] regions, [1] repair rounds, [2] regions walked again.
+// Synchronises the stream (once when every guess holds; the repair loop reads the resolve pass's verdict per round).
+// Returns HSRLE_OK / HSRLE_ERR_FORMAT / HSRLE_ERR_DEVICE.
+static int mono_decode_dev(const MonoHeader &mh, const uint8_t *dStream, uint8_t *dOut, uint8_t *ws, const MonoPlan &m, uint32_t *stats, hipStream_t st)
+{
+  MonoRun run;
+  const int prc = mono_prepare(mh, dStream, dOut, ws, m, &run, st);
+  if (prc != HSRLE_OK)
+    return prc;
+  IndexArgs &ia = run.ia;
+  uint32_t *const ctrl = run.ctrl;
   if (!m.range7 && m.R >= 16384u && g_monoTune[2] == 0u)                  // (small streams: the pilot's launch + read costs more than a widened second try)
   {
     // formats whose junk walks do not die: does the short look-back find the chain on THIS stream?  A pilot over the first 128 regions
@@ -1132,19 +1193,18 @@ static int mono_decode_dev(const MonoHeader &mh, const uint8_t *dStream, uint8_t
     for (uint32_t r = 1; r < 128u; r++) agree += (pe[r - 1] == pg[r]) ? 1u : 0u;
     if (agree < 120u) ia.M = 16384u;
   }
-  if (g_idx[mh.codec](ia, 0, st) != hipSuccess)
+  uint32_t rounds = 0, rewalked = 0, roundTag = 1;
+  uint32_t verdict[12] = { 0 };                                            // [0..3] the resolve pass's verdict, [8] the decode kernel's status
+  if (mono_enqueue_first_try(mh, ws, m, run, st) != HSRLE_OK ||
+      hipMemcpyAsync(verdict, ctrl, 36, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
     return HSRLE_ERR_DEVICE;
-  uint32_t rounds = 0, rewalked = 0, roundTag = 0;
-  uint32_t verdict[4] = { 0, 0, 0, 0 };
+  if (verdict[0] == 0u)
+  {
+    if (stats) { stats[0] = m.R; stats[1] = 0; stats[2] = 0; stats[3] = ia.M; }
+    return (verdict[1] != 0u || verdict[8] != 0u) ? HSRLE_ERR_FORMAT : HSRLE_OK;
+  }
   for (;;)
   {
-    roundTag++;
-    if (launch_resolve(m, ws, mh.p0, mh.U, roundTag, st) != hipSuccess)
-      return HSRLE_ERR_DEVICE;
-    if (hipMemcpyAsync(verdict, ctrl, sizeof(verdict), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
-      return HSRLE_ERR_DEVICE;
-    if (verdict[0] == 0u)
-      break;
     if (rounds++ > m.R)                                    // every round proves at least one more region: cannot happen
       return HSRLE_ERR_DEVICE;
     rewalked += verdict[0];
@@ -1159,22 +1219,25 @@ static int mono_decode_dev(const MonoHeader &mh, const uint8_t *dStream, uint8_t
     else { ia.list = (const uint32_t *)(ws + m.offList); ia.listCount = verdict[0]; ia.roundTag = roundTag; }
     if (g_idx[mh.codec](ia, 0, st) != hipSuccess)
       return HSRLE_ERR_DEVICE;
+    roundTag++;
+    if (launch_resolve(m, ws, mh.p0, mh.U, roundTag, st) != hipSuccess)
+      return HSRLE_ERR_DEVICE;
+    if (hipMemcpyAsync(verdict, ctrl, 16, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+      return HSRLE_ERR_DEVICE;
+    if (verdict[0] == 0u)
+      break;
   }
   if (stats) { stats[0] = m.R; stats[1] = rounds; stats[2] = rewalked; stats[3] = ia.M; }
   if (verdict[1] != 0u)
     return HSRLE_ERR_FORMAT;
 
+  // (the first try's decode lanes found zero records and left their error bits in the status word)
   ia.list = nullptr; ia.listCount = 0;
-  if (g_idx[mh.codec](ia, 1, st) != hipSuccess)
-    return HSRLE_ERR_DEVICE;
-  uint32_t *dStatus = ctrl + 8;
-  DecodeArgs da{ dStream, nullptr, dStream + mh.C + HSRLE_CONTAINER_TAIL_PAD, dOut, mh.U, m.B, 0u, (uint32_t)m.nb, dStatus };
-  da.entries = (const uint32_t *)(ws + m.offRec);
-  da.entryBase = 0;
-  if (g_dec[mh.codec](da, st) != hipSuccess)
+  hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, ctrl + 8, 0u);
+  if (g_idx[mh.codec](ia, 1, st) != hipSuccess || g_dec[mh.codec](run.da, st) != hipSuccess)
     return HSRLE_ERR_DEVICE;
   uint32_t status = 1;
-  if (hipMemcpyAsync(&status, dStatus, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+  if (hipMemcpyAsync(&status, ctrl + 8, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
     return HSRLE_ERR_DEVICE;
   return status == 0u ? HSRLE_OK : HSRLE_ERR_FORMAT;
 }
@@ -2459,6 +2522,27 @@ int hsrle_decompress_mono_dev(int codec, const void *dStream, uint32_t streamSiz
   const int rc = mono_decode_dev(mh, (const uint8_t *)dStream, (uint8_t *)dOut, (uint8_t *)dWorkspace, m, pStats, (hipStream_t)stream);
   if (rc == HSRLE_OK && pUncompressedSize) *pUncompressedSize = mh.U;
   return rc;
+}
+
+int hsrle_decompress_mono_dev_async(int codec, const void *dStream, const uint8_t *pHeader16, uint32_t streamSize, void *dOut, uint64_t outCapacity, void *dWorkspace,
+                                    uint64_t workspaceSize, uint32_t *pUncompressedSize, uint32_t *dStatus, void *stream)
+{
+  if (!dStream || !pHeader16 || !dOut || !dWorkspace || !dStatus || codec < 0 || codec >= kCodecCount || streamSize < 16u || ((uintptr_t)dStream & 127u) != 0u)
+    return HSRLE_ERR_ARGUMENT;
+  if (!device_ok()) return HSRLE_ERR_DEVICE;
+  MonoHeader mh;
+  if (!mono_header(codec, pHeader16, streamSize, outCapacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)outCapacity, &mh))
+    return HSRLE_ERR_FORMAT;
+  const MonoPlan m = plan_mono(mh.codec, mh.U, mh.C, mh.p0);
+  if (workspaceSize < m.total) return HSRLE_ERR_CAPACITY;
+  MonoRun run;
+  int rc = mono_prepare(mh, (const uint8_t *)dStream, (uint8_t *)dOut, (uint8_t *)dWorkspace, m, &run, (hipStream_t)stream);
+  if (rc == HSRLE_OK) rc = mono_enqueue_first_try(mh, (uint8_t *)dWorkspace, m, run, (hipStream_t)stream);
+  if (rc != HSRLE_OK) return rc;
+  hipLaunchKernelGGL(k_mono_status, dim3(1), dim3(1), 0, (hipStream_t)stream, (const uint32_t *)run.ctrl, dStatus);
+  if (hipGetLastError() != hipSuccess) return HSRLE_ERR_DEVICE;
+  if (pUncompressedSize) *pUncompressedSize = mh.U;
+  return HSRLE_OK;
 }
 
 int hsrle_hash_blocks_dev_async(const void *dContainer, const hsrle_container_info_t *info, uint32_t firstBlock, uint32_t blockCount, uint64_t *dHashes, void *stream)

@@ -822,12 +822,15 @@ __device__ __forceinline__ uint32_t walk_emit_records(const READER &s, uint64_t 
 template <int FAM, int S, int AL>
 __global__ __launch_bounds__(64) void k_index_records(const uint8_t *__restrict__ s, uint32_t C, uint32_t p0, uint32_t G, uint32_t R, uint32_t single, uint32_t singleSym,
                                                       const uint32_t *__restrict__ entry, const uint64_t *__restrict__ outStart, const uint32_t *__restrict__ stateIn,
-                                                      uint64_t U, uint32_t B, uint32_t *__restrict__ rec)
+                                                      uint64_t U, uint32_t B, uint32_t *__restrict__ rec, const uint32_t *__restrict__ gate)
 {
   constexpr int KE = IndexState<FAM>::KE;
   constexpr int KS = KE > 0 ? KE : 1;
   const uint32_t r = blockIdx.x * 64u + threadIdx.x;
   if (r >= R) return;
+  // enqueued behind the resolve pass without the host in between: entries that did not pass the check are junk and a walk from junk is
+  // unbounded work (round 4 measured 105 ms) -- the records stay zero, the decoder's lanes end at once, the host repairs and comes again
+  if (gate != nullptr && (gate[0] | gate[1]) != 0u) return;
   const uint32_t x = entry[r];
   if (x == IDX_SKIP) return;
   uint64_t o = outStart[r];
@@ -1087,7 +1090,7 @@ inline hipError_t launch_index(const IndexArgs &a, int records, hipStream_t st)
 {
   if (records)
     hipLaunchKernelGGL((k_index_records<FAM, S, AL>), dim3((a.R + 63u) / 64u), dim3(64), 0, st, a.stream, a.C, a.p0, a.G, a.R, a.single, a.singleSym, a.entry, a.outStart, a.stateIn,
-                       a.U, a.B, a.rec);
+                       a.U, a.B, a.rec, a.gate);
   else
   {
     const uint32_t n = a.list ? a.listCount : a.R;

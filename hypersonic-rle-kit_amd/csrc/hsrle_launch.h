@@ -45,6 +45,7 @@ struct IndexArgs
   uint32_t *mark; uint32_t roundTag; uint32_t extMax;                           //              mark[r] == roundTag: region r is on this round's list
   uint32_t *g, *e; uint64_t *olen; uint32_t *t;                       // walk results per region
   const uint32_t *entry; const uint64_t *outStart; const uint32_t *stateIn; uint64_t U; uint32_t B; uint32_t *rec;   // record pass
+  const uint32_t *gate = nullptr;   // record pass enqueued BEFORE the host has seen the resolve verdict: gate[0] | gate[1] != 0 (regions to repair / malformed) -> writes nothing
 };
 typedef hipError_t (*IndexLaunch)(const IndexArgs &, int records, hipStream_t);
 // container blocks cut into sub-blocks of SB output bytes: entry records for [firstBlock, firstBlock + blockCount) of `a` into rec

@@ -114,6 +114,8 @@ def _lib():
     L.hsrle_decompress_mono_dev.argtypes = [ci, vp, u32, vp, u64, vp, u64, ctypes.POINTER(u32), ctypes.POINTER(u32), vp]
     L.hsrle_compress_mono_workspace_size.restype = u64
     L.hsrle_compress_mono_workspace_size.argtypes = [ci, u32]
+    L.hsrle_decompress_mono_dev_async.restype = ci
+    L.hsrle_decompress_mono_dev_async.argtypes = [ci, vp, ctypes.c_char_p, u32, vp, u64, vp, u64, ctypes.POINTER(u32), vp, vp]
     L.hsrle_compress_mono_dev.restype = ci
     L.hsrle_compress_mono_dev.argtypes = [ci, vp, u32, vp, u64, vp, u64, ctypes.POINTER(u32), ctypes.POINTER(u32), vp]
     L.hsrle_mono_tuning.restype = None
@@ -286,6 +288,29 @@ def mono_decompress_dev(codec, stream_tensor, dst=None, workspace=None, return_s
     if rc != OK:
         raise HsrleError(rc, "hsrle_decompress_mono_dev")
     return (dst[: n.value], tuple(stats)) if return_stats else dst[: n.value]
+
+
+MONO_DONE, MONO_MALFORMED, MONO_NEEDS_REPAIR = 0, 1, 2
+
+
+def mono_decompress_dev_async(codec, stream_tensor, header16, dst, workspace, status, stream_size=None):
+    """hsrle_decompress_mono_dev_async: enqueue the decode of ONE monolithic reference stream on the current stream, nothing synchronises
+    (can be captured in a HIP graph).  header16: the stream's first 16 bytes (host bytes); dst / workspace / status (uint32[1]) are CUDA
+    tensors the caller owns.  Returns the uncompressed size; `status` holds MONO_DONE / MONO_MALFORMED / MONO_NEEDS_REPAIR once the stream
+    has run."""
+    _check_u8_cuda(stream_tensor, "stream")
+    header16 = bytes(header16[:16]).ljust(16, b"\0")
+    csize = int.from_bytes(header16[4:8], "little") if stream_size is None else int(stream_size)
+    n = ctypes.c_uint32(0)
+    rc = _lib().hsrle_decompress_mono_dev_async(codec_id(codec), ctypes.c_void_p(stream_tensor.data_ptr()), header16, csize, ctypes.c_void_p(dst.data_ptr()), dst.numel(),
+                                                ctypes.c_void_p(workspace.data_ptr()), workspace.numel(), ctypes.byref(n), ctypes.c_void_p(status.data_ptr()), _stream_ptr())
+    if rc != OK:
+        raise HsrleError(rc, "hsrle_decompress_mono_dev_async")
+    return n.value
+
+
+def mono_decompress_workspace_size(codec, usize, csize):
+    return int(_lib().hsrle_decompress_mono_workspace_size(codec_id(codec), usize, csize))
 
 
 def call_dropin(name, data, out_cap):

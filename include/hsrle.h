@@ -186,7 +186,7 @@ uint32_t hsrle_decompress_mono(int codec, const uint8_t *pIn, uint32_t inSize, u
  * in device memory, decoded into device memory.  A stream has no random access, so the library first builds an entry-point index
  * (speculative packet walks per stream region, then a pass that PROVES the chain and repairs wrong guesses: csrc/hsrle_index.hip.h)
  * and then runs the block kernel from those entry points.  dStream must be 128-byte aligned and readable up to streamSize + 64.
- * dWorkspace >= hsrle_decompress_mono_workspace_size().  Synchronises `stream`.  pStats (optional, host, 4 values): stream regions,
+ * dWorkspace >= hsrle_decompress_mono_workspace_size().  Synchronises `stream` (once, at the end, when every entry guess holds).  pStats (optional, host, 4 values): stream regions,
  * repair rounds, regions walked again, final look-back of the entry guess.  Returns HSRLE_OK, HSRLE_ERR_FORMAT (malformed stream / sizes do not match the header), ...
  */
 uint64_t hsrle_decompress_mono_workspace_size(int codec, uint32_t uncompressedSize, uint32_t compressedSize);
@@ -208,6 +208,20 @@ int hsrle_compress_mono_dev(int codec, const void *dIn, uint32_t inSize, void *d
 void hsrle_mono_encode_stats(uint32_t stats[4]);
 int hsrle_decompress_mono_dev(int codec, const void *dStream, uint32_t streamSize, void *dOut, uint64_t outCapacity, void *dWorkspace, uint64_t workspaceSize,
                               uint32_t *pUncompressedSize, uint32_t *pStats, void *stream);
+/*
+ * The same without the host in the loop (nothing here synchronises or reads device memory: a HIP graph can capture the call).  The walk,
+ * the proof, the entry records and the decode are enqueued in one go; the records pass is gated ON THE DEVICE by the proof's verdict.
+ * pHeader16: the stream's first 16 bytes in HOST memory (the caller read or received the stream; the launch geometry comes from the two
+ * sizes and the mode byte in it -- rle8_extreme_cpu.h:702-764).  dStatus (device, 4 bytes) receives HSRLE_MONO_DONE (dOut holds the
+ * output), HSRLE_MONO_MALFORMED, or HSRLE_MONO_NEEDS_REPAIR: an entry guess of the walk did not hold on this stream -- dOut is
+ * unspecified, call hsrle_decompress_mono_dev (which repairs; codecs whose junk walks do not die on random literals -- the non-Packed,
+ * non-7-bit-range formats -- see this more often because the synchronous function's pilot pass is skipped here).
+ */
+#define HSRLE_MONO_DONE 0
+#define HSRLE_MONO_MALFORMED 1
+#define HSRLE_MONO_NEEDS_REPAIR 2
+int hsrle_decompress_mono_dev_async(int codec, const void *dStream, const uint8_t *pHeader16, uint32_t streamSize, void *dOut, uint64_t outCapacity, void *dWorkspace,
+                                    uint64_t workspaceSize, uint32_t *pUncompressedSize, uint32_t *dStatus, void *stream);
 /* tuning / test knob of the monolithic decode: output bytes per decode lane (multiple of 128), stream bytes per index lane, look-back
  * bytes of the entry guess; 0 = the library's choice.  Any values give the same output: the index is proven, not assumed.
  * PROCESS-GLOBAL and meant for tests: the one exception to "no library-owned state" -- a thread that changes it between another thread's
