@@ -52,17 +52,21 @@ template <int FAM, int S, int AL, int MODE>
 __device__ __forceinline__ void ppS_block(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t b, uint32_t *__restrict__ sizes, const uint64_t *__restrict__ offsets,
                                           uint8_t *__restrict__ payload, const PpScratch &sc, PpShared<MODE != 0, true, FAM == LUT3> &sh, const u32x4 (&x)[4], uint32_t rec0)
 {
-  static_assert(FAM == PLAIN || FAM == PACKED || FAM == LUT3, "plain, Packed, 3 symbol LUT");
+  static_assert(FAM == PLAIN || FAM == PACKED || FAM == LUT3 || FAM == SHORT0 || FAM == SHORT1, "plain, Packed, 3 symbol LUT, Short with no / a one-symbol list");
   static_assert(S == 2 || S == 3 || S == 4 || S == 6 || S == 8, "symbols of 2, 3, 4, 6 or 8 bytes");
   static_assert(FAM != LUT3 || S >= 3, "the LUT codecs of 1 and 2 byte symbols have runs whose storing depends on the list");
   using TR = Traits<FAM, S, AL>;
+  constexpr bool SH = FAM == SHORT0 || FAM == SHORT1;                  // Short family: one-byte packed header or the 3-byte form (rleX_Xsl_short.h:152-357)
+  constexpr bool SH1 = FAM == SHORT1;                                  // ... with a one-symbol list: the state is (lastRLE, last stored symbol), as for Packed
   constexpr bool PK = FAM == PACKED;
   constexpr bool LUT = FAM == LUT3;
   constexpr uint32_t SU = (uint32_t)S;
   constexpr uint32_t SHORT = TR::SHORT, MEDIUM = TR::MEDIUM, LONG = TR::LONG, MAXR = TR::MAXRANGE;
   constexpr bool R7 = TR::kRange7;
-  constexpr uint32_t TERM = LUT ? 8u : (PK ? 5u : SU + 5u) + (R7 ? 4u : 5u);     // bytes of the literal terminator's fixed part (plain / Packed: of either terminator's)
-  constexpr uint32_t TERM_END = LUT ? 6u : TERM;                       // LUT: the end terminator is shorter (rleX_Xsl.h:319-338)
+  // bytes of the literal terminator's fixed part (plain / Packed: of either terminator's).  Short: 3 header bytes, u16 0, u32 literals + 2 and, without a list,
+  // a zero symbol; the end terminator: 3 header bytes, u16 0, u16 0 and, without a list, one zero byte (rleX_Xsl_short.h:976-1032)
+  constexpr uint32_t TERM = SH ? (SH1 ? 9u : 9u + SU) : (LUT ? 8u : (PK ? 5u : SU + 5u) + (R7 ? 4u : 5u));
+  constexpr uint32_t TERM_END = SH ? (SH1 ? 7u : 8u) : (LUT ? 6u : TERM);   // LUT: the end terminator is shorter (rleX_Xsl.h:319-338)
   constexpr uint32_t HDR = 8u;                                          // stream header: u32 uncompressed, u32 compressed
   const uint32_t lane = threadIdx.x;
   const uint64_t at = (uint64_t)b * B;
@@ -262,9 +266,22 @@ __device__ __forceinline__ void ppS_block(const uint8_t *__restrict__ in, uint64
       // -- emit decisions (rleX_extreme_cpu_encode.h:174-311): a chain through (lastRLE, last symbol)
       // (LUT, symbols of 3 bytes and more: EVERY run is stored -- count >= 2 S >= 6 >= 3 + the largest penalty a block can produce, rleX_Xsl.h:116-132 --
       //  so the chain below only hands lastRLE through the candidates without a run; what the list decides is the symbol's index, further down)
-      const bool sure = isRun && (LUT || count >= LONG);
+      const bool sure = isRun && (LUT || count >= (SH ? TR::SMINL : LONG));
       auto decide = [&](uint32_t iL, uint64_t iY, bool &sm) __attribute__((always_inline)) -> int {
         if constexpr (LUT) { sm = false; return 1; }
+        if constexpr (SH)
+        {
+          // process_symbol of the Short family (rleX_Xsl_short.h:152-215): the packet's size over the one-byte form is a penalty on the shortest run stored;
+          // 1: one-byte header, 2: the 3-byte form (with 16 bit fields behind it where count or range need them)
+          const uint32_t gp = p - iL, range = gp + 2u;
+          sm = SH1 && sym == iY;
+          const uint32_t scu = AL ? count / SU - TR::SMINS / SU + 2u : count - TR::SMINS + 2u;
+          const bool pack1 = gp <= TR::SMAXPR && scu - 2u <= TR::SMAXPC;
+          uint32_t pen = (SH1 && !sm) ? SU : 0u;
+          if (!pack1) pen += 2u + (range <= TR::SMAXTR ? 0u : 2u) + (scu <= TR::SMAXTC ? 0u : 2u);      // (nothing in a block needs a 32 bit field)
+          if (!(count >= TR::SMINL || count >= TR::SMINS + pen)) return 0;
+          return pack1 ? 1 : 2;
+        }
         const uint32_t rng = p - iL + 1u;
         sm = PK && sym == iY;
         const bool shortOk = rng <= MAXR && (PK ? (sm || count >= MEDIUM) : count >= SHORT);   // (count >= 2 S >= the Packed SHORT of 3)
@@ -329,9 +346,13 @@ __device__ __forceinline__ void ppS_block(const uint8_t *__restrict__ in, uint64
     const uint32_t cfield = LUT ? (AL ? count / SU - 3u / SU + 2u : count - 1u) : (AL ? count / SU - SHORT / SU + 1u : count - SHORT + 1u);
     const uint32_t cMax = (PK || LUT) ? 127u : 255u;
     const uint32_t cBytes = LUT ? (cfield <= 127u ? 0u : 2u) : (cfield <= cMax ? 1u : 5u);
-    const uint32_t sBytes = LUT ? (mtf == 3u ? SU : 0u) : ((PK && same) ? 0u : SU);
+    const uint32_t sBytes = LUT ? (mtf == 3u ? SU : 0u) : (((PK || SH1) && same) ? 0u : SU);
     const uint32_t rBytes = LUT ? (rng <= 127u ? 0u : 2u) : ((k == 1) ? 1u : (R7 ? 4u : 5u));
-    const uint32_t hl = k ? (LUT ? 2u : 0u) + cBytes + sBytes + rBytes : 0u;
+    // Short: count field value (+ 2), range = gap + 2; the 3-byte form carries 9 bits of count and SRB of range, 16 bit fields follow where that is not enough
+    [[maybe_unused]] const uint32_t scu = SH ? (AL ? count / SU - TR::SMINS / SU + 2u : count - TR::SMINS + 2u) : 0u;
+    [[maybe_unused]] const uint32_t srange = gap + 2u;
+    const uint32_t hl = !k ? 0u : (SH ? ((k == 1) ? 1u : 3u + (scu > TR::SMAXTC ? 2u : 0u) + (srange > TR::SMAXTR ? 2u : 0u)) + sBytes
+                                      : (LUT ? 2u : 0u) + cBytes + sBytes + rBytes);
     const uint32_t myBytes = k ? hl + gap : 0u;
     const uint32_t incl = wave_scan_add(myBytes | (k ? 0x10000u : 0u));
     const uint32_t tot = wave_lane(incl, 63);
@@ -354,6 +375,22 @@ __device__ __forceinline__ void ppS_block(const uint8_t *__restrict__ in, uint64
           if (mtf == 3u) { pp_or_bytes(sh.img, a, sym, SU); a += SU; }
           if (cBytes) { pp_or_bytes(sh.img, a, (uint64_t)cfield, 2u); a += 2u; }
           if (rBytes) pp_or_bytes(sh.img, a, (uint64_t)rng, 2u);
+        }
+        else if constexpr (SH)
+        {
+          // [list index | count | range] in one byte, or: [index | all-ones count | 9 bit count | SRB bit range] in three (rleX_Xsl_short.h:216-357)
+          const uint32_t mi = (SH1 && !same) ? 1u << (TR::SCB + TR::SRBP) : 0u;
+          if (k == 1) { pp_or_bytes(sh.img, a, (uint64_t)(mi | ((scu - 2u) << TR::SRBP) | gap), 1u); a += 1u; }
+          else
+          {
+            const uint32_t scx = scu <= TR::SMAXTC ? scu : 1u, rx = srange <= TR::SMAXTR ? srange : 1u;      // (1: a 16 bit field follows)
+            const uint32_t f = scx << (TR::SRB - 8u);
+            const uint32_t b0 = (mi | (TR::SCINV << TR::SRBP) | (f >> 8)) & 0xFFu, b1 = (f | (rx >> 8)) & 0xFFu, b2 = rx & 0xFFu;
+            pp_or_bytes(sh.img, a, (uint64_t)(b0 | (b1 << 8) | (b2 << 16)), 3u); a += 3u;
+            if (scx != scu) { pp_or_bytes(sh.img, a, (uint64_t)scu, 2u); a += 2u; }
+            if (rx != srange) { pp_or_bytes(sh.img, a, (uint64_t)srange, 2u); a += 2u; }
+          }
+          if (sBytes) pp_or_bytes(sh.img, a, sym, SU);
         }
         else
         {
@@ -404,7 +441,13 @@ __device__ __forceinline__ void ppS_block(const uint8_t *__restrict__ in, uint64
     }
     if (lane == 16u)
     {
-      if constexpr (LUT)
+      if constexpr (SH)
+      {
+        // end: [all-ones count] [STB] 01, u16 0, u16 0 (, 00);  literals: [all-ones count] [STB] 00, u16 0, u32 literals + 2 (, zero symbol)
+        pp_or_bytes(sh.img, pos, (uint64_t)((TR::SCINV << TR::SRBP) | (TR::STB << 8) | (ended ? 1u << 16 : 0u)), 3u);
+        if (!ended) pp_or_bytes(sh.img, pos + 5u, (uint64_t)(kLit + 2u), 4u);
+      }
+      else if constexpr (LUT)
       {
         // end: u16 (1 << 7) | 1, u16 0, u16 0;  literals: u16 1 << 7, u16 0, u32 literals + 2  (rleX_Xsl.h:319-338)
         sh.img[pos] = ended ? 0x81 : 0x80;

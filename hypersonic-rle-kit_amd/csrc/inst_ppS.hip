@@ -37,8 +37,20 @@ static void reg_lut3(PpLaunch *pp)
   pp[6 + 8 * W + 6] = ppS_launch<LUT3, S, 0>;
 }
 
+// Short family, ids 54 + 8 * w + v: v = 0 sym_short, 1 1symlut_sym_short, 4 byte_short, 5 1symlut_byte_short (no list / a one-symbol list: the chain of the
+// emit decisions runs through (lastRLE, last stored symbol) as it does for plain / Packed)
+template <int S, int W>
+static void reg_short(PpLaunch *pp)
+{
+  pp[54 + 8 * W + 0] = ppS_launch<SHORT0, S, 1>;
+  pp[54 + 8 * W + 1] = ppS_launch<SHORT1, S, 1>;
+  pp[54 + 8 * W + 4] = ppS_launch<SHORT0, S, 0>;
+  pp[54 + 8 * W + 5] = ppS_launch<SHORT1, S, 0>;
+}
+
 void register_ppS(PpLaunch *pp)
 {
+  reg_short<2, 0>(pp); reg_short<3, 1>(pp); reg_short<4, 2>(pp); reg_short<6, 3>(pp); reg_short<8, 4>(pp);
   reg_width<2, 0>(pp); reg_width<3, 1>(pp); reg_width<4, 2>(pp); reg_width<6, 3>(pp); reg_width<8, 4>(pp);
   reg_lut3<3, 1>(pp); reg_lut3<4, 2>(pp); reg_lut3<6, 3>(pp); reg_lut3<8, 4>(pp);
 }

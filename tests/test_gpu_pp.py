@@ -163,3 +163,37 @@ def test_position_parallel_lut3_encoder_bit_exact(hs, oracle, lut_cases, key, na
 def test_position_parallel_lut3_encoder_block_sizes_and_ragged_tails(hs, oracle, lut_cases, key, block, cut):
     data = np.concatenate([lut_cases["few_symbols"][: 2 << 20], lut_cases["butting"][: 1 << 19]])
     _check(hs, oracle, key, data[: data.size - cut], block)
+
+
+# ---- Short family without a list / with a one-symbol list, 2 .. 8 byte symbols (one-byte packed headers; src/rleX_Xsl_short.h:152-357): the emit rule is a
+#      penalty on the shortest stored run that depends on the gap to the run before (and, with the list, on the symbol stored last) ----
+SHORT_KEYS = [f"rle{w}_{v}" for w in (16, 24, 32, 48, 64) for v in ("sym_short", "byte_short", "1symlut_sym_short", "1symlut_byte_short")]
+
+
+@pytest.fixture(scope="module")
+def short_cases(lut_cases):
+    rng = np.random.default_rng(4242)
+    n = 3 << 20
+    # gaps around the packed range limit (15) and the 3-byte form's (2047), run lengths around S + 2 .. S + 12 and the packed count limit
+    near = _periodic(rng, n, [2, 3, 4, 6, 8], 4, 18, [4, 6, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 24, 30, 31, 32, 33, 34, 40])
+    far = _periodic(rng, n, [2, 3, 4, 6, 8], 256, 2300, [8, 12, 16, 20, 24, 520, 530, 1040, 1100, 4090])
+    return dict(lut_cases, near_limits=near, beyond_fields=far)
+
+
+@pytest.mark.parametrize("key", SHORT_KEYS)
+@pytest.mark.parametrize("name", ["periods", "butting", "far_apart", "two_symbols", "few_symbols", "near_limits", "beyond_fields"])
+def test_position_parallel_short_encoder_bit_exact(hs, oracle, short_cases, key, name):
+    _check(hs, oracle, key, short_cases[name], 4096)
+
+
+@pytest.mark.parametrize("key", ["rle16_sym_short", "rle24_1symlut_byte_short", "rle32_byte_short", "rle48_1symlut_sym_short", "rle64_byte_short"])
+@pytest.mark.parametrize("block,cut", [(128, 0), (384, 5), (1024, 77), (1536, 1535), (4096, 4095), (4096, 4081)])
+def test_position_parallel_short_encoder_block_sizes_and_ragged_tails(hs, oracle, short_cases, key, block, cut):
+    data = np.concatenate([short_cases["near_limits"][: 2 << 20], short_cases["butting"][: 1 << 19]])
+    _check(hs, oracle, key, data[: data.size - cut], block)
+
+
+def test_position_parallel_path_is_the_one_that_ran(hs):
+    """The codecs above must not pass on another encoder: hsrle_encode_path says which one a container of this shape takes."""
+    for key in KEYS + WIDE_KEYS + LUT_KEYS + SHORT_KEYS:
+        assert hs.encode_path(key, 8 << 20, 4096) == hs.PATH_POSITION_PARALLEL, key
