@@ -50,23 +50,28 @@ __device__ __forceinline__ void pp_or_bytes(uint8_t *img, uint32_t at, uint64_t 
 
 template <int FAM, int S, int AL, int MODE>
 __device__ __forceinline__ void ppS_block(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t b, uint32_t *__restrict__ sizes, const uint64_t *__restrict__ offsets,
-                                          uint8_t *__restrict__ payload, const PpScratch &sc, PpShared<MODE != 0, true, FAM == LUT3> &sh, const u32x4 (&x)[4], uint32_t rec0)
+                                          uint8_t *__restrict__ payload, const PpScratch &sc, PpShared<MODE != 0, true, FAM == LUT3 || FAM == SHORT3> &sh, const u32x4 (&x)[4], uint32_t rec0)
 {
-  static_assert(FAM == PLAIN || FAM == PACKED || FAM == LUT3 || FAM == SHORT0 || FAM == SHORT1, "plain, Packed, 3 symbol LUT, Short with no / a one-symbol list");
+  static_assert(FAM == PLAIN || FAM == PACKED || FAM == LUT3 || FAM == SHORT0 || FAM == SHORT1 || FAM == SHORT3, "plain, Packed, 3 symbol LUT, Short with no / a one- / a three-symbol list");
+  // Short with the three-symbol list: a new symbol costs S bytes of penalty, so only from 6 byte symbols on is every run (>= 2 S bytes) stored whatever the list
+  // says (2 + S + 2 + 2 <= 2 S; rleX_Xsl_short.h:152-215) -- the narrower ones have runs whose storing depends on the list
+  static_assert(FAM != SHORT3 || S >= 6, "rle48 / rle64 only");
   static_assert(S == 2 || S == 3 || S == 4 || S == 6 || S == 8, "symbols of 2, 3, 4, 6 or 8 bytes");
   static_assert(FAM != LUT3 || S >= 3, "the LUT codecs of 1 and 2 byte symbols have runs whose storing depends on the list");
   using TR = Traits<FAM, S, AL>;
-  constexpr bool SH = FAM == SHORT0 || FAM == SHORT1;                  // Short family: one-byte packed header or the 3-byte form (rleX_Xsl_short.h:152-357)
+  constexpr bool SH = FAM == SHORT0 || FAM == SHORT1 || FAM == SHORT3; // Short family: one-byte packed header or the 3-byte form (rleX_Xsl_short.h:152-357)
   constexpr bool SH1 = FAM == SHORT1;                                  // ... with a one-symbol list: the state is (lastRLE, last stored symbol), as for Packed
+  constexpr bool SH3 = FAM == SHORT3;                                  // ... with the three-symbol list: every run stored, the index as for LUT3
   constexpr bool PK = FAM == PACKED;
   constexpr bool LUT = FAM == LUT3;
+  constexpr bool MTF3 = LUT || SH3;                                    // three-symbol move-to-front list, every run stored
   constexpr uint32_t SU = (uint32_t)S;
   constexpr uint32_t SHORT = TR::SHORT, MEDIUM = TR::MEDIUM, LONG = TR::LONG, MAXR = TR::MAXRANGE;
   constexpr bool R7 = TR::kRange7;
   // bytes of the literal terminator's fixed part (plain / Packed: of either terminator's).  Short: 3 header bytes, u16 0, u32 literals + 2 and, without a list,
   // a zero symbol; the end terminator: 3 header bytes, u16 0, u16 0 and, without a list, one zero byte (rleX_Xsl_short.h:976-1032)
-  constexpr uint32_t TERM = SH ? (SH1 ? 9u : 9u + SU) : (LUT ? 8u : (PK ? 5u : SU + 5u) + (R7 ? 4u : 5u));
-  constexpr uint32_t TERM_END = SH ? (SH1 ? 7u : 8u) : (LUT ? 6u : TERM);   // LUT: the end terminator is shorter (rleX_Xsl.h:319-338)
+  constexpr uint32_t TERM = SH ? ((SH1 || SH3) ? 9u : 9u + SU) : (LUT ? 8u : (PK ? 5u : SU + 5u) + (R7 ? 4u : 5u));
+  constexpr uint32_t TERM_END = SH ? ((SH1 || SH3) ? 7u : 8u) : (LUT ? 6u : TERM);   // LUT: the end terminator is shorter (rleX_Xsl.h:319-338)
   constexpr uint32_t HDR = 8u;                                          // stream header: u32 uncompressed, u32 compressed
   const uint32_t lane = threadIdx.x;
   const uint64_t at = (uint64_t)b * B;
@@ -205,9 +210,15 @@ __device__ __forceinline__ void ppS_block(const uint8_t *__restrict__ in, uint64
       p = rec & 0xFFFu; e = ((rec >> 12) & 0xFFFu) + 1u;
       same = ((rec >> 24) & 1u) != 0u;
       k = have ? 1 + (int)((rec >> 25) & 1u) : 0;
-      if constexpr (LUT) { mtf = (rec >> 24) & 3u; k = have ? 1 : 0; }
+      if constexpr (MTF3) { mtf = (rec >> 24) & 3u; k = have ? 1 : 0; }
       outL = e;
       inL = wave_shr1(outL, carL);
+      if constexpr (SH3)
+      {
+        // (one-byte or 3-byte header: from the gap and the count, as decide() below)
+        const uint32_t cnt = e - p, scu_ = AL ? cnt / SU - TR::SMINS / SU + 2u : cnt - TR::SMINS + 2u;
+        if (have && !(p - inL <= TR::SMAXPR && scu_ - 2u <= TR::SMAXPC)) k = 2;
+      }
       sym = pp_symbol<S>(sh.inb, kPpInPad + (have ? p : 0u));
     }
     else
@@ -266,7 +277,7 @@ __device__ __forceinline__ void ppS_block(const uint8_t *__restrict__ in, uint64
       // -- emit decisions (rleX_extreme_cpu_encode.h:174-311): a chain through (lastRLE, last symbol)
       // (LUT, symbols of 3 bytes and more: EVERY run is stored -- count >= 2 S >= 6 >= 3 + the largest penalty a block can produce, rleX_Xsl.h:116-132 --
       //  so the chain below only hands lastRLE through the candidates without a run; what the list decides is the symbol's index, further down)
-      const bool sure = isRun && (LUT || count >= (SH ? TR::SMINL : LONG));
+      const bool sure = isRun && (MTF3 || count >= (SH ? TR::SMINL : LONG));
       auto decide = [&](uint32_t iL, uint64_t iY, bool &sm) __attribute__((always_inline)) -> int {
         if constexpr (LUT) { sm = false; return 1; }
         if constexpr (SH)
@@ -279,7 +290,7 @@ __device__ __forceinline__ void ppS_block(const uint8_t *__restrict__ in, uint64
           const bool pack1 = gp <= TR::SMAXPR && scu - 2u <= TR::SMAXPC;
           uint32_t pen = (SH1 && !sm) ? SU : 0u;
           if (!pack1) pen += 2u + (range <= TR::SMAXTR ? 0u : 2u) + (scu <= TR::SMAXTC ? 0u : 2u);      // (nothing in a block needs a 32 bit field)
-          if (!(count >= TR::SMINL || count >= TR::SMINS + pen)) return 0;
+          if (!SH3 && !(count >= TR::SMINL || count >= TR::SMINS + pen)) return 0;
           return pack1 ? 1 : 2;
         }
         const uint32_t rng = p - iL + 1u;
@@ -306,7 +317,7 @@ __device__ __forceinline__ void ppS_block(const uint8_t *__restrict__ in, uint64
       }
       k = isRun ? decide(inL, inY, same) : 0;
       carY = (uint64_t)wave_lane((uint32_t)outY, lastLane) | ((uint64_t)wave_lane((uint32_t)(outY >> 32), lastLane) << 32);
-      if constexpr (LUT)
+      if constexpr (MTF3)
       {
         // The list holds the three most recent DISTINCT symbols.  A run whose symbol is the one before it has index 0 and changes nothing; the others
         // ("heads" u_0, u_1, ...: consecutive heads differ) see the list [u_t-1, u_t-2, y_t] with y_t = (u_t-1 == u_t-3) ? y_t-1 : u_t-3 -- "copy from the
@@ -346,7 +357,7 @@ __device__ __forceinline__ void ppS_block(const uint8_t *__restrict__ in, uint64
     const uint32_t cfield = LUT ? (AL ? count / SU - 3u / SU + 2u : count - 1u) : (AL ? count / SU - SHORT / SU + 1u : count - SHORT + 1u);
     const uint32_t cMax = (PK || LUT) ? 127u : 255u;
     const uint32_t cBytes = LUT ? (cfield <= 127u ? 0u : 2u) : (cfield <= cMax ? 1u : 5u);
-    const uint32_t sBytes = LUT ? (mtf == 3u ? SU : 0u) : (((PK || SH1) && same) ? 0u : SU);
+    const uint32_t sBytes = MTF3 ? (mtf == 3u ? SU : 0u) : (((PK || SH1) && same) ? 0u : SU);
     const uint32_t rBytes = LUT ? (rng <= 127u ? 0u : 2u) : ((k == 1) ? 1u : (R7 ? 4u : 5u));
     // Short: count field value (+ 2), range = gap + 2; the 3-byte form carries 9 bits of count and SRB of range, 16 bit fields follow where that is not enough
     [[maybe_unused]] const uint32_t scu = SH ? (AL ? count / SU - TR::SMINS / SU + 2u : count - TR::SMINS + 2u) : 0u;
@@ -359,7 +370,7 @@ __device__ __forceinline__ void ppS_block(const uint8_t *__restrict__ in, uint64
     if constexpr (MODE == 0)
     {
       const uint32_t idx = K + (incl >> 16) - 1u;
-      if (k && idx < sc.recStride) sc.recs[(uint64_t)b * sc.recStride + idx] = p | ((e - 1u) << 12) | (LUT ? mtf << 24 : ((same ? 1u << 24 : 0u) | (k == 2 ? 1u << 25 : 0u)));
+      if (k && idx < sc.recStride) sc.recs[(uint64_t)b * sc.recStride + idx] = p | ((e - 1u) << 12) | (MTF3 ? mtf << 24 : ((same ? 1u << 24 : 0u) | (k == 2 ? 1u << 25 : 0u)));
     }
     else
     {
@@ -379,7 +390,7 @@ __device__ __forceinline__ void ppS_block(const uint8_t *__restrict__ in, uint64
         else if constexpr (SH)
         {
           // [list index | count | range] in one byte, or: [index | all-ones count | 9 bit count | SRB bit range] in three (rleX_Xsl_short.h:216-357)
-          const uint32_t mi = (SH1 && !same) ? 1u << (TR::SCB + TR::SRBP) : 0u;
+          const uint32_t mi = (SH3 ? mtf : ((SH1 && !same) ? 1u : 0u)) << (TR::SCB + TR::SRBP);
           if (k == 1) { pp_or_bytes(sh.img, a, (uint64_t)(mi | ((scu - 2u) << TR::SRBP) | gap), 1u); a += 1u; }
           else
           {
@@ -490,7 +501,7 @@ template <int FAM, int S, int AL, int MODE>
 __global__ __launch_bounds__(64) void k_encodeS_pp(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t nBlocks, uint32_t *__restrict__ sizes,
                                                    const uint64_t *__restrict__ offsets, uint8_t *__restrict__ payload, PpScratch sc)
 {
-  __shared__ PpShared<MODE != 0, true, FAM == LUT3> sh;
+  __shared__ PpShared<MODE != 0, true, FAM == LUT3 || FAM == SHORT3> sh;
   if (MODE != 0 && threadIdx.x < 17u)
   {
     const uint32_t c = threadIdx.x;

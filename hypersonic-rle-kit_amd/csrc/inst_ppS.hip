@@ -48,8 +48,17 @@ static void reg_short(PpLaunch *pp)
   pp[54 + 8 * W + 5] = ppS_launch<SHORT1, S, 0>;
 }
 
+// ... v = 2 3symlut_sym_short, 6 3symlut_byte_short: 6 and 8 byte symbols (every run stored: hsrle_encodeSp.hip.h)
+template <int S, int W>
+static void reg_short3(PpLaunch *pp)
+{
+  pp[54 + 8 * W + 2] = ppS_launch<SHORT3, S, 1>;
+  pp[54 + 8 * W + 6] = ppS_launch<SHORT3, S, 0>;
+}
+
 void register_ppS(PpLaunch *pp)
 {
+  reg_short3<6, 3>(pp); reg_short3<8, 4>(pp);
   reg_short<2, 0>(pp); reg_short<3, 1>(pp); reg_short<4, 2>(pp); reg_short<6, 3>(pp); reg_short<8, 4>(pp);
   reg_width<2, 0>(pp); reg_width<3, 1>(pp); reg_width<4, 2>(pp); reg_width<6, 3>(pp); reg_width<8, 4>(pp);
   reg_lut3<3, 1>(pp); reg_lut3<4, 2>(pp); reg_lut3<6, 3>(pp); reg_lut3<8, 4>(pp);
