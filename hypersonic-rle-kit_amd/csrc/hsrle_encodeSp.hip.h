@@ -29,6 +29,7 @@ __device__ __forceinline__ uint64_t pp_symbol(const uint8_t *inb, uint32_t at)
   const uint32_t q0 = w[0], q1 = w[1];
   uint32_t lo = alignbyte(q1, q0, sb), hi = 0u;
   if constexpr (S > 4) { const uint32_t q2 = w[2]; hi = alignbyte(q2, q1, sb); }
+  if constexpr (S == 1) lo &= 0xFFu;
   if constexpr (S == 2) lo &= 0xFFFFu;
   if constexpr (S == 3) lo &= 0xFFFFFFu;
   if constexpr (S == 6) hi &= 0xFFFFu;
@@ -56,7 +57,10 @@ __device__ __forceinline__ void ppS_block(const uint8_t *__restrict__ in, uint64
   // Short with the three-symbol list: a new symbol costs S bytes of penalty, so only from 6 byte symbols on is every run (>= 2 S bytes) stored whatever the list
   // says (2 + S + 2 + 2 <= 2 S; rleX_Xsl_short.h:152-215) -- the narrower ones have runs whose storing depends on the list
   static_assert(FAM != SHORT3 || S >= 6, "rle48 / rle64 only");
-  static_assert(S == 2 || S == 3 || S == 4 || S == 6 || S == 8, "symbols of 2, 3, 4, 6 or 8 bytes");
+  static_assert(S == 1 || S == 2 || S == 3 || S == 4 || S == 6 || S == 8, "symbols of 1 (Short family only), 2, 3, 4, 6 or 8 bytes");
+  // (8 bit symbols: rle8_multi_short / rle8_1symlut_short -- maximal runs of equal bytes, the same process_symbol, rleX_Xsl_short.h:380-667; the extreme 8 bit
+  //  codecs have their own kernel, hsrle_encode8p.hip.h: their reference bodies have rules of their own)
+  static_assert(S != 1 || ((FAM == SHORT0 || FAM == SHORT1) && AL == 0), "8 bit: Short without a list / with a one-symbol list");
   static_assert(FAM != LUT3 || S >= 3, "the LUT codecs of 1 and 2 byte symbols have runs whose storing depends on the list");
   using TR = Traits<FAM, S, AL>;
   constexpr bool SH = FAM == SHORT0 || FAM == SHORT1 || FAM == SHORT3; // Short family: one-byte packed header or the 3-byte form (rleX_Xsl_short.h:152-357)
@@ -117,7 +121,8 @@ __device__ __forceinline__ void ppS_block(const uint8_t *__restrict__ in, uint64
       {
         const int i = 4 * j + k;
         uint32_t s;
-        if constexpr (S == 2) s = alignbyte(w[i + 1], w[i], 2);
+        if constexpr (S == 1) s = alignbyte(w[i + 1], w[i], 1);
+        else if constexpr (S == 2) s = alignbyte(w[i + 1], w[i], 2);
         else if constexpr (S == 3) s = alignbyte(w[i + 1], w[i], 3);
         else if constexpr (S == 4) s = w[i + 1];
         else if constexpr (S == 6) s = alignbyte(w[i + 2], w[i + 1], 2);
@@ -146,7 +151,8 @@ __device__ __forceinline__ void ppS_block(const uint8_t *__restrict__ in, uint64
     uint64_t full;
     {
       const uint64_t c2 = m64 & shl_in(m64, 1u);
-      if constexpr (S == 2) full = c2;
+      if constexpr (S == 1) full = (TR::SMINS >= 3u) ? c2 : m64;            // (a run of two bytes can only be stored where the codec's shortest run is two)
+      else if constexpr (S == 2) full = c2;
       else if constexpr (S == 3) full = c2 & shl_in(m64, 2u);
       else
       {

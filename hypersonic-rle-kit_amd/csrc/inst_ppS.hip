@@ -59,6 +59,8 @@ static void reg_short3(PpLaunch *pp)
 void register_ppS(PpLaunch *pp)
 {
   reg_short3<6, 3>(pp); reg_short3<8, 4>(pp);
+  pp[50] = ppS_launch<SHORT0, 1, 0>;      // rle8_multi_short
+  pp[51] = ppS_launch<SHORT1, 1, 0>;      // rle8_1symlut_short
   reg_short<2, 0>(pp); reg_short<3, 1>(pp); reg_short<4, 2>(pp); reg_short<6, 3>(pp); reg_short<8, 4>(pp);
   reg_width<2, 0>(pp); reg_width<3, 1>(pp); reg_width<4, 2>(pp); reg_width<6, 3>(pp); reg_width<8, 4>(pp);
   reg_lut3<3, 1>(pp); reg_lut3<4, 2>(pp); reg_lut3<6, 3>(pp); reg_lut3<8, 4>(pp);

@@ -168,6 +168,7 @@ def test_position_parallel_lut3_encoder_block_sizes_and_ragged_tails(hs, oracle,
 # ---- Short family without a list / with a one-symbol list, 2 .. 8 byte symbols (one-byte packed headers; src/rleX_Xsl_short.h:152-357): the emit rule is a
 #      penalty on the shortest stored run that depends on the gap to the run before (and, with the list, on the symbol stored last) ----
 SHORT_KEYS = [f"rle{w}_{v}" for w in (16, 24, 32, 48, 64) for v in ("sym_short", "byte_short", "1symlut_sym_short", "1symlut_byte_short")]
+SHORT_KEYS += ["rle8_multi_short", "rle8_1symlut_short"]                                     # 8 bit: maximal runs of equal bytes through the same process_symbol
 SHORT_KEYS += [f"rle{w}_3symlut_{a}_short" for w in (48, 64) for a in ("sym", "byte")]      # three-symbol list: where every run is stored (>= 6 byte symbols)
 
 
@@ -183,11 +184,19 @@ def short_cases(lut_cases):
 
 @pytest.mark.parametrize("key", SHORT_KEYS)
 @pytest.mark.parametrize("name", ["periods", "butting", "far_apart", "two_symbols", "few_symbols", "initial_entries", "near_limits", "beyond_fields"])
-def test_position_parallel_short_encoder_bit_exact(hs, oracle, short_cases, key, name):
+def test_position_parallel_short_encoder_bit_exact(hs, oracle, short_cases, cases, key, name):
     _check(hs, oracle, key, short_cases[name], 4096)
+    if key.startswith("rle8_") and name in cases:
+        _check(hs, oracle, key, cases[name], 4096)
 
 
-@pytest.mark.parametrize("key", ["rle16_sym_short", "rle24_1symlut_byte_short", "rle32_byte_short", "rle48_1symlut_sym_short", "rle64_byte_short", "rle48_3symlut_byte_short", "rle64_3symlut_sym_short"])
+@pytest.mark.parametrize("key", ["rle8_multi_short", "rle8_1symlut_short"])
+@pytest.mark.parametrize("name", ["zeros", "random", "threes", "short_chains", "mixed", "long_literals", "same_symbol"])
+def test_position_parallel_short_encoder_8bit_data(hs, oracle, cases, key, name):
+    _check(hs, oracle, key, cases[name], 4096)
+
+
+@pytest.mark.parametrize("key", ["rle16_sym_short", "rle24_1symlut_byte_short", "rle32_byte_short", "rle48_1symlut_sym_short", "rle64_byte_short", "rle48_3symlut_byte_short", "rle64_3symlut_sym_short", "rle8_multi_short", "rle8_1symlut_short"])
 @pytest.mark.parametrize("block,cut", [(128, 0), (384, 5), (1024, 77), (1536, 1535), (4096, 4095), (4096, 4081)])
 def test_position_parallel_short_encoder_block_sizes_and_ragged_tails(hs, oracle, short_cases, key, block, cut):
     data = np.concatenate([short_cases["near_limits"][: 2 << 20], short_cases["butting"][: 1 << 19]])
