@@ -2137,6 +2137,141 @@ static uint32_t le_mono_decompress(const uint8_t *pIn, uint32_t inSize, uint8_t 
   return expOut;
 }
 
+// ---- the split-phase helpers (src/rle.h:67-96): statistics, header writer / reader and the stream bodies as separate calls, tables through host structs ----
+
+// rle8_low_entropy_get_compress_info[_only_max_frequency] (rle8_low_entropy_cpu.c:254-439): the statistics and table kernels of le_encode_async, tables back to the host
+static bool le_get_info(const uint8_t *pIn, uint32_t inSize, rle8_low_entropy_compress_info_t *info, uint32_t onlyMax)
+{
+  if (pIn == nullptr || inSize == 0 || info == nullptr || !device_ok())
+    return false;
+  const LePlan p = plan_le(inSize, false);
+  DeviceState &D = this_device();
+  std::lock_guard<std::mutex> lock(D.mu);
+  if (!grow(&D.monoIn, &D.monoInSize, (uint64_t)inSize + 64) || !grow(&D.ws, &D.wsSize, p.total))
+    return false;
+  uint8_t *ws = (uint8_t *)D.ws;
+  Rle8mTables *t = (Rle8mTables *)(ws + p.offTables);
+  if (hipMemcpy(D.monoIn, pIn, inSize, hipMemcpyHostToDevice) != hipSuccess || zero_async(t, sizeof(Rle8mTables), nullptr) != hipSuccess)
+    return false;
+  {
+    const uint32_t waves = (uint32_t)(((uint64_t)inSize + 4095u) / 4096u);
+    uint32_t grid = waves < 32768u ? waves : 32768u;
+    if ((uint64_t)grid * kRle8mStatsPieces < waves) grid = (waves + kRle8mStatsPieces - 1u) / kRle8mStatsPieces;
+    hipLaunchKernelGGL(k_rle8m_stats_wave, dim3(grid), dim3(64), 0, nullptr, (const uint8_t *)D.monoIn, inSize, t, 255u);
+  }
+  hipLaunchKernelGGL(k_rle8m_info, dim3(1), dim3(256), 0, nullptr, t, 1u, ws + p.offTmpInfo, onlyMax);
+  Rle8mTables ht;
+  uint8_t used = 0;
+  if (hipGetLastError() != hipSuccess || hipMemcpy(&ht, t, sizeof(ht), hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(&used, ws + p.offTmpInfo + 12u + 32u, 1, hipMemcpyDeviceToHost) != hipSuccess)
+    return false;
+  for (int i = 0; i < 256; i++) { info->rle[i] = ht.rle[i] != 0; info->symbolsByProb[i] = ht.order[i]; }
+  info->symbolCount = used;                                              // (a uint8: 256 symbols in use -> 0, rle8_low_entropy_cpu.c:333)
+  return true;
+}
+
+// rle8_low_entropy[_short]_compress_with_info (rle8_low_entropy_cpu.c:474-543, rle8_low_entropy_short_cpu.c:128-198): the body for the caller's tables
+static uint32_t le_compress_with_info(const uint8_t *pIn, uint32_t inSize, const rle8_low_entropy_compress_info_t *info, uint8_t *pOut, uint32_t outSize, uint32_t maxLen)
+{
+  if (pIn == nullptr || inSize == 0 || info == nullptr || pOut == nullptr || outSize < inSize || !device_ok())
+    return 0;
+  Rle8mTables ht;
+  memset(&ht, 0, sizeof(ht));
+  for (uint32_t i = 0; i < 256u; i++)
+  {
+    const uint8_t flag = ((const uint8_t *)info->rle)[i] ? 1 : 0;
+    ht.rle[i] = flag; ht.order[i] = info->symbolsByProb[i];
+    ht.rleBits[i >> 5] |= (uint32_t)flag << (i & 31u);
+  }
+  ht.listed = info->symbolCount ? info->symbolCount : 255u;
+  ht.headerSize = 12u + 33u + ht.listed;                                 // (as k_rle8m_info counts it: an rle8m header of one section)
+  const uint32_t H = ht.headerSize - 4u;
+  const LePlan p = plan_le(inSize, true);
+  const uint64_t cap = 2ull * inSize + 512ull;                           // a body is at most twice its input (every byte a flagged symbol with its code)
+  DeviceState &D = this_device();
+  std::lock_guard<std::mutex> lock(D.mu);
+  if (!grow(&D.monoIn, &D.monoInSize, (uint64_t)inSize + 64) || !grow(&D.monoOut, &D.monoOutSize, cap + 64) || !grow(&D.ws, &D.wsSize, p.total))
+    return 0;
+  if (!D.monoAux && hipMalloc(&D.monoAux, 256) != hipSuccess)
+    return 0;
+  uint32_t *dStatus = (uint32_t *)((uint8_t *)D.monoAux + 64);
+  uint8_t *ws = (uint8_t *)D.ws;
+  Rle8mTables *t = (Rle8mTables *)(ws + p.offTables);
+  uint32_t *cuts = (uint32_t *)(ws + p.offCuts), *sizes = (uint32_t *)(ws + p.offSizes);
+  uint64_t *offsets = (uint64_t *)(ws + p.offOffsets);
+  if (hipMemcpy(D.monoIn, pIn, inSize, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(t, &ht, sizeof(ht), hipMemcpyHostToDevice) != hipSuccess ||
+      zero_async(dStatus, 8, nullptr) != hipSuccess)
+    return 0;
+  hipLaunchKernelGGL(k_le_cuts, dim3((p.pieces + 63u) / 64u), dim3(64), 0, nullptr, (const uint8_t *)D.monoIn, inSize, kLePiece, p.pieces, cuts);
+  hipLaunchKernelGGL(k_le_encode_wave, dim3(p.pieces), dim3(64), 0, nullptr, (const uint8_t *)D.monoIn, inSize, (const uint32_t *)cuts, p.pieces, (const Rle8mTables *)t, ws + p.offSlots, sizes, maxLen);
+  if (scan_sizes(sizes, p.pieces, offsets, ws, p.w, nullptr) != hipSuccess)
+    return 0;
+  hipLaunchKernelGGL(k_le_place, dim3((p.pieces + 3u) / 4u), dim3(256), 0, nullptr, (const uint8_t *)(ws + p.offSlots), (const uint32_t *)cuts, (const uint64_t *)offsets, (const Rle8mTables *)t,
+                     (uint8_t *)D.monoOut, cap, inSize, p.pieces, dStatus);
+  uint32_t status = 1, size = 0;
+  if (hipGetLastError() != hipSuccess || hipMemcpy(&status, dStatus, 4, hipMemcpyDeviceToHost) != hipSuccess || status != 0u)
+    return 0;
+  if (hipMemcpy(&size, D.monoOut, 4, hipMemcpyDeviceToHost) != hipSuccess || size < H || size - H > outSize)
+    return 0;
+  if (size > H && hipMemcpy(pOut, (const uint8_t *)D.monoOut + H, size - H, hipMemcpyDeviceToHost) != hipSuccess)
+    return 0;
+  return size - H;
+}
+
+// rle8_low_entropy[_short]_decompress_with_info (rle8_low_entropy_cpu.c:930-1022, rle8_low_entropy_short_cpu.c:440-534): the body becomes a stream again --
+// header and the tables' symbols in front of it, in device memory -- and takes the way of le_mono_decompress (the decode kernels read their tables from the stream)
+static uint32_t le_decompress_with_info(const uint8_t *pIn, const uint8_t *pEnd, const rle8_low_entropy_decompress_info_t *info, uint8_t *pOut, uint32_t expOut)
+{
+  if (pIn == nullptr || pEnd == nullptr || pEnd < pIn || info == nullptr || pOut == nullptr || expOut == 0 || !device_ok())
+    return 0;
+  const uint64_t body64 = (uint64_t)(pEnd - pIn);
+  constexpr uint32_t dataStart = 8u + 33u + 255u;
+  if (body64 > 0xFFFFFF00ull - dataStart)
+    return 0;
+  const uint32_t body = (uint32_t)body64, expIn = dataStart + body;
+  uint8_t head[dataStart];
+  memset(head, 0, sizeof(head));
+  memcpy(head, &expIn, 4); memcpy(head + 4, &expOut, 4);
+  for (uint32_t i = 0; i < 256u; i++)
+    if (((const uint8_t *)info->rle)[i]) head[8u + (i >> 3)] |= (uint8_t)(1u << (i & 7u));
+  head[8u + 32u] = 255u;
+  // the symbols in the order of their codes' counts: the inverse of symbolToCount, which must be a permutation (what read_decompress_info produces)
+  bool seen[256] = { false };
+  for (uint32_t sym = 0; sym < 256u; sym++)
+  {
+    const uint32_t c = info->symbolToCount[sym];
+    if (seen[c]) return 0;
+    seen[c] = true;
+    if (c < 255u) head[8u + 33u + c] = (uint8_t)sym;
+  }
+  const LePlan p = plan_le(body, false);
+  const LePlan p1 = plan_le(body, false, expIn + 128u);
+  DeviceState &D = this_device();
+  std::lock_guard<std::mutex> lock(D.mu);
+  if (!grow(&D.monoIn, &D.monoInSize, (uint64_t)expIn + 256) || !grow(&D.monoOut, &D.monoOutSize, (uint64_t)expOut + 64) || !grow(&D.ws, &D.wsSize, p.total > p1.total ? p.total : p1.total))
+    return 0;
+  if (!D.monoAux && hipMalloc(&D.monoAux, 256) != hipSuccess)
+    return 0;
+  uint32_t *dStatus = (uint32_t *)((uint8_t *)D.monoAux + 64);
+  if (hipMemcpy(D.monoIn, head, dataStart, hipMemcpyHostToDevice) != hipSuccess || (body != 0u && hipMemcpy((uint8_t *)D.monoIn + dataStart, pIn, body, hipMemcpyHostToDevice) != hipSuccess) ||
+      hipMemset((uint8_t *)D.monoIn + expIn, 0, 128) != hipSuccess)
+    return 0;
+  uint32_t status[2] = { 1, 0 };
+  for (int attempt = 0; attempt < 2; attempt++)
+  {
+    if (le_decode_async(D.monoIn, expIn, dataStart, expOut, D.monoOut, expOut, D.ws, D.wsSize, dStatus, attempt != 0, nullptr) != HSRLE_OK)
+      return 0;
+    if (hipMemcpy(status, dStatus, 8, hipMemcpyDeviceToHost) != hipSuccess)
+      return 0;
+    if (status[1] == 0u) break;
+  }
+  if (status[0] != 0u || status[1] != 0u)
+    return 0;
+  if (hipMemcpy(pOut, D.monoOut, expOut, hipMemcpyDeviceToHost) != hipSuccess)
+    return 0;
+  return expOut;
+}
+
 // device-resident forms (benchmarks, pipelines that keep the data on the GPU).  variant: bit 0 the Short form, bit 1 only_max_frequency.
 uint64_t hsrle_low_entropy_workspace_size(uint32_t inSize) { return inSize == 0 ? 0 : plan_le(inSize, true).total; }
 int hsrle_low_entropy_compress_dev_async(const void *dIn, uint32_t inSize, int variant, void *dOut, uint64_t outCapacity, void *dWorkspace, uint64_t workspaceSize, uint32_t *dStatus, void *stream)
@@ -2187,6 +2322,44 @@ uint32_t rle8_low_entropy_decompress(const uint8_t *pIn, const uint32_t inSize, 
 uint32_t rle8_low_entropy_short_compress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize) { return le_mono_compress(pIn, inSize, pOut, outSize, 32u, 0u); }
 uint32_t rle8_low_entropy_short_compress_only_max_frequency(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize) { return le_mono_compress(pIn, inSize, pOut, outSize, 32u, 1u); }
 uint32_t rle8_low_entropy_short_decompress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize) { return le_mono_decompress(pIn, inSize, pOut, outSize); }
+
+bool rle8_low_entropy_get_compress_info(const uint8_t *pIn, const uint32_t inSize, rle8_low_entropy_compress_info_t *pCompressInfo) { return le_get_info(pIn, inSize, pCompressInfo, 0u); }
+bool rle8_low_entropy_get_compress_info_only_max_frequency(const uint8_t *pIn, const uint32_t inSize, rle8_low_entropy_compress_info_t *pCompressInfo) { return le_get_info(pIn, inSize, pCompressInfo, 1u); }
+uint32_t rle8_low_entropy_write_compress_info(rle8_low_entropy_compress_info_t *pCompressInfo, uint8_t *pOut, const uint32_t outSize)
+{
+  // host only (rle8_low_entropy_cpu.c:441-472): 32 flag bytes, the count byte, the symbols (a count of 0 stands for 256 in use: 255 are written)
+  if (pCompressInfo == nullptr || pOut == nullptr || outSize < 256u / 8u + 256u + 1u)
+    return 0;
+  memset(pOut, 0, 32);
+  for (uint32_t i = 0; i < 256u; i++)
+    if (((const uint8_t *)pCompressInfo->rle)[i]) pOut[i >> 3] |= (uint8_t)(1u << (i & 7u));
+  pOut[32] = pCompressInfo->symbolCount;
+  const uint32_t listed = pCompressInfo->symbolCount ? pCompressInfo->symbolCount : 255u;
+  memcpy(pOut + 33, pCompressInfo->symbolsByProb, listed);
+  return 33u + listed;
+}
+uint32_t rle8_low_entropy_read_decompress_info(const uint8_t *pIn, const uint32_t inSize, rle8_low_entropy_decompress_info_t *pDecompressInfo)
+{
+  // host only (rle8_low_entropy_cpu.c:545-605): the listed symbols get the counts 0, 1, ... in the order they are listed, the others the counts behind them in
+  // ascending order.  (The reference does not look at inSize beyond "not 0"; here a header that does not fit is refused.)
+  if (pIn == nullptr || pDecompressInfo == nullptr || inSize < 33u)
+    return 0;
+  uint32_t listed = pIn[32];
+  if (listed == 0u) listed = 255u;
+  if (inSize < 33u + listed)
+    return 0;
+  bool isListed[256] = { false };
+  for (uint32_t i = 0; i < 256u; i++) pDecompressInfo->rle[i] = ((pIn[i >> 3] >> (i & 7u)) & 1u) != 0u;
+  for (uint32_t i = 0; i < listed; i++) { pDecompressInfo->symbolToCount[pIn[33u + i]] = (uint8_t)i; isListed[pIn[33u + i]] = true; }
+  uint32_t next = listed;
+  for (uint32_t sym = 0; sym < 256u; sym++)
+    if (!isListed[sym]) pDecompressInfo->symbolToCount[sym] = (uint8_t)next++;
+  return 33u + listed;
+}
+uint32_t rle8_low_entropy_compress_with_info(const uint8_t *pIn, const uint32_t inSize, const rle8_low_entropy_compress_info_t *pCompressInfo, uint8_t *pOut, const uint32_t outSize) { return le_compress_with_info(pIn, inSize, pCompressInfo, pOut, outSize, 255u); }
+uint32_t rle8_low_entropy_short_compress_with_info(const uint8_t *pIn, const uint32_t inSize, const rle8_low_entropy_compress_info_t *pCompressInfo, uint8_t *pOut, const uint32_t outSize) { return le_compress_with_info(pIn, inSize, pCompressInfo, pOut, outSize, 32u); }
+uint32_t rle8_low_entropy_decompress_with_info(const uint8_t *pIn, const uint8_t *pEnd, const rle8_low_entropy_decompress_info_t *pDecompressInfo, uint8_t *pOut, const uint32_t expectedOutSize) { return le_decompress_with_info(pIn, pEnd, pDecompressInfo, pOut, expectedOutSize); }
+uint32_t rle8_low_entropy_short_decompress_with_info(const uint8_t *pIn, const uint8_t *pEnd, const rle8_low_entropy_decompress_info_t *pDecompressInfo, uint8_t *pOut, const uint32_t expectedOutSize) { return le_decompress_with_info(pIn, pEnd, pDecompressInfo, pOut, expectedOutSize); }
 
 // ---- rle8m: names of the reference's GPU decode path (src/rle.h:464-466) and of its CPU twin (src/rle.h:63) ----
 bool rle8m_opencl_init(const size_t inputDataSize, const size_t outputDataSize, const size_t maxSubsectionCount)

@@ -453,8 +453,7 @@ uint32_t rle8m_compress(const uint32_t subSections, const uint8_t *pIn, const ui
  * the encoder cuts its input at run boundaries (no token crosses one), the decoder cuts the stream anywhere and finds out from the byte
  * values in front of a cut whether it starts with a symbol or a repeat code (csrc/hsrle_rle8m.hip.h).  Unlike the reference a stream that
  * outgrows `outSize` is a failure, never a write behind the caller's buffer (rle8_low_entropy_cpu.c:476 only asks for outSize >= inSize).
- * Not provided: the split-phase helpers that pass the codec's tables through host structs (rle8_low_entropy_get_compress_info*,
- * _write_compress_info, _compress_with_info, _read_decompress_info, _decompress_with_info and their Short twins, src/rle.h:67-96). */
+ * The split-phase helpers that pass the codec's tables through host structs follow below. */
 uint32_t rle8_low_entropy_compress_bounds(const uint32_t inSize);
 uint32_t rle8_low_entropy_decompressed_size(const uint8_t *pIn, const uint32_t inSize);
 uint32_t rle8_low_entropy_compress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize);
@@ -464,6 +463,28 @@ uint32_t rle8_low_entropy_short_compress_bounds(const uint32_t inSize);
 uint32_t rle8_low_entropy_short_compress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize);
 uint32_t rle8_low_entropy_short_compress_only_max_frequency(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize);
 uint32_t rle8_low_entropy_short_decompress(const uint8_t *pIn, const uint32_t inSize, uint8_t *pOut, const uint32_t outSize);
+
+/* The split-phase helpers of the same codec (src/rle.h:67-96; src/rle8_low_entropy_cpu.c:254-600, :930-1022, src/rle8_low_entropy_short_cpu.c:128-534):
+ * the statistics pass, the header writer / reader and the two stream bodies as separate calls, tables handed through host structs with the
+ * reference's layout.  rle8_low_entropy_compress is exactly  [u32 size][u32 inSize] + write_compress_info(get_compress_info) +
+ * compress_with_info,  as in the reference (rle8_low_entropy_cpu.c:11-50), and the tests check that identity.
+ *   get_compress_info*      statistics + tables on the GPU (k_rle8m_stats_wave, k_rle8m_info), false = bad arguments / no device
+ *   write_compress_info     host only: 32 flag bytes, the symbol count (a uint8: 256 symbols are written as 0 and then 255 of them, sic), the symbols
+ *   compress_with_info      the stream body for ANY tables (rle[] / symbolsByProb[] need not come from get_compress_info); returns its size,
+ *                           0 = failure.  Unlike the reference a body that outgrows `outSize` is a failure, not a write behind the buffer.
+ *   read_decompress_info    host only; returns the bytes of the info (33 + listed symbols)
+ *   decompress_with_info    pIn .. pEnd = the body; returns expectedOutSize, 0 = malformed body or tables that are not a permutation
+ *                           (the reference returns expectedOutSize whatever it read)                                                  */
+typedef struct rle8_low_entropy_compress_info_t { bool rle[256]; uint8_t symbolsByProb[256]; uint8_t symbolCount; } rle8_low_entropy_compress_info_t;   /* src/rle.h:67-72 */
+typedef struct rle8_low_entropy_decompress_info_t { bool rle[256]; uint8_t symbolToCount[256]; } rle8_low_entropy_decompress_info_t;                     /* src/rle.h:81-85 */
+bool rle8_low_entropy_get_compress_info(const uint8_t *pIn, const uint32_t inSize, rle8_low_entropy_compress_info_t *pCompressInfo);
+bool rle8_low_entropy_get_compress_info_only_max_frequency(const uint8_t *pIn, const uint32_t inSize, rle8_low_entropy_compress_info_t *pCompressInfo);
+uint32_t rle8_low_entropy_write_compress_info(rle8_low_entropy_compress_info_t *pCompressInfo, uint8_t *pOut, const uint32_t outSize);
+uint32_t rle8_low_entropy_compress_with_info(const uint8_t *pIn, const uint32_t inSize, const rle8_low_entropy_compress_info_t *pCompressInfo, uint8_t *pOut, const uint32_t outSize);
+uint32_t rle8_low_entropy_read_decompress_info(const uint8_t *pIn, const uint32_t inSize, rle8_low_entropy_decompress_info_t *pDecompressInfo);
+uint32_t rle8_low_entropy_decompress_with_info(const uint8_t *pIn, const uint8_t *pEnd, const rle8_low_entropy_decompress_info_t *pDecompressInfo, uint8_t *pOut, const uint32_t expectedOutSize);
+uint32_t rle8_low_entropy_short_compress_with_info(const uint8_t *pIn, const uint32_t inSize, const rle8_low_entropy_compress_info_t *pCompressInfo, uint8_t *pOut, const uint32_t outSize);
+uint32_t rle8_low_entropy_short_decompress_with_info(const uint8_t *pIn, const uint8_t *pEnd, const rle8_low_entropy_decompress_info_t *pDecompressInfo, uint8_t *pOut, const uint32_t expectedOutSize);
 
 /* The same, device resident (variant: bit 0 the Short form, bit 1 only_max_frequency).  Compress only enqueues (the stream's size is its
  * first u32; *dStatus != 0: the stream did not fit `outCapacity`); decompress reads the header and the verdict (two stream synchronisations). */
