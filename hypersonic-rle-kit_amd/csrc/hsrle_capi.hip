@@ -2681,7 +2681,8 @@ uint64_t hsrle_decompress_mono_workspace_size(int codec, uint32_t uncompressedSi
 int hsrle_decompress_mono_dev(int codec, const void *dStream, uint32_t streamSize, void *dOut, uint64_t outCapacity, void *dWorkspace, uint64_t workspaceSize,
                               uint32_t *pUncompressedSize, uint32_t *pStats, void *stream)
 {
-  if (!dStream || !dOut || !dWorkspace || codec < 0 || codec >= kCodecCount || streamSize < codec_header_size(codec) || ((uintptr_t)dStream & 127u) != 0u)
+  if (!dStream || !dOut || !dWorkspace || codec < 0 || codec >= kCodecCount || streamSize < codec_header_size(codec) || ((uintptr_t)dStream & 127u) != 0u ||
+      ((uintptr_t)dWorkspace & 15u) != 0u)                              // (the workspace is cleared with 16-byte stores: mono_prepare)
     return HSRLE_ERR_ARGUMENT;
   if (!device_ok()) return HSRLE_ERR_DEVICE;
   uint8_t h16[16] = { 0 };
@@ -2700,7 +2701,8 @@ int hsrle_decompress_mono_dev(int codec, const void *dStream, uint32_t streamSiz
 int hsrle_decompress_mono_dev_async(int codec, const void *dStream, const uint8_t *pHeader16, uint32_t streamSize, void *dOut, uint64_t outCapacity, void *dWorkspace,
                                     uint64_t workspaceSize, uint32_t *pUncompressedSize, uint32_t *dStatus, void *stream)
 {
-  if (!dStream || !pHeader16 || !dOut || !dWorkspace || !dStatus || codec < 0 || codec >= kCodecCount || streamSize < 16u || ((uintptr_t)dStream & 127u) != 0u)
+  if (!dStream || !pHeader16 || !dOut || !dWorkspace || !dStatus || codec < 0 || codec >= kCodecCount || streamSize < 16u || ((uintptr_t)dStream & 127u) != 0u ||
+      ((uintptr_t)dWorkspace & 15u) != 0u)
     return HSRLE_ERR_ARGUMENT;
   if (!device_ok()) return HSRLE_ERR_DEVICE;
   MonoHeader mh;

@@ -232,6 +232,11 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   // 128 bit codecs launch this one for plain containers (inst_w128.hip).
   if constexpr (!ENT) entries = nullptr;
   using TR = Traits<FAM, S, AL>;
+#ifdef HSRLE_DEC_TRIPS   // A/B builds: one cap for every instantiation
+  constexpr uint32_t CAP = HSRLE_DEC_TRIPS;
+#else
+  constexpr uint32_t CAP = (S >= 2 && S <= 8) ? 4u : ((S == 1 && TR::kShort) ? 6u : 0u);   // packets per lane and round, 0 = a round lasts until every lane has its T bytes (see HS_ROWPOS below)
+#endif
   constexpr int TS = T;                      // tile row stride: no pad -- the 16-byte chunks of a row are XOR-swizzled by the row index instead (TSW)
   constexpr int RS = R;                      // ring row stride: no pad, no mirror -- chunks are XOR-swizzled by the row index (rowx), every 8-byte piece is addressed on its own
   constexpr int CPR = T / 16;                // 16-byte chunks per tile row == lanes that serve one row in top-up / flush
@@ -556,10 +561,20 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     }
   }
 
+  // CAPPED ROUNDS (round 5).  A round used to last until every lane had its T output bytes, i.e. as long as the lane with the most packets: on video-shaped
+  // data (many short packets, unevenly spread) half the lane trips were idle.  With CAP != 0 a round is at most CAP packets per lane: the tile row is a RING of T
+  // bytes addressed by the output position mod T, a lane may run up to T bytes ahead of what it has flushed (target = base + T), the flush writes the 64-byte
+  // halves that are complete (whole write requests, as before) and a lane that waits for stream bytes goes on in the next round -- the sum of the per-round
+  // maxima becomes (nearly) the maximum of the sums.  Measured per family, 4 GiB, same box (LAB_NOTEBOOK.md, round 5 call 48): 2 .. 8 byte symbols CAP = 4:
+  // video-shaped +11 ... +63 % (rle64_7symlut_byte_short_greedy streams 885 -> 1 445 GiB/s), run data -2 ... +13 %; 8 bit Short CAP = 6: +10 ... +27 % / -2 ... +3 %;
+  // 8 bit plain / Packed / LUT and 128 bit: -5 ... +3 % with any CAP (few, large packets: what a round costs besides its trips is what the cap multiplies) -> 0.
+#define HS_ROWPOS(pos) (CAP != 0u ? ((pos) & ((uint32_t)T - 1u)) : ((pos) - base))
+#define HS_ROWWRAP(x) (CAP != 0u ? ((x) & ((uint32_t)T - 1u)) : (x))
   uint32_t base = 0;      // block offset of the first byte of the tile row (multiple of 16); the row holds [base, o)
 
   // every spin is bounded: a malformed stream (or a bug) ends as DEC_ERR_STREAM, never as a hang
-  uint32_t roundsLeft = B / (uint32_t)T + B / 16u + 64u; // output rounds + worst-case starved rounds (>= 16 stream bytes each)
+  // output rounds + worst-case starved rounds (>= 16 stream bytes each); capped rounds: a round is at least one packet (>= 1 output byte) of every lane that is not starved
+  uint32_t roundsLeft = (CAP != 0u ? B : B / (uint32_t)T) + B / 16u + 64u;
 
 #ifdef HSRLE_STAMPS
   unsigned long long tIssue = 0, tDecode = 0, tFlush = 0, tLand = 0, nRounds = 0, nIter = 0, t0, t1;
@@ -575,12 +590,14 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     t0 = __builtin_readcyclecounter(); nRounds++;
 #endif
 
-    const uint32_t flushTarget = umin((o / (uint32_t)T + 1u) * (uint32_t)T, blen);
+    static_assert(CAP == 0u || (T == Q && T == 128), "capped rounds: one step per round");
+    const uint32_t flushTarget = CAP != 0u ? umin(base + (uint32_t)T, blen) : umin((o / (uint32_t)T + 1u) * (uint32_t)T, blen);
 
 #pragma unroll 1
     for (int step = 0; step < T / Q; step++)
     {
-    const uint32_t target = umin((o / (uint32_t)Q + 1u) * (uint32_t)Q, flushTarget);
+    const uint32_t target = CAP != 0u ? flushTarget : umin((o / (uint32_t)Q + 1u) * (uint32_t)Q, flushTarget);
+    [[maybe_unused]] uint32_t tripsLeft = CAP;
     [[maybe_unused]] uint32_t itersLeft = 2u * (uint32_t)Q + 16u;
 
     // Pass 0 decodes with the ring as it stands.  A lane whose packet needs bytes that were not resident (the ring holds
@@ -605,6 +622,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
       {
         const bool act = (fl & (F_DONE | F_STALL)) == 0u && o < target;
         if (__ballot(act) == 0ull) break;
+        if constexpr (CAP != 0u) { if (tripsLeft-- == 0u) break; }
         // every trip of an active lane either consumes stream bytes (a header is >= 2 bytes), produces output bytes, or
         // deactivates the lane (done / stall), so the loop is bounded by the resident stream bytes plus the step's output
 
@@ -774,7 +792,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
             if (n == 0u) fl |= F_STALL;                                   // literals not resident yet: continue next pass
             else
             {
-              const uint32_t q = o - base, c = q & 15u;
+              const uint32_t q = HS_ROWPOS(o), c = q & 15u;
               const uint32_t d0 = q & ~15u;
               const uint32_t srcp = sp - c;
               const uint32_t total = c + n;
@@ -788,7 +806,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
                 xb = lds_ld64(ring + (rowx ^ ((s8 + k + 8u) & RMASK)));
                 xc = lds_ld64(ring + (rowx ^ ((s8 + k + 16u) & RMASK)));
                 w = funnel24(xa, xb, xc, sh);
-                lds_st128(row + ((d0 + k) ^ tsw), w);
+                lds_st128(row + (HS_ROWWRAP(d0 + k) ^ tsw), w);
               }
               acc = w;
               sp += n;
@@ -801,14 +819,14 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
           if (lit == 0u && run != 0u && o < target)
           {
             const uint32_t m = umin(run, target - o);
-            const uint32_t q = o - base, c = q & 15u;
+            const uint32_t q = HS_ROWPOS(o), c = q & 15u;
             const uint32_t d0 = q & ~15u;
             const uint32_t total = c + m;
             const u32x4 v = u32x4{ sym4, sym4, sym4, sym4 };
             const u32x4 w = HS_MERGE_LOW(acc, v, c);
             lds_st128(row + (d0 ^ tsw), w);
             for (uint32_t k = 16; k < total; k += 16)
-              lds_st128(row + ((d0 + k) ^ tsw), v);
+              lds_st128(row + (HS_ROWWRAP(d0 + k) ^ tsw), v);
             acc = (total <= 16u) ? w : v;
             run -= m;
             o += m;
@@ -826,6 +844,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     uint32_t fl = (done ? F_DONE : 0u) | (last ? F_LAST : 0u);
     while ((fl & F_DONE) == 0u && o < target)
     {
+      if constexpr (CAP != 0u) { if (tripsLeft-- == 0u) break; }
       if (itersLeft-- == 0u) { err |= DEC_ERR_STREAM; fl |= F_DONE; break; }
 #ifdef HSRLE_STAMPS
       nIter++;
@@ -1222,7 +1241,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
         const uint32_t n = umin(umin(lit, target - o), resident);
         if (n == 0) break;                                             // literals not resident yet: continue next round
 
-        const uint32_t q = o - base, c = q & 15u;
+        const uint32_t q = HS_ROWPOS(o), c = q & 15u;
         const uint32_t d0 = q & ~15u;
         const uint32_t srcp = sp - c;
         const uint32_t total = c + n;                                  // bytes from dst that must end up valid
@@ -1236,7 +1255,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
           xb = lds_ld64(ring + (rowx ^ ((s8 + k + 8u) & RMASK)));
           xc = lds_ld64(ring + (rowx ^ ((s8 + k + 16u) & RMASK)));
           w = funnel24(xa, xb, xc, sh);
-          lds_st128(row + ((d0 + k) ^ tsw), w);
+          lds_st128(row + (HS_ROWWRAP(d0 + k) ^ tsw), w);
         }
         acc = w;
         sp += n;
@@ -1248,7 +1267,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
       if (lit == 0 && run != 0 && o < target)
       {
         const uint32_t m = umin(run, target - o);
-        const uint32_t q = o - base, c = q & 15u;
+        const uint32_t q = HS_ROWPOS(o), c = q & 15u;
         const uint32_t d0 = q & ~15u;
         const uint32_t total = c + m;
 
@@ -1261,7 +1280,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
             const u32x4 w = HS_MERGE_LOW(acc, v, c);
             lds_st128(row + (d0 ^ tsw), w);
             for (uint32_t k = 16; k < total; k += 16)
-              lds_st128(row + ((d0 + k) ^ tsw), v);
+              lds_st128(row + (HS_ROWWRAP(d0 + k) ^ tsw), v);
             acc = (total <= 16u) ? w : v;
           }
           else
@@ -1274,7 +1293,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
             {
               const uint32_t t = e0; e0 = e1; e1 = e2; e2 = t;
               w = u32x4{ e0, e1, e2, e0 };
-              lds_st128(row + ((d0 + k) ^ tsw), w);
+              lds_st128(row + (HS_ROWWRAP(d0 + k) ^ tsw), w);
             }
             acc = w;
           }
@@ -1291,6 +1310,12 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     HS_STAMP(tDecode)
     wave_sync();                                                   // every lane is done reading the ring and writing its row
     if (pass != 0) break;
+    if constexpr (CAP != 0u)
+    {
+      topup();                                                       // (capped rounds: a lane that waits for stream bytes goes on in the next round)
+      wave_sync();
+      break;
+    }
 
     // ---- top-up: the loads issued one step ago have had the whole decode to arrive; they move into the ring first (this wait
     //      never includes the flush stores below: vmcnt counts loads and stores in order), then the next piece is requested --
@@ -1307,7 +1332,8 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     //      chunk in `acc` and re-writes it at tile offset 0 in the next round, so there is no byte-granular path ----
     const uint32_t produced = o - base;
     const bool tailNow = active && o == blen && (produced & 15u) != 0u;   // only the last block of a buffer can have one
-    const uint32_t chunks = active ? (produced >> 4) : 0u;
+    // (capped rounds: whole 64-byte halves; everything at the block's end)
+    const uint32_t chunks = !active ? 0u : ((CAP != 0u && o != blen) ? ((produced >> 6) << 2) : (produced >> 4));
 #ifdef HSRLE_STAMPS
     if (active && produced != (uint32_t)T) tIssue += 1ull << 40;          // diagnostic: partial rows
 #endif
@@ -1327,7 +1353,8 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
       {
         const int q = h + k;
         const uint32_t r = (uint32_t)q * RPI + lane / CPR, c = lane % CPR;
-        fv[k] = lds_ld128(tile + r * TS + ((c * 16u) ^ tsw_of(r)));
+        if constexpr (CAP != 0u) fv[k] = lds_ld128(tile + r * TS + ((((fi[q] & ~15u) + c * 16u) & ((uint32_t)T - 1u)) ^ tsw_of(r)));
+        else fv[k] = lds_ld128(tile + r * TS + ((c * 16u) ^ tsw_of(r)));
         fAt[k] = (c < (fi[q] & 15u)) ? (fi[q] & ~15u) + c * 16u : 0xFFFFFFFFu;
       }
 #pragma unroll
@@ -1348,7 +1375,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     base += chunks << 4;
     if (tailNow)
     {
-      const uint32_t at = chunks << 4;
+      const uint32_t at = CAP != 0u ? (base & ((uint32_t)T - 1u)) : (chunks << 4);   // (capped rounds: base is already behind the flushed chunks)
       for (uint32_t k = 0; k < (produced & 15u); k++)
         out[(uint64_t)b * B + base + k] = row[(at ^ tsw) + k];
       base = o;                                                        // written exactly once

@@ -47,7 +47,11 @@ __global__ __launch_bounds__(64) void k_encode_greedy_blocks(const uint8_t *__re
     return;
   if constexpr (MONO) { if (blocks && ringSel != nullptr && b >= ringSel[0]) return; }
   if constexpr (MONO) { if (ld_fresh64(monoSyms + 8ull * b + 7) == 0ull) return; }   // repair rounds switch most chunks off
+#ifdef HSRLE_GREEDY_DRY   // timing-only diagnostic build (never shipped): the scan without its output stores (sizes are still written, the payload is not)
+  const bool dry = true;
+#else
   const bool dry = MONO && monoDry != 0u;
+#endif
 
   const uint64_t start = MONO ? monoStarts[b] : (uint64_t)b * B;
   if constexpr (MONO)
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(64) void k_encode_greedy_blocks(const uint8_t *__re
   // (a chunk that is not its stream's last must end exactly on its boundary: a scan that ran past it would write bytes the next chunk writes again.
   //  The cut rule -- stretches of >= 4 S + 11 bytes -- makes that impossible as far as anyone has seen; size 0 is how a chunk says "not me", and the
   //  callers check it: k_mono_zero_sizes / k_split_check)
-  if (!dry) sizes[b] = (MONO && !lastChunk && i != n) ? 0u : s.s.at;
+  if (!dry || !MONO) sizes[b] = (MONO && !lastChunk && i != n) ? 0u : s.s.at;
   if constexpr (MONO)
   {
 #pragma unroll

@@ -186,7 +186,7 @@ uint32_t hsrle_decompress_mono(int codec, const uint8_t *pIn, uint32_t inSize, u
  * in device memory, decoded into device memory.  A stream has no random access, so the library first builds an entry-point index
  * (speculative packet walks per stream region, then a pass that PROVES the chain and repairs wrong guesses: csrc/hsrle_index.hip.h)
  * and then runs the block kernel from those entry points.  dStream must be 128-byte aligned and readable up to streamSize + 64.
- * dWorkspace >= hsrle_decompress_mono_workspace_size().  Synchronises `stream` (once, at the end, when every entry guess holds).  pStats (optional, host, 4 values): stream regions,
+ * dWorkspace >= hsrle_decompress_mono_workspace_size(), 16-byte aligned.  Synchronises `stream` (once, at the end, when every entry guess holds).  pStats (optional, host, 4 values): stream regions,
  * repair rounds, regions walked again, final look-back of the entry guess.  Returns HSRLE_OK, HSRLE_ERR_FORMAT (malformed stream / sizes do not match the header), ...
  */
 uint64_t hsrle_decompress_mono_workspace_size(int codec, uint32_t uncompressedSize, uint32_t compressedSize);

@@ -885,3 +885,38 @@ def test_input_and_output_need_no_alignment(hs, oracle, key):
             torch.cuda.synchronize()
             host = outbuf.cpu().numpy().tobytes()
             assert int(status[0].item()) == 0 and host[off : off + size] == data and set(host[:off]) == {0xA5} and set(host[off + size :]) == {0xA5}, f"{key}: output at offset {off}, block size {block}"
+
+
+@pytest.mark.parametrize("key", ["rle8_3symlut_short", "rle8_7symlut_short", "rle16_3symlut_byte_short_greedy", "rle16_7symlut_byte_short_greedy", "rle24_3symlut_byte_short_greedy",
+                                 "rle16_3symlut_sym_short", "rle32_7symlut_byte_short", "rle64_7symlut_byte_short_greedy", "rle8_3symlut", "rle16_sym_packed"])
+def test_blocks_with_a_packet_for_every_few_bytes(hs, oracle, key):
+    """The most packets a block can hold: symbols of the move-to-front list coming back all the time (a one-byte packet for every 2 .. S output bytes with the
+    Short headers; the Greedy encoders store 2-byte pieces of listed symbols), next to blocks of one long run and of literals only.  The decoders' rounds are
+    capped at a few packets per lane (csrc/hsrle_decode.hip.h, CAPPED ROUNDS), so their bound on the number of rounds has to hold for such blocks --
+    and lanes whose neighbours are through after one packet."""
+    import torch
+
+    codec = CODEC_BY_KEY[key]
+    S = codec.S
+    rng = random.Random(4711)
+    syms = [bytes([v]) * S for v in (0x00, 0x7F, 0xFF, 0x01, 0x7E)] + [bytes(rng.randrange(256) for _ in range(S)) for _ in range(3)]
+    parts = []
+    for blk in range(192):
+        kind = blk % 4
+        if kind == 0:                                                    # listed symbols in turn, two of each: a packet per 2 S bytes (8 bit: per 2 bytes)
+            parts.append(b"".join(syms[(i // 2) % 3] for i in range(4096 // S + 1))[:4096])
+        elif kind == 1:                                                  # ... single occurrences: what the Greedy scan stores as a run of one listed symbol (or its first bytes)
+            parts.append(b"".join(syms[rng.randrange(5)][: rng.choice([2, S])] + bytes([rng.randrange(256)]) for _ in range(4096))[:4096])
+        elif kind == 2:
+            parts.append(syms[blk % len(syms)] * (4096 // S + 1))
+            parts[-1] = parts[-1][:4096]
+        else:
+            parts.append(bytes(rng.randrange(256) for _ in range(4096)))
+    data = b"".join(parts)
+    src = _to_dev(data)
+    container, info = hs.compress(key, src, block_size=4096)
+    cinfo, streams = hs.split_container(container.cpu().numpy().tobytes())
+    expect = oracle.compress_blocks(codec, np.frombuffer(data, dtype=np.uint8), 4096)
+    assert streams == expect, f"{key}: block streams differ from the oracle"
+    out = hs.decompress(container)
+    assert torch.equal(out, src), f"{key}: decode differs"
