@@ -232,10 +232,14 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   // 128 bit codecs launch this one for plain containers (inst_w128.hip).
   if constexpr (!ENT) entries = nullptr;
   using TR = Traits<FAM, S, AL>;
+#ifndef HSRLE_DEC_STARVED_MIN
+#define HSRLE_DEC_STARVED_MIN 32u        // capped rounds: lanes starved of literal bytes that make the round go on without a flush (below)
+#endif
 #ifdef HSRLE_DEC_TRIPS   // A/B builds: one cap for every instantiation
   constexpr uint32_t CAP = HSRLE_DEC_TRIPS;
 #else
-  constexpr uint32_t CAP = (S >= 2 && S <= 8) ? 4u : ((S == 1 && TR::kShort) ? 6u : 0u);   // packets per lane and round, 0 = a round lasts until every lane has its T bytes (see HS_ROWPOS below)
+  // packets per lane and round, 0 = a round lasts until every lane has its T bytes (see HS_ROWPOS below)
+  constexpr uint32_t CAP = (S >= 2 && S <= 8) ? 4u : ((S == 1 && (FAM == SHORT3 || FAM == SHORT7)) ? 8u : 0u);
 #endif
   constexpr int TS = T;                      // tile row stride: no pad -- the 16-byte chunks of a row are XOR-swizzled by the row index instead (TSW)
   constexpr int RS = R;                      // ring row stride: no pad, no mirror -- chunks are XOR-swizzled by the row index (rowx), every 8-byte piece is addressed on its own
@@ -565,9 +569,10 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
   // data (many short packets, unevenly spread) half the lane trips were idle.  With CAP != 0 a round is at most CAP packets per lane: the tile row is a RING of T
   // bytes addressed by the output position mod T, a lane may run up to T bytes ahead of what it has flushed (target = base + T), the flush writes the 64-byte
   // halves that are complete (whole write requests, as before) and a lane that waits for stream bytes goes on in the next round -- the sum of the per-round
-  // maxima becomes (nearly) the maximum of the sums.  Measured per family, 4 GiB, same box (LAB_NOTEBOOK.md, round 5 call 48): 2 .. 8 byte symbols CAP = 4:
-  // video-shaped +11 ... +63 % (rle64_7symlut_byte_short_greedy streams 885 -> 1 445 GiB/s), run data -2 ... +13 %; 8 bit Short CAP = 6: +10 ... +27 % / -2 ... +3 %;
-  // 8 bit plain / Packed / LUT and 128 bit: -5 ... +3 % with any CAP (few, large packets: what a round costs besides its trips is what the cap multiplies) -> 0.
+  // maxima becomes (nearly) the maximum of the sums.  Measured per family, 4 GiB, same box (LAB_NOTEBOOK.md, round 5 calls 48, 52, 53): 2 .. 8 byte symbols CAP = 4:
+  // video-shaped +8 ... +64 % (rle64_7symlut_byte_short_greedy streams 886 -> 1 422 GiB/s), run data -5 ... +10 %, random bytes +-1 %; the 8 bit Short codecs with a
+  // 3 / 7 symbol list CAP = 8: +13 ... +22 % / -5 ... +2 %; the other 8 bit codecs and 128 bit: -7 ... +6 % with any CAP (few, large packets: what a round costs
+  // besides its trips is what the cap multiplies) -> 0.
 #define HS_ROWPOS(pos) (CAP != 0u ? ((pos) & ((uint32_t)T - 1u)) : ((pos) - base))
 #define HS_ROWWRAP(x) (CAP != 0u ? ((x) & ((uint32_t)T - 1u)) : (x))
   uint32_t base = 0;      // block offset of the first byte of the tile row (multiple of 16); the row holds [base, o)
@@ -583,6 +588,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
 #define HS_STAMP(acc)
 #endif
 
+  [[maybe_unused]] bool skippedFlush = false;                          // capped rounds: the last trip went round again without a flush
   while (__ballot(!done && o < blen) != 0ull)
   {
     if (roundsLeft-- == 0u) { err |= DEC_ERR_STREAM; break; }
@@ -590,6 +596,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     t0 = __builtin_readcyclecounter(); nRounds++;
 #endif
 
+    [[maybe_unused]] bool starved = false;                              // capped rounds: this lane stopped for LITERAL bytes that were not resident (not for its cap, not for a header)
     static_assert(CAP == 0u || (T == Q && T == 128), "capped rounds: one step per round");
     const uint32_t flushTarget = CAP != 0u ? umin(base + (uint32_t)T, blen) : umin((o / (uint32_t)T + 1u) * (uint32_t)T, blen);
 
@@ -608,6 +615,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     for (int pass = 0; pass < 2; pass++)
     {
     const uint32_t avail0 = E;                                         // bytes [.., avail0) are readable during this pass
+    if constexpr (CAP != 0u) { starved = false; tripsLeft = CAP; }
 
     if constexpr (S == 1)
     {
@@ -789,7 +797,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
           {
             const uint32_t resident = (avail0 > sp) ? avail0 - sp : 0u;
             const uint32_t n = umin(umin(lit, target - o), resident);
-            if (n == 0u) fl |= F_STALL;                                   // literals not resident yet: continue next pass
+            if (n == 0u) { fl |= F_STALL; starved = true; }                // literals not resident yet: continue next pass
             else
             {
               const uint32_t q = HS_ROWPOS(o), c = q & 15u;
@@ -1239,7 +1247,7 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
       {
         const uint32_t resident = (avail0 > sp) ? avail0 - sp : 0u;
         const uint32_t n = umin(umin(lit, target - o), resident);
-        if (n == 0) break;                                             // literals not resident yet: continue next round
+        if (n == 0) { starved = true; break; }                         // literals not resident yet: continue next round
 
         const uint32_t q = HS_ROWPOS(o), c = q & 15u;
         const uint32_t d0 = q & ~15u;
@@ -1312,7 +1320,9 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     if (pass != 0) break;
     if constexpr (CAP != 0u)
     {
-      topup();                                                       // (capped rounds: a lane that waits for stream bytes goes on in the next round)
+      // capped rounds: lanes that have not reached their target are the rule, not a sign of starvation: one pass, then the top-up (see below for the lanes that
+      // stopped in the middle of a literal stretch)
+      topup();
       wave_sync();
       break;
     }
@@ -1326,6 +1336,18 @@ __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict_
     wave_sync();
     if (__ballot(!done && o < target) == 0ull) break;                // nobody starved (the common case)
     }
+    }
+
+    // Capped rounds: a lane that stopped in the middle of a LITERAL stretch because the ring ran dry (literal-heavy data uses up the ring within a pass) gets
+    // one more pass on the topped-up ring before the flush -- without it such lanes make half a row per round (random bytes: -27 %).  As a second trip of the
+    // round loop, not as pass 1 of the loop above: that form keeps two decode passes' state alive across the top-up (rle48_7symlut: 166 -> 188 VGPRs, a wave
+    // per SIMD less, -13 ... -18 %).  A lane that only waits for a header's bytes does not ask for it (64-byte rings do that all the time).
+    if constexpr (CAP != 0u)
+    {
+#ifndef HSRLE_DEC_NO_SECOND_PASS   // (A/B builds)
+      if (!skippedFlush && (uint32_t)__builtin_popcountll(__ballot(starved && !done)) >= HSRLE_DEC_STARVED_MIN) { skippedFlush = true; continue; }
+      skippedFlush = false;
+#endif
     }
 
     // ---- flush: whole 16-byte chunks only.  A row that ends inside a chunk (lane starved, or the block tail) keeps that
