@@ -188,7 +188,24 @@ __global__ __launch_bounds__(64) void k_encode_greedy_blocks(const uint8_t *__re
   while ((MONO && !lastChunk) ? !stopped : i < n)
   {
     ensure(i);
-    if (count != 0u && i + SU <= nT)
+    // inside a run: W = 8 (6 for 3 / 6 byte symbols) bytes against the symbol's pattern per trip -- what W / S of the reference's steps do (each compares one
+    // symbol and stops at the first that differs, taking its matching leading bytes along: the first differing BYTE says both; rleX_Xsl_short.h:800-860).  One
+    // step per trip of the ONE loop, not a loop of its own: a phase that only the lanes inside a run execute makes the others wait (round 4's literal skip).
+    constexpr uint32_t W = (S == 3 || S == 6) ? 6u : 8u;
+    if (S < 8 && count != 0u && i + W <= nT)
+    {
+      uint32_t x0, x1, p0, p1;
+      ring.get64(i, x0, x1);
+      if constexpr (S == 2) { p0 = y0 * 0x00010001u; p1 = p0; }
+      else if constexpr (S == 3) { p0 = y0 | (y0 << 24); p1 = y0 >> 8; }
+      else if constexpr (S == 4) { p0 = y0; p1 = y0; }
+      else { p0 = y0; p1 = y1; }                                         // S == 6: y1 holds bytes 4, 5
+      const uint64_t diff = ((uint64_t)(x0 ^ p0) | ((uint64_t)(x1 ^ p1) << 32)) & (W == 8u ? ~0ull : 0xFFFFFFFFFFFFull);
+      if (diff == 0ull) { count += W; i += W; continue; }
+      const uint32_t e = (uint32_t)__builtin_ctzll(diff) >> 3;           // bytes that still belong to the run: whole symbols, then the leading bytes of the one that differs
+      count += e; i += e;
+    }
+    else if (count != 0u && i + SU <= nT)
     {
       uint32_t x0, x1;
       sym_at(i, x0, x1);
