@@ -420,7 +420,7 @@ int hsrle_experiments_enabled(void);
 #define HSRLE_PATH_RING 0
 #define HSRLE_PATH_SPLIT 1
 #define HSRLE_PATH_RUN_LIST 2
-#define HSRLE_PATH_POSITION_PARALLEL 3   /* round 5: one wave per block, blocks of at most 4 KiB, any number of them: rle8_multi, rle8_packed_multi, the plain / Packed codecs of 2 .. 8 byte symbols, the 3 symbol LUT codecs of 3 .. 8 byte symbols */
+#define HSRLE_PATH_POSITION_PARALLEL 3   /* round 5: one wave per block, blocks of at most 4 KiB, any number of them: rle8_multi, rle8_packed_multi, the plain / Packed codecs of 2 .. 8 byte symbols, the 3 symbol LUT codecs of 3 .. 8 byte symbols, the Short codecs with no / one symbol in the list (1 .. 8 byte symbols) and with three (6 / 8 byte symbols): 56 codecs */
 int hsrle_encode_path(int codec, uint64_t uncompressedSize, uint32_t blockSize);
 
 /* A hash of the library's sources and build flags (set by the Makefile; "unknown" for other build recipes): measurement files that
