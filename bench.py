@@ -385,6 +385,59 @@ def config5_rows(hsrle, torch, dev, with_cpu):
     return rows
 
 
+def video_rows(hsrle, torch, dev, with_cpu):
+    """Side measurement (not `value`): decode and encode of the 8 GiB VIDEO-SHAPED buffer (many short packets, unevenly spread: what the capped decoder rounds of
+    round 5 are for) for a few codecs of the families the 110-codec sweep has its weakest rows in.  No reference-minted manifests exist for
+    these buffers: `exact` = the decode equals the input and the status word is 0; `cpu_streams_match_gpu` = the first 64 MiB of block streams equal the
+    compiled reference's."""
+    import numpy as np
+    from hsrle_testlib import CODEC_BY_KEY
+
+    rows = []
+    size, block = 8 << 30, 4096
+    dst = torch.empty(hsrle.container_bound(size, block), dtype=torch.uint8, device=dev)
+    ws = torch.empty(hsrle.workspace_size(size, block), dtype=torch.uint8, device=dev)
+    out = torch.empty(size, dtype=torch.uint8, device=dev)
+    for key in ("rle8_packed_multi", "rle16_sym_packed", "rle32_3symlut_byte", "rle48_7symlut_byte", "rle64_3symlut_byte", "rle24_byte_short", "rle64_7symlut_byte_short"):
+        codec = CODEC_BY_KEY[key]
+        src = hsrle.synth(hsrle.SYNTH_VIDEO, codec.S, 5, size, device=dev)
+        status = torch.zeros(16, dtype=torch.int32, device=dev)
+
+        def timed(fn, warm, reps):
+            for _ in range(warm):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+
+        enc_ms = timed(lambda: hsrle.compress_async(key, src, dst, block, workspace=ws), 1, 3)
+        info = hsrle.container_info(dst)
+        container = dst[: info.totalSize]
+        dec_ms = timed(lambda: hsrle.decompress_async(container, info, out, status), 2, 5)
+        exact = int(status[0].item()) == 0 and torch.equal(out, src)
+        alg = size + info.totalSize
+        row = {"codec": key, "ratio": round(info.totalSize / size, 4), "decode_GiBps": round(size / 2**30 / (dec_ms * 1e-3), 1), "encode_GiBps": round(size / 2**30 / (enc_ms * 1e-3), 1),
+               "decode_frac": round(alg / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "encode_frac": round(alg / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "exact": bool(exact)}
+        if with_cpu:
+            nb = (64 << 20) // block
+            p0 = info.payload_start
+            prefix_end = p0 + int(container[64 + 8 * nb : 64 + 8 * nb + 8].view(torch.int64).item()) + 64
+            prefix = container[: min(prefix_end, container.numel())].cpu().numpy().tobytes()
+            sample = src[: nb * block].cpu().numpy()
+            cd = cpu_baseline(prefix, nb, block, key, sample.tobytes(), budget_s=0.4, all_cores=False)
+            ce = cpu_encode_baseline(sample, block, key, prefix[p0:], np.frombuffer(prefix, dtype=np.uint64, count=nb + 1, offset=64), budget_s=0.4)
+            row.update({"cpu_decode_GiBps": cd["value"], "cpu_encode_GiBps": ce["value"], "cpu_kind": cd["kind"], "cpu_cores": 1,
+                        "cpu_streams_match_gpu": bool(ce["streams_match_gpu"] and cd["matches_gpu_input"])})
+        rows.append(row)
+        del src
+    return rows
+
+
 def kernel_name(codec_key):
     """The decode kernel instantiation behind a codec id (hsrle_decode.hip.h: k_decode_blocks<FAM, S, AL, T, R, Q, SGL>)."""
     from hsrle_testlib import CODEC_BY_KEY, FAMILY_NAMES
@@ -692,6 +745,14 @@ def main():
                                                             "cpu_sample": "reference CPU codec, one core, first 64 MiB of the same buffer, block by block" if not args.no_cpu else None}
             except Exception as ex:  # noqa: BLE001
                 line.setdefault("extras", {})["config5"] = {"error": repr(ex)[:300]}
+            try:
+                tv = time.time()
+                torch.cuda.empty_cache()
+                rows = video_rows(hsrle, torch, dev, with_cpu=not args.no_cpu)
+                line["extras"]["video_shaped"] = {"workload": "8 GiB video-shaped(W, seed 5), 4 KiB blocks: the data shape of BASELINE config 3 at the size of config 2", "rows": rows,
+                                                  "all_exact": bool(rows) and all(r["exact"] for r in rows), "seconds": round(time.time() - tv, 1)}
+            except Exception as ex:  # noqa: BLE001
+                line["extras"]["video_shaped"] = {"error": repr(ex)[:300]}
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(line) + "\n").encode())
 
