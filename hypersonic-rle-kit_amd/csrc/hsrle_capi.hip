@@ -1024,7 +1024,7 @@ static MonoPlan plan_mono(int codec, uint32_t U, uint32_t C, uint32_t p0)
   m.offStateIn = at; at += align_up(4ull * m.R * ks, 256);
   m.offFix = at; at += align_up(4ull * m.R, 256);
   m.offList = at; at += align_up(4ull * m.R, 256);
-  m.offMark = at; at += align_up(4ull * m.R, 256);
+  m.offMark = at; at += align_up(4ull * m.R, 256);        // (mark | ctrl | rec stay neighbours in this order: mono_prepare clears [offMark, offFast) in one launch)
   m.offCtrl = at; at += 256;
   m.offRec = at; at += align_up(4ull * kEntryRecDwords * m.nb, 256);
   m.offFast = at; at += 256;                                             // the parallel resolve passes: flag + carries, totals per batch of 1 024 regions
