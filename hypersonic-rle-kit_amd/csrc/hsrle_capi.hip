@@ -80,6 +80,7 @@ static void init_tables()
   std::call_once(g_tableOnce, [] {
     register_w8(g_dec, g_enc, g_idx, g_sub, g_menc, g_wenc);
     register_pp8(g_pp);
+    register_pp8s(g_pp);
     register_ppS(g_pp);
     register_w16(g_dec, g_enc, g_idx, g_sub, g_menc);
     register_w24(g_dec, g_enc, g_idx, g_sub, g_menc);
@@ -664,7 +665,7 @@ static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, ui
   // (8 bit Single / 128 bit, small containers of 1 .. 4 KiB blocks: the split encode needs regions the general workspace does not reserve --
   //  the library's own scratch has them, a caller's workspace if it was sized by hsrle_compress_workspace_size_codec)
   Workspace w = plan_workspace(U, B);
-  if (split_codec_small(codec) && B <= 4096u)
+  if (split_codec_small(codec) && B <= 4096u && !pp_applies(codec, (uint32_t)w.nBlocks, B))
   {
     // (only where the split encode will really run: its regions are 2 - 3 x the input -- ADVICE r4)
     const Workspace w2 = plan_workspace(U, B, true);

@@ -207,3 +207,98 @@ def test_position_parallel_path_is_the_one_that_ran(hs):
     """The codecs above must not pass on another encoder: hsrle_encode_path says which one a container of this shape takes."""
     for key in KEYS + WIDE_KEYS + LUT_KEYS + SHORT_KEYS:
         assert hs.encode_path(key, 8 << 20, 4096) == hs.PATH_POSITION_PARALLEL, key
+
+
+# ---- 8 bit Single (csrc/hsrle_encode8sp.hip.h; reference: src/rle8_extreme_cpu.c:53-153, src/rle8_extreme_cpu.h:346-700, :1103-1321) ----
+SINGLE_KEYS = ["rle8_single", "rle8_packed_single"]
+
+
+def _favourite(rng, n, sym, run_lengths, gaps, alphabet=256):
+    """runs of ONE favourite byte between literal stretches that never hold it twice in a row: what the runs do is what the test says"""
+    out = np.empty(n + 8192, dtype=np.uint8)
+    at = 0
+    while at < n:
+        g = int(rng.choice(gaps))
+        lit = rng.integers(0, alphabet, g, dtype=np.uint8)
+        lit[lit == sym] = (sym + 1) % alphabet
+        out[at : at + g] = lit
+        at += g
+        R = int(rng.choice(run_lengths))
+        out[at : at + R] = sym
+        at += R
+    return out[:n].copy()
+
+
+def _wasted_groups(rng, n):
+    """the body's wasted-chances rule (:1244-1285) on runs of zeros: groups of short runs a few bytes apart behind gaps of more than 255 bytes -- and behind
+    0 .. 70 stored runs, so that a group sits at any place of a 64-candidate round (literals never hold a zero)"""
+    parts = []
+    total = 0
+
+    def add(a):
+        nonlocal total
+        parts.append(a)
+        total += a.size
+
+    while total < n:
+        for _ in range(int(rng.integers(0, 71))):
+            add(rng.integers(1, 250, int(rng.integers(1, 4)), dtype=np.uint8))
+            add(np.zeros(int(rng.choice([2, 3, 4, 5, 9])), dtype=np.uint8))
+        add(rng.integers(1, 250, int(rng.choice([250, 254, 255, 256, 257, 300, 700])), dtype=np.uint8))
+        for _ in range(int(rng.choice([1, 2, 3, 3, 3, 4, 5, 7]))):
+            add(np.zeros(int(rng.choice([2, 3, 4, 5, 6, 7])), dtype=np.uint8))
+            add(rng.integers(1, 250, int(rng.choice([1, 2, 10, 60, 120, 125, 130, 240])), dtype=np.uint8))
+    return np.concatenate(parts)[:n].copy()
+
+
+@pytest.fixture(scope="module")
+def single_cases():
+    rng = np.random.default_rng(60606)
+    n = 4 << 20
+    return {
+        "zeros": np.zeros(n, dtype=np.uint8),
+        "random": rng.integers(0, 256, n, dtype=np.uint8),
+        "two_symbols": rng.integers(0, 2, n, dtype=np.uint8),
+        "three_symbols": rng.integers(0, 3, n, dtype=np.uint8),
+        "short_runs": _favourite(rng, n, 7, [1, 2, 2, 3, 3, 4, 4, 5, 6, 7, 8, 9, 10, 11], [1, 1, 2, 3, 5, 14, 15, 16, 17, 31]),      # > 64 candidates per block
+        "far_apart": _favourite(rng, n, 200, [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 40, 300], [0, 1, 100, 250, 254, 255, 256, 257, 300, 900]),
+        "long_runs": _favourite(rng, n, 0, [15, 16, 17, 31, 32, 33, 250, 255, 256, 257, 258, 259, 260, 1000, 5000], [1, 3, 16, 200, 400]),
+        "wasted": _wasted_groups(rng, n),
+    }
+
+
+@pytest.mark.parametrize("key", SINGLE_KEYS)
+@pytest.mark.parametrize("name", ["zeros", "random", "two_symbols", "three_symbols", "short_runs", "far_apart", "long_runs", "wasted"])
+def test_position_parallel_single_encoder_bit_exact(hs, oracle, single_cases, key, name):
+    _check(hs, oracle, key, single_cases[name], 4096)
+
+
+@pytest.mark.parametrize("key", SINGLE_KEYS)
+@pytest.mark.parametrize("block,cut", [(128, 0), (256, 1), (384, 5), (1024, 77), (1536, 1535), (2048, 2047), (3968, 13), (4096, 4095), (4096, 4081), (4096, 4080), (4096, 4079), (4096, 4064), (4096, 4033)])
+def test_position_parallel_single_encoder_block_sizes_and_ragged_tails(hs, oracle, single_cases, key, block, cut):
+    data = np.concatenate([single_cases["short_runs"][: 1 << 20], single_cases["far_apart"][: 1 << 20], single_cases["wasted"][: 1 << 20], single_cases["long_runs"][: 1 << 20]])
+    _check(hs, oracle, key, data[: data.size - cut], block)
+
+
+@pytest.mark.parametrize("key", SINGLE_KEYS)
+@pytest.mark.parametrize("kind", [SYNTH_RUNS, SYNTH_VIDEO])
+def test_position_parallel_single_encoder_synthetic_workloads(hs, oracle, key, kind):
+    data = oracle.synth(kind, 1, 11, (16 << 20) + 999)
+    _check(hs, oracle, key, data, 4096)
+
+
+@pytest.mark.parametrize("key", SINGLE_KEYS)
+def test_position_parallel_single_encoder_fuzz_blocks(hs, oracle, key):
+    """the fuzz grammar of the reference's own fuzzer + inputs dominated by one favourite byte, as many small blocks"""
+    import random
+
+    from hsrle_testlib import FUZZ_LENGTHS, fuzz_sections, single_symbol_mix
+
+    rng = random.Random(99)
+    parts = []
+    for _ in range(400):
+        parts.append(fuzz_sections(rng, 8, FUZZ_LENGTHS))
+        parts.append(single_symbol_mix(rng, rng.choice([300, 3000, 9000])))
+    data = np.frombuffer(b"".join(parts), dtype=np.uint8).copy()
+    for block in (128, 640, 4096):
+        _check(hs, oracle, key, data, block)
