@@ -118,6 +118,7 @@ constexpr int kDecodeRing = HSRLE_DECODE_RING; // per-lane stream ring in LDS (k
 void register_w8(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub, MonoEncodeLaunch *menc, WaveEncodeLaunch *wenc);
 void register_pp8(PpLaunch *pp);
 void register_pp8s(PpLaunch *pp);
+void register_pp128(PpLaunch *pp);
 void register_ppS(PpLaunch *pp);
 void register_w16(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub, MonoEncodeLaunch *menc);
 void register_w24(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub, MonoEncodeLaunch *menc);

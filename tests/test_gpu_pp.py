@@ -302,3 +302,92 @@ def test_position_parallel_single_encoder_fuzz_blocks(hs, oracle, key):
     data = np.frombuffer(b"".join(parts), dtype=np.uint8).copy()
     for block in (128, 640, 4096):
         _check(hs, oracle, key, data, block)
+
+
+# ---- 128 bit symbols (csrc/hsrle_encode128p.hip.h; reference: src/rle128_extreme_cpu.h:32-497) ----
+KEYS_128 = ["rle128_sym", "rle128_sym_packed", "rle128_byte", "rle128_byte_packed"]
+
+
+def _periodic128(rng, n, alphabet):
+    """stretches of period 1 .. 32 bytes of many lengths around 16 / 32 / 48 bytes, cut mid-symbol, behind literal stretches of 0 .. 300 bytes"""
+    out = bytearray()
+    while len(out) < n:
+        out += bytes(rng.randrange(alphabet) for _ in range(rng.choice([0, 1, 2, 5, 15, 16, 17, 40, 300])))
+        P = rng.choice([1, 1, 2, 4, 8, 16, 16, 16, 32])
+        sym = bytes(rng.randrange(alphabet) for _ in range(P))
+        k = rng.choice([16, 17, 20, 31, 32, 33, 35, 36, 37, 40, 47, 48, 49, 63, 64, 65, 100, 300, 1000])
+        out += (sym * (k // P + 2))[:k]
+    return bytes(out[:n])
+
+
+def _tails128(rng, n):
+    """a stored run, a few other bytes, then the run's symbol again inside the last 32 bytes of the block: the byte steps at the end of the input
+    (:270-300) -- Packed stores `runs` of 3 .. 16 equal bytes there -- and the pair at n - 32"""
+    c = rng.randrange(256)
+    lead = rng.choice([2, 3, 4, 5, 8, 12, 15, 16])
+    sym = bytes([c]) * lead + bytes(rng.randrange(256) for _ in range(16 - lead))
+    g = bytes(rng.choice([c, rng.randrange(256)]) for _ in range(rng.choice([0, 1, 2, 3, 5, 8, 13, 16])))
+    endpart = (sym * 3)[: rng.choice([17, 18, 20, 24, 30, 31, 32, 33, 40])]
+    k = max(32, n - len(g) - len(endpart) - rng.choice([0, 3, 50]))
+    pre = bytes(rng.randrange(256) for _ in range(rng.choice([0, 3, 50])))
+    blk = pre + (sym * (k // 16 + 1))[:k] + g + endpart
+    return (blk + bytes(rng.randrange(256) for _ in range(n)))[:n]
+
+
+@pytest.fixture(scope="module")
+def cases128():
+    import random
+
+    rng = random.Random(128128)
+    nrng = np.random.default_rng(128)
+    n = 2 << 20
+    out = {}
+    for name, alphabet in (("periodic", 256), ("periodic_small", 3), ("periodic_one", 1)):
+        out[name] = np.frombuffer(b"".join(_periodic128(rng, 4096, alphabet) for _ in range(n // 4096)), dtype=np.uint8).copy()
+    out["tails_4096"] = np.frombuffer(b"".join(_tails128(rng, 4096) for _ in range(n // 4096)), dtype=np.uint8).copy()
+    out["tails_256"] = np.frombuffer(b"".join(_tails128(rng, 256) for _ in range(n // 256)), dtype=np.uint8).copy()
+    out["zeros"] = np.zeros(n, dtype=np.uint8)
+    out["random"] = nrng.integers(0, 256, n, dtype=np.uint8)
+    out["two_symbols"] = nrng.integers(0, 2, n, dtype=np.uint8)
+    return out
+
+
+@pytest.mark.parametrize("key", KEYS_128)
+@pytest.mark.parametrize("name", ["periodic", "periodic_small", "periodic_one", "tails_4096", "zeros", "random", "two_symbols"])
+def test_position_parallel_128_encoder_bit_exact(hs, oracle, cases128, key, name):
+    _check(hs, oracle, key, cases128[name], 4096)
+
+
+@pytest.mark.parametrize("key", KEYS_128)
+def test_position_parallel_128_encoder_small_blocks_end_of_input_rules(hs, oracle, cases128, key):
+    _check(hs, oracle, key, cases128["tails_256"], 256)
+
+
+@pytest.mark.parametrize("key", KEYS_128)
+@pytest.mark.parametrize("block,cut", [(128, 0), (256, 1), (384, 5), (1024, 77), (1536, 1535), (2048, 2047), (3968, 13), (4096, 4095), (4096, 4081), (4096, 4080), (4096, 4079), (4096, 4065), (4096, 4064), (4096, 4063), (4096, 4049), (4096, 4033)])
+def test_position_parallel_128_encoder_block_sizes_and_ragged_tails(hs, oracle, cases128, key, block, cut):
+    data = np.concatenate([cases128["periodic"][: 1 << 20], cases128["periodic_small"][: 1 << 19], cases128["tails_4096"][: 1 << 19]])
+    _check(hs, oracle, key, data[: data.size - cut], block)
+
+
+@pytest.mark.parametrize("key", KEYS_128)
+@pytest.mark.parametrize("kind", [SYNTH_RUNS, SYNTH_VIDEO])
+def test_position_parallel_128_encoder_synthetic_workloads(hs, oracle, key, kind):
+    data = oracle.synth(kind, 16, 11, (16 << 20) + 999)
+    _check(hs, oracle, key, data, 4096)
+
+
+@pytest.mark.parametrize("key", KEYS_128)
+def test_position_parallel_128_encoder_fuzz_blocks(hs, oracle, key):
+    import random
+
+    from hsrle_testlib import FUZZ_LENGTHS, fuzz_sections, mixed_runs
+
+    rng = random.Random(1281)
+    parts = []
+    for _ in range(300):
+        parts.append(fuzz_sections(rng, 8, FUZZ_LENGTHS))
+        parts.append(mixed_runs(rng, rng.choice([300, 3000, 9000])))
+    data = np.frombuffer(b"".join(parts), dtype=np.uint8).copy()
+    for block in (128, 640, 4096):
+        _check(hs, oracle, key, data, block)
