@@ -82,6 +82,7 @@ static void init_tables()
     register_pp8(g_pp);
     register_pp8s(g_pp);
     register_pp128(g_pp);
+    register_ppL(g_pp);
     register_ppS(g_pp);
     register_w16(g_dec, g_enc, g_idx, g_sub, g_menc);
     register_w24(g_dec, g_enc, g_idx, g_sub, g_menc);

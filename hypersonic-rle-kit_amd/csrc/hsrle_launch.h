@@ -119,6 +119,7 @@ void register_w8(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBloc
 void register_pp8(PpLaunch *pp);
 void register_pp8s(PpLaunch *pp);
 void register_pp128(PpLaunch *pp);
+void register_ppL(PpLaunch *pp);
 void register_ppS(PpLaunch *pp);
 void register_w16(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub, MonoEncodeLaunch *menc);
 void register_w24(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub, MonoEncodeLaunch *menc);

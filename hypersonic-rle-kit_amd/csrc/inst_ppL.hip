@@ -1,0 +1,39 @@
+// inst_ppL.hip -- instantiations of the position-parallel LUT encoder (hsrle_encodeLp.hip.h): the 7 symbol LUT codecs of every width, the 3 symbol LUT codecs of 1 / 2 byte symbols
+#include "hsrle_launch.h"
+#include "hsrle_encodeLp.hip.h"
+
+namespace hsrle {
+
+template <int FAM, int S, int AL>
+static hipError_t ppL_launch(const PpArgs &a, int phase, hipStream_t st)
+{
+  PpScratch sc;
+  sc.recs = (uint32_t *)a.scratch;
+  sc.recStride = pp_record_stride(a.B);
+  sc.recCount = sc.recs + (uint64_t)sc.recStride * a.nBlocks + 64u;
+  sc.stamps = nullptr;
+  if (phase == 0)
+    hipLaunchKernelGGL((k_encodeL_pp<FAM, S, AL, 0>), dim3(a.nBlocks), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.sizes, a.offsets, a.payload, sc);
+  else
+    hipLaunchKernelGGL((k_encodeL_pp<FAM, S, AL, 1>), dim3(a.nBlocks), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.sizes, a.offsets, a.payload, sc);
+  return hipGetLastError();
+}
+
+// codec ids 6 + 8 * w + v: w = width index (16, 24, 32, 48, 64 bit), v = 3 7symlut_sym, 7 7symlut_byte
+template <int S, int W>
+static void reg_lut7(PpLaunch *pp)
+{
+  pp[6 + 8 * W + 3] = ppL_launch<LUT7, S, 1>;
+  pp[6 + 8 * W + 7] = ppL_launch<LUT7, S, 0>;
+}
+
+void register_ppL(PpLaunch *pp)
+{
+  pp[2] = ppL_launch<LUT3, 1, 0>;         // rle8_3symlut
+  pp[3] = ppL_launch<LUT7, 1, 0>;         // rle8_7symlut
+  pp[6 + 2] = ppL_launch<LUT3, 2, 1>;     // rle16_3symlut_sym
+  pp[6 + 6] = ppL_launch<LUT3, 2, 0>;     // rle16_3symlut_byte
+  reg_lut7<2, 0>(pp); reg_lut7<3, 1>(pp); reg_lut7<4, 2>(pp); reg_lut7<6, 3>(pp); reg_lut7<8, 4>(pp);
+}
+
+} // namespace hsrle

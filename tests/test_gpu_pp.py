@@ -391,3 +391,67 @@ def test_position_parallel_128_encoder_fuzz_blocks(hs, oracle, key):
     data = np.frombuffer(b"".join(parts), dtype=np.uint8).copy()
     for block in (128, 640, 4096):
         _check(hs, oracle, key, data, block)
+
+
+# ---- LUT codecs whose packets depend on the list beyond a closed form (csrc/hsrle_encodeLp.hip.h): every 7 symbol LUT codec, the 3 symbol LUT codecs of 1 / 2 byte
+#      symbols (reference: src/rleX_Xsl.h:93-346, src/rleX_Xsl_multibyte_encoder.h:18-370) ----
+LUTG_KEYS = ["rle8_3symlut", "rle8_7symlut", "rle16_3symlut_sym", "rle16_3symlut_byte"] + [f"rle{w}_7symlut_{a}" for w in (16, 24, 32, 48, 64) for a in ("sym", "byte")]
+
+
+def _list_marginal(rng, n, S, alphabet, lengths, gaps):
+    """runs of exactly the lengths whose storing depends on the list (3 + penalty bytes) among longer ones, symbols out of a small alphabet so that they come
+    back while they are still listed -- or just after they dropped out -- behind gaps on both sides of the range field's limit (63 / 127)"""
+    out = np.empty(n + 8192, dtype=np.uint8)
+    syms = rng.integers(0, 256, (alphabet, S), dtype=np.uint8)
+    at = 0
+    while at < n:
+        g = int(rng.choice(gaps))
+        lit = rng.integers(0, 256, g, dtype=np.uint8)
+        out[at : at + g] = lit
+        at += g
+        R = int(rng.choice(lengths))
+        out[at : at + R] = np.tile(syms[int(rng.integers(0, alphabet))], R // S + 2)[:R]
+        at += R
+    return out[:n].copy()
+
+
+@pytest.fixture(scope="module")
+def lutg_cases(lut_cases, cases):
+    rng = np.random.default_rng(7007)
+    n = 2 << 20
+    out = dict(lut_cases)
+    for name in ("zeros", "random", "threes", "short_chains", "mixed", "long_literals", "same_symbol"):
+        out["b_" + name] = cases[name][:n]
+    gaps = [0, 1, 2, 5, 20, 60, 61, 62, 63, 64, 100, 124, 125, 126, 127, 128, 200]
+    for S in (1, 2, 3, 4, 6, 8):
+        out[f"marginal{S}_few"] = _list_marginal(rng, n, S, 5, [3, 3, 4, 5, 5, 6, 7, 8, 2 * S, 2 * S + 1, 3 * S, 40], gaps)
+        out[f"marginal{S}_nine"] = _list_marginal(rng, n, S, 9, [3, 4, 5, 5, 6, 2 * S, 2 * S + 1, 2 * S + 2, 3 * S + 1, 130, 131, 140], gaps)
+    return out
+
+
+def _symbytes(key):
+    return int(key.split("_")[0][3:]) // 8
+
+
+@pytest.mark.parametrize("key", LUTG_KEYS)
+@pytest.mark.parametrize("name", ["periods", "butting", "far_apart", "two_symbols", "few_symbols", "initial_entries", "b_zeros", "b_random", "b_threes", "b_short_chains", "b_mixed",
+                                  "b_long_literals", "b_same_symbol", "marginal_few", "marginal_nine", "marginal1_few", "marginal2_nine"])
+def test_position_parallel_lut_general_encoder_bit_exact(hs, oracle, lutg_cases, key, name):
+    if name in ("marginal_few", "marginal_nine"):
+        name = name.replace("marginal", f"marginal{_symbytes(key)}")
+    _check(hs, oracle, key, lutg_cases[name], 4096)
+
+
+@pytest.mark.parametrize("key", ["rle8_3symlut", "rle8_7symlut", "rle16_3symlut_byte", "rle16_7symlut_sym", "rle32_7symlut_byte", "rle64_7symlut_sym"])
+@pytest.mark.parametrize("block,cut", [(128, 0), (384, 5), (1024, 77), (1536, 1535), (4096, 4095), (4096, 4081)])
+def test_position_parallel_lut_general_encoder_block_sizes_and_ragged_tails(hs, oracle, lutg_cases, key, block, cut):
+    S = _symbytes(key)
+    data = np.concatenate([lutg_cases[f"marginal{S}_few"][: 1 << 20], lutg_cases["few_symbols"][: 1 << 19], lutg_cases["b_short_chains"][: 1 << 19], lutg_cases["butting"][: 1 << 19]])
+    _check(hs, oracle, key, data[: data.size - cut], block)
+
+
+@pytest.mark.parametrize("key", LUTG_KEYS)
+@pytest.mark.parametrize("kind", [SYNTH_RUNS, SYNTH_VIDEO])
+def test_position_parallel_lut_general_encoder_synthetic_workloads(hs, oracle, key, kind):
+    data = oracle.synth(kind, _symbytes(key), 11, (8 << 20) + 999)
+    _check(hs, oracle, key, data, 4096)
