@@ -646,7 +646,7 @@ static bool pp_applies(int codec, uint32_t nBlocks, uint32_t B)
   return force == 1u || nBlocks >= kPpMinBlocks;
 }
 
-static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, uint64_t cap, uint32_t B, void *dWs, uint64_t wsSize, hipStream_t st)
+static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, uint64_t cap, uint32_t B, void *dWs, uint64_t wsSize, hipStream_t st, bool noSplit = false)
 {
   if (codec < 0 || codec >= kCodecCount || dIn == nullptr || dOut == nullptr || U == 0)
     return HSRLE_ERR_ARGUMENT;
@@ -667,7 +667,7 @@ static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, ui
   // (8 bit Single / 128 bit, small containers of 1 .. 4 KiB blocks: the split encode needs regions the general workspace does not reserve --
   //  the library's own scratch has them, a caller's workspace if it was sized by hsrle_compress_workspace_size_codec)
   Workspace w = plan_workspace(U, B);
-  if (split_codec_small(codec) && B <= 4096u && !pp_applies(codec, (uint32_t)w.nBlocks, B))
+  if (!noSplit && split_codec_small(codec) && B <= 4096u && !pp_applies(codec, (uint32_t)w.nBlocks, B))
   {
     // (only where the split encode will really run: its regions are 2 - 3 x the input -- ADVICE r4)
     const Workspace w2 = plan_workspace(U, B, true);
@@ -1352,7 +1352,8 @@ static int compress_split(int codec, const uint8_t *dIn, uint64_t U, uint32_t B,
   uint32_t *flags = (uint32_t *)(ws + w.spFlags), *sizes = (uint32_t *)(ws + w.spSizes), *firstChunk = (uint32_t *)(ws + w.spFirst), *ctrl = (uint32_t *)(ws + w.spCtrl);
   Workspace sw{};
   sw.offL1 = w.spL1; sw.offL2 = w.spL2; sw.offL3 = w.spL3;
-  if (zero2_async(ctrl, 64, sizes, 4ull * (maxChunks + 1ull), st) != hipSuccess)   // (graph capturable: not hipMemsetAsync, see zero_async)
+  static_assert(9u + kSplitPiecesMax - 1u <= 16u, "the list-verify rounds count into ctrl[9 + round]: below the verdict flag ctrl[24]");
+  if (zero2_async(ctrl, 128, sizes, 4ull * (maxChunks + 1ull), st) != hipSuccess)   // (graph capturable: not hipMemsetAsync, see zero_async; 256 bytes are reserved)
     return HSRLE_ERR_DEVICE;
   const dim3 cgrid((pieces + 63u) / 64u);
   const bool single = codec == 4 || codec == 5 || codec == kSingleShort;
@@ -1423,7 +1424,7 @@ static int compress_split(int codec, const uint8_t *dIn, uint64_t U, uint32_t B,
   }
   const bool laneChunks = single || S == 16 || codec >= kGreedyBase;     // per-lane chunk encoders: a chunk that missed its boundary run says so with size 0
   if (laneChunks)
-    hipLaunchKernelGGL(k_split_check, dim3((nBlocks + 255u) / 256u), dim3(256), 0, st, (const uint32_t *)firstChunk, (const uint64_t *)starts, (const uint32_t *)sizes, nBlocks, ctrl + 15);   // (ctrl[15]: zeroed above)
+    hipLaunchKernelGGL(k_split_check, dim3((nBlocks + 255u) / 256u), dim3(256), 0, st, (const uint32_t *)firstChunk, (const uint64_t *)starts, (const uint32_t *)sizes, nBlocks, ctrl + 24);   // (ctrl[24]: zeroed above; outside the rounds' counters ctrl[9 ..] and the Single encoders' ctrl[12] -- ADVICE r5)
   if (scan_sizes(sizes, maxChunks, chunkOff, ws, sw, st) != hipSuccess)
     return HSRLE_ERR_DEVICE;
   launch_compact_var(G <= 2048u, (const uint8_t *)(ws + w.spSlots), (const uint64_t *)slotOff, (const uint64_t *)chunkOff, payload, maxChunks, st);
@@ -1433,7 +1434,7 @@ static int compress_split(int codec, const uint8_t *dIn, uint64_t U, uint32_t B,
   auto finish = [=] __device__(uint64_t payloadSize) { finish_container(container, codecId, U, B, nBlocks, payloadSize); };
   hipLaunchKernelGGL((k_split_finish<decltype(finish)>), dim3((nBlocks + 255u) / 256u), dim3(256), 0, st, (const uint32_t *)firstChunk, (const uint64_t *)chunkOff, nBlocks, offsets, payload, finish);
   if (laneChunks)
-    hipLaunchKernelGGL(k_split_verdict, dim3(1), dim3(64), 0, st, (const uint32_t *)(ctrl + 15), container);
+    hipLaunchKernelGGL(k_split_verdict, dim3(1), dim3(64), 0, st, (const uint32_t *)(ctrl + 24), container);
   return hipGetLastError() == hipSuccess ? HSRLE_OK : HSRLE_ERR_DEVICE;
 }
 
@@ -1746,10 +1747,12 @@ static int rle8m_decode_async(const void *dStream, uint64_t streamSize, uint32_t
 }
 
 // rle8m encode (device resident): workspace = [Rle8mTables][offsets u64 x (sections + 1)] + the slots / sizes / scan levels of plan_workspace
+// (launch_le_stats below: three words per 4 KiB of input)
+static inline uint64_t le_stats_ws_bytes(uint64_t n) { return 3ull * align_up(4ull * ((n + 4095ull) / 4096ull + 1ull), 256); }
 struct Rle8mPlan
 {
   Workspace w;
-  uint64_t offTables, offOffsets, total;
+  uint64_t offTables, offOffsets, offStats, total;
   uint32_t slotStride;
 };
 
@@ -1766,6 +1769,7 @@ static Rle8mPlan plan_rle8m(uint32_t n, uint32_t sections)
   uint64_t at = 0;
   p.offTables = at; at += align_up(sizeof(Rle8mTables), 256);
   p.offOffsets = at; at += align_up(((uint64_t)sections + 1ull) * 8ull, 256);
+  p.offStats = at; at += le_stats_ws_bytes(n);
   w.offSlots = at; at += align_up((uint64_t)sections * p.slotStride, 256);
   w.offSizes = at; at += align_up((uint64_t)sections * 4ull, 256);
   w.offL1 = at; at += align_up((w.t1 + 1) * 8ull, 256);
@@ -1774,6 +1778,23 @@ static Rle8mPlan plan_rle8m(uint32_t n, uint32_t sections)
   w.total = at;
   p.total = at;
   return p;
+}
+
+// the statistics of the low-entropy encoders (rle8_low_entropy_cpu.c:264-296) over the whole input: k_rle8m_stats_wave piece by piece, the pieces' run starts
+// scanned, the token boundaries of runs that cross pieces added (hsrle_rle8m.hip.h, round 6: no lane follows a run through global memory any more).
+// wsStats: le_stats_ws_bytes(n) bytes; *pRunStart4 (optional): the start of the run that covers the first byte of every 4 KiB piece (k_le_cuts)
+static hipError_t launch_le_stats(const uint8_t *dIn, uint32_t n, Rle8mTables *t, uint32_t maxLen, uint8_t *wsStats, hipStream_t st, uint32_t maxWaves = 32768u, const uint32_t **pRunStart4 = nullptr)
+{
+  const uint32_t p4 = (uint32_t)(((uint64_t)n + 4095u) / 4096u);
+  const uint64_t stride = align_up(4ull * ((uint64_t)p4 + 1ull), 256);
+  uint32_t *lastB4 = (uint32_t *)wsStats, *firstB4 = (uint32_t *)(wsStats + stride), *runStart4 = (uint32_t *)(wsStats + 2ull * stride);
+  uint32_t grid = p4 < maxWaves ? p4 : maxWaves;
+  if ((uint64_t)grid * kRle8mStatsPieces < p4) grid = (p4 + kRle8mStatsPieces - 1u) / kRle8mStatsPieces;   // (no wave gets more pieces than its packed counters hold)
+  hipLaunchKernelGGL(k_rle8m_stats_wave, dim3(grid), dim3(64), 0, st, dIn, n, t, maxLen, lastB4, firstB4);
+  hipLaunchKernelGGL(k_le_scan_last, dim3(1), dim3(1024), 0, st, (const uint32_t *)lastB4, p4, runStart4);
+  hipLaunchKernelGGL(k_le_stats_fixup, dim3((p4 + 255u) / 256u), dim3(256), 0, st, dIn, n, p4, (const uint32_t *)lastB4, (const uint32_t *)firstB4, (const uint32_t *)runStart4, t, maxLen);
+  if (pRunStart4) *pRunStart4 = runStart4;
+  return hipGetLastError();
 }
 
 static uint32_t rle8m_bounds(uint32_t sections, uint32_t n) { return n + (256 / 8) + 1 + 256 + 4u * (2u + sections - 1u + 1u); }
@@ -1806,10 +1827,8 @@ static int rle8m_encode_async(const void *dIn, uint32_t n, uint32_t sections, vo
     hipLaunchKernelGGL(k_rle8m_stats, dim3((pieces + 63u) / 64u), dim3(64), 0, st, (const uint8_t *)dIn, n, pieces, t, maxLen);
   else
   {
-    const uint32_t waves = (uint32_t)(((uint64_t)n + 4095u) / 4096u);
-    uint32_t grid = waves < g_rle8mStatsWaves ? waves : g_rle8mStatsWaves;
-    if ((uint64_t)grid * kRle8mStatsPieces < waves) grid = (waves + kRle8mStatsPieces - 1u) / kRle8mStatsPieces;   // (no wave gets more pieces than its packed counters hold)
-    hipLaunchKernelGGL(k_rle8m_stats_wave, dim3(grid), dim3(64), 0, st, (const uint8_t *)dIn, n, t, maxLen);
+    if (launch_le_stats((const uint8_t *)dIn, n, t, maxLen, ws + p.offStats, st, g_rle8mStatsWaves) != hipSuccess)
+      return HSRLE_ERR_DEVICE;
   }
   hipLaunchKernelGGL(k_rle8m_info, dim3(1), dim3(256), 0, st, t, sections, (uint8_t *)dOut, onlyMax);
   static const int forced = (int)knob_u32("HSRLE_RLE8M_ENCODE", 0);   // 1 = lane, 2 = wave kernel (A/B runs)
@@ -1984,7 +2003,7 @@ struct LePlan
 {
   Workspace w;                   // scan levels for the piece sizes
   uint32_t pieces;
-  uint64_t offTables, offTmpInfo, offCuts, offSizes, offOffsets, offSlots, total;
+  uint64_t offTables, offTmpTables, offTmpInfo, offCuts, offStats, offSizes, offOffsets, offSlots, total;
 };
 static LePlan plan_le(uint64_t bytes, bool withSlots, uint32_t piece = kLePiece)
 {
@@ -1999,8 +2018,10 @@ static LePlan plan_le(uint64_t bytes, bool withSlots, uint32_t piece = kLePiece)
   w.t3 = (w.t2 + kScanTile - 1) / kScanTile;
   uint64_t at = 0;
   p.offTables = at; at += align_up(sizeof(Rle8mTables), 256);
+  p.offTmpTables = at; at += align_up(sizeof(Rle8mTables), 256);   // (le_compress_with_info: the statistics pass that only feeds the cut finder)
   p.offTmpInfo = at; at += 512;
   p.offCuts = at; at += align_up(4ull * ((uint64_t)p.pieces + 1ull), 256);
+  p.offStats = at; at += le_stats_ws_bytes(bytes);                      // per 4 KiB of input: last / first run start, and the start of the run that enters (launch_le_stats)
   p.offSizes = at; at += align_up(4ull * ((uint64_t)p.pieces + 1ull), 256);
   p.offOffsets = at; at += align_up(8ull * ((uint64_t)p.pieces + 2ull), 256);
   w.offL1 = at; at += align_up((w.t1 + 1) * 8ull, 256);
@@ -2028,15 +2049,12 @@ static int le_encode_async(const void *dIn, uint32_t n, void *dOut, uint64_t out
   uint64_t *offsets = (uint64_t *)(ws + p.offOffsets);
   if (zero_async(t, sizeof(Rle8mTables), st) != hipSuccess || (dStatus && zero_async(dStatus, 8, st) != hipSuccess))
     return HSRLE_ERR_DEVICE;
-  {
-    const uint32_t waves = (uint32_t)(((uint64_t)n + 4095u) / 4096u);
-    uint32_t grid = waves < 32768u ? waves : 32768u;
-    if ((uint64_t)grid * kRle8mStatsPieces < waves) grid = (waves + kRle8mStatsPieces - 1u) / kRle8mStatsPieces;
-    hipLaunchKernelGGL(k_rle8m_stats_wave, dim3(grid), dim3(64), 0, st, (const uint8_t *)dIn, n, t, maxLen);
-  }
+  const uint32_t *runStart4 = nullptr;
+  if (launch_le_stats((const uint8_t *)dIn, n, t, maxLen, ws + p.offStats, st, 32768u, &runStart4) != hipSuccess)
+    return HSRLE_ERR_DEVICE;
   hipLaunchKernelGGL(k_rle8m_info, dim3(1), dim3(256), 0, st, t, 1u, ws + p.offTmpInfo, onlyMax);
   hipLaunchKernelGGL(k_le_move_info, dim3(1), dim3(64), 0, st, (const uint8_t *)(ws + p.offTmpInfo), (const Rle8mTables *)t, (uint8_t *)dOut);
-  hipLaunchKernelGGL(k_le_cuts, dim3((p.pieces + 63u) / 64u), dim3(64), 0, st, (const uint8_t *)dIn, n, kLePiece, p.pieces, cuts);
+  hipLaunchKernelGGL(k_le_cuts, dim3((p.pieces + 63u) / 64u), dim3(64), 0, st, (const uint8_t *)dIn, n, kLePiece, p.pieces, runStart4, (const Rle8mTables *)t, maxLen, cuts);
   hipLaunchKernelGGL(k_le_encode_wave, dim3(p.pieces), dim3(64), 0, st, (const uint8_t *)dIn, n, (const uint32_t *)cuts, p.pieces, (const Rle8mTables *)t, ws + p.offSlots, sizes, maxLen);
   if (scan_sizes(sizes, p.pieces, offsets, ws, p.w, st) != hipSuccess)
     return HSRLE_ERR_DEVICE;
@@ -2156,12 +2174,8 @@ static bool le_get_info(const uint8_t *pIn, uint32_t inSize, rle8_low_entropy_co
   Rle8mTables *t = (Rle8mTables *)(ws + p.offTables);
   if (hipMemcpy(D.monoIn, pIn, inSize, hipMemcpyHostToDevice) != hipSuccess || zero_async(t, sizeof(Rle8mTables), nullptr) != hipSuccess)
     return false;
-  {
-    const uint32_t waves = (uint32_t)(((uint64_t)inSize + 4095u) / 4096u);
-    uint32_t grid = waves < 32768u ? waves : 32768u;
-    if ((uint64_t)grid * kRle8mStatsPieces < waves) grid = (waves + kRle8mStatsPieces - 1u) / kRle8mStatsPieces;
-    hipLaunchKernelGGL(k_rle8m_stats_wave, dim3(grid), dim3(64), 0, nullptr, (const uint8_t *)D.monoIn, inSize, t, 255u);
-  }
+  if (launch_le_stats((const uint8_t *)D.monoIn, inSize, t, 255u, ws + p.offStats, nullptr) != hipSuccess)
+    return false;
   hipLaunchKernelGGL(k_rle8m_info, dim3(1), dim3(256), 0, nullptr, t, 1u, ws + p.offTmpInfo, onlyMax);
   Rle8mTables ht;
   uint8_t used = 0;
@@ -2205,7 +2219,14 @@ static uint32_t le_compress_with_info(const uint8_t *pIn, uint32_t inSize, const
   if (hipMemcpy(D.monoIn, pIn, inSize, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(t, &ht, sizeof(ht), hipMemcpyHostToDevice) != hipSuccess ||
       zero_async(dStatus, 8, nullptr) != hipSuccess)
     return 0;
-  hipLaunchKernelGGL(k_le_cuts, dim3((p.pieces + 63u) / 64u), dim3(64), 0, nullptr, (const uint8_t *)D.monoIn, inSize, kLePiece, p.pieces, cuts);
+  {
+    // (the cuts need the pieces' run starts: the statistics pass into a scratch table -- the caller's tables in `t` stay as they are)
+    Rle8mTables *scratchT = (Rle8mTables *)(ws + p.offTmpTables);
+    const uint32_t *runStart4 = nullptr;
+    if (zero_async(scratchT, sizeof(Rle8mTables), nullptr) != hipSuccess || launch_le_stats((const uint8_t *)D.monoIn, inSize, scratchT, maxLen, ws + p.offStats, nullptr, 32768u, &runStart4) != hipSuccess)
+      return 0;
+    hipLaunchKernelGGL(k_le_cuts, dim3((p.pieces + 63u) / 64u), dim3(64), 0, nullptr, (const uint8_t *)D.monoIn, inSize, kLePiece, p.pieces, runStart4, (const Rle8mTables *)t, maxLen, cuts);
+  }
   hipLaunchKernelGGL(k_le_encode_wave, dim3(p.pieces), dim3(64), 0, nullptr, (const uint8_t *)D.monoIn, inSize, (const uint32_t *)cuts, p.pieces, (const Rle8mTables *)t, ws + p.offSlots, sizes, maxLen);
   if (scan_sizes(sizes, p.pieces, offsets, ws, p.w, nullptr) != hipSuccess)
     return 0;
@@ -2493,11 +2514,22 @@ int hsrle_compress_dev_async(int codec, const void *dIn, uint64_t inSize, void *
 
 int hsrle_compress_dev(int codec, const void *dIn, uint64_t inSize, void *dOut, uint64_t outCapacity, uint32_t blockSize, uint64_t *pContainerSize, void *stream)
 {
-  const int rc = compress_async(codec, dIn, inSize, dOut, outCapacity, blockSize, nullptr, 0, (hipStream_t)stream);
+  int rc = compress_async(codec, dIn, inSize, dOut, outCapacity, blockSize, nullptr, 0, (hipStream_t)stream);
   if (rc != HSRLE_OK) return rc;
   ContainerHeader h;
   if (hipMemcpyAsync(&h, dOut, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess || hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
     return HSRLE_ERR_DEVICE;
+  static const char magic[8] = { 'H', 'S', 'R', 'L', 'E', 'K', 'I', 'T' };
+  if (memcmp(h.magic, magic, 8) != 0)
+  {
+    // the split encode struck its own container (a per-lane chunk encoder missed its boundary run: k_split_verdict): the synchronous entry sees it here
+    // and encodes the container again with one lane per block -- as the monolithic path falls back; the enqueue-only entry cannot
+    rc = compress_async(codec, dIn, inSize, dOut, outCapacity, blockSize, nullptr, 0, (hipStream_t)stream, true);
+    if (rc != HSRLE_OK) return rc;
+    if (hipMemcpyAsync(&h, dOut, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess || hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+      return HSRLE_ERR_DEVICE;
+    if (memcmp(h.magic, magic, 8) != 0) return HSRLE_ERR_DEVICE;
+  }
   if (pContainerSize) *pContainerSize = h.totalSize;
   return HSRLE_OK;
 }
@@ -2678,15 +2710,24 @@ int hsrle_compress_mono_dev(int codec, const void *dIn, uint32_t inSize, void *d
 uint64_t hsrle_decompress_mono_workspace_size(int codec, uint32_t uncompressedSize, uint32_t compressedSize)
 {
   if (codec < 0 || codec >= kCodecCount || uncompressedSize == 0 || compressedSize < 10u) return 0;
-  return plan_mono(codec, uncompressedSize, compressedSize, codec_header_size(codec)).total;
+  return plan_mono(codec, uncompressedSize, compressedSize, codec_header_size(codec)).total + 16u;   // (+ 16: a workspace that is not 16-byte aligned is aligned here)
+}
+
+// the workspace is cleared with 16-byte stores (mono_prepare): a caller that sub-allocates from a byte pool may hand over any address -- it is rounded up, what
+// is left must still hold the plan (hsrle_decompress_mono_workspace_size() includes the 16 bytes)
+static inline void mono_align_workspace(void *&dWorkspace, uint64_t &workspaceSize)
+{
+  const uint64_t skip = (16u - (uint32_t)((uintptr_t)dWorkspace & 15u)) & 15u;
+  dWorkspace = (uint8_t *)dWorkspace + skip;
+  workspaceSize = workspaceSize > skip ? workspaceSize - skip : 0u;
 }
 
 int hsrle_decompress_mono_dev(int codec, const void *dStream, uint32_t streamSize, void *dOut, uint64_t outCapacity, void *dWorkspace, uint64_t workspaceSize,
                               uint32_t *pUncompressedSize, uint32_t *pStats, void *stream)
 {
-  if (!dStream || !dOut || !dWorkspace || codec < 0 || codec >= kCodecCount || streamSize < codec_header_size(codec) || ((uintptr_t)dStream & 127u) != 0u ||
-      ((uintptr_t)dWorkspace & 15u) != 0u)                              // (the workspace is cleared with 16-byte stores: mono_prepare)
+  if (!dStream || !dOut || !dWorkspace || codec < 0 || codec >= kCodecCount || streamSize < codec_header_size(codec) || ((uintptr_t)dStream & 127u) != 0u)
     return HSRLE_ERR_ARGUMENT;
+  mono_align_workspace(dWorkspace, workspaceSize);
   if (!device_ok()) return HSRLE_ERR_DEVICE;
   uint8_t h16[16] = { 0 };
   if (hipMemcpyAsync(h16, dStream, streamSize < 16u ? streamSize : 16u, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess || hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
@@ -2704,9 +2745,10 @@ int hsrle_decompress_mono_dev(int codec, const void *dStream, uint32_t streamSiz
 int hsrle_decompress_mono_dev_async(int codec, const void *dStream, const uint8_t *pHeader16, uint32_t streamSize, void *dOut, uint64_t outCapacity, void *dWorkspace,
                                     uint64_t workspaceSize, uint32_t *pUncompressedSize, uint32_t *dStatus, void *stream)
 {
-  if (!dStream || !pHeader16 || !dOut || !dWorkspace || !dStatus || codec < 0 || codec >= kCodecCount || streamSize < 16u || ((uintptr_t)dStream & 127u) != 0u ||
-      ((uintptr_t)dWorkspace & 15u) != 0u)
+  // (the same smallest stream as the synchronous entry: the codec's header; pHeader16 holds the stream's first min(16, streamSize) bytes, zeros behind them)
+  if (!dStream || !pHeader16 || !dOut || !dWorkspace || !dStatus || codec < 0 || codec >= kCodecCount || streamSize < codec_header_size(codec) || ((uintptr_t)dStream & 127u) != 0u)
     return HSRLE_ERR_ARGUMENT;
+  mono_align_workspace(dWorkspace, workspaceSize);
   if (!device_ok()) return HSRLE_ERR_DEVICE;
   MonoHeader mh;
   if (!mono_header(codec, pHeader16, streamSize, outCapacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)outCapacity, &mh))

@@ -404,7 +404,8 @@ __global__ __launch_bounds__(64) void k_rle8m_stats(const uint8_t *__restrict__ 
 // leaves it, through global memory) -- to LDS histograms; one flush of the histograms per wave.  (k_rle8m_stats above walks a byte
 // per lane and trip: 1.87 ms per GiB, as long as the encode kernel; kept for HSRLE_RLE8M_STATS=1 A/B runs.)
 constexpr uint32_t kRle8mStatsPieces = 15;    // 4 KiB pieces per wave at most (15 * 4096 < 65536: the packed LDS counters)
-__global__ __launch_bounds__(64) void k_rle8m_stats_wave(const uint8_t *__restrict__ d, uint32_t n, Rle8mTables *__restrict__ t, uint32_t maxLen)
+__global__ __launch_bounds__(64) void k_rle8m_stats_wave(const uint8_t *__restrict__ d, uint32_t n, Rle8mTables *__restrict__ t, uint32_t maxLen, uint32_t *__restrict__ lastB4,
+                                                          uint32_t *__restrict__ firstB4)
 {
   constexpr uint32_t P = 4096u;
   __shared__ __attribute__((aligned(16))) uint8_t bytes[P + 16u];
@@ -461,6 +462,13 @@ __global__ __launch_bounds__(64) void k_rle8m_stats_wave(const uint8_t *__restri
       uint64_t starts = ~((m << 1) | prevEq);
       const uint32_t mine = (len > base) ? ((len - base < 64u) ? len - base : 64u) : 0u;
       if (mine < 64u) starts &= (mine == 0u) ? 0ull : ((1ull << mine) - 1ull);
+      // Round 6: a run is counted PIECE BY PIECE -- the part of it inside this piece, clipped at the piece's end -- instead of being followed through global
+      // memory by the one lane that holds its start (all-equal input: one lane walked the whole buffer).  prob is a byte count; pcount = runs + the token
+      // boundaries inside runs (start + j maxLen, j >= 1): a run that STARTS here adds 1 + (its bytes in this piece) / maxLen; the boundaries of the run that
+      // ENTERS the piece from the left depend on where that run started: the piece's first and last run start go to firstB4 / lastB4, k_le_scan_last turns them
+      // into every piece's run start, k_le_stats_fixup adds what is missing (and takes the final run's boundaries out again: it counts once, :295-296).
+      uint32_t ownFirst = (starts != 0ull) ? a + base + (uint32_t)__builtin_ctzll(starts) : 0xFFFFFFFFu;
+      uint32_t ownLast = (starts != 0ull) ? a + base + 63u - (uint32_t)__builtin_clzll(starts) : 0u;
       while (starts != 0ull)
       {
         const uint32_t p = (uint32_t)__builtin_ctzll(starts);
@@ -468,45 +476,37 @@ __global__ __launch_bounds__(64) void k_rle8m_stats_wave(const uint8_t *__restri
         // set bits from p on
         const uint64_t sh = m >> p;
         uint32_t ones = (p == 0u && m == ~0ull) ? 64u : (uint32_t)__builtin_ctzll(~sh | ((p == 0u) ? 0ull : (1ull << (64u - p))));
-        uint64_t L;
-        if (ones < 64u - p) L = 1ull + ones;
-        else
+        uint32_t total = ones;
+        if (ones >= 64u - p)
         {
-          // through the following words of the piece, then through global memory
+          // through the following words of the piece
           uint32_t w2 = w + 1u;
-          uint64_t total = ones;
-          bool open = true;
-          while (open && w2 < P / 64u)
+          while (w2 < P / 64u)
           {
             const uint64_t mm = eqw[w2];
             if (mm == ~0ull) { total += 64u; w2++; }
-            else { total += (uint32_t)__builtin_ctzll(~mm); open = false; }
+            else { total += (uint32_t)__builtin_ctzll(~mm); break; }
           }
-          if (open)
-          {
-            // the run leaves the piece: d[a + P - 1] == d[a + P]; count on from a + P
-            const uint32_t sy = bytes[base + p];
-            uint64_t g = (uint64_t)a + P;                                 // first position not yet known to belong to the run... it does (the last bit was set)
-            g += 1u;
-            const uint64_t rep = (uint64_t)sy * 0x0101010101010101ull;
-            while (g + 8u <= (uint64_t)n && ld64(d + g) == rep) g += 8u;       // (eight bytes per trip; the walk is one lane's)
-            while (g < (uint64_t)n && (uint32_t)d[g] == sy) g++;
-            total = g - 1u - ((uint64_t)a + base + p);                    // set bits = run length - 1
-          }
-          L = 1ull + total;
         }
+        const uint32_t endIn = (base + p + 1u + total < len) ? base + p + 1u + total : len;   // the run's end inside the piece
+        const uint32_t Lc = endIn - (base + p);
         const uint32_t sy = bytes[base + p];
-        const bool toEnd = (uint64_t)a + base + p + L == (uint64_t)n;     // the run that reaches the end of the input counts once
-        // the usual run (< 255 bytes: one count) is ONE LDS atomic into the packed table (pcount << 16 | prob: a wave sees at most
-        // kRle8mStatsPieces * 4096 bytes, so neither half overflows); the others go to the global table directly
-        // (round 4: with the Short form's maxLen of 32 a run of 32 .. 254 bytes counts L / 32 + 1 times; it stays in the packed table too --
-        //  both halves grow by at most L -- instead of going to the global one: every zero run of a video-shaped buffer did, 13.6 GiB/s)
-        if (L < 255ull) atomicAdd(&pk[sy], ((toEnd ? 1u : (uint32_t)L / maxLen + 1u) << 16) | (uint32_t)L);
-        else
-        {
-          atomicAdd(&t->prob[sy], (uint32_t)L);
-          atomicAdd(&t->pcount[sy], toEnd ? 1u : (uint32_t)(L / (uint64_t)maxLen) + 1u);
-        }
+        atomicAdd(&pk[sy], ((1u + Lc / maxLen) << 16) | Lc);               // (a wave sees at most kRle8mStatsPieces * 4096 bytes: neither half overflows)
+      }
+#pragma unroll
+      for (int dd = 32; dd >= 1; dd >>= 1)
+      {
+        const uint32_t f = (uint32_t)__shfl_xor((int)ownFirst, dd, 64), l = (uint32_t)__shfl_xor((int)ownLast, dd, 64);
+        ownFirst = f < ownFirst ? f : ownFirst;
+        ownLast = l > ownLast ? l : ownLast;
+      }
+      if (lane == 0u)
+      {
+        lastB4[piece] = ownLast;
+        firstB4[piece] = ownFirst;
+        // the bytes of the run that enters from the left (its token boundaries: k_le_stats_fixup)
+        const uint32_t f = ownFirst == 0xFFFFFFFFu ? len : ownFirst - a;
+        if (f != 0u) atomicAdd(&pk[bytes[0]], f);
       }
     }
   }
@@ -753,8 +753,89 @@ __global__ __launch_bounds__(256) void k_rle8m_place(const uint8_t *__restrict__
 constexpr uint32_t kLeNone = 0xFFFFFFFFu;
 constexpr uint32_t kLeCarryLimit = 1u << 16;    // flagged-valued stretch in front of a piece longer than this: the caller falls back to one wave
 
-// cuts[k], k >= 1: the first position in [k G, (k + 1) G) whose byte differs from its predecessor (kLeNone: the whole piece continues a run)
-__global__ __launch_bounds__(64) void k_le_cuts(const uint8_t *__restrict__ d, uint32_t n, uint32_t G, uint32_t P, uint32_t *__restrict__ cuts)
+// runStart4[k] = the last run start in front of 4 KiB piece k = max(lastB4[0 .. k - 1]) (0: the run that covers the piece's first byte starts at position 0).
+// One workgroup walks the table 4 096 entries at a time (262 144 pieces per GiB).  Round 6.
+__global__ __launch_bounds__(1024) void k_le_scan_last(const uint32_t *__restrict__ lastB4, uint32_t P, uint32_t *__restrict__ runStart4)
+{
+  __shared__ uint32_t waveMax[16];
+  __shared__ uint32_t carryS;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+  if (tid == 0u) carryS = 0u;
+  __syncthreads();
+  for (uint32_t base = 0; base < P; base += 4096u)
+  {
+    const uint32_t k0 = base + 4u * tid;
+    uint32_t own[4];
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; j++) own[j] = (k0 + j < P) ? lastB4[k0 + j] : 0u;
+    const uint32_t m01 = own[0] > own[1] ? own[0] : own[1], m23 = own[2] > own[3] ? own[2] : own[3];
+    uint32_t v = m01 > m23 ? m01 : m23;                                    // inclusive max over the wave's threads
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1)
+    {
+      const uint32_t o = (uint32_t)__shfl_up((int)v, dd, 64);
+      if ((int)lane >= dd && o > v) v = o;
+    }
+    if (lane == 63u) waveMax[wv] = v;
+    __syncthreads();
+    uint32_t front = carryS;                                              // everything in front of this wave
+    for (uint32_t w = 0; w < wv; w++) front = waveMax[w] > front ? waveMax[w] : front;
+    const uint32_t exclInWave = (uint32_t)__shfl_up((int)v, 1, 64);
+    uint32_t run = front;
+    if (lane != 0u && exclInWave > run) run = exclInWave;
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; j++)
+    {
+      if (k0 + j < P) runStart4[k0 + j] = run;
+      run = own[j] > run ? own[j] : run;
+    }
+    __syncthreads();
+    if (tid == 1023u) carryS = run;
+    __syncthreads();
+  }
+}
+
+// what k_rle8m_stats_wave could not know: the token boundaries of the run that enters a 4 KiB piece from the left (it started at runStart4[piece]) -- and the
+// final run of the input counts ONCE (rle8_low_entropy_cpu.c:295-296), so its boundaries are taken out again.  One lane per piece; nearly every lane adds nothing.
+__global__ __launch_bounds__(256) void k_le_stats_fixup(const uint8_t *__restrict__ d, uint32_t n, uint32_t P, const uint32_t *__restrict__ lastB4, const uint32_t *__restrict__ firstB4,
+                                                        const uint32_t *__restrict__ runStart4, Rle8mTables *__restrict__ t, uint32_t maxLen)
+{
+  // (collected per workgroup first: with the Short form's 32-byte tokens every fourth piece of a video-shaped buffer adds to pcount[0] -- 65 536 atomics on one
+  //  address per GiB cost more than the statistics pass)
+  __shared__ uint32_t add[256];
+  add[threadIdx.x] = 0u;
+  __syncthreads();
+  const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+  if (k < P)
+  {
+    const uint64_t a = (uint64_t)k * 4096u;
+    const uint64_t b = (a + 4096u < (uint64_t)n) ? a + 4096u : (uint64_t)n;
+    const uint32_t fb = firstB4[k];
+    if (k != 0u && (uint64_t)fb != a)
+    {
+      const uint64_t rs = runStart4[k], f = fb == 0xFFFFFFFFu ? b : (uint64_t)fb;
+      const uint32_t cnt = (uint32_t)((f - rs) / maxLen - (a - rs) / maxLen);
+      if (cnt != 0u) atomicAdd(&add[d[a]], cnt);
+    }
+    if (k == P - 1u)
+    {
+      const uint64_t rsF = lastB4[k] > runStart4[k] ? lastB4[k] : runStart4[k];
+      const uint32_t sub = (uint32_t)(((uint64_t)n - rsF) / maxLen);
+      if (sub != 0u) atomicSub(&t->pcount[d[n - 1u]], sub);
+    }
+  }
+  __syncthreads();
+  const uint32_t v = add[threadIdx.x];
+  if (v != 0u) atomicAdd(&t->pcount[threadIdx.x], v);
+}
+
+// cuts[k], k >= 1: where piece k begins -- the first position at or behind k G at which the sequential encoder (compress_with_info, :474-543) starts a token
+// whatever came before: a run boundary; any position inside a run of a symbol that is NOT flagged (every byte is a token of its own); inside a run of a flagged
+// symbol the positions runStart + j maxLen (the tokens of a long run are counted from its start).  Within maxLen bytes there is always one, so all-equal input
+// -- the codec's best case -- gets a piece per G bytes too.  Cuts inside a run keep clear of the input's last 256 bytes (the end-of-input rule, :515-540, belongs
+// to the piece that ends the input); kLeNone: no cut (the piece is part of its predecessor).
+__global__ __launch_bounds__(64) void k_le_cuts(const uint8_t *__restrict__ d, uint32_t n, uint32_t G, uint32_t P, const uint32_t *__restrict__ runStart, const Rle8mTables *__restrict__ t,
+                                                uint32_t maxLen, uint32_t *__restrict__ cuts)
 {
   const uint32_t k = blockIdx.x * 64u + threadIdx.x;
   if (k >= P) return;
@@ -763,11 +844,31 @@ __global__ __launch_bounds__(64) void k_le_cuts(const uint8_t *__restrict__ d, u
   const uint64_t e = (a + G < (uint64_t)n) ? a + G : (uint64_t)n;
   ByteWindow w{ d, n };
   uint32_t prev = w.get((uint32_t)a - 1u);
+  const uint32_t c0 = w.get((uint32_t)a);
   uint32_t cut = kLeNone;
-  for (uint64_t i = a; i < e; i++)
+  if (c0 != prev) cut = (uint32_t)a;
+  else
   {
-    const uint32_t c = w.get((uint32_t)i);
-    if (c != prev) { cut = (uint32_t)i; break; }
+    const bool flagged = ((t->rleBits[c0 >> 5] >> (c0 & 31u)) & 1u) != 0u;
+    const uint64_t clear = n > 256u ? (uint64_t)n - 256u : 0ull;         // cuts inside a run: in front of this position only
+    const uint64_t rs = runStart[a >> 12];                                // (a table entry per 4 KiB: k_le_scan_last)
+    const uint64_t grid = flagged ? rs + ((a - rs + maxLen - 1u) / maxLen) * (uint64_t)maxLen : a;   // the first token start at or behind a if the run goes on
+    for (uint64_t i = a; i < e; i++)
+    {
+      if (i == grid) { if (i < clear) cut = (uint32_t)i; break; }
+      const uint32_t c = w.get((uint32_t)i);
+      if (c != prev) { cut = (uint32_t)i; break; }
+      prev = c;
+    }
+    if (cut == kLeNone && grid >= clear)
+    {
+      // (near the end of the input only run boundaries are cuts: look for one in the rest of the piece)
+      for (uint64_t i = a + 1u; i < e; i++)
+      {
+        const uint32_t c = w.get((uint32_t)i);
+        if (c != c0) { cut = (uint32_t)i; break; }
+      }
+    }
   }
   cuts[k] = cut;
 }

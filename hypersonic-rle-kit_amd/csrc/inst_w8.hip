@@ -17,10 +17,18 @@ namespace hsrle {
 
 // ids 0 / 1 (rle8_multi, rle8_packed_multi): their encoders only write mode 0 -> the kernel without the Single mode (k_decode_blocks SGL);
 // ids 4 / 5 (the Single codecs) and any stream whose mode byte says 1 (hsrle_capi.hip: mono_decompress) -> the general kernel
-static hipError_t dec_plain(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<PLAIN, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep, false>, k_decode_blocks<PLAIN, 1, 0, kDecodeTile, 64, kDecodeStep, false>, a, st); }
-static hipError_t dec_packed(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<PACKED, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep, false>, k_decode_blocks<PACKED, 1, 0, kDecodeTile, 64, kDecodeStep, false>, a, st); }
-static hipError_t dec_plain_any(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<PLAIN, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep, true>, k_decode_blocks<PLAIN, 1, 0, kDecodeTile, 64, kDecodeStep, true>, a, st); }
-static hipError_t dec_packed_any(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<PACKED, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep, true>, k_decode_blocks<PACKED, 1, 0, kDecodeTile, 64, kDecodeStep, true>, a, st); }
+// the list-free 8 bit decoders' tile row / step (A/B builds: -DHSRLE_DEC8_TILE=64 -DHSRLE_DEC8_STEP=64)
+#ifndef HSRLE_DEC8_TILE
+#define HSRLE_DEC8_TILE HSRLE_DECODE_TILE
+#endif
+#ifndef HSRLE_DEC8_STEP
+#define HSRLE_DEC8_STEP HSRLE_DECODE_STEP
+#endif
+constexpr int kDec8Tile = HSRLE_DEC8_TILE, kDec8Step = HSRLE_DEC8_STEP;
+static hipError_t dec_plain(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<PLAIN, 1, 0, kDec8Tile, kDecodeRing, kDec8Step, false>, k_decode_blocks<PLAIN, 1, 0, kDec8Tile, 64, kDec8Step, false>, a, st); }
+static hipError_t dec_packed(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<PACKED, 1, 0, kDec8Tile, kDecodeRing, kDec8Step, false>, k_decode_blocks<PACKED, 1, 0, kDec8Tile, 64, kDec8Step, false>, a, st); }
+static hipError_t dec_plain_any(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<PLAIN, 1, 0, kDec8Tile, kDecodeRing, kDec8Step, true>, k_decode_blocks<PLAIN, 1, 0, kDec8Tile, 64, kDec8Step, true>, a, st); }
+static hipError_t dec_packed_any(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<PACKED, 1, 0, kDec8Tile, kDecodeRing, kDec8Step, true>, k_decode_blocks<PACKED, 1, 0, kDec8Tile, 64, kDec8Step, true>, a, st); }
 static hipError_t dec_lut3(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<LUT3, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, k_decode_blocks<LUT3, 1, 0, kDecodeTile, 64, kDecodeStep>, a, st); }
 static hipError_t dec_lut7(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<LUT7, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, k_decode_blocks<LUT7, 1, 0, kDecodeTile, 64, kDecodeStep>, a, st); }
 

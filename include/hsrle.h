@@ -186,7 +186,7 @@ uint32_t hsrle_decompress_mono(int codec, const uint8_t *pIn, uint32_t inSize, u
  * in device memory, decoded into device memory.  A stream has no random access, so the library first builds an entry-point index
  * (speculative packet walks per stream region, then a pass that PROVES the chain and repairs wrong guesses: csrc/hsrle_index.hip.h)
  * and then runs the block kernel from those entry points.  dStream must be 128-byte aligned and readable up to streamSize + 64.
- * dWorkspace >= hsrle_decompress_mono_workspace_size(), 16-byte aligned.  Synchronises `stream` (once, at the end, when every entry guess holds).  pStats (optional, host, 4 values): stream regions,
+ * dWorkspace >= hsrle_decompress_mono_workspace_size() bytes at any address (the library rounds it up to 16 bytes itself; the size includes that slack).  Synchronises `stream` (once, at the end, when every entry guess holds).  pStats (optional, host, 4 values): stream regions,
  * repair rounds, regions walked again, final look-back of the entry guess.  Returns HSRLE_OK, HSRLE_ERR_FORMAT (malformed stream / sizes do not match the header), ...
  */
 uint64_t hsrle_decompress_mono_workspace_size(int codec, uint32_t uncompressedSize, uint32_t compressedSize);
@@ -211,7 +211,8 @@ int hsrle_decompress_mono_dev(int codec, const void *dStream, uint32_t streamSiz
 /*
  * The same without the host in the loop (nothing here synchronises or reads device memory: a HIP graph can capture the call).  The walk,
  * the proof, the entry records and the decode are enqueued in one go; the records pass is gated ON THE DEVICE by the proof's verdict.
- * pHeader16: the stream's first 16 bytes in HOST memory (the caller read or received the stream; the launch geometry comes from the two
+ * pHeader16: the stream's first 16 bytes in HOST memory (zeros behind a stream shorter than that; the smallest stream is the codec's header, as for the
+ * synchronous entry) (the caller read or received the stream; the launch geometry comes from the two
  * sizes and the mode byte in it -- rle8_extreme_cpu.h:702-764).  dStatus (device, 4 bytes) receives HSRLE_MONO_DONE (dOut holds the
  * output), HSRLE_MONO_MALFORMED, or HSRLE_MONO_NEEDS_REPAIR: an entry guess of the walk did not hold on this stream -- dOut is
  * unspecified, call hsrle_decompress_mono_dev (which repairs; codecs whose junk walks do not die on random literals -- the non-Packed,

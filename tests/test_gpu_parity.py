@@ -344,7 +344,12 @@ def test_low_entropy_unsectioned_forms_match_the_oracle(hs, oracle):
               # whose bytes are ALL flagged values (symbol, code, symbol ... with codes that are flagged symbols themselves: the decoder cannot
               # find a piece's parity within its look-back and falls back to one wave), flagged runs of 32 / 255 + 1 bytes at the cuts
               b"\x00" * (1 << 20), mixed_runs(rng, 300000, alphabet=2), b"\x00\x00\x01\x01" * 100000,
-              (b"\x07" * 16383 + b"\x09" + b"\x07" * 33 + b"ab" * 100) * 9, b"q" * 16384 + b"q" * 256 + bytes(rng.randrange(256) for _ in range(40000)) + b"z" * 70000]
+              (b"\x07" * 16383 + b"\x09" + b"\x07" * 33 + b"ab" * 100) * 9, b"q" * 16384 + b"q" * 256 + bytes(rng.randrange(256) for _ in range(40000)) + b"z" * 70000,
+              # round 6: pieces that begin INSIDE a run (cuts at run start + k * 255 / 32 for a flagged symbol, anywhere for one that is not flagged): runs of
+              # many lengths across many pieces, runs that end inside the input's last 256 bytes, a long run of a symbol that stays unflagged
+              b"\x05" * (3 * 16384 + 77), b"\x05" * (5 * 16384 + 255), b"\x05" * (2 * 16384 + 100) + b"\x06" * (4 * 16384 + 31) + b"\x05" * 200,
+              b"ab" * 30000 + b"c" * 100000 + b"ab" * 50, bytes(rng.randrange(256) for _ in range(3000)) + b"\x00" * 200001 + b"\x01" * 99999 + b"\x00" * 16384 + b"x",
+              bytes(rng.randrange(2, 256) for _ in range(120000)) + b"\x01" * 40000 + bytes(rng.randrange(2, 256) for _ in range(300000)) + b"\x01" * 33000]
     for it in range(120):
         length = rng.choice([1, 2, 3, 15, 16, 17, 31, 32, 33, 34, 63, 64, 65, 100, 254, 255, 256, 257, 258, 300, 511, 512, 513, 700, 1000, 3000])
         alphabet = [rng.randrange(256) for _ in range(rng.choice([1, 2, 3, 5, 17]))]

@@ -17,8 +17,8 @@ L.hsrle_low_entropy_decompress_dev.argtypes = [vp, u64, vp, u64, vp, u64, ctypes
 cpu = Reference() if os.path.exists(REF_SO) else Oracle()
 names = ("rle8_low_entropy", "rle8_low_entropy_short", "rle8_low_entropy_only_max_frequency", "rle8_low_entropy_short_only_max_frequency")
 print("library build", hsrle.build_id(), "| %d MiB, device resident | CPU: %s, one core, first 64 MiB" % (size >> 20, "compiled reference" if isinstance(cpu, Reference) else "oracle"))
-for kind, kname in ((1, "video"), (0, "runs")):
-    src = hsrle.synth(kind, 1, 2, size)
+for kind, kname in ((1, "video"), (0, "runs"), (2, "zeros")):   # zeros: ONE run of a flagged symbol -- cut inside the run since round 6 (k_le_cuts)
+    src = hsrle.synth(kind, 1, 2, size) if kind < 2 else torch.zeros(size, dtype=torch.uint8, device="cuda")
     dst = torch.empty(size + 297, dtype=torch.uint8, device="cuda")
     ws = torch.empty(L.hsrle_low_entropy_workspace_size(size), dtype=torch.uint8, device="cuda")
     status = torch.zeros(4, dtype=torch.int32, device="cuda")
