@@ -1160,7 +1160,10 @@ static int mono_enqueue_first_try(const MonoHeader &mh, uint8_t *ws, const MonoP
   run.ia.gate = run.ctrl;
   const hipError_t e = g_idx[mh.codec](run.ia, 1, st);
   run.ia.gate = nullptr;
-  if (e != hipSuccess || g_dec[mh.codec](run.da, st) != hipSuccess)
+  run.da.gate = run.ctrl;                                                // (the decode too: nothing to decode from records that were not written)
+  const hipError_t e2 = e != hipSuccess ? e : g_dec[mh.codec](run.da, st);
+  run.da.gate = nullptr;
+  if (e2 != hipSuccess)
     return HSRLE_ERR_DEVICE;
   return HSRLE_OK;
 }
@@ -1313,7 +1316,8 @@ static uint32_t split_pieces(uint32_t B)
   return (k == kSplitPiecesMax && B % (kSplitPiecesMax * 128u) == 0u) ? k : kSplitPieces;
 }
 
-static bool run_list_codec(int codec) { return codec <= 3 || (codec >= 6 && codec <= 45) || (codec >= kShortBase8 && codec < kGreedyBase); }
+// (round 6: the codecs with a position-parallel encoder have no run list instantiation any more -- hsrle_inst_generic.inc: pp_covers; callers run behind init_tables())
+static bool run_list_codec(int codec) { return (codec <= 3 || (codec >= 6 && codec <= 45) || (codec >= kShortBase8 && codec < kGreedyBase)) && !g_pp[codec]; }
 
 // the codecs that have a many-lane chunk encoder but no run list encoder: small containers of 1 .. 4 KiB blocks take the split encode IF the
 // caller's workspace has its regions (hsrle_compress_workspace_size_codec; the library's own scratch always has)

@@ -218,8 +218,11 @@ template <int FAM, int S, int AL, int T, int R, int Q = T, bool SGL = true, bool
 __global__ __launch_bounds__(64) void k_decode_blocks(const uint8_t *__restrict__ payload, const uint64_t *__restrict__ offsets,
                                                       const uint8_t *__restrict__ payloadEnd, uint8_t *__restrict__ out, uint64_t U,
                                                       uint32_t B, uint32_t firstBlock, uint32_t blockCount, uint32_t *__restrict__ status,
-                                                      const uint32_t *__restrict__ entries, uint32_t entryBase)
+                                                      const uint32_t *__restrict__ entries, uint32_t entryBase, const uint32_t *__restrict__ gate)
 {
+  // gate != nullptr (monolithic streams, the decode enqueued behind the index passes without the host in between): the resolve pass left regions to repair or
+  // found the chain malformed -- the entry records were not written, so there is nothing to decode: dOut and the status word stay untouched
+  if (gate != nullptr && (gate[0] | gate[1]) != 0u) return;
   // entries != nullptr: lane b starts from entry record (b - entryBase) -- the decoder state at output position b * B of a stream that
   // lies somewhere in `payload` (ONE monolithic reference stream, or sub-block b of a container block; hsrle_index.hip.h writes the
   // records) -- instead of from the header of block stream b; everything behind the prologue is the same: a lane still produces the

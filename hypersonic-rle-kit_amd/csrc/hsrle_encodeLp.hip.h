@@ -154,6 +154,7 @@ __device__ __forceinline__ void ppL_block(uint64_t U, uint32_t B, uint32_t b, ui
 
   // ---- 2. one candidate (or record) per lane, 64 per round ----
   uint32_t carL = 0, carE = 0;
+  bool exactFirst = false;                           // the list indices of the next round come from the exact mode straight away (hsrle_encodeLp.hip.h: see there)
   uint32_t pos = HDR;
   uint32_t K_ = 0;                                   // stored runs so far
   bool ended = false;
@@ -234,12 +235,14 @@ __device__ __forceinline__ void ppL_block(uint64_t U, uint32_t B, uint32_t b, ui
       uint64_t F = 0, lastAll = 0;
       int prevO = -1;
       bool manySymbols = true, exactDone = false;
-      auto distinct_symbols = [&]() __attribute__((always_inline)) {
-        F = 0ull; lastAll = 0ull; prevO = -1;
+      uint32_t dTrips = 0;                               // distinct stored symbols the last call found
+      auto distinct_symbols = [&](uint32_t maxTrips = 64u) __attribute__((always_inline)) -> bool {
+        F = 0ull; lastAll = 0ull; prevO = -1; dTrips = 0u;
         const uint64_t belowT = (1ull << lane) - 1ull;
         uint64_t rem = __ballot(k != 0);
         while (rem != 0ull)
         {
+          if (dTrips++ == maxTrips) return false;
           const int leader = (int)__builtin_ctzll(rem);
           const uint64_t sg = (uint64_t)wave_lane((uint32_t)sym, leader) | ((uint64_t)wave_lane((uint32_t)(sym >> 32), leader) << 32);
           const uint64_t ms = __ballot(k != 0 && sym == sg);
@@ -253,6 +256,7 @@ __device__ __forceinline__ void ppL_block(uint64_t U, uint32_t B, uint32_t b, ui
             if (sym == sg) prevO = (int)j;
           }
         }
+        return true;
       };
       // my symbol's place in the list in front of the round (K: not there), and the places that lanes in front of me store again (a prefix OR over the lanes)
       auto list_place = [&](uint32_t &place, uint32_t &renewedBefore, uint32_t &renewedAll) __attribute__((always_inline)) {
@@ -307,6 +311,35 @@ __device__ __forceinline__ void ppL_block(uint64_t U, uint32_t B, uint32_t b, ui
         if (k) sh.symList[KU + rho] = sym;
         wave_sync();
         const uint32_t t0 = KU + rho;                                      // my predecessors: entries t0 - 1, t0 - 2, ...
+        // the index from the exact mode's sets (distinct_symbols() has run): the distinct symbols stored behind my symbol's last occurrence, or -- not stored in
+        // this round yet -- the round's distinct symbols in front of me + the listed symbols in front of mine that have not been renewed
+        auto exact_index = [&](uint32_t mIn) __attribute__((always_inline)) -> uint32_t {
+          uint32_t place, renewedBefore, renewedAll;
+          list_place(place, renewedBefore, renewedAll);
+          uint32_t mm = mIn;
+          if (isRun)
+          {
+            if (prevO >= 0) mm = (uint32_t)__builtin_popcountll(F & ~((2ull << prevO) - 1ull));
+            else
+            {
+              const uint32_t dR = (uint32_t)__builtin_popcountll(F);
+              mm = (dR >= KU || place >= KU) ? KU : dR + (uint32_t)__builtin_popcount(~renewedBefore & ((1u << place) - 1u));
+            }
+            if (mm > KU) mm = KU;
+          }
+          return mm;
+        };
+        uint32_t m = KU;
+        exactDone = false;
+        // (a block whose last round ran in the exact mode with few distinct symbols starts there: data over a small alphabet stays that way)
+        bool viaPredecessors = true;
+        if (exactFirst)
+        {
+          if (distinct_symbols(24u)) { exactDone = true; manySymbols = false; m = exact_index(KU); viaPredecessors = false; }
+          else exactFirst = false;
+        }
+        if (viaPredecessors)
+        {
         uint32_t dist = KU + 1u;
 #pragma unroll
         for (int ii = K; ii >= 1; ii--)
@@ -322,7 +355,6 @@ __device__ __forceinline__ void ppL_block(uint64_t U, uint32_t B, uint32_t b, ui
           const uint32_t reach = (dist <= KU ? dist - 1u : KU);
           if (i <= reach && dw > reach - i) distinct++;
         }
-        uint32_t m = KU;
         bool slow = false;
         if (isRun)
         {
@@ -330,7 +362,6 @@ __device__ __forceinline__ void ppL_block(uint64_t U, uint32_t B, uint32_t b, ui
           else if (distinct < KU) slow = true;                             // not among the K predecessors, and those hold a duplicate: look further back
         }
         manySymbols = (uint32_t)__builtin_popcountll(__ballot(k != 0 && dist > KU)) > 16u;
-        exactDone = false;
         if (__ballot(slow) != 0ull && manySymbols)
         {
           // many different symbols in the round (their first occurrences have no equal among their K predecessors): the few unsettled lanes walk further back,
@@ -386,19 +417,8 @@ __device__ __forceinline__ void ppL_block(uint64_t U, uint32_t B, uint32_t b, ui
         {
           distinct_symbols();
           exactDone = true;
-          uint32_t place, renewedBefore, renewedAll;
-          list_place(place, renewedBefore, renewedAll);
-          if (isRun)
-          {
-            if (prevO >= 0) m = (uint32_t)__builtin_popcountll(F & ~((2ull << prevO) - 1ull));      // distinct symbols stored behind my symbol's last occurrence
-            else
-            {
-              // not stored in this round yet: the round's distinct symbols in front of me, then the listed symbols in front of mine that have not been renewed
-              const uint32_t dR = (uint32_t)__builtin_popcountll(F);
-              m = (dR >= KU || place >= KU) ? KU : dR + (uint32_t)__builtin_popcount(~renewedBefore & ((1u << place) - 1u));
-            }
-            if (m > KU) m = KU;
-          }
+          m = exact_index(m);
+        }
         }
         mtf = m;
         const bool notInNow = m == KU;
@@ -408,6 +428,8 @@ __device__ __forceinline__ void ppL_block(uint64_t U, uint32_t B, uint32_t b, ui
         wave_sync();
         if (!changed) break;
       }
+
+      exactFirst = exactDone && dTrips <= 16u;
 
       // the list behind the round (only where another round follows): the round's last occurrences from the most recent down, then what is left of the old list
       if (r0 + 64u < R)

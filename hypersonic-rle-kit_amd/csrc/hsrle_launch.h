@@ -33,6 +33,7 @@ struct DecodeArgs
   int *residentWorkgroups = nullptr; // query mode: no launch; receives the number of workgroups (= waves) of this kernel that fit on one CU
   const uint32_t *entries = nullptr; // lane b starts from entry record b - entryBase (hsrle_index.hip.h) instead of from a block stream header
   uint32_t entryBase = 0;
+  const uint32_t *gate = nullptr;    // decode enqueued BEFORE the host has seen the index passes' verdict: gate[0] | gate[1] != 0 (regions to repair / malformed) -> the kernel returns at once
 };
 
 // index passes over one monolithic stream (hsrle_index.hip.h)
@@ -137,7 +138,7 @@ inline hipError_t launch_decode(KERNEL k, const DecodeArgs &a, hipStream_t st)
   if (a.residentWorkgroups != nullptr)
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(a.residentWorkgroups, k, 64, 0);
   const uint32_t grid = (a.blockCount + 63u) / 64u;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(64), 0, st, a.payload, a.offsets, a.payloadEnd, a.out, a.U, a.B, a.firstBlock, a.blockCount, a.status, a.entries, a.entryBase);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(64), 0, st, a.payload, a.offsets, a.payloadEnd, a.out, a.U, a.B, a.firstBlock, a.blockCount, a.status, a.entries, a.entryBase, a.gate);
   return hipGetLastError();
 }
 

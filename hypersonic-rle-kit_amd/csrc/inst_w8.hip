@@ -24,11 +24,14 @@ namespace hsrle {
 #ifndef HSRLE_DEC8_STEP
 #define HSRLE_DEC8_STEP HSRLE_DECODE_STEP
 #endif
-constexpr int kDec8Tile = HSRLE_DEC8_TILE, kDec8Step = HSRLE_DEC8_STEP;
-static hipError_t dec_plain(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<PLAIN, 1, 0, kDec8Tile, kDecodeRing, kDec8Step, false>, k_decode_blocks<PLAIN, 1, 0, kDec8Tile, 64, kDec8Step, false>, a, st); }
-static hipError_t dec_packed(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<PACKED, 1, 0, kDec8Tile, kDecodeRing, kDec8Step, false>, k_decode_blocks<PACKED, 1, 0, kDec8Tile, 64, kDec8Step, false>, a, st); }
-static hipError_t dec_plain_any(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<PLAIN, 1, 0, kDec8Tile, kDecodeRing, kDec8Step, true>, k_decode_blocks<PLAIN, 1, 0, kDec8Tile, 64, kDec8Step, true>, a, st); }
-static hipError_t dec_packed_any(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<PACKED, 1, 0, kDec8Tile, kDecodeRing, kDec8Step, true>, k_decode_blocks<PACKED, 1, 0, kDec8Tile, 64, kDec8Step, true>, a, st); }
+#ifndef HSRLE_DEC8_RING
+#define HSRLE_DEC8_RING HSRLE_DECODE_RING
+#endif
+constexpr int kDec8Tile = HSRLE_DEC8_TILE, kDec8Step = HSRLE_DEC8_STEP, kDec8Ring = HSRLE_DEC8_RING;
+static hipError_t dec_plain(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<PLAIN, 1, 0, kDec8Tile, kDec8Ring, kDec8Step, false>, k_decode_blocks<PLAIN, 1, 0, kDec8Tile, 64, kDec8Step, false>, a, st); }
+static hipError_t dec_packed(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<PACKED, 1, 0, kDec8Tile, kDec8Ring, kDec8Step, false>, k_decode_blocks<PACKED, 1, 0, kDec8Tile, 64, kDec8Step, false>, a, st); }
+static hipError_t dec_plain_any(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<PLAIN, 1, 0, kDec8Tile, kDec8Ring, kDec8Step, true>, k_decode_blocks<PLAIN, 1, 0, kDec8Tile, 64, kDec8Step, true>, a, st); }
+static hipError_t dec_packed_any(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<PACKED, 1, 0, kDec8Tile, kDec8Ring, kDec8Step, true>, k_decode_blocks<PACKED, 1, 0, kDec8Tile, 64, kDec8Step, true>, a, st); }
 static hipError_t dec_lut3(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<LUT3, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, k_decode_blocks<LUT3, 1, 0, kDecodeTile, 64, kDecodeStep>, a, st); }
 static hipError_t dec_lut7(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<LUT7, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, k_decode_blocks<LUT7, 1, 0, kDecodeTile, 64, kDecodeStep>, a, st); }
 
@@ -44,9 +47,13 @@ static hipError_t dec_short_single(const DecodeArgs &a, hipStream_t st) { return
 template <int FAM>
 static hipError_t enc_multi8(const EncodeArgs &a, hipStream_t st)
 {
-  static const uint32_t force = knob_u32("HSRLE_RUNLIST", 0u);
-  if (run_list_applies(a.nBlocks, a.B, a.U, force) && a.residentWorkgroups == nullptr)
-    return launch_run_list(k_encode8_runlist<FAM>, a, st);
+  // (round 6: plain / Packed / Short without and with a one-symbol list are position-parallel for every block the run list encoder took)
+  if constexpr (FAM == SHORT3 || FAM == SHORT7)
+  {
+    static const uint32_t force = knob_u32("HSRLE_RUNLIST", 0u);
+    if (run_list_applies(a.nBlocks, a.B, a.U, force) && a.residentWorkgroups == nullptr)
+      return launch_run_list(k_encode8_runlist<FAM>, a, st);
+  }
   return launch_encode_ring<1>(k_encode8_blocks<FAM, false, 256>, k_encode8_blocks<FAM, false, 128>, a, st);
 }
 static hipError_t enc_plain(const EncodeArgs &a, hipStream_t st) { return enc_multi8<PLAIN>(a, st); }
