@@ -2507,7 +2507,10 @@ uint64_t hsrle_compress_workspace_size_codec(int codec, uint64_t inSize, uint32_
 {
   if (blockSize == 0) blockSize = HSRLE_DEFAULT_BLOCK_SIZE;
   if (!valid_block_size(blockSize) || inSize == 0 || codec < 0 || codec >= kCodecCount) return 0;
-  return plan_workspace(inSize, blockSize, split_codec_small(codec) && blockSize <= 4096u).total;
+  init_tables();
+  // (round 6: 8 bit Single and 128 bit containers of <= 4 KiB blocks are position-parallel -- no split regions; rle8_single_short and the Greedy codecs with a one-symbol list still take them)
+  const bool split = split_codec_small(codec) && blockSize <= 4096u && !pp_applies(codec, (uint32_t)block_count(inSize, blockSize), blockSize);
+  return plan_workspace(inSize, blockSize, split).total;
 }
 
 int hsrle_compress_dev_async(int codec, const void *dIn, uint64_t inSize, void *dOut, uint64_t outCapacity, uint32_t blockSize, void *dWorkspace,

@@ -192,14 +192,22 @@ __device__ __forceinline__ uint32_t pps_pick(PpSingleShared<EMIT> &sh, const u32
 }
 
 // one block by one wave.  MODE 0: sizes[b], the symbol and the block's records; MODE 1: the stream, written to payload + offsets[b]
-template <bool PK, int MODE>
+// CODEC 0: rle8_single, 1: rle8_packed_single, 2: rle8_single_short (the Short family's Single codec, src/rleX_Xsl_short.h with SINGLE: wrapper :380-523, body
+// :1058-1120 -- the same estimator and the same window scanner; every run end goes through process_symbol, :152-372: stored iff count >= 11 or count >= 2 + the
+// bytes its packet needs beyond the one-byte form; one rule for body and tail, no wasted chances, no symbol in the packets; tools/single_pp_model.py: model_short)
+template <int CODEC, int MODE>
 __device__ __forceinline__ void pps_block(uint64_t U, uint32_t B, uint32_t b, uint32_t *__restrict__ sizes, const uint64_t *__restrict__ offsets, uint8_t *__restrict__ payload,
                                           const PpScratch &sc, PpSingleShared<MODE != 0> &sh, const u32x4 (&x)[4], uint32_t rec0)
 {
-  constexpr uint32_t SHORT = PK ? 2u : 4u, LONG = PK ? 10u : 8u;
-  constexpr uint32_t SURE = PK ? 6u : 8u;            // body: stored whatever the range (Packed: the MEDIUM rule, :1195)
-  constexpr uint32_t TERM = 10u;                     // 00 | u32 0 | 00 | u32 (0 or literals + 1)
-  constexpr uint32_t HDR = 10u;                      // u32 uncompressed, u32 compressed, mode = 1, the symbol
+  constexpr bool PK = CODEC == 1, SS = CODEC == 2;
+  constexpr uint32_t SHORT = (PK || SS) ? 2u : 4u, LONG = SS ? 11u : (PK ? 10u : 8u);
+  constexpr uint32_t SURE = SS ? 11u : (PK ? 6u : 8u);   // body: stored whatever the range (Packed: the MEDIUM rule, :1195; Short: SMINL)
+  constexpr uint32_t TERM = SS ? 9u : 10u;           // 00 | u32 0 | 00 | u32 (0 or literals + 1);  Short: F0 08 00 | u16 0 | u32 literals + 2
+  constexpr uint32_t TERM_END = SS ? 7u : 10u;       // Short: F0 08 01 | u16 0 | u16 0
+  constexpr uint32_t HDR = SS ? 9u : 10u;            // u32 uncompressed, u32 compressed, mode = 1, the symbol;  Short: no mode byte
+  // Short header parameters without a list (hsrle_common.hip.h: Traits<SHORT_SINGLE, 1, 0>): one byte [count - 2 : 4 | gap : 4], or three: [F | 9 bit count | 11 bit gap + 2]
+  // with 16 bit fields behind them where count > 511 or gap + 2 > 2047
+  constexpr uint32_t S_MAXPR = 15u, S_MAXPC = 14u, S_MAXTR = 2047u, S_MAXTC = 511u;
   const uint32_t lane = threadIdx.x;
   const uint64_t at = (uint64_t)b * B;
   const uint32_t n = (uint32_t)((U - at) < (uint64_t)B ? (U - at) : (uint64_t)B);
@@ -249,7 +257,7 @@ __device__ __forceinline__ void pps_block(uint64_t U, uint32_t B, uint32_t b, ui
     const uint32_t carryStart = wave_shr1((uint32_t)wave_scan_max(ownStart), 0xFFFFFFFFu);
     // candidates: runs of at least SHORT bytes (no start at the last byte or in the SHORT - 2 positions in front of it)
     uint64_t near = starts;
-    if constexpr (!PK)
+    if constexpr (SHORT == 4u)
     {
       const uint32_t sTop = wave_shr1((uint32_t)(starts >> 32), 0u);
       near |= ((starts << 1) | (uint64_t)(sTop >> 31)) | ((starts << 2) | (uint64_t)(sTop >> 30));
@@ -358,6 +366,14 @@ __device__ __forceinline__ void pps_block(uint64_t U, uint32_t B, uint32_t b, ui
         kk = 0;
         if (!cand) return in;
         const uint32_t iL = in & 0x1FFFu;
+        if constexpr (SS)
+        {
+          const uint32_t gp = p - iL;
+          const bool one = gp <= S_MAXPR && L - 2u <= S_MAXPC;
+          const uint32_t pen = one ? 0u : 2u + (gp + 2u <= S_MAXTR ? 0u : 2u) + (L <= S_MAXTC ? 0u : 2u);
+          if (L >= 11u || L >= 2u + pen) { kk = one ? 1 : 2; return e; }
+          return in;
+        }
         const uint32_t rng = p - iL + 1u;
         if (rng <= 255u) { kk = 1; return e; }
         if (L >= (vec ? SURE : LONG)) { kk = 2; return e; }
@@ -405,7 +421,7 @@ __device__ __forceinline__ void pps_block(uint64_t U, uint32_t B, uint32_t b, ui
     const uint32_t L = e - p, gap = p - inL, rng = gap + 1u;
     const uint32_t cfield = L - SHORT + 1u;
     const uint32_t cb = cfield <= 255u ? 1u : 5u, rbytes = (k == 1) ? 1u : 5u;
-    const uint32_t hl = cb + rbytes;
+    const uint32_t hl = SS ? ((k == 1) ? 1u : 3u + (L > S_MAXTC ? 2u : 0u) + (rng + 1u > S_MAXTR ? 2u : 0u)) : cb + rbytes;
     const uint32_t myBytes = k ? hl + gap : 0u;
     const uint32_t incl = wave_scan_add(myBytes | (k ? 0x10000u : 0u));    // bytes below bit 16, stored runs above
     const uint32_t tot = wave_lane(incl, 63);
@@ -421,7 +437,22 @@ __device__ __forceinline__ void pps_block(uint64_t U, uint32_t B, uint32_t b, ui
       if (k)
       {
         // header (rle8_extreme_cpu.h:1148-1182): [count - SHORT + 1, or 00 and a u32] [range, or 00 and a u32]
-        if (cb == 1u && k == 1) pp_or_bytes(sh.img, at0, (uint64_t)(cfield | (rng << 8)), 2u);
+        if constexpr (SS)
+        {
+          // (rleX_Xsl_short.h:216-357 without a list index)
+          const uint32_t srange = gap + 2u;
+          if (k == 1) pp_or_bytes(sh.img, at0, (uint64_t)(((L - 2u) << 4) | gap), 1u);
+          else
+          {
+            const uint32_t scx = L <= S_MAXTC ? L : 1u, rx = srange <= S_MAXTR ? srange : 1u;       // (1: a 16 bit field follows)
+            const uint32_t f = scx << 3;
+            pp_or_bytes(sh.img, at0, (uint64_t)(((0xF0u | (f >> 8)) & 0xFFu) | (((f | (rx >> 8)) & 0xFFu) << 8) | ((rx & 0xFFu) << 16)), 3u);
+            uint32_t a = at0 + 3u;
+            if (scx != L) { pp_or_bytes(sh.img, a, (uint64_t)L, 2u); a += 2u; }
+            if (rx != srange) pp_or_bytes(sh.img, a, (uint64_t)srange, 2u);
+          }
+        }
+        else if (cb == 1u && k == 1) pp_or_bytes(sh.img, at0, (uint64_t)(cfield | (rng << 8)), 2u);
         else
         {
           pp_or_bytes(sh.img, at0, cb == 1u ? (uint64_t)cfield : (uint64_t)cfield << 8, cb);
@@ -447,7 +478,7 @@ __device__ __forceinline__ void pps_block(uint64_t U, uint32_t B, uint32_t b, ui
 
   // ---- 3. terminator, stream size (:512-694) ----
   const uint32_t kLit = ended ? 0u : n - carL;
-  const uint32_t streamSize = pos + TERM + kLit;
+  const uint32_t streamSize = pos + (ended ? TERM_END : TERM) + kLit;
   if constexpr (MODE == 0)
   {
     if (lane == 0u) { sizes[b] = streamSize; sc.recCount[b] = ((K <= sc.recStride) ? K : kPpsNoRecords) | (sym << 16); }
@@ -455,12 +486,21 @@ __device__ __forceinline__ void pps_block(uint64_t U, uint32_t B, uint32_t b, ui
   }
   else
   {
-    if (lane < 10u)
+    if (lane < HDR)
     {
       const uint64_t h = (uint64_t)n | ((uint64_t)streamSize << 32);
-      sh.img[lane] = lane < 8u ? (uint8_t)(h >> (8u * lane)) : (lane == 8u ? (uint8_t)1 : (uint8_t)sym);
+      sh.img[lane] = lane < 8u ? (uint8_t)(h >> (8u * lane)) : ((lane == 8u && !SS) ? (uint8_t)1 : (uint8_t)sym);
     }
-    if (lane == 16u && !ended) pp_or_bytes(sh.img, pos + 6u, (uint64_t)(kLit + 1u), 4u);
+    if constexpr (SS)
+    {
+      // end: F0 08 01, u16 0, u16 0;  literals: F0 08 00, u16 0, u32 literals + 2  (rleX_Xsl_short.h:976-1032 with SINGLE)
+      if (lane == 16u)
+      {
+        pp_or_bytes(sh.img, pos, (uint64_t)(0xF0u | (8u << 8) | (ended ? 1u << 16 : 0u)), 3u);
+        if (!ended) pp_or_bytes(sh.img, pos + 5u, (uint64_t)(kLit + 2u), 4u);
+      }
+    }
+    else if (lane == 16u && !ended) pp_or_bytes(sh.img, pos + 6u, (uint64_t)(kLit + 1u), 4u);
     wave_sync();
     // the long stretches and the literals behind the last stored run: every lane a chunk
     {
@@ -485,7 +525,7 @@ __device__ __forceinline__ void pps_block(uint64_t U, uint32_t B, uint32_t b, ui
   }
 }
 
-template <bool PK, int MODE>
+template <int CODEC, int MODE>
 __global__ __launch_bounds__(64) void k_encode8s_pp(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t nBlocks, uint32_t *__restrict__ sizes,
                                                     const uint64_t *__restrict__ offsets, uint8_t *__restrict__ payload, PpScratch sc)
 {
@@ -509,7 +549,7 @@ __global__ __launch_bounds__(64) void k_encode8s_pp(const uint8_t *__restrict__ 
     pp_load(in, U, B, b, x);
     uint32_t rec0 = 0;
     if constexpr (MODE == 1) rec0 = sc.recs[(uint64_t)b * sc.recStride + threadIdx.x];
-    pps_block<PK, MODE>(U, B, b, sizes, offsets, payload, sc, sh, x, rec0);
+    pps_block<CODEC, MODE>(U, B, b, sizes, offsets, payload, sc, sh, x, rec0);
   }
 }
 

@@ -86,26 +86,27 @@ def test_encode_path_selection(lib):
     cid = lambda n: lib.hsrle_codec_from_name(n.encode())
     RING, SPLIT, RUN_LIST, PP = 0, 1, 2, 3
     frame = 88473600
-    # round 5: the position-parallel encoders take every container of <= 4 KiB blocks of their 56 codecs, whatever its size
+    # rounds 5 / 6: the position-parallel encoders take every container of <= 4 KiB blocks of their 76 codecs (all 50 extreme codecs among them), whatever its size
     for name in ("rle8_multi", "rle8_packed_multi", "rle16_sym", "rle16_byte_packed", "rle24_sym_packed", "rle32_byte_packed", "rle48_3symlut_sym", "rle64_3symlut_byte", "rle24_3symlut_byte",
                  "rle16_sym_short", "rle16_1symlut_sym_short", "rle24_byte_short", "rle48_1symlut_byte_short", "rle64_sym_short",
-                 "rle8_multi_short", "rle8_1symlut_short", "rle48_3symlut_sym_short", "rle64_3symlut_byte_short"):
+                 "rle8_multi_short", "rle8_1symlut_short", "rle48_3symlut_sym_short", "rle64_3symlut_byte_short",
+                 "rle8_3symlut", "rle8_7symlut", "rle16_3symlut_sym", "rle16_3symlut_byte", "rle16_7symlut_byte", "rle24_7symlut_byte", "rle64_7symlut_sym",
+                 "rle8_single", "rle8_packed_single", "rle8_single_short", "rle128_sym", "rle128_sym_packed", "rle128_byte", "rle128_byte_packed"):
         assert cid(name) >= 0
         for size, block in ((frame, 4096), (frame, 1024), (frame, 512), (8 << 30, 4096), (4096, 128)):
             assert lib.hsrle_encode_path(cid(name), size, block) == PP, (name, size, block)
         assert lib.hsrle_encode_path(cid(name), frame, 8192) == SPLIT, name         # a wave holds 4 KiB: larger blocks by chunks
         assert lib.hsrle_encode_path(cid(name), 8 << 30, 8192) == RING, name
-    for name in ("rle8_3symlut", "rle8_7symlut", "rle16_3symlut_byte", "rle24_7symlut_byte", "rle64_7symlut_sym",
-                 "rle8_3symlut_short", "rle8_7symlut_short", "rle16_3symlut_sym_short", "rle32_3symlut_byte_short", "rle64_7symlut_byte_short"):
+    for name in ("rle8_3symlut_short", "rle8_7symlut_short", "rle16_3symlut_sym_short", "rle32_3symlut_byte_short", "rle64_7symlut_byte_short"):
         assert cid(name) >= 0
         assert lib.hsrle_encode_path(cid(name), frame, 4096) == RUN_LIST, name
         assert lib.hsrle_encode_path(cid(name), frame, 1024) == RUN_LIST, name
         assert lib.hsrle_encode_path(cid(name), 8 << 30, 4096) == RING, name        # 2 097 152 blocks
         assert lib.hsrle_encode_path(cid(name), frame, 8192) == SPLIT, name         # run list: blocks of 1 .. 4 KiB only
         assert lib.hsrle_encode_path(cid(name), frame, 512) == RING, name
-    for name in ("rle8_single", "rle8_packed_single", "rle128_sym", "rle128_byte_packed", "rle16_3symlut_byte_short_greedy"):
-        assert lib.hsrle_encode_path(cid(name), frame, 4096) == RING, name          # (Single / 128 bit: split only with a workspace sized for the codec -- the host cannot know)
-    for name in ("rle8_single", "rle8_packed_single", "rle128_sym", "rle128_byte_packed", "rle16_1symlut_byte_short_greedy", "rle64_1symlut_byte_short_greedy", "rle8_single_short"):
+    for name in ("rle16_1symlut_byte_short_greedy", "rle16_3symlut_byte_short_greedy"):
+        assert lib.hsrle_encode_path(cid(name), frame, 4096) == RING, name          # (split only with a workspace sized for the codec -- the host cannot know)
+    for name in ("rle16_1symlut_byte_short_greedy", "rle64_1symlut_byte_short_greedy", "rle8_single_short"):
         assert lib.hsrle_encode_path(cid(name), frame, 8192) == SPLIT, name         # round 4: their chunk encoders take the blocks of a container too
     lib.hsrle_compress_workspace_size.restype = ctypes.c_uint64
     lib.hsrle_compress_workspace_size.argtypes = [ctypes.c_uint64, ctypes.c_uint32]
@@ -113,12 +114,14 @@ def test_encode_path_selection(lib):
     lib.hsrle_compress_workspace_size_codec.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_uint32]
     general = lib.hsrle_compress_workspace_size(frame, 4096)
     assert lib.hsrle_compress_workspace_size_codec(cid("rle8_packed_multi"), frame, 4096) == general
-    assert lib.hsrle_compress_workspace_size_codec(cid("rle8_single"), frame, 4096) > 2 * frame > general
+    assert lib.hsrle_compress_workspace_size_codec(cid("rle8_single"), frame, 4096) == general          # round 6: position-parallel, no split regions
+    assert lib.hsrle_compress_workspace_size_codec(cid("rle8_single_short"), frame, 4096) == general
+    assert lib.hsrle_compress_workspace_size_codec(cid("rle16_1symlut_byte_short_greedy"), frame, 4096) > 2 * frame > general
     assert lib.hsrle_compress_workspace_size_codec(cid("rle32_1symlut_byte_short_greedy"), frame, 4096) > 2 * frame
     for name in ("rle16_3symlut_byte_short_greedy", "rle64_7symlut_byte_short_greedy"):     # lists of 3 / 7 symbols decide the greedy scan's runs: one lane per block
         assert lib.hsrle_encode_path(cid(name), frame, 8192) == RING and lib.hsrle_compress_workspace_size_codec(cid(name), frame, 4096) == general
     assert lib.hsrle_compress_workspace_size_codec(cid("rle128_sym"), 8 << 30, 4096) == lib.hsrle_compress_workspace_size(8 << 30, 4096)
-    assert lib.hsrle_encode_path(cid("rle8_single_short"), frame, 4096) == RING and lib.hsrle_compress_workspace_size_codec(cid("rle8_single_short"), frame, 4096) > 2 * frame
+    assert lib.hsrle_encode_path(cid("rle8_single_short"), frame, 4096) == PP and lib.hsrle_compress_workspace_size_codec(cid("rle8_single_short"), frame, 4096) == general   # round 6
     assert lib.hsrle_encode_path(-1, frame, 4096) == -1 and lib.hsrle_encode_path(0, frame, 1000) == -1 and lib.hsrle_encode_path(0, 0, 4096) == -1
 
 

@@ -210,7 +210,7 @@ def test_position_parallel_path_is_the_one_that_ran(hs):
 
 
 # ---- 8 bit Single (csrc/hsrle_encode8sp.hip.h; reference: src/rle8_extreme_cpu.c:53-153, src/rle8_extreme_cpu.h:346-700, :1103-1321) ----
-SINGLE_KEYS = ["rle8_single", "rle8_packed_single"]
+SINGLE_KEYS = ["rle8_single", "rle8_packed_single", "rle8_single_short"]   # (the Short family's Single codec: same kernel, process_symbol's rule)
 
 
 def _favourite(rng, n, sym, run_lengths, gaps, alphabet=256):

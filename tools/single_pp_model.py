@@ -126,6 +126,91 @@ def model(d, sym, packed):
     return bytes(out)
 
 
+def model_short(d, sym):
+    """rle8_single_short (src/rleX_Xsl_short.h with SINGLE: wrapper :380-523, body :1058-1120, process_symbol :152-372): the same window scanner, no wasted
+    chances, one rule for body and tail -- count >= 11, or count >= 2 + the bytes the packet needs beyond the one-byte form"""
+    n = len(d)
+    MINS, MINL, MAXPR, MAXPC, MAXTR, CINV, RBP, RB, TB = 2, 11, 15, 14, 2047, 15, 4, 11, 8
+    end = n - 16
+    m = [1 if b == sym else 0 for b in d] + [0] * 64
+    runs = []
+    j = 0
+    while j < n:
+        if m[j]:
+            e = j
+            while e < n and m[e]:
+                e += 1
+            runs.append((j, e))
+            j = e
+        else:
+            j += 1
+    quirk = -1
+    if end > 0 and any(max(end, 1) <= p <= end + 15 for (p, e) in runs):
+        a0 = 0
+        if m[0]:
+            a0 = min(runs[0][1], 64)
+        for (p, e) in runs:
+            if e - p >= 2 and e < end:
+                a0 = max(a0, e)
+        w = a0
+        hit = False
+        while w < end:
+            win = m[w:w + 16]
+            pop = sum(win)
+            if pop == 0 or (not win[15] and pop < 2):
+                w += 16
+                continue
+            f = w + win.index(1)
+            Lf = 0
+            while Lf < 2 and m[f + Lf]:
+                Lf += 1
+            if Lf >= 2:
+                hit = True
+                break
+            w = f + Lf
+        if not hit and m[w]:
+            quirk = w
+    out = bytearray(struct.pack("<IIB", n, 0, sym))
+    lastRLE = 0
+    ended = False
+    for (p, e) in runs:
+        if p == quirk:
+            p += 1
+        count = e - p
+        if count < MINS:
+            continue
+        gap = p - lastRLE
+        rng = gap + 2
+        single = gap <= MAXPR and count - 2 <= MAXPC
+        pen = 0
+        if not single:
+            pen = 2 + (0 if rng <= MAXTR else 2) + (0 if count <= 511 else 2)
+        if not (count >= MINL or count >= MINS + pen):
+            continue
+        if single:
+            out.append(((count - 2) << RBP) | gap)
+        else:
+            scx = count if count <= 511 else 1
+            rx = rng if rng <= MAXTR else 1
+            out.append((CINV << RBP) | (((scx << (RB - 8)) >> 8) & 0xFF))
+            out.append(((scx << (RB - 8)) | (rx >> 8)) & 0xFF)
+            out.append(rx & 0xFF)
+            if scx != count:
+                out += struct.pack("<H", count)
+            if rx != rng:
+                out += struct.pack("<H", rng)
+        out += bytes(d[lastRLE:p])
+        lastRLE = e
+        if e >= n:
+            ended = True
+    if ended:
+        out += bytes([CINV << RBP, TB, 1]) + b"\0" * 4
+    else:
+        out += bytes([CINV << RBP, TB, 0]) + b"\0" * 2 + struct.pack("<I", n - lastRLE + 2) + bytes(d[lastRLE:n])
+    struct.pack_into("<I", out, 4, len(out))
+    return bytes(out)
+
+
 def triples(rng, n, sym):
     """runs of the symbol of 2 .. 9 bytes in groups: gaps beyond 255 bytes in front of a group, a few bytes inside it"""
     out = bytearray()
@@ -154,9 +239,9 @@ def main():
         cut = rng.choice([0, 0, 1, 3, 15, 16, 17])
         if cut and len(data) > cut:
             data = data[:len(data) - cut]
-        for key in ("rle8_single", "rle8_packed_single"):
+        for key in ("rle8_single", "rle8_packed_single", "rle8_single_short"):
             want = ora.compress(CODEC_BY_KEY[key], data)
-            got = model(data, want[9], key == "rle8_packed_single")
+            got = model_short(data, want[8]) if key == "rle8_single_short" else model(data, want[9], key == "rle8_packed_single")
             if got != want:
                 bad += 1
                 if bad <= 5:
