@@ -42,17 +42,25 @@ struct PpLutShared
 
 template <int FAM, int S, int AL, int MODE>
 __device__ __forceinline__ void ppL_block(uint64_t U, uint32_t B, uint32_t b, uint32_t *__restrict__ sizes, const uint64_t *__restrict__ offsets, uint8_t *__restrict__ payload,
-                                          const PpScratch &sc, PpLutShared<MODE != 0, (FAM == LUT3 ? 3 : 7)> &sh, const u32x4 (&x)[4], uint32_t rec0)
+                                          const PpScratch &sc, PpLutShared<MODE != 0, ((FAM == LUT3 || FAM == SHORT3) ? 3 : 7)> &sh, const u32x4 (&x)[4], uint32_t rec0)
 {
-  static_assert(FAM == LUT3 || FAM == LUT7, "3 / 7 symbol LUT");
+  static_assert(FAM == LUT3 || FAM == LUT7 || FAM == SHORT3 || FAM == SHORT7, "3 / 7 symbol LUT, or the Short family with a 3 / 7 symbol list");
   static_assert(S == 1 || S == 2 || S == 3 || S == 4 || S == 6 || S == 8, "symbols of 1, 2, 3, 4, 6 or 8 bytes");
   static_assert(S != 1 || AL == 0, "8 bit: byte-aligned by nature");
-  constexpr int K = FAM == LUT3 ? 3 : 7;
+  // Short family (src/rleX_Xsl_short.h:152-372): the same list, one-byte or three-byte headers, and process_symbol's rule -- count >= S + 11, or count >= 2 + the
+  // bytes the packet needs beyond the one-byte form, S of them for a symbol that is not in the list: with symbols of up to 4 bytes WHETHER a run is stored depends on
+  // the list for every count below S + 11 (from 6 bytes on every run is stored: 2 S >= 2 + S + 4)
+  constexpr bool SH = FAM == SHORT3 || FAM == SHORT7;
+  using TR = Traits<FAM, S, AL>;
+  constexpr int K = (FAM == LUT3 || FAM == SHORT3) ? 3 : 7;
   constexpr uint32_t KU = (uint32_t)K;
   constexpr uint32_t SU = (uint32_t)S;
   constexpr uint32_t RB = K == 3 ? 7u : 6u, MAXR = (1u << RB) - 1u, MAXC = 127u, MSH = K == 3 ? 14u : 13u;
-  constexpr bool NARROW = S <= 2;                                       // storing a run can depend on the list
-  constexpr uint32_t TERM = 8u, TERM_END = 6u, HDR = 8u;
+  constexpr bool NARROW = SH ? S <= 4 : S <= 2;                         // storing a run can depend on the list
+  constexpr uint32_t TERM = SH ? 9u : 8u, TERM_END = SH ? 7u : 6u, HDR = 8u;
+  // a run of this many bytes is stored whatever the state: LUT 3 + (2 + 1); Short 2 + the largest penalty a short count can meet (S for a new symbol, 2 for the
+  // three-byte form, 2 for a 16 bit range; a 16 bit count means a run beyond S + 11 anyway)
+  constexpr uint32_t SURE = SH ? (TR::SMINS + SU + 4u < TR::SMINL ? TR::SMINS + SU + 4u : TR::SMINL) : 6u;
   const uint32_t lane = threadIdx.x;
   const uint64_t at = (uint64_t)b * B;
   const uint32_t n = (uint32_t)((U - at) < (uint64_t)B ? (U - at) : (uint64_t)B);
@@ -131,7 +139,8 @@ __device__ __forceinline__ void ppL_block(uint64_t U, uint32_t B, uint32_t b, ui
     uint64_t full;
     {
       const uint64_t c2 = m64 & shl_in(m64, 1u);
-      if constexpr (S <= 2) full = c2;
+      if constexpr (S == 1 && SH) full = m64;                            // (Short: a run of two bytes of a listed symbol right behind the run before is stored)
+      else if constexpr (S <= 2) full = c2;
       else if constexpr (S == 3) full = c2 & shl_in(m64, 2u);
       else
       {
@@ -275,7 +284,7 @@ __device__ __forceinline__ void ppL_block(uint64_t U, uint32_t B, uint32_t b, ui
       };
 
       // -- which runs are stored, and the symbols' list indices: a fixed point (see the header); one iteration where no run is short enough to depend on the list
-      const bool sure = isRun && (!NARROW || count >= 6u);
+      const bool sure = isRun && (!NARROW || count >= SURE);
       const bool anyOpen = NARROW && __ballot(isRun && !sure) != 0ull;
       bool notIn = true;                                                   // the guess: the symbol is not in the list ...
       if (anyOpen)
@@ -286,11 +295,23 @@ __device__ __forceinline__ void ppL_block(uint64_t U, uint32_t B, uint32_t b, ui
       }
       for (uint32_t iter = 0; iter < 70u; iter++)
       {
-        auto stored_if = [&](uint32_t iL) __attribute__((always_inline)) -> bool {
-          const uint32_t rng = p - iL + 2u;
-          const uint32_t pen = (rng <= MAXR ? 0u : 2u) + (notIn ? 1u : 0u);   // (a count field beyond 127 means a run of >= S + 10 bytes)
-          return count >= SU + 10u || count >= 3u + pen;
+        auto stored_with = [&](uint32_t iL, bool flagNotIn) __attribute__((always_inline)) -> bool {
+          if constexpr (SH)
+          {
+            const uint32_t gp = p - iL;
+            const uint32_t scu = (AL && S != 1) ? count / SU - TR::SMINS / SU + 2u : count - TR::SMINS + 2u;
+            const bool pack1 = gp <= TR::SMAXPR && scu - 2u <= TR::SMAXPC;
+            const uint32_t pen = (flagNotIn ? SU : 0u) + (pack1 ? 0u : 2u + (gp + 2u <= TR::SMAXTR ? 0u : 2u) + (scu <= TR::SMAXTC ? 0u : 2u));
+            return count >= TR::SMINL || count >= TR::SMINS + pen;
+          }
+          else
+          {
+            const uint32_t rng = p - iL + 2u;
+            const uint32_t pen = (rng <= MAXR ? 0u : 2u) + (flagNotIn ? 1u : 0u);   // (a count field beyond 127 means a run of >= S + 10 bytes)
+            return count >= SU + 10u || count >= 3u + pen;
+          }
         };
+        auto stored_if = [&](uint32_t iL) __attribute__((always_inline)) -> bool { return stored_with(iL, notIn); };
         outL = e;
         bool outKnown = sure || !have, inKnown = !have;
         for (uint32_t pass = 0; pass < 66u; pass++)
@@ -422,8 +443,8 @@ __device__ __forceinline__ void ppL_block(uint64_t U, uint32_t B, uint32_t b, ui
         }
         mtf = m;
         const bool notInNow = m == KU;
-        // (the flag matters only for a run of exactly 3 + the range's penalty bytes)
-        const bool changed = anyOpen && __ballot(isRun && !sure && notInNow != notIn && count == 3u + ((p - inL + 2u) <= MAXR ? 0u : 2u)) != 0ull;
+        // (the flag matters only where the two answers differ: LUT: a run of exactly 3 + the range's penalty bytes)
+        const bool changed = anyOpen && __ballot(isRun && !sure && notInNow != notIn && stored_with(inL, true) != stored_with(inL, false)) != 0ull;
         notIn = notInNow;
         wave_sync();
         if (!changed) break;
@@ -434,33 +455,32 @@ __device__ __forceinline__ void ppL_block(uint64_t U, uint32_t B, uint32_t b, ui
       // the list behind the round (only where another round follows): the round's last occurrences from the most recent down, then what is left of the old list
       if (r0 + 64u < R)
       {
-        // (cheap first: the last 2 K + 1 stored symbols usually hold K distinct ones -- every lane walks the same entries)
+        // (cheap first: the last 2 K + 2 entries -- stored symbols, then the list in front of the round -- usually hold K distinct ones.  Lane i takes the entry
+        //  i places from the end and learns from the lanes below it whether its symbol has been seen: 2 K + 1 readlane trips for the wave instead of a walk
+        //  in which every lane does the same 7-compare steps)
         const uint32_t nSt = wave_lane(wave_scan_add(k ? 1u : 0u), 63);
-        uint64_t seen[K];
-#pragma unroll
-        for (int i = 0; i < K; i++) seen[i] = 0ull;
-        uint32_t cntSeen = 0;
-        for (int32_t t = (int32_t)(KU + nSt) - 1, steps = 0; manySymbols && t >= 0 && cntSeen < KU && steps < 2 * K + 1; t--, steps++)
+        constexpr uint32_t WIN = 2u * KU + 2u;
+        const int32_t tMine = (int32_t)(KU + nSt) - 1 - (int32_t)lane;
+        const bool inWin = manySymbols && lane < WIN && tMine >= 0;
+        uint64_t hv = 0ull, newM = 0ull;
+        bool dup = false;
+        if (manySymbols)                                                     // (wave-uniform; data over a small alphabet goes straight to the exact sets below)
         {
-          const uint64_t h = sh.symList[t];
-          bool isNew = true;
+          hv = inWin ? sh.symList[tMine] : 0ull;
 #pragma unroll
-          for (int i = 0; i < K; i++) isNew = isNew && !((uint32_t)i < cntSeen && seen[i] == h);
-          if (isNew)
+          for (uint32_t j = 0; j + 1u < WIN; j++)
           {
-#pragma unroll
-            for (int i = 0; i < K; i++) if ((uint32_t)i == cntSeen) seen[i] = h;
-            cntSeen++;
+            const uint64_t hj = (uint64_t)wave_lane((uint32_t)hv, (int)j) | ((uint64_t)wave_lane((uint32_t)(hv >> 32), (int)j) << 32);
+            if (lane > j && hj == hv) dup = true;
           }
+          newM = __ballot(inWin && !dup);
         }
-        if (cntSeen == KU)
+        const uint32_t cntSeen = (uint32_t)__builtin_popcountll(newM);
+        if (cntSeen >= KU)
         {
+          const uint32_t rank = (uint32_t)__builtin_popcountll(newM & ((1ull << lane) - 1ull));
           wave_sync();
-          if (lane == 0u)
-          {
-#pragma unroll
-            for (int i = 0; i < K; i++) sh.carList[K - 1 - i] = seen[i];   // (seen[0]: the most recent)
-          }
+          if (inWin && !dup && rank < KU) sh.carList[KU - 1u - rank] = hv;   // (rank 0: the most recent)
           wave_sync();
         }
         else
@@ -493,7 +513,10 @@ __device__ __forceinline__ void ppL_block(uint64_t U, uint32_t B, uint32_t b, ui
     // ---- packet header (rleX_Xsl.h:190-250): u16 {index, count, range}, [symbol if new], [u16 count], [u16 range] ----
     const uint32_t cfield = (AL && S != 1) ? count / SU - 3u / SU + 2u : count - 1u;
     const uint32_t cBytes = cfield <= MAXC ? 0u : 2u, sBytes = mtf == KU ? SU : 0u, rBytes = rng <= MAXR ? 0u : 2u;
-    const uint32_t hl = !k ? 0u : 2u + cBytes + sBytes + rBytes;
+    // Short: count field value (+ 2); the one-byte form where gap and count fit, else three bytes with 16 bit fields behind them where 9 / SRB bits are not enough
+    [[maybe_unused]] const uint32_t scu = (AL && S != 1) ? count / SU - TR::SMINS / SU + 2u : count - TR::SMINS + 2u;
+    [[maybe_unused]] const bool pack1 = gap <= TR::SMAXPR && scu - 2u <= TR::SMAXPC;
+    const uint32_t hl = !k ? 0u : (SH ? (pack1 ? 1u : 3u + (scu > TR::SMAXTC ? 2u : 0u) + (rng > TR::SMAXTR ? 2u : 0u)) + sBytes : 2u + cBytes + sBytes + rBytes);
     const uint32_t myBytes = k ? hl + gap : 0u;
     const uint32_t incl = wave_scan_add(myBytes | (k ? 0x10000u : 0u));
     const uint32_t tot = wave_lane(incl, 63);
@@ -509,11 +532,30 @@ __device__ __forceinline__ void ppL_block(uint64_t U, uint32_t B, uint32_t b, ui
       if (k)
       {
         uint32_t a = at0;
+        if constexpr (SH)
+        {
+          // [list index | count | range] in one byte, or [index | all-ones count | 9 bit count | SRB bit range] in three (rleX_Xsl_short.h:216-357), then the symbol if new
+          const uint32_t mi = mtf << (TR::SCB + TR::SRBP);
+          if (pack1) { pp_or_bytes(sh.img, a, (uint64_t)(mi | ((scu - 2u) << TR::SRBP) | gap), 1u); a += 1u; }
+          else
+          {
+            const uint32_t scx = scu <= TR::SMAXTC ? scu : 1u, rx = rng <= TR::SMAXTR ? rng : 1u;      // (1: a 16 bit field follows)
+            const uint32_t f = scx << (TR::SRB - 8u);
+            const uint32_t b0 = (mi | (TR::SCINV << TR::SRBP) | (f >> 8)) & 0xFFu, b1 = (f | (rx >> 8)) & 0xFFu, b2 = rx & 0xFFu;
+            pp_or_bytes(sh.img, a, (uint64_t)(b0 | (b1 << 8) | (b2 << 16)), 3u); a += 3u;
+            if (scx != scu) { pp_or_bytes(sh.img, a, (uint64_t)scu, 2u); a += 2u; }
+            if (rx != rng) { pp_or_bytes(sh.img, a, (uint64_t)rng, 2u); a += 2u; }
+          }
+          if (mtf == KU) pp_or_bytes(sh.img, a, sym, SU);
+        }
+        else
+        {
         const uint32_t c7 = cfield <= MAXC ? cfield : 1u, r7 = rng <= MAXR ? rng : 1u;   // (1: a 16 bit field follows; nothing in a block needs 32)
         pp_or_bytes(sh.img, a, (uint64_t)((mtf << MSH) | (c7 << RB) | r7), 2u); a += 2u;
         if (mtf == KU) { pp_or_bytes(sh.img, a, sym, SU); a += SU; }
         if (cBytes) { pp_or_bytes(sh.img, a, (uint64_t)cfield, 2u); a += 2u; }
         if (rBytes) pp_or_bytes(sh.img, a, (uint64_t)rng, 2u);
+        }
         ds = at0 + hl;
         if (gap > kPpCoopMin) { const uint32_t slot = atomicAdd(&sh.jobCount, 1u); sh.jobs[slot] = (uint64_t)inL | ((uint64_t)ds << 13) | ((uint64_t)gap << 26); }
         else if (gap != 0u) nch = ((ds + gap - 1u) >> 4) - (ds >> 4) + 1u;
@@ -548,8 +590,17 @@ __device__ __forceinline__ void ppL_block(uint64_t U, uint32_t B, uint32_t b, ui
     if (lane == 16u)
     {
       // end: u16 (1 << RB) | 1, u16 0, u16 0;  literals: u16 1 << RB, u16 0, u32 literals + 2
-      sh.img[pos] = (uint8_t)((1u << RB) | (ended ? 1u : 0u));
-      if (!ended) pp_or_bytes(sh.img, pos + 4u, (uint64_t)(kLit + 2u), 4u);
+      if constexpr (SH)
+      {
+        // end: [all-ones count] [STB] 01, u16 0, u16 0;  literals: [all-ones count] [STB] 00, u16 0, u32 literals + 2  (rleX_Xsl_short.h:976-1032; a list: no symbol behind)
+        pp_or_bytes(sh.img, pos, (uint64_t)((TR::SCINV << TR::SRBP) | (TR::STB << 8) | (ended ? 1u << 16 : 0u)), 3u);
+        if (!ended) pp_or_bytes(sh.img, pos + 5u, (uint64_t)(kLit + 2u), 4u);
+      }
+      else
+      {
+        sh.img[pos] = (uint8_t)((1u << RB) | (ended ? 1u : 0u));
+        if (!ended) pp_or_bytes(sh.img, pos + 4u, (uint64_t)(kLit + 2u), 4u);
+      }
     }
     wave_sync();
     {
@@ -577,7 +628,7 @@ template <int FAM, int S, int AL, int MODE>
 __global__ __launch_bounds__(64) void k_encodeL_pp(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t nBlocks, uint32_t *__restrict__ sizes,
                                                    const uint64_t *__restrict__ offsets, uint8_t *__restrict__ payload, PpScratch sc)
 {
-  __shared__ PpLutShared<MODE != 0, (FAM == LUT3 ? 3 : 7)> sh;
+  __shared__ PpLutShared<MODE != 0, ((FAM == LUT3 || FAM == SHORT3) ? 3 : 7)> sh;
   if (MODE != 0 && threadIdx.x < 17u)
   {
     const uint32_t c = threadIdx.x;

@@ -455,3 +455,33 @@ def test_position_parallel_lut_general_encoder_block_sizes_and_ragged_tails(hs, 
 def test_position_parallel_lut_general_encoder_synthetic_workloads(hs, oracle, key, kind):
     data = oracle.synth(kind, _symbytes(key), 11, (8 << 20) + 999)
     _check(hs, oracle, key, data, 4096)
+
+
+# ---- Short family with a 3 / 7 symbol list where storing a run depends on the list (csrc/hsrle_encodeLp.hip.h; reference: src/rleX_Xsl_short.h:152-372) ----
+SHORTL_KEYS = [f"rle{w}_3symlut_{a}_short" for w in (16, 24, 32) for a in ("sym", "byte")] + \
+              [f"rle{w}_7symlut_{a}_short" for w in (16, 24, 32, 48, 64) for a in ("sym", "byte")]
+
+
+@pytest.mark.parametrize("key", SHORTL_KEYS)
+@pytest.mark.parametrize("name", ["periods", "butting", "far_apart", "two_symbols", "few_symbols", "initial_entries", "near_limits", "beyond_fields", "b_threes", "b_short_chains", "b_mixed",
+                                  "b_same_symbol", "marginal_few", "marginal_nine", "marginal1_few"])
+def test_position_parallel_short_list_encoder_bit_exact(hs, oracle, short_cases, lutg_cases, key, name):
+    if name in ("marginal_few", "marginal_nine"):
+        name = name.replace("marginal", f"marginal{_symbytes(key)}")
+    data = short_cases[name] if name in short_cases else lutg_cases[name]
+    _check(hs, oracle, key, data, 4096)
+
+
+@pytest.mark.parametrize("key", ["rle16_3symlut_sym_short", "rle16_7symlut_byte_short", "rle24_3symlut_sym_short", "rle32_7symlut_byte_short", "rle64_7symlut_sym_short"])
+@pytest.mark.parametrize("block,cut", [(128, 0), (384, 5), (1024, 77), (1536, 1535), (4096, 4095), (4096, 4081)])
+def test_position_parallel_short_list_encoder_block_sizes_and_ragged_tails(hs, oracle, short_cases, lutg_cases, key, block, cut):
+    S = _symbytes(key)
+    data = np.concatenate([lutg_cases[f"marginal{S}_few"][: 1 << 20], short_cases["near_limits"][: 1 << 19], lutg_cases["b_short_chains"][: 1 << 19], short_cases["butting"][: 1 << 19]])
+    _check(hs, oracle, key, data[: data.size - cut], block)
+
+
+@pytest.mark.parametrize("key", SHORTL_KEYS)
+@pytest.mark.parametrize("kind", [SYNTH_RUNS, SYNTH_VIDEO])
+def test_position_parallel_short_list_encoder_synthetic_workloads(hs, oracle, key, kind):
+    data = oracle.synth(kind, _symbytes(key), 11, (8 << 20) + 999)
+    _check(hs, oracle, key, data, 4096)
