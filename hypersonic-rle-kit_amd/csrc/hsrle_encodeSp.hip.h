@@ -6,7 +6,7 @@
 //
 // Replaces: src/rleX_extreme_cpu_encode.h:14-609 (run discovery :315-371, extension :79-163, emit rule :174-311, terminators :384-603; the 24 / 48 bit
 //           forms in src/rle24_extreme_cpu_encode.h, src/rle48_extreme_cpu_encode.h) -- and, in this library, the ring / run list encoders + staging
-//           slots + k_compact for containers of these codecs (hsrle_encodeS.hip.h, hsrle_encodeSr.hip.h).
+//           slots + k_compact for containers of these codecs (hsrle_encodeS.hip.h; the run list encoders of these widths were removed in round 6).
 //
 // Run discovery on match bits m[j] = (d[j] == d[j + S]) (the oracle's runs_next): a maximal stretch of L >= S set bits from position s
 // means that the bytes [s, s + L + S) have period S.  The reference's scan starts a run at the first p >= (end of the run before) inside the stretch

@@ -256,25 +256,6 @@ inline hipError_t launch_encode_ring(K256 k256, K128 k128, const EncodeArgs &a, 
   return hipGetLastError();
 }
 
-// the encoders of 3 / 4 byte symbols on big containers of 1 .. 4 KiB blocks: probe, then the ring encoder AND the run list encoder -- the one
-// that was not chosen returns at once (k_list_decide, hsrle_ring_probe.hip.h).  Small containers never come here (run_list_applies), and
-// without scratch, with other block sizes or when the run list is switched off (HSRLE_RUNLIST=2, experiment builds) it is the ring encoder.
-template <int S, typename KRING, typename KLIST>
-inline hipError_t launch_encode_list_or_ring(KRING kring, KLIST klist, const EncodeArgs &a, hipStream_t st)
-{
-  static const uint32_t forced = knob_u32("HSRLE_RUNLIST", 0u);
-  if (a.residentWorkgroups != nullptr || a.ringSel == nullptr || forced == 2u || a.B < 1024u || a.B > 4096u || a.nBlocks < 131072u)
-    return launch_encode(kring, a, st, 0);
-  if (zero_async(a.ringSel, 16, st) != hipSuccess) return hipErrorUnknown;   // (a kernel, not hipMemsetAsync: hsrle_common.hip.h zero_async)
-  hipLaunchKernelGGL((k_ring_probe<S>), dim3(256), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.ringSel);
-  hipLaunchKernelGGL((k_list_decide<S>), dim3(1), dim3(64), 0, st, a.ringSel);
-  hipLaunchKernelGGL(kring, dim3((a.nBlocks + 63u) / 64u), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, (const uint64_t *)nullptr, (uint64_t *)nullptr,
-                     (const uint64_t *)nullptr, 0u, (uint64_t *)nullptr, 0u, (const uint32_t *)a.ringSel);
-  const uint32_t bpw = 64u;
-  hipLaunchKernelGGL(klist, dim3((a.nBlocks + bpw - 1u) / bpw), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.slots, a.slotStride, a.sizes, bpw, (const uint32_t *)a.ringSel);
-  return hipGetLastError();
-}
-
 #ifdef HSRLE_EXPERIMENTS
 template <typename KERNEL>
 inline hipError_t launch_wave_encode(KERNEL k, const WaveEncodeArgs &a, hipStream_t st)

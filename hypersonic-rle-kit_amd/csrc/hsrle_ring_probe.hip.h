@@ -70,18 +70,4 @@ __global__ void k_ring_decide(uint32_t *__restrict__ sel)
   sel[0] = pick;
 }
 
-// 3 and 4 byte symbols, big containers: ring encoder (k_encodeS_blocks, sel[0] = 128 = its ring) or run list encoder (k_encodeS_runlist,
-// sel[0] = 1)?  The run list encoder's work grows with the number of candidates, the ring encoder's with the bytes: at 4 GiB the run list
-// is 11 - 17 % faster on run-distributed data (7 - 9 runs per KiB) and 22 - 48 % slower on video-shaped data (37 - 38 per KiB;
-// experiments/r04/call26.sh).  Runs per KiB from the same probe: the run list below kRunListRunsPerKiB.
-constexpr uint32_t kRunListRunsPerKiB = 16;
-constexpr uint32_t kSelRunList = 1;
-template <int S>
-__global__ void k_list_decide(uint32_t *__restrict__ sel)
-{
-  if (threadIdx.x != 0u) return;
-  const uint64_t n = sel[1], r = sel[3];
-  sel[0] = (n != 0u && r * 1024u / n < kRunListRunsPerKiB) ? kSelRunList : 128u;
-}
-
 } // namespace hsrle

@@ -74,7 +74,7 @@ def test_blocks_bit_exact_and_roundtrip(hs, oracle, codec):
 @pytest.mark.parametrize("codec", CODECS, ids=lambda c: c.key)
 def test_small_containers_of_1_to_4_kib_blocks_bit_exact(hs, oracle, codec):
     """Containers of fewer than 131 072 blocks of 1 .. 4 KiB: rle8_multi / rle8_packed_multi and the plain / Packed / LUT codecs of 4, 6, 8 byte
-    symbols go through the run list encoders (csrc/hsrle_encode8r.hip.h, hsrle_encodeSr.hip.h), the others through the split encode or the
+    symbols went through the run list encoders until round 6 (now: the position-parallel encoders; csrc/hsrle_encode8r.hip.h still serves rle8_3symlut_short / rle8_7symlut_short), the others through the split encode or the
     ring encoders.  Whatever the path: every block stream == the oracle's, ragged last block included; decode == input."""
     rng = random.Random(4242 + CODECS.index(codec))
     parts = _inputs(777 + CODECS.index(codec), 60)
