@@ -2,6 +2,9 @@
 // (reference: src/rle.h:101-103, :173-175, :199-208).  rle8_decompress / rle8_packed_decompress decode both the multi
 // and the single mode, so the Single codec ids share the multi decode kernels.
 #include "hsrle_decode.hip.h"
+#ifdef HSRLE_DEC8_PE
+#include "experiments/hsrle_decode8pe.hip.h"
+#endif
 #include "hsrle_encode.hip.h"
 #include "hsrle_encode8.hip.h"
 #include "hsrle_encode8r.hip.h"
@@ -28,8 +31,13 @@ namespace hsrle {
 #define HSRLE_DEC8_RING HSRLE_DECODE_RING
 #endif
 constexpr int kDec8Tile = HSRLE_DEC8_TILE, kDec8Step = HSRLE_DEC8_STEP, kDec8Ring = HSRLE_DEC8_RING;
+#ifdef HSRLE_DEC8_PE   // experiment build: parse + expand (csrc/experiments/hsrle_decode8pe.hip.h) for plain containers of the two list-free multi-symbol codecs
+static hipError_t dec_plain(const DecodeArgs &a, hipStream_t st) { return a.entries ? launch_decode(k_decode_blocks<PLAIN, 1, 0, kDec8Tile, kDec8Ring, kDec8Step, false>, a, st) : launch_decode(k_decode8_pe<PLAIN>, a, st); }
+static hipError_t dec_packed(const DecodeArgs &a, hipStream_t st) { return a.entries ? launch_decode(k_decode_blocks<PACKED, 1, 0, kDec8Tile, kDec8Ring, kDec8Step, false>, a, st) : launch_decode(k_decode8_pe<PACKED>, a, st); }
+#else
 static hipError_t dec_plain(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<PLAIN, 1, 0, kDec8Tile, kDec8Ring, kDec8Step, false>, k_decode_blocks<PLAIN, 1, 0, kDec8Tile, 64, kDec8Step, false>, a, st); }
 static hipError_t dec_packed(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<PACKED, 1, 0, kDec8Tile, kDec8Ring, kDec8Step, false>, k_decode_blocks<PACKED, 1, 0, kDec8Tile, 64, kDec8Step, false>, a, st); }
+#endif
 static hipError_t dec_plain_any(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<PLAIN, 1, 0, kDec8Tile, kDec8Ring, kDec8Step, true>, k_decode_blocks<PLAIN, 1, 0, kDec8Tile, 64, kDec8Step, true>, a, st); }
 static hipError_t dec_packed_any(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<PACKED, 1, 0, kDec8Tile, kDec8Ring, kDec8Step, true>, k_decode_blocks<PACKED, 1, 0, kDec8Tile, 64, kDec8Step, true>, a, st); }
 static hipError_t dec_lut3(const DecodeArgs &a, hipStream_t st) { return launch_decode_ring(k_decode_blocks<LUT3, 1, 0, kDecodeTile, kDecodeRing, kDecodeStep>, k_decode_blocks<LUT3, 1, 0, kDecodeTile, 64, kDecodeStep>, a, st); }
