@@ -314,6 +314,7 @@ __device__ __forceinline__ void pp128_block(uint64_t U, uint32_t B, uint32_t b, 
     // ---- MODE 1: the stream from the block's records ----
     const uint32_t *const myRecs = sc.recs + (uint64_t)b * sc.recStride;
     const uint32_t R = sc.recCount[b];
+    const uint64_t myOffset = offsets[b];                                 // (asked for at the start, needed at the very end)
     wave_sync();
     uint32_t carL = 0, pos = HDR;
     bool ended = false;
@@ -395,7 +396,7 @@ __device__ __forceinline__ void pp128_block(uint64_t U, uint32_t B, uint32_t b, 
     }
     wave_sync();
     {
-      uint8_t *const dst = payload + offsets[b];
+      uint8_t *const dst = payload + myOffset;
       const uint32_t nFull = streamSize >> 4, tail = streamSize & 15u;
       for (uint32_t c = lane; c < nFull; c += 64u)
         st128(dst + 16u * c, lds_ld128(sh.img + 16u * c));

@@ -66,6 +66,10 @@ __device__ __forceinline__ int32_t wave_scan_max(int32_t v)     // inclusive; va
 }
 __device__ __forceinline__ uint32_t wave_lane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 
+#ifndef HSRLE_PP8_INPUT_LDS
+#define HSRLE_PP8_INPUT_LDS 1   // (round 6: 8 GiB rle8_packed_multi encode 1 727 -> 1 841 GiB/s; 0 = the global gather, A/B builds)
+#endif
+constexpr bool kPp8InputLds = HSRLE_PP8_INPUT_LDS != 0;        // MODE 0: a candidate's symbol from an LDS copy of the block instead of a global gather (A/B builds)
 constexpr uint32_t kPpCoopMin = 80u;                            // literal stretches longer than this are copied by the whole wave, shorter ones by their packet's lane
 constexpr uint32_t kPpJobs = kPpMaxBlock / (kPpCoopMin + 4u) + 2u;
 constexpr uint32_t kPpInPad = 16u;                              // the input image starts 16 bytes into its buffer (a literal window may begin up to 15 bytes in front of its stretch)
@@ -115,7 +119,7 @@ __device__ __forceinline__ void pp_load(const uint8_t *__restrict__ in, uint64_t
 // records (MODE 1; requested together with the input)
 template <int FAM, int MODE>
 __device__ __forceinline__ void pp_block(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t b, uint32_t *__restrict__ sizes, const uint64_t *__restrict__ offsets,
-                                         uint8_t *__restrict__ payload, const PpScratch &sc, PpShared<MODE != 0> &sh, const u32x4 (&x)[4], uint32_t rec0)
+                                         uint8_t *__restrict__ payload, const PpScratch &sc, PpShared<MODE != 0, kPp8InputLds || MODE != 0> &sh, const u32x4 (&x)[4], uint32_t rec0)
 {
   static_assert(FAM == PLAIN || FAM == PACKED, "the two list-free 8 bit multi-symbol codecs");
   constexpr bool PK = FAM == PACKED;
@@ -128,6 +132,12 @@ __device__ __forceinline__ void pp_block(const uint8_t *__restrict__ in, uint64_
   const uint32_t base = lane * 64u;
   const u32x4 zero4 = u32x4{ 0, 0, 0, 0 };
   const uint32_t *const myRecs = sc.recs + (uint64_t)b * sc.recStride;
+  // (the stream's place: asked for at the start, needed at the very end -- not a dependent load in front of the copy-out)
+  [[maybe_unused]] uint64_t myOffset = 0;
+  if constexpr (MODE == 1) myOffset = offsets[b];
+  // (and the block's second 64 records, where its record area holds that many: a block of more than 64 stored runs -- the rule on video-shaped data -- does not wait for them in its second round)
+  [[maybe_unused]] uint32_t rec1 = 0;                                    // (the third and fourth 64 too: measured no better, four loads for every block)
+  if constexpr (MODE == 1) { if (sc.recStride >= 128u) rec1 = myRecs[64u + threadIdx.x]; }
 
 #ifdef HSRLE_PP_STAMPS
   unsigned long long pst[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, pt0 = __builtin_amdgcn_s_memtime();
@@ -148,6 +158,11 @@ __device__ __forceinline__ void pp_block(const uint8_t *__restrict__ in, uint64_
     if (lane == 0u) sh.jobCount = 0u;
 #pragma unroll
     for (uint32_t j = 0; j < 4u; j++) lds_st128(sh.inb + kPpInPad + base + 16u * j, x[j]);   // (the first use of the input: the zeroing above ran while it was on its way)
+  }
+  if constexpr (MODE == 0 && kPp8InputLds)
+  {
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; j++) lds_st128(sh.inb + kPpInPad + base + 16u * j, x[j]);
   }
   HS_PSTAMP(0)
 
@@ -227,7 +242,7 @@ __device__ __forceinline__ void pp_block(const uint8_t *__restrict__ in, uint64_
     int k = 0;
     if (fromRecs)
     {
-      const uint32_t rec = (r0 == 0u) ? rec0 : (have ? myRecs[r0 + lane] : 0u);
+      const uint32_t rec = (r0 == 0u) ? rec0 : ((r0 == 64u && sc.recStride >= 128u) ? rec1 : (have ? myRecs[r0 + lane] : 0u));
       p = rec & 0xFFFu; e = ((rec >> 12) & 0xFFFu) + 1u;
       same = ((rec >> 24) & 1u) != 0u;
       k = have ? 1 + (int)((rec >> 25) & 1u) : 0;
@@ -254,7 +269,7 @@ __device__ __forceinline__ void pp_block(const uint8_t *__restrict__ in, uint64_
       p = (sBelow != 0ull) ? (iq << 6) + 63u - (uint32_t)__builtin_clzll(sBelow) : cs;
       e = q + 1u;
       const uint32_t count = e - p;
-      if constexpr (MODE != 0) sym = (uint32_t)sh.inb[kPpInPad + (have ? p : 0u)]; else sym = have ? (uint32_t)d[p] : 0u;
+      if constexpr (MODE != 0 || kPp8InputLds) sym = (uint32_t)sh.inb[kPpInPad + (have ? p : 0u)]; else sym = have ? (uint32_t)d[p] : 0u;
       bool body = true;
       if constexpr (PK)
       {
@@ -438,7 +453,7 @@ __device__ __forceinline__ void pp_block(const uint8_t *__restrict__ in, uint64_
     HS_PSTAMP(4)
     // ---- 4. the image leaves LDS once: whole 16-byte chunks at their final (unaligned) addresses, the last bytes one per lane ----
     {
-      uint8_t *const dst = payload + offsets[b];
+      uint8_t *const dst = payload + myOffset;
       const uint32_t nFull = streamSize >> 4, tail = streamSize & 15u;
       for (uint32_t c = lane; c < nFull; c += 64u)
         st128(dst + 16u * c, lds_ld128(sh.img + 16u * c));
@@ -456,7 +471,7 @@ template <int FAM, int MODE>
 __global__ __launch_bounds__(64) void k_encode8_pp(const uint8_t *__restrict__ in, uint64_t U, uint32_t B, uint32_t nBlocks, uint32_t *__restrict__ sizes,
                                                    const uint64_t *__restrict__ offsets, uint8_t *__restrict__ payload, PpScratch sc)
 {
-  __shared__ PpShared<MODE != 0> sh;
+  __shared__ PpShared<MODE != 0, kPp8InputLds || MODE != 0> sh;
   if constexpr (MODE != 0)
   {
     if (threadIdx.x < 17u)

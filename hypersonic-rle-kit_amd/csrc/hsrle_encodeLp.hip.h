@@ -67,6 +67,12 @@ __device__ __forceinline__ void ppL_block(uint64_t U, uint32_t B, uint32_t b, ui
   const uint32_t base = lane * 64u;
   const u32x4 zero4 = u32x4{ 0, 0, 0, 0 };
   const uint32_t *const myRecs = sc.recs + (uint64_t)b * sc.recStride;
+  // (the stream's place: asked for at the start, needed at the very end -- not a dependent load in front of the copy-out)
+  [[maybe_unused]] uint64_t myOffset = 0;
+  if constexpr (MODE == 1) myOffset = offsets[b];
+  // (and the block's second 64 records, where its record area holds that many: a block of more than 64 stored runs -- the rule on video-shaped data -- does not wait for them in its second round)
+  [[maybe_unused]] uint32_t rec1 = 0;                                    // (the third and fourth 64 too: measured no better, four loads for every block)
+  if constexpr (MODE == 1) { if (sc.recStride >= 128u) rec1 = myRecs[64u + threadIdx.x]; }
 
   uint32_t recN = kPpNoRecords;
   if constexpr (MODE == 1) recN = sc.recCount[b];
@@ -177,7 +183,7 @@ __device__ __forceinline__ void ppL_block(uint64_t U, uint32_t B, uint32_t b, ui
     uint32_t mtf = 0;
     if (fromRecs)
     {
-      const uint32_t rec = (r0 == 0u) ? rec0 : (have ? myRecs[r0 + lane] : 0u);
+      const uint32_t rec = (r0 == 0u) ? rec0 : ((r0 == 64u && sc.recStride >= 128u) ? rec1 : (have ? myRecs[r0 + lane] : 0u));
       p = rec & 0xFFFu; e = ((rec >> 12) & 0xFFFu) + 1u;
       mtf = (rec >> 24) & 7u;
       k = have ? 1 : 0;
@@ -615,7 +621,7 @@ __device__ __forceinline__ void ppL_block(uint64_t U, uint32_t B, uint32_t b, ui
     }
     wave_sync();
     {
-      uint8_t *const dst = payload + offsets[b];
+      uint8_t *const dst = payload + myOffset;
       const uint32_t nFull = streamSize >> 4, tail = streamSize & 15u;
       for (uint32_t c = lane; c < nFull; c += 64u)
         st128(dst + 16u * c, lds_ld128(sh.img + 16u * c));
