@@ -70,6 +70,10 @@ __device__ __forceinline__ uint32_t wave_lane(uint32_t v, int l) { return (uint3
 #define HSRLE_PP8_INPUT_LDS 1   // (round 6: 8 GiB rle8_packed_multi encode 1 727 -> 1 841 GiB/s; 0 = the global gather, A/B builds)
 #endif
 constexpr bool kPp8InputLds = HSRLE_PP8_INPUT_LDS != 0;        // MODE 0: a candidate's symbol from an LDS copy of the block instead of a global gather (A/B builds)
+#ifndef HSRLE_PP8_BPW
+#define HSRLE_PP8_BPW 1
+#endif
+constexpr uint32_t kPp8Bpw = HSRLE_PP8_BPW;                      // blocks per wave of k_encode8_pp, the next block's input requested ahead (A/B builds; round 6, 8 GiB: 2 -> 1 745, 4 -> 1 775 GiB/s against 1 836 with one block per wave)
 constexpr uint32_t kPpCoopMin = 80u;                            // literal stretches longer than this are copied by the whole wave, shorter ones by their packet's lane
 constexpr uint32_t kPpJobs = kPpMaxBlock / (kPpCoopMin + 4u) + 2u;
 constexpr uint32_t kPpInPad = 16u;                              // the input image starts 16 bytes into its buffer (a literal window may begin up to 15 bytes in front of its stretch)
@@ -485,14 +489,43 @@ __global__ __launch_bounds__(64) void k_encode8_pp(const uint8_t *__restrict__ i
     }
     wave_sync();
   }
-  const uint32_t b = xcd_tile(blockIdx.x, gridDim.x);
-  if (b < nBlocks)
+  if constexpr (kPp8Bpw == 1u)
   {
-    u32x4 x[4];
-    pp_load(in, U, B, b, x);
-    uint32_t rec0 = 0;
-    if constexpr (MODE == 1) rec0 = sc.recs[(uint64_t)b * sc.recStride + threadIdx.x];   // (the first 64 records -- or garbage in front of fewer: requested with the input)
-    pp_block<FAM, MODE>(in, U, B, b, sizes, offsets, payload, sc, sh, x, rec0);
+    const uint32_t b = xcd_tile(blockIdx.x, gridDim.x);
+    if (b < nBlocks)
+    {
+      u32x4 x[4];
+      pp_load(in, U, B, b, x);
+      uint32_t rec0 = 0;
+      if constexpr (MODE == 1) rec0 = sc.recs[(uint64_t)b * sc.recStride + threadIdx.x];   // (the first 64 records -- or garbage in front of fewer: requested with the input)
+      pp_block<FAM, MODE>(in, U, B, b, sizes, offsets, payload, sc, sh, x, rec0);
+    }
+  }
+  else
+  {
+    // kPp8Bpw consecutive blocks per wave, the next block's input (and first records) requested before the current block is worked on
+    const uint32_t b0 = xcd_tile(blockIdx.x, gridDim.x) * kPp8Bpw;
+    if (b0 >= nBlocks) return;
+    u32x4 x[4], xn[4];
+    uint32_t rec0 = 0, rec0n = 0;
+    pp_load(in, U, B, b0, x);
+    if constexpr (MODE == 1) rec0 = sc.recs[(uint64_t)b0 * sc.recStride + threadIdx.x];
+    for (uint32_t i = 0; i < kPp8Bpw; i++)
+    {
+      const uint32_t b = b0 + i;
+      if (b >= nBlocks) break;
+      const bool more = i + 1u < kPp8Bpw && b + 1u < nBlocks;
+      if (more)
+      {
+        pp_load(in, U, B, b + 1u, xn);
+        if constexpr (MODE == 1) rec0n = sc.recs[(uint64_t)(b + 1u) * sc.recStride + threadIdx.x];
+      }
+      pp_block<FAM, MODE>(in, U, B, b, sizes, offsets, payload, sc, sh, x, rec0);
+      wave_sync();
+#pragma unroll
+      for (int j = 0; j < 4; j++) x[j] = xn[j];
+      rec0 = rec0n;
+    }
   }
 }
 

@@ -13,9 +13,9 @@ static hipError_t pp_launch(const PpArgs &a, int phase, hipStream_t st)
   sc.recCount = sc.recs + (uint64_t)sc.recStride * a.nBlocks + 64u;   // (+ 64: the last block's lanes read 64 words from its first record on)
   sc.stamps = a.scratch + ((pp_scratch_bytes(a.nBlocks, a.B) + 255ull) & ~255ull);   // (diagnostic builds: 128 bytes per block behind the scratch, in the caller's slot area)
   if (phase == 0)
-    hipLaunchKernelGGL((k_encode8_pp<FAM, 0>), dim3(a.nBlocks), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.sizes, a.offsets, a.payload, sc);
+    hipLaunchKernelGGL((k_encode8_pp<FAM, 0>), dim3((a.nBlocks + kPp8Bpw - 1u) / kPp8Bpw), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.sizes, a.offsets, a.payload, sc);
   else
-    hipLaunchKernelGGL((k_encode8_pp<FAM, 1>), dim3(a.nBlocks), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.sizes, a.offsets, a.payload, sc);
+    hipLaunchKernelGGL((k_encode8_pp<FAM, 1>), dim3((a.nBlocks + kPp8Bpw - 1u) / kPp8Bpw), dim3(64), 0, st, a.in, a.U, a.B, a.nBlocks, a.sizes, a.offsets, a.payload, sc);
   return hipGetLastError();
 }
 
