@@ -72,6 +72,7 @@ static IndexLaunch g_idx[kCodecCount];
 static SubBlockLaunch g_sub[kCodecCount];
 static MonoEncodeLaunch g_menc[kCodecCount];
 static WaveEncodeLaunch g_wenc[kCodecCount];
+static PpwLaunch g_ppw[2];                         // ... for units of any length (hsrle_encode8pw.hip.h): rle8_multi, rle8_packed_multi
 static PpLaunch g_pp[kCodecCount];                  // position-parallel encoders (hsrle_encode8p.hip.h)
 static std::once_flag g_tableOnce;
 
@@ -80,6 +81,7 @@ static void init_tables()
   std::call_once(g_tableOnce, [] {
     register_w8(g_dec, g_enc, g_idx, g_sub, g_menc, g_wenc);
     register_pp8(g_pp);
+    register_pp8w(g_ppw);
     register_pp8s(g_pp);
     register_pp128(g_pp);
     register_ppL(g_pp);
@@ -646,6 +648,19 @@ static bool pp_applies(int codec, uint32_t nBlocks, uint32_t B)
   return force == 1u || nBlocks >= kPpMinBlocks;
 }
 
+// ... and, window by window, their containers of blocks above 4 KiB (hsrle_encode8pw.hip.h), whatever their size: 8 MiB of 8 KiB / 64 KiB blocks 19 / 51 us against
+// 211 / 1 187 us of the split encode, 8 GiB 5.0 / 5.0 ms against 7.4 / 7.6 of the ring encoders + k_compact (1 MiB blocks: 5.5 against 20.7; experiments/r06, calls 22, 25)
+#ifndef HSRLE_PPW_MIN_BLOCKS
+#define HSRLE_PPW_MIN_BLOCKS 1u
+#endif
+constexpr uint32_t kPpwMinBlocks = HSRLE_PPW_MIN_BLOCKS;   // (A/B builds: 0xFFFFFFFF = never, also for the monolithic streams)
+static bool ppw_applies(int codec, uint32_t nBlocks, uint32_t B)
+{
+  static const uint32_t force = knob_u32("HSRLE_PP", 0u);
+  if ((codec != 0 && codec != 1) || !g_ppw[codec] || B <= kPpMaxBlock || force == 2u) return false;
+  return force == 1u || nBlocks >= kPpwMinBlocks;
+}
+
 static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, uint64_t cap, uint32_t B, void *dWs, uint64_t wsSize, hipStream_t st, bool noSplit = false)
 {
   if (codec < 0 || codec >= kCodecCount || dIn == nullptr || dOut == nullptr || U == 0)
@@ -730,6 +745,27 @@ static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, ui
     else if (scan_sizes(sizes, nBlocks, offsets, ws, w, st) != hipSuccess)
       rc = HSRLE_ERR_DEVICE;
     if (rc == HSRLE_OK && g_pp[codec](pa, 1, st) != hipSuccess)
+      rc = HSRLE_ERR_DEVICE;
+  }
+  else if (w.nChunks <= 1 && ppw_applies(codec, nBlocks, B))
+  {
+    // the same encoder, a block walked in windows of 4 KiB: a wave per block leaves sizes, window states and records; after the scan a wave per window writes
+    // the packets of the runs that end in it.  States and records live in the slot area (1 056 bytes per window).
+    PpwArgs pa{};
+    pa.in = (const uint8_t *)dIn; pa.U = U; pa.B = B; pa.nUnits = nBlocks; pa.sizes = sizes; pa.offsets = offsets; pa.payload = payload;
+    pa.nWindows = nBlocks * ((B + kPpwWindow - 1u) / kPpwWindow);
+    pa.states = (uint32_t *)(ws + w.offSlots);
+    pa.recs = (uint32_t *)(ws + w.offSlots + align_up(4ull * kPpwStateWords * pa.nWindows, 256));
+    if (g_ppw[codec](pa, 0, st) != hipSuccess)
+      rc = HSRLE_ERR_DEVICE;
+    else if (nBlocks <= kScanSmallMax && (((uintptr_t)sizes) & 15u) == 0u)
+    {
+      hipLaunchKernelGGL(k_scan_small_finish, dim3((nBlocks + kScanTile - 1u) / kScanTile), dim3(kScanThreads), 0, st, (const uint32_t *)sizes, nBlocks, offsets, container, (uint32_t)codec, U, B);
+      finished = true;
+    }
+    else if (scan_sizes(sizes, nBlocks, offsets, ws, w, st) != hipSuccess)
+      rc = HSRLE_ERR_DEVICE;
+    if (rc == HSRLE_OK && g_ppw[codec](pa, 1, st) != hipSuccess)
       rc = HSRLE_ERR_DEVICE;
   }
   else if (w.nChunks <= 1 && w.spSlots != 0 && split_encode_applies(codec, w.nBlocks, B))
@@ -1448,18 +1484,26 @@ static thread_local uint32_t g_monoEncLast[4] = { 0, 0, 0, 0 };   // this thread
 struct MonoEncPlan
 {
   uint32_t G, pieces;
+  bool windowed;                                       // rle8_multi / rle8_packed_multi: chunks of any length by the windowed position-parallel encoder (hsrle_encode8pw.hip.h)
   uint64_t offCutPos, offCutSym, offFlags, offIdx, offStarts, offSyms, offSlotOff, offSizes, offOffsets, offL1, offL2, offL3, offCtrl, offSlots, total;
   uint64_t offGuess, offListOut, offRoll1, offRoll2;   // codecs with a move-to-front list: 8 words per chunk / per 64 / per 4096 chunks
   uint64_t offPick;                                    // 8 bit Single: the symbol pick's sums (k_single_pick_mono)
   uint64_t offJobs; uint32_t jobCap;                   // 8 bit Single: literal stretches noted by the chunk encoders for k_copy_jobs
 };
 
-static MonoEncPlan plan_mono_encode(uint32_t U, bool lists = true)
+static bool mono_windowed(int codec) { return (codec == 0 || codec == 1) && g_ppw[codec] != nullptr && kPpwMinBlocks != 0xFFFFFFFFu && knob_u32("HSRLE_PP", 0u) != 2u; }
+
+static MonoEncPlan plan_mono_encode(uint32_t U, int codec, bool lists = true)
 {
   MonoEncPlan m;
+  init_tables();
+  m.windowed = mono_windowed(codec);
   // ~131 072 pieces (= lanes) keep the device busy: 1 GiB: 8 KiB pieces 780 GiB/s, 4 KiB 720; 256 MiB: 2 KiB 523, 4 KiB 321; 88 MB: 1 KiB 286, 2 KiB 224
   uint32_t G = 1024u;
   while (G < 8192u && ((uint64_t)U + G - 1u) / G > 131072ull) G *= 2u;
+  // windowed: a chunk is a WAVE's work and every chunk ends with a partial window, so the pieces are several windows long as soon as that leaves
+  // ~6 000 of them (1 GiB: 4 / 8 / 16 / 32 / 64 / 128 KiB pieces 1.72 / 1.23 / 1.09 / 1.00 / 0.95 / 0.97 ms; 88 MB: 0.25 / 0.22 / 0.20 / 0.21 / 0.22 / 0.26)
+  if (m.windowed) { G = 8192u; while (G < 65536u && (uint64_t)U / G > 6000ull) G *= 2u; }
   if (g_monoTune[1] >= 32u && g_monoTune[1] <= (1u << 24)) G = g_monoTune[1];
   m.G = G;
   m.pieces = (uint32_t)(((uint64_t)U + G - 1u) / G);
@@ -1490,12 +1534,15 @@ static MonoEncPlan plan_mono_encode(uint32_t U, bool lists = true)
     m.offRoll1 = at; at += align_up(64ull * ((n + 1) / 64 + 1), 256);
     m.offRoll2 = at; at += align_up(64ull * ((n + 1) / 4096 + 1), 256);
   }
-  m.offSlots = at; at += align_up((uint64_t)U + ((uint64_t)U >> 7) + 256ull * (n + 2) + 4096ull, 256);
+  // (windowed: no staging slots -- the window states and records live there: 32 + 1 024 bytes per window, at most U / 4 096 + chunks windows)
+  const uint64_t windowsMax = ((uint64_t)U >> 12) + n + 1ull;
+  const uint64_t slotBytes = (uint64_t)U + ((uint64_t)U >> 7) + 256ull * (n + 2) + 4096ull, windowBytes = align_up(4ull * kPpwStateWords * windowsMax, 256) + 4ull * kPpwStride * windowsMax + 512ull;
+  m.offSlots = at; at += align_up(m.windowed && windowBytes > slotBytes ? windowBytes : slotBytes, 256);
   m.total = at;
   return m;
 }
 
-// dOut: capacity >= rle_compress_bounds(U).  Synchronises the stream twice (chunk count, stream size).
+// dOut: capacity >= rle_compress_bounds(U).  Synchronises the stream twice (chunk count, stream size) -- the windowed encoders once, at the end.
 static int mono_encode_dev(int codec, const uint8_t *dIn, uint32_t U, uint8_t *dOut, uint8_t *ws, const MonoEncPlan &m, uint32_t *pSize, uint32_t *pChunks, hipStream_t st)
 {
   init_tables();
@@ -1543,6 +1590,30 @@ static int mono_encode_dev(int codec, const uint8_t *dIn, uint32_t U, uint8_t *d
     return HSRLE_ERR_DEVICE;
   hipLaunchKernelGGL(k_mono_scatter, dim3((m.pieces + 255u) / 256u), dim3(256), 0, st, (const uint64_t *)cutPos, (const uint64_t *)cutSym, (const uint32_t *)flags, (const uint64_t *)idx,
                      m.pieces, (uint64_t)U, starts, syms, slotOff, ctrl);
+  // rle8_multi / rle8_packed_multi: the windowed position-parallel encoder takes chunks of any length (hsrle_encode8pw.hip.h) -- no step bound, no staging slots
+  const uint64_t windowsMax = ((uint64_t)U >> 12) + m.pieces + 1ull;
+  const bool windowed = m.windowed && mono_windowed(codec);
+  if (windowed)
+  {
+    // every piece may be a chunk: a wave per possible chunk (those behind the last one write a zero size), a wave per possible window -- nothing is read back
+    // before the end
+    PpwArgs pa{};
+    pa.in = dIn; pa.U = U; pa.B = 0u; pa.nUnits = m.pieces + 1u; pa.starts = starts; pa.syms = syms; pa.count = ctrl; pa.sizes = sizes; pa.offsets = offsets; pa.payload = dOut + hs;
+    pa.nWindows = (uint32_t)windowsMax;
+    pa.states = (uint32_t *)(ws + m.offSlots);
+    pa.recs = (uint32_t *)(ws + m.offSlots + align_up(4ull * kPpwStateWords * windowsMax, 256));
+    if (g_ppw[codec](pa, 0, st) != hipSuccess || scan_sizes(sizes, pa.nUnits, offsets, ws, w, st) != hipSuccess || g_ppw[codec](pa, 1, st) != hipSuccess)
+      return HSRLE_ERR_DEVICE;
+    hipLaunchKernelGGL(k_mono_finish, dim3(1), dim3(64), 0, st, dOut, U, hs, (const uint64_t *)offsets, (const uint32_t *)ctrl, ctrl, 0u);
+    uint32_t back[4] = { 0, 0, 0, 0 };                                    // chunks, -, stream size, error
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(back, ctrl, 16, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+      return HSRLE_ERR_DEVICE;
+    if (back[0] == 0u || back[0] > m.pieces + 1u || back[3] != 0u || back[2] == 0u)
+      return HSRLE_ERR_DEVICE;
+    if (pChunks) *pChunks = back[0];
+    *pSize = back[2];
+    return HSRLE_OK;
+  }
   hipLaunchKernelGGL(k_mono_longest, dim3((m.pieces + 1u + 255u) / 256u), dim3(256), 0, st, (const uint64_t *)starts, ctrl);
   uint32_t head[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
   if (hipMemcpyAsync(head, ctrl, 40, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
@@ -1661,7 +1732,7 @@ static uint32_t mono_compress(int codec, const uint8_t *pIn, uint32_t inSize, ui
   // many lanes where the codec allows it (cuts behind long runs, hsrle_mono_encode.hip.h); else -- and for inputs of one piece -- one lane
   if (mono_cut_long(codec) != 0u && g_menc[codec])
   {
-    const MonoEncPlan m = plan_mono_encode(inSize);
+    const MonoEncPlan m = plan_mono_encode(inSize, codec);
     if (m.pieces >= 2u)
     {
       if (!grow(&D.monoWs, &D.monoWsSize, m.total))
@@ -1979,7 +2050,7 @@ int hsrle_encode_path(int codec, uint64_t uncompressedSize, uint32_t blockSize)
   if (codec < 0 || codec >= kCodecCount || uncompressedSize == 0 || !valid_block_size(blockSize)) return -1;
   const Workspace w = plan_workspace(uncompressedSize, blockSize);
   init_tables();
-  if (w.nChunks <= 1 && pp_applies(codec, (uint32_t)w.nBlocks, blockSize)) return HSRLE_PATH_POSITION_PARALLEL;
+  if (w.nChunks <= 1 && (pp_applies(codec, (uint32_t)w.nBlocks, blockSize) || ppw_applies(codec, (uint32_t)w.nBlocks, blockSize))) return HSRLE_PATH_POSITION_PARALLEL;
   if (w.nChunks <= 1 && w.spSlots != 0 && split_encode_applies(codec, w.nBlocks, blockSize)) return HSRLE_PATH_SPLIT;
   if (w.nChunks <= 1 && run_list_codec(codec) && run_list_applies(w.nBlocks, blockSize, uncompressedSize, knob_u32("HSRLE_RUNLIST", 0u))) return HSRLE_PATH_RUN_LIST;
   return HSRLE_PATH_RING;
@@ -2699,7 +2770,7 @@ void hsrle_mono_encode_stats(uint32_t stats[4])
 uint64_t hsrle_compress_mono_workspace_size(int codec, uint32_t inSize)
 {
   if (codec < 0 || codec >= kCodecCount || inSize == 0 || inSize > (1u << 30) || mono_cut_long(codec) == 0u) return 0;
-  return plan_mono_encode(inSize).total;
+  return plan_mono_encode(inSize, codec).total;
 }
 
 int hsrle_compress_mono_dev(int codec, const void *dIn, uint32_t inSize, void *dOut, uint64_t outCapacity, void *dWorkspace, uint64_t workspaceSize, uint32_t *pStreamSize,
@@ -2709,7 +2780,7 @@ int hsrle_compress_mono_dev(int codec, const void *dIn, uint32_t inSize, void *d
   if (inSize > (1u << 30) || mono_cut_long(codec) == 0u) return HSRLE_ERR_UNSUPPORTED;
   if (outCapacity < bounds32(inSize)) return HSRLE_ERR_CAPACITY;
   if (!device_ok()) return HSRLE_ERR_DEVICE;
-  const MonoEncPlan m = plan_mono_encode(inSize);
+  const MonoEncPlan m = plan_mono_encode(inSize, codec);
   if (workspaceSize < m.total) return HSRLE_ERR_CAPACITY;
   return mono_encode_dev(codec, (const uint8_t *)dIn, inSize, (uint8_t *)dOut, (uint8_t *)dWorkspace, m, pStreamSize, pChunks, (hipStream_t)stream);
 }

@@ -94,6 +94,29 @@ struct PpArgs
 inline uint32_t pp_record_stride(uint32_t B) { return B / 4u < kPpRecords ? B / 4u : kPpRecords; }      // (4 * stride + 4 bytes per block: less than a staging slot of B + 193)
 inline uint64_t pp_scratch_bytes(uint64_t nBlocks, uint32_t B) { return (4ull * pp_record_stride(B) + 4ull) * nBlocks + 256ull; }
 typedef hipError_t (*PpLaunch)(const PpArgs &, int phase, hipStream_t);
+// the same encoder for units of any length, window by window (hsrle_encode8pw.hip.h): phase 0 = one wave per unit (sizes[], window states, records),
+// phase 1 = one wave per window (the packets of the runs that end in it)
+constexpr uint32_t kPpwWindow = kPpMaxBlock;                    // bytes per window
+constexpr uint32_t kPpwStateWords = 8u;                          // per window: posW, lastRLE, openStart, lastSymbol, stored runs, unit, window in unit, -
+constexpr uint32_t kPpwEmpty = 0xFFFFFFFEu;                      // state word 4: no such window
+constexpr uint32_t kPpwStride = kPpRecords;                      // records per window
+
+struct PpwArgs
+{
+  const uint8_t *in; uint64_t U;
+  uint32_t B;                     // != 0: the units are the blocks of a container (header + terminator each); 0: the chunks of ONE stream (no header, the last one ends it)
+  uint32_t nUnits;                // blocks / an upper bound of the chunks
+  const uint64_t *starts;         // chunks: [count + 1] input positions
+  const uint64_t *syms;           // chunks: lastSymbol in front of each
+  const uint32_t *count;          // chunks: how many there are (device)
+  uint32_t *sizes; const uint64_t *offsets; uint8_t *payload;
+  uint32_t *states;               // [nWindows][kPpwStateWords]
+  uint32_t *recs;                 // [nWindows][kPpwStride]
+  uint32_t nWindows;
+};
+inline uint64_t ppw_scratch_bytes(uint64_t nWindows) { return nWindows * (4ull * kPpwStateWords + 4ull * kPpwStride) + 512ull; }
+
+typedef hipError_t (*PpwLaunch)(const PpwArgs &, int phase, hipStream_t);
 typedef hipError_t (*DecodeLaunch)(const DecodeArgs &, hipStream_t);
 typedef hipError_t (*EncodeLaunch)(const EncodeArgs &, hipStream_t);
 
@@ -118,6 +141,7 @@ constexpr int kDecodeRing = HSRLE_DECODE_RING; // per-lane stream ring in LDS (k
 
 void register_w8(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub, MonoEncodeLaunch *menc, WaveEncodeLaunch *wenc);
 void register_pp8(PpLaunch *pp);
+void register_pp8w(PpwLaunch *ppw);   // [0] rle8_multi, [1] rle8_packed_multi
 void register_pp8s(PpLaunch *pp);
 void register_pp128(PpLaunch *pp);
 void register_ppL(PpLaunch *pp);

@@ -96,6 +96,10 @@ def test_encode_path_selection(lib):
         assert cid(name) >= 0
         for size, block in ((frame, 4096), (frame, 1024), (frame, 512), (8 << 30, 4096), (4096, 128)):
             assert lib.hsrle_encode_path(cid(name), size, block) == PP, (name, size, block)
+        if name in ("rle8_multi", "rle8_packed_multi"):      # round 6: blocks of any size, a wave per 4 KiB window (csrc/hsrle_encode8pw.hip.h)
+            for size, block in ((frame, 8192), (8 << 30, 8192), (8 << 30, 65536), (1 << 20, 1 << 20), (frame, 4224)):
+                assert lib.hsrle_encode_path(cid(name), size, block) == PP, (name, size, block)
+            continue
         assert lib.hsrle_encode_path(cid(name), frame, 8192) == SPLIT, name         # a wave holds 4 KiB: larger blocks by chunks
         assert lib.hsrle_encode_path(cid(name), 8 << 30, 8192) == RING, name
     for name in ("rle8_3symlut_short", "rle8_7symlut_short"):      # (the two Short codecs with a list that are not position-parallel: every pair of equal bytes would be a candidate)

@@ -91,6 +91,84 @@ def test_position_parallel_encoder_synthetic_workloads(hs, oracle, key, kind):
     _check(hs, oracle, key, data, 4096)
 
 
+# ---- the same two codecs, units of any length walked in 4 KiB windows (csrc/hsrle_encode8pw.hip.h): blocks above 4 KiB, monolithic streams ----
+def _edge_runs(rng, n):
+    """runs placed on the 4 KiB window edges: ending 0 .. 3 bytes in front of / behind an edge, runs of two across it, runs of many windows, literal stretches of many windows"""
+    out = rng.integers(0, 256, n, dtype=np.uint8)
+    at = 4096
+    while at + 40000 < n:
+        kind = int(rng.integers(0, 6))
+        d = int(rng.integers(-3, 4))
+        if kind == 0:
+            L = int(rng.choice([2, 3, 4, 5, 6, 10, 11, 12]))
+            out[at + d - L // 2 : at + d - L // 2 + L] = rng.integers(0, 4)
+        elif kind == 1:
+            L = int(rng.choice([2, 3, 4, 6, 11, 130, 300]))
+            out[at + d - L : at + d] = rng.integers(0, 4)                    # ends at the edge + d
+        elif kind == 2:
+            L = int(rng.choice([2, 3, 4, 6, 11, 130, 300]))
+            out[at + d : at + d + L] = rng.integers(0, 4)                    # starts at the edge + d
+        elif kind == 3:
+            out[at + d - 5000 : at + d + int(rng.choice([1, 2, 3, 4096, 9000]))] = rng.integers(0, 4)   # many windows long
+        elif kind == 4:
+            out[at - 3 : at + 3] = rng.integers(0, 256, 6, dtype=np.uint8)     # nothing at this edge
+        else:
+            v = int(rng.integers(0, 4))
+            out[at - 8 : at - 4] = v; out[at - 2 : at + 2] = v; out[at + 5 : at + 8] = v   # short runs of ONE symbol around the edge (Packed: the same-symbol rule)
+        at += 4096 * int(rng.choice([1, 1, 2, 3, 7]))
+    return out
+
+
+@pytest.fixture(scope="module")
+def window_cases(cases):
+    rng = np.random.default_rng(60606)
+    out = dict(cases)
+    out["edges"] = _edge_runs(rng, 4 << 20)
+    return out
+
+
+WINDOW_NAMES = ["zeros", "random", "two_symbols", "threes", "short_chains", "mixed", "long_literals", "same_symbol", "edges"]
+
+
+@pytest.mark.parametrize("key", KEYS)
+@pytest.mark.parametrize("name", WINDOW_NAMES)
+@pytest.mark.parametrize("block,cut", [(4224, 0), (8192, 777), (12416, 1), (65536, 4097), (1 << 20, 65533)])
+def test_windowed_encoder_blocks_bit_exact(hs, oracle, window_cases, key, name, block, cut):
+    data = window_cases[name]
+    assert hs.lib().hsrle_encode_path(hs.codec_id(key), data.size - cut, block) == 3      # HSRLE_PATH_POSITION_PARALLEL
+    _check(hs, oracle, key, data[: data.size - cut], block)
+
+
+@pytest.mark.parametrize("key", KEYS)
+def test_windowed_encoder_takes_the_headline_buffer_with_large_blocks(hs, key):
+    for block in (8192, 65536):
+        assert hs.lib().hsrle_encode_path(hs.codec_id(key), 8 << 30, block) == 3
+
+
+@pytest.mark.parametrize("key", KEYS)
+@pytest.mark.parametrize("name", WINDOW_NAMES)
+@pytest.mark.parametrize("n", [4 << 20, (1 << 20) + 4097, 123457, 8193])
+def test_windowed_encoder_monolithic_stream_bit_exact(hs, oracle, window_cases, key, name, n):
+    """hsrle_compress_mono_dev: ONE stream, cut behind long runs, a wave per chunk then a wave per window == the reference's stream (src/rle8_extreme_cpu.h:86-344)"""
+    import torch
+
+    part = window_cases[name][:n]
+    got = hs.mono_compress_dev(key, torch.from_numpy(part).cuda()).cpu().numpy().tobytes()
+    assert got == oracle.compress(CODEC_BY_KEY[key], part.tobytes())
+
+
+@pytest.mark.parametrize("key", KEYS)
+@pytest.mark.parametrize("kind", [SYNTH_RUNS, SYNTH_VIDEO])
+def test_windowed_encoder_synthetic_workloads(hs, oracle, key, kind):
+    import torch
+
+    data = oracle.synth(kind, 1, 12, (24 << 20) + 4099)
+    _check(hs, oracle, key, data, 65536)
+    _check(hs, oracle, key, data, 16384)
+    got = hs.mono_compress_dev(key, torch.from_numpy(data).cuda()).cpu().numpy().tobytes()
+    assert got == oracle.compress(CODEC_BY_KEY[key], data.tobytes())
+
+
 # ---- 2 .. 8 byte symbols, plain and Packed (csrc/hsrle_encodeSp.hip.h; reference: src/rleX_extreme_cpu_encode.h:14-609) ----
 WIDE_KEYS = [f"rle{w}_{v}" for w in (16, 24, 32, 48, 64) for v in ("sym", "sym_packed", "byte", "byte_packed")]
 

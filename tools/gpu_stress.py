@@ -31,7 +31,7 @@ while time.time()-t0<budget:
     if tail and len(data)>tail: data=data[:len(data)-tail]
     arr=np.frombuffer(data,dtype=np.uint8)
     src=torch.from_numpy(arr.copy()).cuda()
-    for bs in rng.sample([128,256,384,1024,1536,3072,4096,65536],3):
+    for bs in rng.sample([128,256,384,1024,1536,3072,4096,4224,8192,12416,65536],3):
         for c in rng.sample(CODECS,min(10,len(CODECS))):
             cont,info=hsrle.compress(c.key,src,block_size=bs)
             _,streams=hsrle.split_container(cont.cpu().numpy().tobytes())
