@@ -658,6 +658,7 @@ static bool ppw_applies(int codec, uint32_t nBlocks, uint32_t B)
 {
   static const uint32_t force = knob_u32("HSRLE_PP", 0u);
   if ((codec != 0 && codec != 1) || !g_ppw[codec] || B <= kPpMaxBlock || force == 2u) return false;
+  if ((uint64_t)nBlocks * ((B + kPpwWindow - 1u) / kPpwWindow) > 0xFFFFFFF0ull) return false;            // (windows are counted in 32 bits: 16 TiB)
   return force == 1u || nBlocks >= kPpwMinBlocks;
 }
 
@@ -1479,6 +1480,8 @@ static int compress_split(int codec, const uint8_t *dIn, uint64_t U, uint32_t B,
 }
 
 constexpr uint32_t kMonoListRounds = 64u;     // repair rounds of the guessed move-to-front lists before the caller falls back to one lane
+__global__ void k_copy_word(const uint32_t *__restrict__ from, uint32_t *__restrict__ to) { *to = *from; }
+
 static thread_local uint32_t g_monoEncLast[4] = { 0, 0, 0, 0 };   // this thread's last list-codec encode: extra rounds, chunks encoded again in rounds 1, 2, chunks the proof rejected (hsrle_mono_encode_stats)
 
 struct MonoEncPlan
@@ -1559,7 +1562,7 @@ static int mono_encode_dev(int codec, const uint8_t *dIn, uint32_t U, uint8_t *d
   Workspace w{};
   w.offL1 = m.offL1; w.offL2 = m.offL2; w.offL3 = m.offL3;
 
-  if (hipMemsetAsync(ctrl, 0, 64, st) != hipSuccess)
+  if (zero_async(ctrl, 64, st) != hipSuccess)                            // (a kernel, not hipMemsetAsync: the windowed flow below can be captured in a HIP graph, see zero_async)
     return HSRLE_ERR_DEVICE;
   if (single)
   {
@@ -1605,6 +1608,12 @@ static int mono_encode_dev(int codec, const uint8_t *dIn, uint32_t U, uint8_t *d
     if (g_ppw[codec](pa, 0, st) != hipSuccess || scan_sizes(sizes, pa.nUnits, offsets, ws, w, st) != hipSuccess || g_ppw[codec](pa, 1, st) != hipSuccess)
       return HSRLE_ERR_DEVICE;
     hipLaunchKernelGGL(k_mono_finish, dim3(1), dim3(64), 0, st, dOut, U, hs, (const uint64_t *)offsets, (const uint32_t *)ctrl, ctrl, 0u);
+    if (pSize == nullptr)
+    {
+      // hsrle_compress_mono_dev_async: the size stays on the device (the stream's own header holds it; pChunks, if given, is a DEVICE word that receives it too)
+      if (pChunks) hipLaunchKernelGGL(k_copy_word, dim3(1), dim3(1), 0, st, (const uint32_t *)(ctrl + 2), pChunks);
+      return hipGetLastError() == hipSuccess ? HSRLE_OK : HSRLE_ERR_DEVICE;
+    }
     uint32_t back[4] = { 0, 0, 0, 0 };                                    // chunks, -, stream size, error
     if (hipGetLastError() != hipSuccess || hipMemcpyAsync(back, ctrl, 16, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
       return HSRLE_ERR_DEVICE;
@@ -2783,6 +2792,19 @@ int hsrle_compress_mono_dev(int codec, const void *dIn, uint32_t inSize, void *d
   const MonoEncPlan m = plan_mono_encode(inSize, codec);
   if (workspaceSize < m.total) return HSRLE_ERR_CAPACITY;
   return mono_encode_dev(codec, (const uint8_t *)dIn, inSize, (uint8_t *)dOut, (uint8_t *)dWorkspace, m, pStreamSize, pChunks, (hipStream_t)stream);
+}
+
+int hsrle_compress_mono_dev_async(int codec, const void *dIn, uint32_t inSize, void *dOut, uint64_t outCapacity, void *dWorkspace, uint64_t workspaceSize, uint32_t *dStreamSize,
+                                  void *stream)
+{
+  if (!dIn || !dOut || !dWorkspace || codec < 0 || codec >= kCodecCount || inSize == 0) return HSRLE_ERR_ARGUMENT;
+  if (inSize > (1u << 30) || mono_cut_long(codec) == 0u) return HSRLE_ERR_UNSUPPORTED;
+  if (outCapacity < bounds32(inSize)) return HSRLE_ERR_CAPACITY;
+  if (!device_ok()) return HSRLE_ERR_DEVICE;
+  const MonoEncPlan m = plan_mono_encode(inSize, codec);
+  if (!m.windowed) return HSRLE_ERR_UNSUPPORTED;                          // (the other codecs' flows read chunk counts and list verdicts back)
+  if (workspaceSize < m.total) return HSRLE_ERR_CAPACITY;
+  return mono_encode_dev(codec, (const uint8_t *)dIn, inSize, (uint8_t *)dOut, (uint8_t *)dWorkspace, m, nullptr, dStreamSize, (hipStream_t)stream);
 }
 
 uint64_t hsrle_decompress_mono_workspace_size(int codec, uint32_t uncompressedSize, uint32_t compressedSize)

@@ -118,6 +118,8 @@ def _lib():
     L.hsrle_decompress_mono_dev_async.argtypes = [ci, vp, ctypes.c_char_p, u32, vp, u64, vp, u64, ctypes.POINTER(u32), vp, vp]
     L.hsrle_compress_mono_dev.restype = ci
     L.hsrle_compress_mono_dev.argtypes = [ci, vp, u32, vp, u64, vp, u64, ctypes.POINTER(u32), ctypes.POINTER(u32), vp]
+    L.hsrle_compress_mono_dev_async.restype = ci
+    L.hsrle_compress_mono_dev_async.argtypes = [ci, vp, u32, vp, u64, vp, u64, vp, vp]
     L.hsrle_mono_tuning.restype = None
     L.hsrle_mono_tuning.argtypes = [u32, u32, u32]
     L.hsrle_mono_encode_stats.restype = None
@@ -258,6 +260,17 @@ def mono_compress_dev(codec, src, dst=None, workspace=None, return_chunks=False)
     if rc != OK:
         raise HsrleError(rc, "hsrle_compress_mono_dev")
     return (dst[: size.value], chunks.value) if return_chunks else dst[: size.value]
+
+
+def mono_compress_dev_async(codec, src, dst, workspace, size_out=None):
+    """hsrle_compress_mono_dev_async (rle8_multi / rle8_packed_multi): enqueue the encode of ONE monolithic reference stream on the current stream; nothing
+    synchronises (can be captured in a HIP graph).  dst (>= compress_bounds(n) bytes), workspace (>= hsrle_compress_mono_workspace_size) and size_out
+    (uint32[1] or None) are CUDA tensors the caller owns; the stream's size is also in bytes 4 .. 7 of dst once the stream has run."""
+    _check_u8_cuda(src, "src")
+    rc = _lib().hsrle_compress_mono_dev_async(codec_id(codec), ctypes.c_void_p(src.data_ptr()), src.numel(), ctypes.c_void_p(dst.data_ptr()), dst.numel(),
+                                              ctypes.c_void_p(workspace.data_ptr()), workspace.numel(), ctypes.c_void_p(size_out.data_ptr() if size_out is not None else None), _stream_ptr())
+    if rc != OK:
+        raise HsrleError(rc, "hsrle_compress_mono_dev_async")
 
 
 def mono_encode_stats():

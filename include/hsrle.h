@@ -198,6 +198,8 @@ uint64_t hsrle_decompress_mono_workspace_size(int codec, uint32_t uncompressedSi
  * (csrc/hsrle_mono_encode.hip.h).  The codecs with a move-to-front list get the list in front of every piece from a dry pass, and the
  * result is checked piece by piece (wrong guesses are encoded again); HSRLE_ERR_UNSUPPORTED if that does not settle, and for the other
  * codecs (the drop-in functions then use one lane).
+ * Round 6: rle8_multi / rle8_packed_multi do not use the block kernels' chunk mode any more -- a wave per chunk, then a wave per 4 KiB window
+ * (csrc/hsrle_encode8pw.hip.h), nothing read back before the end.
  * dOut capacity >= rle_compress_bounds(inSize); dWorkspace >= hsrle_compress_mono_workspace_size(); synchronises `stream`.
  * hsrle_mono_encode_stats: of the calling thread's last list-codec encode: extra rounds, pieces encoded again in rounds 1 and 2,
  * pieces the final check rejected (0 unless the library is wrong).
@@ -206,6 +208,14 @@ uint64_t hsrle_compress_mono_workspace_size(int codec, uint32_t inSize);
 int hsrle_compress_mono_dev(int codec, const void *dIn, uint32_t inSize, void *dOut, uint64_t outCapacity, void *dWorkspace, uint64_t workspaceSize, uint32_t *pStreamSize,
                             uint32_t *pChunks, void *stream);
 void hsrle_mono_encode_stats(uint32_t stats[4]);
+/*
+ * rle8_multi / rle8_packed_multi (round 6: their chunks go to the windowed position-parallel encoder, csrc/hsrle_encode8pw.hip.h -- no chunk count, no step bound
+ * and no list verdict has to come back to the host): the same encode without the host in the loop.  Nothing here synchronises or reads device memory, a HIP
+ * graph can capture the call.  The stream's size is in its own header (bytes 4 .. 7, as the reference writes it: src/rle8_extreme_cpu.h:330-338) and, if
+ * dStreamSize (DEVICE, 4 bytes) is not NULL, there.  HSRLE_ERR_UNSUPPORTED for every other codec (use hsrle_compress_mono_dev).
+ */
+int hsrle_compress_mono_dev_async(int codec, const void *dIn, uint32_t inSize, void *dOut, uint64_t outCapacity, void *dWorkspace, uint64_t workspaceSize, uint32_t *dStreamSize,
+                                  void *stream);
 int hsrle_decompress_mono_dev(int codec, const void *dStream, uint32_t streamSize, void *dOut, uint64_t outCapacity, void *dWorkspace, uint64_t workspaceSize,
                               uint32_t *pUncompressedSize, uint32_t *pStats, void *stream);
 /*
@@ -422,6 +432,7 @@ int hsrle_experiments_enabled(void);
 #define HSRLE_PATH_SPLIT 1
 #define HSRLE_PATH_RUN_LIST 2
 #define HSRLE_PATH_POSITION_PARALLEL 3   /* round 5: one wave per block, blocks of at most 4 KiB, any number of them: rle8_multi, rle8_packed_multi, the plain / Packed codecs of 2 .. 8 byte symbols, the 3 symbol LUT codecs of 3 .. 8 byte symbols, the Short codecs with no / one symbol in the list (1 .. 8 byte symbols) and with three (6 / 8 byte symbols): 56 codecs */
+/* round 6: ... and rle8_multi / rle8_packed_multi with blocks of ANY size (a block walked in 4 KiB windows: csrc/hsrle_encode8pw.hip.h) */
 int hsrle_encode_path(int codec, uint64_t uncompressedSize, uint32_t blockSize);
 
 /* A hash of the library's sources and build flags (set by the Makefile; "unknown" for other build recipes): measurement files that

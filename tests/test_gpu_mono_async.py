@@ -168,3 +168,66 @@ def test_async_mono_decode_in_a_hip_graph(hs, oracle):
         torch.cuda.synchronize()
         assert int(status.item()) == hs.MONO_DONE
         assert torch.equal(out.cpu(), torch.from_numpy(data))
+
+
+# ---- the encode side (round 6): hsrle_compress_mono_dev_async, rle8_multi / rle8_packed_multi (csrc/hsrle_encode8pw.hip.h) ----
+@pytest.mark.parametrize("key", ["rle8_multi", "rle8_packed_multi"])
+@pytest.mark.parametrize("kind", [SYNTH_RUNS, SYNTH_VIDEO])
+def test_async_mono_encode_equals_the_reference_stream(hs, oracle, key, kind):
+    """The enqueue-only encode: the stream (its size from its own header and from the device word) == the oracle's (src/rle8_extreme_cpu.h:86-344)."""
+    import torch
+
+    data = oracle.synth(kind, 1, 21, (5 << 20) + 333)
+    src = torch.from_numpy(data).cuda()
+    dst = torch.full((hs.compress_bounds(data.size) + 64,), 0xEE, dtype=torch.uint8, device="cuda")
+    ws = torch.empty(hs.lib().hsrle_compress_mono_workspace_size(hs.codec_id(key), data.size), dtype=torch.uint8, device="cuda")
+    size = torch.full((1,), 0x7FFFFFFF, dtype=torch.int32, device="cuda")
+    hs.mono_compress_dev_async(key, src, dst, ws, size)
+    torch.cuda.synchronize()
+    want = oracle.compress(CODEC_BY_KEY[key], data.tobytes())
+    assert int(size.item()) == len(want)
+    got = dst[: len(want)].cpu().numpy().tobytes()
+    assert int.from_bytes(got[4:8], "little") == len(want)
+    assert got == want
+
+
+def test_async_mono_encode_refuses_the_other_codecs(hs):
+    import torch
+
+    src = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+    dst = torch.empty(hs.compress_bounds(src.numel()) + 64, dtype=torch.uint8, device="cuda")
+    for key in ("rle8_3symlut", "rle16_sym_packed", "rle8_single"):
+        ws = torch.empty(max(hs.lib().hsrle_compress_mono_workspace_size(hs.codec_id(key), src.numel()), 256), dtype=torch.uint8, device="cuda")
+        with pytest.raises(hs.HsrleError):
+            hs.mono_compress_dev_async(key, src, dst, ws)
+
+
+def test_async_mono_encode_in_a_hip_graph(hs, oracle):
+    """Captured once, replayed on new input bytes of the same size: every replay's stream == the oracle's."""
+    import torch
+
+    key = "rle8_packed_multi"
+    n = (6 << 20) + 17
+    inputs = [oracle.synth(SYNTH_RUNS, 1, 31, n), oracle.synth(SYNTH_VIDEO, 1, 32, n), oracle.synth(SYNTH_RUNS, 1, 33, n)]
+    src = torch.from_numpy(inputs[0]).cuda()
+    dst = torch.empty(hs.compress_bounds(n) + 64, dtype=torch.uint8, device="cuda")
+    ws = torch.empty(hs.lib().hsrle_compress_mono_workspace_size(hs.codec_id(key), n), dtype=torch.uint8, device="cuda")
+    size = torch.zeros(1, dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        hs.mono_compress_dev_async(key, src, dst, ws, size)                  # warm-up outside the capture (module load)
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        hs.mono_compress_dev_async(key, src, dst, ws, size)
+    for data in (inputs[1], inputs[2], inputs[0]):
+        src.copy_(torch.from_numpy(data))
+        dst.fill_(0xEE)
+        ws.fill_(0xC3)
+        size.zero_()
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        want = oracle.compress(CODEC_BY_KEY[key], data.tobytes())
+        assert int(size.item()) == len(want)
+        assert dst[: len(want)].cpu().numpy().tobytes() == want
