@@ -72,6 +72,7 @@ static IndexLaunch g_idx[kCodecCount];
 static SubBlockLaunch g_sub[kCodecCount];
 static MonoEncodeLaunch g_menc[kCodecCount];
 static WaveEncodeLaunch g_wenc[kCodecCount];
+static PpwLaunch g_ppwS[kCodecCount];               // ... and the codecs of hsrle_encodeSp.hip.h (hsrle_encodeSpw.hip.h), by codec id
 static PpwLaunch g_ppw[2];                         // ... for units of any length (hsrle_encode8pw.hip.h): rle8_multi, rle8_packed_multi
 static PpLaunch g_pp[kCodecCount];                  // position-parallel encoders (hsrle_encode8p.hip.h)
 static std::once_flag g_tableOnce;
@@ -82,6 +83,7 @@ static void init_tables()
     register_w8(g_dec, g_enc, g_idx, g_sub, g_menc, g_wenc);
     register_pp8(g_pp);
     register_pp8w(g_ppw);
+    register_ppSw(g_ppwS);
     register_pp8s(g_pp);
     register_pp128(g_pp);
     register_ppL(g_pp);
@@ -654,10 +656,16 @@ static bool pp_applies(int codec, uint32_t nBlocks, uint32_t B)
 #define HSRLE_PPW_MIN_BLOCKS 1u
 #endif
 constexpr uint32_t kPpwMinBlocks = HSRLE_PPW_MIN_BLOCKS;   // (A/B builds: 0xFFFFFFFF = never, also for the monolithic streams)
+static PpwLaunch ppw_launcher(int codec) { return (codec < 0 || codec >= kCodecCount) ? nullptr : ((codec <= 1) ? g_ppw[codec] : g_ppwS[codec]); }
+// (the plain / Packed codecs write 8 or 32 bit fields whatever the block size; the LUT / Short forms choose their field widths -- and the reference its penalties, with
+//  thresholds of 0xFFFFF: rleX_Xsl.h:130, rleX_Xsl_short.h:178 -- by the values: below 1 MiB per block no count or range gets there and "every run is stored" holds)
+constexpr uint32_t kPpwListMaxBlock = (1u << 20) - 128u;
 static bool ppw_applies(int codec, uint32_t nBlocks, uint32_t B)
 {
   static const uint32_t force = knob_u32("HSRLE_PP", 0u);
-  if ((codec != 0 && codec != 1) || !g_ppw[codec] || B <= kPpMaxBlock || force == 2u) return false;
+  if (!ppw_launcher(codec) || B <= kPpMaxBlock || force == 2u) return false;
+  const bool anyBlock = codec <= 1 || (codec >= 6 && codec < 46 && ((codec - 6) & 2) == 0);                   // 8 bit multi, plain / Packed of 2 .. 8 byte symbols
+  if (!anyBlock && B > kPpwListMaxBlock) return false;
   if ((uint64_t)nBlocks * ((B + kPpwWindow - 1u) / kPpwWindow) > 0xFFFFFFF0ull) return false;            // (windows are counted in 32 bits: 16 TiB)
   return force == 1u || nBlocks >= kPpwMinBlocks;
 }
@@ -756,8 +764,9 @@ static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, ui
     pa.in = (const uint8_t *)dIn; pa.U = U; pa.B = B; pa.nUnits = nBlocks; pa.sizes = sizes; pa.offsets = offsets; pa.payload = payload;
     pa.nWindows = nBlocks * ((B + kPpwWindow - 1u) / kPpwWindow);
     pa.states = (uint32_t *)(ws + w.offSlots);
-    pa.recs = (uint32_t *)(ws + w.offSlots + align_up(4ull * kPpwStateWords * pa.nWindows, 256));
-    if (g_ppw[codec](pa, 0, st) != hipSuccess)
+    pa.recs = (uint32_t *)(ws + w.offSlots + align_up(4ull * (codec <= 1 ? kPpwStateWords : kPpwSStateWords) * pa.nWindows, 256));
+    const PpwLaunch launch = ppw_launcher(codec);
+    if (launch(pa, 0, st) != hipSuccess)
       rc = HSRLE_ERR_DEVICE;
     else if (nBlocks <= kScanSmallMax && (((uintptr_t)sizes) & 15u) == 0u)
     {
@@ -766,7 +775,7 @@ static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, ui
     }
     else if (scan_sizes(sizes, nBlocks, offsets, ws, w, st) != hipSuccess)
       rc = HSRLE_ERR_DEVICE;
-    if (rc == HSRLE_OK && g_ppw[codec](pa, 1, st) != hipSuccess)
+    if (rc == HSRLE_OK && launch(pa, 1, st) != hipSuccess)
       rc = HSRLE_ERR_DEVICE;
   }
   else if (w.nChunks <= 1 && w.spSlots != 0 && split_encode_applies(codec, w.nBlocks, B))

@@ -215,6 +215,59 @@ def test_position_parallel_wide_encoder_block_sizes_and_ragged_tails(hs, oracle,
     _check(hs, oracle, key, data[: data.size - cut], block)
 
 
+# ---- the same codecs (and the LUT / Short ones below) with blocks above 4 KiB: walked in 4 KiB windows (csrc/hsrle_encodeSpw.hip.h) ----
+WINDOWED_S_KEYS = WIDE_KEYS + [f"rle{w}_3symlut_{v}" for w in (24, 32, 48, 64) for v in ("sym", "byte")] + ["rle8_multi_short", "rle8_1symlut_short"] + \
+    [f"rle{w}_{v}_short" for w in (16, 24, 32, 48, 64) for v in ("sym", "1symlut_sym", "byte", "1symlut_byte")] + [f"rle{w}_3symlut_{v}_short" for w in (48, 64) for v in ("sym", "byte")]
+
+
+@pytest.fixture(scope="module")
+def windowed_wide_cases(wide_cases):
+    rng = np.random.default_rng(8088)
+    n = 3 << 20
+    out = dict(wide_cases)
+    out["edges"] = _edge_runs(rng, n)
+    out["long_literals"] = _periodic(rng, n, [2, 3, 4, 6, 8], 256, 8000, [8, 12, 16, 19, 24, 36, 48, 7000])      # literal stretches of several windows
+    out["zeros"] = np.zeros(n, dtype=np.uint8)
+    return out
+
+
+def test_windowed_wide_encoder_covers_the_codecs_of_the_block_kernel(hs):
+    assert len(WINDOWED_S_KEYS) == 54
+    for key in WINDOWED_S_KEYS:
+        assert hs.lib().hsrle_encode_path(hs.codec_id(key), 64 << 20, 8192) == 3, key
+        assert hs.lib().hsrle_encode_path(hs.codec_id(key), 8 << 30, 65536) == 3, key
+
+
+@pytest.mark.parametrize("key", WINDOWED_S_KEYS)
+@pytest.mark.parametrize("block,cut", [(4224, 0), (8192, 777), (65536, 4097)])
+def test_windowed_wide_encoder_blocks_bit_exact(hs, oracle, windowed_wide_cases, key, block, cut):
+    for name in ("periods", "butting", "far_apart", "two_symbols", "edges", "long_literals", "zeros"):
+        data = windowed_wide_cases[name]
+        _check(hs, oracle, key, data[: data.size - cut], block)
+
+
+@pytest.mark.parametrize("key", ["rle16_sym_packed", "rle24_byte", "rle32_3symlut_byte", "rle48_sym_short", "rle64_3symlut_byte_short", "rle64_byte_packed", "rle8_1symlut_short"])
+def test_windowed_wide_encoder_large_blocks_and_wide_fields(hs, oracle, windowed_wide_cases, key):
+    """blocks of 512 KiB: counts and ranges beyond 16 bits (the LUT / Short forms then carry 32 bit fields: src/rleX_Xsl.h:190-250, src/rleX_Xsl_short.h:216-357)"""
+    rng = np.random.default_rng(99)
+    n = 3 << 20
+    data = rng.integers(0, 256, n, dtype=np.uint8)
+    S = CODEC_BY_KEY[key].S
+    data[100000:300000] = np.tile(rng.integers(0, 256, S, dtype=np.uint8), 200000 // S + 1)[:200000]         # a run of 200 000 bytes
+    data[(1 << 19) + 90000 : (1 << 19) + 90000 + 4 * S + 3] = 7                                                  # a short run 90 000 literal bytes into the second block
+    data[(1 << 20) + 70000 : (1 << 20) + 300000] = 0
+    _check(hs, oracle, key, data, 1 << 19)
+    _check(hs, oracle, key, windowed_wide_cases["zeros"], 1 << 19)
+
+
+@pytest.mark.parametrize("key", ["rle16_byte_packed", "rle32_sym", "rle64_3symlut_byte", "rle24_1symlut_byte_short"])
+@pytest.mark.parametrize("kind", [SYNTH_RUNS, SYNTH_VIDEO])
+def test_windowed_wide_encoder_synthetic_workloads(hs, oracle, key, kind):
+    data = oracle.synth(kind, CODEC_BY_KEY[key].S, 13, (24 << 20) + 4099)
+    _check(hs, oracle, key, data, 65536)
+    _check(hs, oracle, key, data, 12416)
+
+
 # ---- 3 symbol LUT codecs of 3 .. 8 byte symbols (every run stored; the symbol's list index through streak heads) ----
 LUT_KEYS = [f"rle{w}_3symlut_{a}" for w in (24, 32, 48, 64) for a in ("sym", "byte")]
 
