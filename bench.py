@@ -385,22 +385,24 @@ def config5_rows(hsrle, torch, dev, with_cpu):
     return rows
 
 
-def video_rows(hsrle, torch, dev, with_cpu):
+def video_rows(hsrle, torch, dev, with_cpu, kind=None, block=4096, keys=("rle8_packed_multi", "rle16_sym_packed", "rle32_3symlut_byte", "rle48_7symlut_byte", "rle64_3symlut_byte", "rle24_byte_short", "rle64_7symlut_byte_short")):
     """Side measurement (not `value`): decode and encode of the 8 GiB VIDEO-SHAPED buffer (many short packets, unevenly spread: what the capped decoder rounds of
     round 5 are for) for a few codecs of the families the 110-codec sweep has its weakest rows in.  No reference-minted manifests exist for
     these buffers: `exact` = the decode equals the input and the status word is 0; `cpu_streams_match_gpu` = the first 64 MiB of block streams equal the
-    compiled reference's."""
+    compiled reference's.  Round 6: the same rows for other shapes -- `kind` (None: video-shaped), `block`, `keys` -- serve `extras.large_blocks` (64 KiB blocks: the
+    windowed position-parallel encoders)."""
     import numpy as np
     from hsrle_testlib import CODEC_BY_KEY
 
     rows = []
-    size, block = 8 << 30, 4096
+    size = 8 << 30
+    kind = hsrle.SYNTH_VIDEO if kind is None else kind
     dst = torch.empty(hsrle.container_bound(size, block), dtype=torch.uint8, device=dev)
     ws = torch.empty(hsrle.workspace_size(size, block), dtype=torch.uint8, device=dev)
     out = torch.empty(size, dtype=torch.uint8, device=dev)
-    for key in ("rle8_packed_multi", "rle16_sym_packed", "rle32_3symlut_byte", "rle48_7symlut_byte", "rle64_3symlut_byte", "rle24_byte_short", "rle64_7symlut_byte_short"):
+    for key in keys:
         codec = CODEC_BY_KEY[key]
-        src = hsrle.synth(hsrle.SYNTH_VIDEO, codec.S, 5, size, device=dev)
+        src = hsrle.synth(kind, codec.S, 5, size, device=dev)
         status = torch.zeros(16, dtype=torch.int32, device=dev)
 
         def timed(fn, warm, reps):
@@ -753,6 +755,17 @@ def main():
                                                   "all_exact": bool(rows) and all(r["exact"] for r in rows), "seconds": round(time.time() - tv, 1)}
             except Exception as ex:  # noqa: BLE001
                 line["extras"]["video_shaped"] = {"error": repr(ex)[:300]}
+            try:
+                tl = time.time()
+                torch.cuda.empty_cache()
+                rows = video_rows(hsrle, torch, dev, with_cpu=not args.no_cpu, kind=hsrle.SYNTH_RUNS, block=65536,
+                                  keys=("rle8_packed_multi", "rle8_multi", "rle16_sym_packed", "rle32_byte", "rle64_3symlut_byte", "rle24_byte_short"))
+                line["extras"]["large_blocks"] = {"workload": "8 GiB run-distributed(W, seed 5), 64 KiB blocks: every block walked in 4 KiB windows by the windowed position-parallel encoders "
+                                                              "(round 6; encode path = hsrle_encode_path)", "rows": rows, "all_exact": bool(rows) and all(r["exact"] for r in rows),
+                                                  "encode_path": {r["codec"]: int(hsrle.lib().hsrle_encode_path(hsrle.codec_id(r["codec"]), 8 << 30, 65536)) for r in rows},
+                                                  "seconds": round(time.time() - tl, 1)}
+            except Exception as ex:  # noqa: BLE001
+                line["extras"]["large_blocks"] = {"error": repr(ex)[:300]}
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(line) + "\n").encode())
 

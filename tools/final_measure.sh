@@ -11,6 +11,7 @@ export TMPDIR=/tmp
 O="$R/gpurun_out/${tag}_final"; mkdir -p "$O"
 {
   bash tools/traffic.sh "${tag}final" > "$O/traffic.log" 2>&1; cp "gpurun_out/traffic_${tag}final/traffic.json" "$O/traffic.json"
+  cp "$O/traffic.json" "profiles/${tag}_traffic.json"   # (on the box's copy of the tree: bench.py takes `roofline.traffic` from the PMC file of THIS build)
   timeout 900 python bench.py > "$O/bench.json" 2> "$O/bench.err"; tail -c 400 "$O/bench.json"
   cd /tmp || exit 1
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -o k -- python3 "$R/bench.py" --no-extras > "$O/stats.log" 2>&1
