@@ -176,7 +176,7 @@ WIDE_KEYS = [f"rle{w}_{v}" for w in (16, 24, 32, 48, 64) for v in ("sym", "sym_p
 def _periodic(rng, n, periods, alphabet, literal_max, lengths):
     """stretches with the given periods (in bytes; not only the codec's own symbol width), cut mid-symbol, butting against each other and against
     stretches of another period that share bytes with them: run starts that depend on where the run before ended"""
-    out = np.empty(n + 8192, dtype=np.uint8)
+    out = np.empty(n + 8192 + literal_max + max(lengths), dtype=np.uint8)
     at = 0
     while at < n:
         L = int(rng.integers(0, literal_max + 1))
