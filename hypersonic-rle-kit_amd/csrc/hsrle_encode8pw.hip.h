@@ -498,20 +498,40 @@ __global__ __launch_bounds__(64) void k_encode8_ppw_emit(PpwArgs a)
   const uint32_t gw = xcd_tile(blockIdx.x, gridDim.x);
   if (gw >= a.nWindows) return;
   const uint32_t *const st = a.states + (uint64_t)gw * kPpwStateWords;
-  const uint32_t sv = (threadIdx.x < kPpwStateWords) ? st[threadIdx.x] : 0u;
-  const uint32_t recN = wave_lane(sv, 4);
-  if (recN == kPpwEmpty) return;
   const uint32_t *const myRecs = a.recs + (uint64_t)gw * kPpwStride;
-  const uint32_t rec0 = myRecs[threadIdx.x];
-  const uint32_t u = wave_lane(sv, 5), w = wave_lane(sv, 6);
+  uint32_t sv, rec0, recN, u, w, unitSize = 0;
+  uint64_t unitAt = 0;
   PpwUnit q;
-  if (!ppw_unit(a, u, q)) return;
   u32x4 x[4];
-  ppw_load(q.d, q.n, w * kPpwWindow, x);
+  if (a.B != 0u)
+  {
+    // blocks: which block and window this is follows from the window's number -- the state, the first records and the input are asked for together
+    // (one memory round trip less in a wave that lives for a handful of them)
+    const uint32_t slots = (a.B + kPpwWindow - 1u) / kPpwWindow;
+    u = gw / slots; w = gw - u * slots;
+    ppw_unit(a, u, q);
+    if (w * kPpwWindow >= q.n) return;                                   // (the last, short block: no such window)
+    sv = (threadIdx.x < kPpwStateWords) ? st[threadIdx.x] : 0u;
+    rec0 = myRecs[threadIdx.x];
+    unitSize = a.sizes[u]; unitAt = a.offsets[u];
+    ppw_load(q.d, q.n, w * kPpwWindow, x);
+    recN = wave_lane(sv, 4);
+  }
+  else
+  {
+    sv = (threadIdx.x < kPpwStateWords) ? st[threadIdx.x] : 0u;
+    recN = wave_lane(sv, 4);
+    if (recN == kPpwEmpty) return;
+    rec0 = myRecs[threadIdx.x];
+    u = wave_lane(sv, 5); w = wave_lane(sv, 6);
+    if (!ppw_unit(a, u, q)) return;
+    unitSize = a.sizes[u]; unitAt = a.offsets[u];
+    ppw_load(q.d, q.n, w * kPpwWindow, x);
+  }
   uint32_t pos = wave_lane(sv, 0), carL = wave_lane(sv, 1), openStart = wave_lane(sv, 2), carY = wave_lane(sv, 3);
   bool ended = false;
   wave_sync();
-  ppw_window<FAM, 1>(q.d, q.n, q.nT, w, q.hasHeader, q.hasTerm, carL, carY, pos, openStart, ended, nullptr, const_cast<uint32_t *>(myRecs), u, a.sizes[u], a.payload + a.offsets[u], sh, x, recN, rec0);
+  ppw_window<FAM, 1>(q.d, q.n, q.nT, w, q.hasHeader, q.hasTerm, carL, carY, pos, openStart, ended, nullptr, const_cast<uint32_t *>(myRecs), u, unitSize, a.payload + unitAt, sh, x, recN, rec0);
 }
 
 } // namespace hsrle

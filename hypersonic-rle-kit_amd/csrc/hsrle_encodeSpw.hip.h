@@ -616,18 +616,22 @@ __global__ __launch_bounds__(64) void k_encodeS_ppw_emit(PpwArgs a)
   }
   const uint32_t gw = xcd_tile(blockIdx.x, gridDim.x);
   if (gw >= a.nWindows) return;
+  // (which block and window this is follows from the window's number: the state, the first records and the input are asked for together)
   const uint32_t *const st = a.states + (uint64_t)gw * kPpwSStateWords;
-  const uint32_t sv = (threadIdx.x < kPpwSStateWords) ? st[threadIdx.x] : 0u;
-  const uint32_t recN = wave_lane(sv, 12);
-  if (recN == kPpwEmpty) return;
   const uint32_t *const myRecs = a.recs + (uint64_t)gw * kPpwStride;
-  const uint32_t rec0 = myRecs[threadIdx.x];
-  const uint32_t u = wave_lane(sv, 13), w = wave_lane(sv, 14);
+  const uint32_t slots = (a.B + kPpwWindow - 1u) / kPpwWindow;
+  const uint32_t u = gw / slots, w = gw - u * slots;
   const uint64_t at = (uint64_t)u * a.B;
   const uint8_t *const d = a.in + at;
   const uint32_t n = (uint32_t)((a.U - at) < (uint64_t)a.B ? (a.U - at) : (uint64_t)a.B);
+  if (w * kPpwWindow >= n) return;                                       // (the last, short block: no such window)
+  const uint32_t sv = (threadIdx.x < kPpwSStateWords) ? st[threadIdx.x] : 0u;
+  const uint32_t rec0 = myRecs[threadIdx.x];
+  const uint32_t unitSize = a.sizes[u];
+  const uint64_t unitAt = a.offsets[u];
   u32x4 x[4];
   ppw_load(d, n, w * kPpwWindow, x);
+  const uint32_t recN = wave_lane(sv, 12);
   PpSwCarry cs;
   cs.pos = wave_lane(sv, 0); cs.carL = wave_lane(sv, 1); cs.openStart = wave_lane(sv, 2); cs.carE = wave_lane(sv, 3);
   cs.carY = (uint64_t)wave_lane(sv, 4) | ((uint64_t)wave_lane(sv, 5) << 32);
@@ -636,7 +640,7 @@ __global__ __launch_bounds__(64) void k_encodeS_ppw_emit(PpwArgs a)
   cs.lY = (uint64_t)wave_lane(sv, 10) | ((uint64_t)wave_lane(sv, 11) << 32);
   cs.ended = false;
   wave_sync();
-  ppSw_window<FAM, S, AL, 1>(d, n, w, cs, wave_lane(sv, 15), nullptr, const_cast<uint32_t *>(myRecs), u, a.sizes[u], a.payload + a.offsets[u], sh, x, recN, rec0);
+  ppSw_window<FAM, S, AL, 1>(d, n, w, cs, wave_lane(sv, 15), nullptr, const_cast<uint32_t *>(myRecs), u, unitSize, a.payload + unitAt, sh, x, recN, rec0);
 }
 
 } // namespace hsrle
