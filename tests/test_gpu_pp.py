@@ -268,6 +268,21 @@ def test_windowed_wide_encoder_synthetic_workloads(hs, oracle, key, kind):
     _check(hs, oracle, key, data, 12416)
 
 
+@pytest.mark.parametrize("key", ["rle8_packed_multi", "rle8_multi", "rle16_sym_packed", "rle32_byte", "rle64_byte_packed", "rle24_sym"])
+def test_windowed_encoder_blocks_of_many_mebibytes(hs, oracle, cases, key):
+    """blocks of 16 MiB (4 096 windows each): positions, counts and ranges far beyond 16 bits -- a run of 5 MiB, literal stretches of 3 MiB, a ragged last block"""
+    rng = np.random.default_rng(1234)
+    n = (40 << 20) + 12345
+    data = np.resize(cases["mixed"], n).copy()
+    S = CODEC_BY_KEY[key].S
+    data[(2 << 20) : (7 << 20)] = np.tile(rng.integers(0, 256, S, dtype=np.uint8), (5 << 20) // S + 1)[: 5 << 20]
+    data[(9 << 20) : (12 << 20)] = rng.integers(0, 256, 3 << 20, dtype=np.uint8)
+    data[(15 << 20) + 4000 : (17 << 20) + 100] = 0                                 # a run across the first block's end
+    data[(33 << 20) : (36 << 20)] = rng.integers(0, 256, 3 << 20, dtype=np.uint8)
+    assert hs.lib().hsrle_encode_path(hs.codec_id(key), n, 16 << 20) == 3
+    _check(hs, oracle, key, data, 16 << 20)
+
+
 # ---- 3 symbol LUT codecs of 3 .. 8 byte symbols (every run stored; the symbol's list index through streak heads) ----
 LUT_KEYS = [f"rle{w}_3symlut_{a}" for w in (24, 32, 48, 64) for a in ("sym", "byte")]
 
