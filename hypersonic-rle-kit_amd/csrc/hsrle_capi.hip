@@ -72,6 +72,7 @@ static IndexLaunch g_idx[kCodecCount];
 static SubBlockLaunch g_sub[kCodecCount];
 static MonoEncodeLaunch g_menc[kCodecCount];
 static WaveEncodeLaunch g_wenc[kCodecCount];
+static PpwLaunch g_ppwL[kCodecCount];               // ... and those of hsrle_encodeLp.hip.h (hsrle_encodeLpw.hip.h)
 static PpwLaunch g_ppwS[kCodecCount];               // ... and the codecs of hsrle_encodeSp.hip.h (hsrle_encodeSpw.hip.h), by codec id
 static PpwLaunch g_ppw[2];                         // ... for units of any length (hsrle_encode8pw.hip.h): rle8_multi, rle8_packed_multi
 static PpLaunch g_pp[kCodecCount];                  // position-parallel encoders (hsrle_encode8p.hip.h)
@@ -84,6 +85,7 @@ static void init_tables()
     register_pp8(g_pp);
     register_pp8w(g_ppw);
     register_ppSw(g_ppwS);
+    register_ppLw(g_ppwL);
     register_pp8s(g_pp);
     register_pp128(g_pp);
     register_ppL(g_pp);
@@ -656,7 +658,9 @@ static bool pp_applies(int codec, uint32_t nBlocks, uint32_t B)
 #define HSRLE_PPW_MIN_BLOCKS 1u
 #endif
 constexpr uint32_t kPpwMinBlocks = HSRLE_PPW_MIN_BLOCKS;   // (A/B builds: 0xFFFFFFFF = never, also for the monolithic streams)
-static PpwLaunch ppw_launcher(int codec) { return (codec < 0 || codec >= kCodecCount) ? nullptr : ((codec <= 1) ? g_ppw[codec] : g_ppwS[codec]); }
+// words of a window's state record: the 8 bit pair 8, the codecs of hsrle_encodeSp.hip.h 16, those of hsrle_encodeLp.hip.h (the list travels with it) 32
+static uint32_t ppw_state_words(int codec) { return codec <= 1 ? kPpwStateWords : (g_ppwL[codec] ? kPpwLStateWords : kPpwSStateWords); }
+static PpwLaunch ppw_launcher(int codec) { return (codec < 0 || codec >= kCodecCount) ? nullptr : ((codec <= 1) ? g_ppw[codec] : (g_ppwL[codec] ? g_ppwL[codec] : g_ppwS[codec])); }
 // (the plain / Packed codecs write 8 or 32 bit fields whatever the block size; the LUT / Short forms choose their field widths -- and the reference its penalties, with
 //  thresholds of 0xFFFFF: rleX_Xsl.h:130, rleX_Xsl_short.h:178 -- by the values: below 1 MiB per block no count or range gets there and "every run is stored" holds)
 constexpr uint32_t kPpwListMaxBlock = (1u << 20) - 128u;
@@ -764,7 +768,7 @@ static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, ui
     pa.in = (const uint8_t *)dIn; pa.U = U; pa.B = B; pa.nUnits = nBlocks; pa.sizes = sizes; pa.offsets = offsets; pa.payload = payload;
     pa.nWindows = nBlocks * ((B + kPpwWindow - 1u) / kPpwWindow);
     pa.states = (uint32_t *)(ws + w.offSlots);
-    pa.recs = (uint32_t *)(ws + w.offSlots + align_up(4ull * (codec <= 1 ? kPpwStateWords : kPpwSStateWords) * pa.nWindows, 256));
+    pa.recs = (uint32_t *)(ws + w.offSlots + align_up(4ull * ppw_state_words(codec) * pa.nWindows, 256));
     const PpwLaunch launch = ppw_launcher(codec);
     if (launch(pa, 0, st) != hipSuccess)
       rc = HSRLE_ERR_DEVICE;

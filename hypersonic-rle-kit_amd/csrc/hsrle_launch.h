@@ -117,6 +117,7 @@ struct PpwArgs
 inline uint64_t ppw_scratch_bytes(uint64_t nWindows) { return nWindows * (4ull * kPpwStateWords + 4ull * kPpwStride) + 512ull; }
 
 typedef hipError_t (*PpwLaunch)(const PpwArgs &, int phase, hipStream_t);
+constexpr uint32_t kPpwLStateWords = 32u;                        // ... of the general LUT kernel's (hsrle_encodeLpw.hip.h): the list travels in the state record
 constexpr uint32_t kPpwSStateWords = 16u;                        // ... of the 1 .. 8 byte symbol codecs' windowed encoder (hsrle_encodeSpw.hip.h): more state crosses a window's edge
 typedef hipError_t (*DecodeLaunch)(const DecodeArgs &, hipStream_t);
 typedef hipError_t (*EncodeLaunch)(const EncodeArgs &, hipStream_t);
@@ -143,6 +144,7 @@ constexpr int kDecodeRing = HSRLE_DECODE_RING; // per-lane stream ring in LDS (k
 void register_w8(DecodeLaunch *dec, EncodeLaunch *enc, IndexLaunch *idx, SubBlockLaunch *sub, MonoEncodeLaunch *menc, WaveEncodeLaunch *wenc);
 void register_pp8(PpLaunch *pp);
 void register_pp8w(PpwLaunch *ppw);   // [0] rle8_multi, [1] rle8_packed_multi
+void register_ppLw(PpwLaunch *ppw);   // [codec id]: the codecs of hsrle_encodeLp.hip.h, blocks above 4 KiB
 void register_ppSw(PpwLaunch *ppw);   // [codec id]: the codecs of hsrle_encodeSp.hip.h, blocks above 4 KiB
 void register_pp8s(PpLaunch *pp);
 void register_pp128(PpLaunch *pp);

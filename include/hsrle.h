@@ -432,9 +432,9 @@ int hsrle_experiments_enabled(void);
 #define HSRLE_PATH_SPLIT 1
 #define HSRLE_PATH_RUN_LIST 2
 #define HSRLE_PATH_POSITION_PARALLEL 3   /* round 5: one wave per block, blocks of at most 4 KiB, any number of them: rle8_multi, rle8_packed_multi, the plain / Packed codecs of 2 .. 8 byte symbols, the 3 symbol LUT codecs of 3 .. 8 byte symbols, the Short codecs with no / one symbol in the list (1 .. 8 byte symbols) and with three (6 / 8 byte symbols): 56 codecs */
-/* round 6: ... and, with blocks ABOVE 4 KiB walked in 4 KiB windows (a wave per block, then a wave per window: csrc/hsrle_encode8pw.hip.h, hsrle_encodeSpw.hip.h):
- * rle8_multi / rle8_packed_multi and the plain / Packed codecs of 2 .. 8 byte symbols with blocks of any size; the 3 symbol LUT codecs of 3 .. 8 byte symbols and the Short
- * codecs of hsrle_encodeSp.hip.h with blocks below 1 MiB: 56 codecs */
+/* round 6: ... and, with blocks ABOVE 4 KiB walked in 4 KiB windows (a wave per block, then a wave per window: csrc/hsrle_encode8pw.hip.h, hsrle_encodeSpw.hip.h,
+ * hsrle_encodeLpw.hip.h): rle8_multi / rle8_packed_multi and the plain / Packed codecs of 2 .. 8 byte symbols with blocks of any size; every LUT codec and the
+ * position-parallel Short codecs with blocks below 1 MiB: 86 codecs (not: the 8 bit Single codecs, the 128 bit codecs) */
 int hsrle_encode_path(int codec, uint64_t uncompressedSize, uint32_t blockSize);
 
 /* A hash of the library's sources and build flags (set by the Makefile; "unknown" for other build recipes): measurement files that

@@ -96,11 +96,11 @@ def test_encode_path_selection(lib):
         assert cid(name) >= 0
         for size, block in ((frame, 4096), (frame, 1024), (frame, 512), (8 << 30, 4096), (4096, 128)):
             assert lib.hsrle_encode_path(cid(name), size, block) == PP, (name, size, block)
-        # round 6: blocks above 4 KiB walked in 4 KiB windows (csrc/hsrle_encode8pw.hip.h, hsrle_encodeSpw.hip.h): the two 8 bit multi-symbol codecs and the 54 codecs of
-        # hsrle_encodeSp.hip.h -- plain / Packed with blocks of any size, the LUT / Short forms below 1 MiB per block (their field widths and penalties go by value)
+        # round 6: blocks above 4 KiB walked in 4 KiB windows (csrc/hsrle_encode8pw.hip.h, hsrle_encodeSpw.hip.h, hsrle_encodeLpw.hip.h): the two 8 bit multi-symbol codecs, the 54
+        # codecs of hsrle_encodeSp.hip.h and the 30 of hsrle_encodeLp.hip.h -- plain / Packed with blocks of any size, the LUT / Short forms below 1 MiB per block (their field
+        # widths and penalties go by value).  Not windowed: the 8 bit Single codecs and the 128 bit codecs
         windowed_any = name in ("rle8_multi", "rle8_packed_multi", "rle16_sym", "rle16_byte_packed", "rle24_sym_packed", "rle32_byte_packed")
-        windowed_list = name in ("rle48_3symlut_sym", "rle64_3symlut_byte", "rle24_3symlut_byte", "rle16_sym_short", "rle16_1symlut_sym_short", "rle24_byte_short",
-                                 "rle48_1symlut_byte_short", "rle64_sym_short", "rle8_multi_short", "rle8_1symlut_short", "rle48_3symlut_sym_short", "rle64_3symlut_byte_short")
+        windowed_list = name not in ("rle8_single", "rle8_packed_single", "rle8_single_short", "rle128_sym", "rle128_sym_packed", "rle128_byte", "rle128_byte_packed") and not windowed_any
         if windowed_any or windowed_list:
             for size, block in ((frame, 8192), (8 << 30, 8192), (8 << 30, 65536), (1 << 20, 1 << 19), (frame, 4224)):
                 assert lib.hsrle_encode_path(cid(name), size, block) == PP, (name, size, block)

@@ -268,6 +268,51 @@ def test_windowed_wide_encoder_synthetic_workloads(hs, oracle, key, kind):
     _check(hs, oracle, key, data, 12416)
 
 
+# ---- ... and the general LUT kernel's codecs (csrc/hsrle_encodeLpw.hip.h): the list travels from window to window ----
+WINDOWED_L_KEYS = ["rle8_3symlut", "rle8_7symlut", "rle16_3symlut_sym", "rle16_3symlut_byte"] + [f"rle{w}_7symlut_{v}" for w in (16, 24, 32, 48, 64) for v in ("sym", "byte")] + \
+    [f"rle{w}_3symlut_{v}_short" for w in (16, 24, 32) for v in ("sym", "byte")] + [f"rle{w}_7symlut_{v}_short" for w in (16, 24, 32, 48, 64) for v in ("sym", "byte")]
+
+
+def test_windowed_lut_encoder_covers_the_codecs_of_the_block_kernel(hs):
+    assert len(WINDOWED_L_KEYS) == 30
+    for key in WINDOWED_L_KEYS:
+        assert hs.lib().hsrle_encode_path(hs.codec_id(key), 64 << 20, 8192) == 3, key
+        assert hs.lib().hsrle_encode_path(hs.codec_id(key), 8 << 30, 65536) == 3, key
+        assert hs.lib().hsrle_encode_path(hs.codec_id(key), 8 << 30, 1 << 20) != 3, key       # (1 MiB per block: the reference's 20 bit penalty thresholds are in reach)
+
+
+@pytest.mark.parametrize("key", WINDOWED_L_KEYS)
+@pytest.mark.parametrize("block,cut", [(4224, 0), (8192, 777), (65536, 4097)])
+def test_windowed_lut_encoder_blocks_bit_exact(hs, oracle, windowed_wide_cases, cases, key, block, cut):
+    for name in ("periods", "butting", "far_apart", "two_symbols", "edges", "long_literals", "zeros"):
+        data = windowed_wide_cases[name]
+        _check(hs, oracle, key, data[: data.size - cut], block)
+    for name in ("threes", "short_chains", "same_symbol"):                      # (8 / 16 bit symbols: runs whose storing depends on the list)
+        data = cases[name][: 2 << 20]
+        _check(hs, oracle, key, data[: data.size - cut], block)
+
+
+@pytest.mark.parametrize("key", ["rle8_7symlut", "rle16_3symlut_byte", "rle32_7symlut_sym", "rle64_7symlut_byte", "rle16_7symlut_sym_short", "rle24_3symlut_byte_short"])
+def test_windowed_lut_encoder_large_blocks_and_wide_fields(hs, oracle, windowed_wide_cases, key):
+    rng = np.random.default_rng(98)
+    n = 3 << 20
+    data = rng.integers(0, 256, n, dtype=np.uint8)
+    S = CODEC_BY_KEY[key].S
+    data[100000:300000] = np.tile(rng.integers(0, 256, S, dtype=np.uint8), 200000 // S + 1)[:200000]
+    data[(1 << 19) + 90000 : (1 << 19) + 90000 + 4 * S + 3] = 7
+    data[(1 << 20) + 70000 : (1 << 20) + 300000] = 0
+    _check(hs, oracle, key, data, 1 << 19)
+    _check(hs, oracle, key, windowed_wide_cases["zeros"], 1 << 19)
+
+
+@pytest.mark.parametrize("key", ["rle8_3symlut", "rle8_7symlut", "rle16_7symlut_byte", "rle48_7symlut_sym", "rle32_7symlut_byte_short"])
+@pytest.mark.parametrize("kind", [SYNTH_RUNS, SYNTH_VIDEO])
+def test_windowed_lut_encoder_synthetic_workloads(hs, oracle, key, kind):
+    data = oracle.synth(kind, CODEC_BY_KEY[key].S, 14, (24 << 20) + 4099)
+    _check(hs, oracle, key, data, 65536)
+    _check(hs, oracle, key, data, 12416)
+
+
 @pytest.mark.parametrize("key", ["rle8_packed_multi", "rle8_multi", "rle16_sym_packed", "rle32_byte", "rle64_byte_packed", "rle24_sym"])
 def test_windowed_encoder_blocks_of_many_mebibytes(hs, oracle, cases, key):
     """blocks of 16 MiB (4 096 windows each): positions, counts and ranges far beyond 16 bits -- a run of 5 MiB, literal stretches of 3 MiB, a ragged last block"""
