@@ -541,7 +541,7 @@ struct Workspace
 
 // splitSmall: reserve the split-encode regions for blocks of 1 .. 4 KiB too (the codecs without a run list encoder -- 8 bit Single, 128 bit --
 // take the split encode there: split_codec_small(); hsrle_compress_workspace_size_codec)
-static Workspace plan_workspace(uint64_t U, uint32_t B, bool splitSmall = false)
+static Workspace plan_workspace(uint64_t U, uint32_t B, bool splitSmall = false, bool noSplit = false)
 {
   Workspace w;
   w.nBlocks = block_count(U, B);
@@ -564,7 +564,8 @@ static Workspace plan_workspace(uint64_t U, uint32_t B, bool splitSmall = false)
   w.spPieces = w.nBlocks * kSplitPiecesMax; w.spMaxChunks = w.spPieces + w.nBlocks;
   w.spCutPos = w.spCutSym = w.spFlags = w.spIdx = w.spStarts = w.spSyms = w.spSlotOff = w.spSizes = w.spChunkOff = w.spFirst = w.spCtrl = w.spGuess = w.spListOut = w.spSlots = w.spL1 = w.spL2 = w.spL3 = 0;
   w.spPick = 0; w.spJobs = 0; w.spJobCap = 0;
-  if (w.nBlocks < kSplitEncodeBelow && B >= 1024u && B <= (1u << 20) && (kExperiments || B > 4096u || splitSmall))
+  // (noSplit: a codec whose blocks above 4 KiB go to the windowed position-parallel encoders never takes the split encode -- its regions, 2.3 x the input, are not reserved)
+  if (!noSplit && w.nBlocks < kSplitEncodeBelow && B >= 1024u && B <= (1u << 20) && (kExperiments || B > 4096u || splitSmall))
   {
     const uint64_t np = w.spPieces, nc = w.spMaxChunks;
     const uint64_t s1 = (nc + 2 + kScanTile - 1) / kScanTile, s2 = (s1 + kScanTile - 1) / kScanTile, s3 = (s2 + kScanTile - 1) / kScanTile;
@@ -694,7 +695,7 @@ static int compress_async(int codec, const void *dIn, uint64_t U, void *dOut, ui
 
   // (8 bit Single / 128 bit, small containers of 1 .. 4 KiB blocks: the split encode needs regions the general workspace does not reserve --
   //  the library's own scratch has them, a caller's workspace if it was sized by hsrle_compress_workspace_size_codec)
-  Workspace w = plan_workspace(U, B);
+  Workspace w = plan_workspace(U, B, false, ppw_applies(codec, (uint32_t)block_count(U, B), B));
   if (!noSplit && split_codec_small(codec) && B <= 4096u && !pp_applies(codec, (uint32_t)w.nBlocks, B))
   {
     // (only where the split encode will really run: its regions are 2 - 3 x the input -- ADVICE r4)
@@ -2603,7 +2604,8 @@ uint64_t hsrle_compress_workspace_size_codec(int codec, uint64_t inSize, uint32_
   init_tables();
   // (round 6: 8 bit Single and 128 bit containers of <= 4 KiB blocks are position-parallel -- no split regions; rle8_single_short and the Greedy codecs with a one-symbol list still take them)
   const bool split = split_codec_small(codec) && blockSize <= 4096u && !pp_applies(codec, (uint32_t)block_count(inSize, blockSize), blockSize);
-  return plan_workspace(inSize, blockSize, split).total;
+  // (... and the windowed encoders take blocks above 4 KiB without the split regions: 1.05 x the input instead of 3.4 x)
+  return plan_workspace(inSize, blockSize, split, block_count(inSize, blockSize) <= 0xFFFFFFF0ull && ppw_applies(codec, (uint32_t)block_count(inSize, blockSize), blockSize)).total;
 }
 
 int hsrle_compress_dev_async(int codec, const void *dIn, uint64_t inSize, void *dOut, uint64_t outCapacity, uint32_t blockSize, void *dWorkspace,

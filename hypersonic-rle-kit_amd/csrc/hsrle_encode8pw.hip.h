@@ -153,7 +153,7 @@ __device__ __forceinline__ void ppw_window(const uint8_t *__restrict__ d, uint32
   uint32_t K = 0;                                      // stored runs of this window
   // MODE 1: the window's first packet may reach back in front of the window: its header's length, the literal bytes in front of the edge
   [[maybe_unused]] bool firstSeen = false;
-  [[maybe_unused]] uint32_t hlFirst = 0, extLen = 0;
+  [[maybe_unused]] uint32_t hlFirst = 0, extLen = 0, imgShift = 0;    // imgShift: the image starts this many bytes in, so that what follows the first header is 16-byte aligned in LDS
   for (uint32_t r0 = 0; r0 < R; r0 += 64u)
   {
     const bool have = r0 + lane < R;
@@ -287,7 +287,6 @@ __device__ __forceinline__ void ppw_window(const uint8_t *__restrict__ d, uint32
     {
       const uint32_t myBytes = k ? hl + gapImg : 0u;
       const uint32_t incl = wave_scan_add(myBytes);
-      const uint32_t at0 = imgPos + incl - myBytes;
       if (!firstSeen)
       {
         const uint64_t stored = __ballot(k != 0);
@@ -297,8 +296,11 @@ __device__ __forceinline__ void ppw_window(const uint8_t *__restrict__ d, uint32
           firstSeen = true;
           hlFirst = wave_lane(hl, fl);
           extLen = wave_lane(gap - gapImg, fl);
+          // (literals in front of the window: the image is written in two pieces around them -- the second one starts on a 16-byte boundary of the LDS image)
+          if (extLen != 0u) { imgShift = (16u - hlFirst) & 15u; imgPos += imgShift; }
         }
       }
+      const uint32_t at0 = imgPos + incl - myBytes;
       uint32_t nch = 0, ds = 0;
       if (k)
       {
@@ -352,6 +354,17 @@ __device__ __forceinline__ void ppw_window(const uint8_t *__restrict__ d, uint32
     if (term)
     {
       const uint32_t kLit = ended ? 0u : n - carL;
+      if (!ended)
+      {
+        const uint32_t from = carL > ws ? carL : ws;
+        tailSrc = from - ws; tailLen = n - from;
+        if (!firstSeen)
+        {
+          // (no stored run in this window: the terminator is its first "header", the trailing literals may begin in front of the window)
+          firstSeen = true; hlFirst = TERM; extLen = from - carL;
+          if (extLen != 0u) { imgShift = (16u - TERM) & 15u; imgPos += imgShift; }
+        }
+      }
       if (lane >= 16u && lane < 16u + TERM)
       {
         const uint32_t t = lane - 16u;
@@ -367,12 +380,6 @@ __device__ __forceinline__ void ppw_window(const uint8_t *__restrict__ d, uint32
           v = (t >= 7u) ? (wv >> (8u * (t - 7u))) & 0xFFu : 0u;
         }
         if (v != 0u) sh.img[imgPos + t] = (uint8_t)v;
-      }
-      if (!ended)
-      {
-        const uint32_t from = carL > ws ? carL : ws;
-        tailSrc = from - ws; tailLen = n - from;
-        if (!firstSeen) { firstSeen = true; hlFirst = TERM; extLen = from - carL; }
       }
       imgSize = imgPos + TERM + tailLen;
     }
@@ -400,7 +407,7 @@ __device__ __forceinline__ void ppw_window(const uint8_t *__restrict__ d, uint32
     }
     else
     {
-      if (lane < hlFirst) out[lane] = sh.img[lane];
+      if (lane < hlFirst) out[lane] = sh.img[imgShift + lane];
       {
         const uint8_t *const src = d + carL0;
         uint8_t *const to = out + hlFirst;
@@ -411,11 +418,12 @@ __device__ __forceinline__ void ppw_window(const uint8_t *__restrict__ d, uint32
       }
       {
         uint8_t *const to = out + hlFirst + extLen;
-        const uint32_t rest = imgSize - hlFirst;
+        const uint32_t from = imgShift + hlFirst;                              // (a multiple of 16)
+        const uint32_t rest = imgSize - from;
         const uint32_t nFull = rest >> 4, tail = rest & 15u;
         for (uint32_t c = lane; c < nFull; c += 64u)
-          st128(to + 16u * c, ppw_img16(sh.img, hlFirst + 16u * c));
-        if (lane < tail) to[16u * nFull + lane] = sh.img[hlFirst + 16u * nFull + lane];
+          st128(to + 16u * c, lds_ld128(sh.img + from + 16u * c));
+        if (lane < tail) to[16u * nFull + lane] = sh.img[from + 16u * nFull + lane];
       }
     }
   }

@@ -219,7 +219,7 @@ __device__ __forceinline__ void ppSw_window(const uint8_t *__restrict__ d, uint3
   bool ended = cs.ended;
   uint32_t pCarOut = 0xFFFFFFFFu;                       // MODE 0: the start of the (one) stored run of this window that began in front of it
   [[maybe_unused]] bool firstSeen = false;
-  [[maybe_unused]] uint32_t hlFirst = 0, extLen = 0;
+  [[maybe_unused]] uint32_t hlFirst = 0, extLen = 0, imgShift = 0;    // imgShift: the image starts this many bytes in, so that what follows the first header is 16-byte aligned in LDS
   for (uint32_t r0 = 0; r0 < R; r0 += 64u)
   {
     const bool have = r0 + lane < R;
@@ -399,7 +399,6 @@ __device__ __forceinline__ void ppSw_window(const uint8_t *__restrict__ d, uint3
     {
       const uint32_t myBytes = k ? hl + gapImg : 0u;
       const uint32_t incl = wave_scan_add(myBytes);
-      const uint32_t at0 = imgPos + incl - myBytes;
       if (!firstSeen)
       {
         const uint64_t stored = __ballot(k != 0);
@@ -409,8 +408,11 @@ __device__ __forceinline__ void ppSw_window(const uint8_t *__restrict__ d, uint3
           firstSeen = true;
           hlFirst = wave_lane(hl, fl);
           extLen = wave_lane(gap - gapImg, fl);
+          // (literals in front of the window: the image is written in two pieces around them -- the second one starts on a 16-byte boundary of the LDS image)
+          if (extLen != 0u) { imgShift = (16u - hlFirst) & 15u; imgPos += imgShift; }
         }
       }
+      const uint32_t at0 = imgPos + incl - myBytes;
       uint32_t nch = 0, ds = 0;
       if (k)
       {
@@ -489,6 +491,17 @@ __device__ __forceinline__ void ppSw_window(const uint8_t *__restrict__ d, uint3
     if (lastWindow)
     {
       const uint32_t kLit = ended ? 0u : n - carL;
+      if (!ended)
+      {
+        const uint32_t from = carL > ws ? carL : ws;
+        tailSrc = from - ws; tailLen = n - from;
+        if (!firstSeen)
+        {
+          // (no stored run in this window: the terminator is its first "header", the trailing literals may begin in front of the window)
+          firstSeen = true; hlFirst = TERM; extLen = from - carL;
+          if (extLen != 0u) { imgShift = (16u - TERM) & 15u; imgPos += imgShift; }
+        }
+      }
       if (lane == 16u)
       {
         const uint32_t at = imgPos;
@@ -510,12 +523,6 @@ __device__ __forceinline__ void ppSw_window(const uint8_t *__restrict__ d, uint3
           if constexpr (R7) pp_or_bytes(sh.img, a0 + 5u, (uint64_t)((val << 1) | 1u), 4u);
           else pp_or_bytes(sh.img, a0 + 5u, (uint64_t)val << 8, 5u);
         }
-      }
-      if (!ended)
-      {
-        const uint32_t from = carL > ws ? carL : ws;
-        tailSrc = from - ws; tailLen = n - from;
-        if (!firstSeen) { firstSeen = true; hlFirst = TERM; extLen = from - carL; }
       }
       imgSize = imgPos + (ended ? TERM_END : TERM) + tailLen;
     }
@@ -543,7 +550,7 @@ __device__ __forceinline__ void ppSw_window(const uint8_t *__restrict__ d, uint3
     }
     else
     {
-      if (lane < hlFirst) out[lane] = sh.img[lane];
+      if (lane < hlFirst) out[lane] = sh.img[imgShift + lane];
       {
         const uint8_t *const src = d + carL0;
         uint8_t *const to = out + hlFirst;
@@ -554,11 +561,12 @@ __device__ __forceinline__ void ppSw_window(const uint8_t *__restrict__ d, uint3
       }
       {
         uint8_t *const to = out + hlFirst + extLen;
-        const uint32_t rest = imgSize - hlFirst;
+        const uint32_t from = imgShift + hlFirst;                              // (a multiple of 16)
+        const uint32_t rest = imgSize - from;
         const uint32_t nFull = rest >> 4, tail = rest & 15u;
         for (uint32_t c = lane; c < nFull; c += 64u)
-          st128(to + 16u * c, ppw_img16(sh.img, hlFirst + 16u * c));
-        if (lane < tail) to[16u * nFull + lane] = sh.img[hlFirst + 16u * nFull + lane];
+          st128(to + 16u * c, lds_ld128(sh.img + from + 16u * c));
+        if (lane < tail) to[16u * nFull + lane] = sh.img[from + 16u * nFull + lane];
       }
     }
   }
@@ -598,7 +606,6 @@ __global__ __launch_bounds__(64) void k_encodeS_ppw_scan(PpwArgs a)
     for (int j = 0; j < 4; j++) x[j] = xn[j];
   }
   if (threadIdx.x == 0u) a.sizes[u] = cs.pos + (cs.ended ? TERM_END : TERM + (n - cs.carL));
-  for (uint32_t s = windows + threadIdx.x; s < slots; s += 64u) a.states[(gw0 + s) * kPpwSStateWords + 12u] = kPpwEmpty;
 }
 
 // Pass 2: one wave per window

@@ -132,6 +132,10 @@ def test_encode_path_selection(lib):
     for name in ("rle16_3symlut_byte_short_greedy", "rle64_7symlut_byte_short_greedy"):     # lists of 3 / 7 symbols decide the greedy scan's runs: one lane per block
         assert lib.hsrle_encode_path(cid(name), frame, 8192) == RING and lib.hsrle_compress_workspace_size_codec(cid(name), frame, 4096) == general
     assert lib.hsrle_compress_workspace_size_codec(cid("rle128_sym"), 8 << 30, 4096) == lib.hsrle_compress_workspace_size(8 << 30, 4096)
+    # round 6: blocks above 4 KiB of a windowed codec never take the split encode: no split regions in the codec's own workspace size (the general size keeps them)
+    for name in ("rle8_packed_multi", "rle32_byte", "rle64_3symlut_byte", "rle16_7symlut_sym"):
+        assert lib.hsrle_compress_workspace_size_codec(cid(name), frame, 8192) < 1.2 * frame < lib.hsrle_compress_workspace_size(frame, 8192), name
+    assert lib.hsrle_compress_workspace_size_codec(cid("rle128_sym"), frame, 8192) == lib.hsrle_compress_workspace_size(frame, 8192)      # (not windowed: split encode)
     assert lib.hsrle_encode_path(cid("rle8_single_short"), frame, 4096) == PP and lib.hsrle_compress_workspace_size_codec(cid("rle8_single_short"), frame, 4096) == general   # round 6
     assert lib.hsrle_encode_path(-1, frame, 4096) == -1 and lib.hsrle_encode_path(0, frame, 1000) == -1 and lib.hsrle_encode_path(0, 0, 4096) == -1
 
